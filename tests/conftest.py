@@ -1,0 +1,40 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name)))
+
+
+@pytest.fixture(scope="session")
+def weights():
+    from mobileposer_amd.synthetic import make_weights
+    return make_weights(0)
+
+
+@pytest.fixture(scope="session")
+def smpl():
+    from mobileposer_amd.synthetic import synthetic_smpl
+    return synthetic_smpl()
+
+
+def geodesic(Ra, Rb):
+    """Angle (rad) between rotation matrices [...,3,3] (float64 inside)."""
+    Ra = np.asarray(Ra, dtype=np.float64)
+    Rb = np.asarray(Rb, dtype=np.float64)
+    D = np.swapaxes(Ra, -1, -2) @ Rb
+    # robust: angle = 2*asin(||D - I||_F / (2*sqrt(2)))
+    n = np.linalg.norm(D - np.eye(3), axis=(-1, -2))
+    return 2.0 * np.arcsin(np.clip(n / (2.0 * np.sqrt(2.0)), 0.0, 1.0))

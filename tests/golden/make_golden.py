@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running THE REFERENCE ITSELF on CPU.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU box):
+
+    python tests/golden/make_golden.py
+
+What it does: installs a stub ``lightning`` module (the reference's model classes
+derive from L.LightningModule, models/net.py:7,22), writes the synthetic SMPL pickle of
+``mobileposer_amd.synthetic.synthetic_smpl`` to ``<tmp>/smpl/basicmodel_m.pkl`` (paths are
+CWD-relative, config.py:28-30), imports ``mobileposer`` from /root/reference, loads the seeded
+numpy weights of ``mobileposer_amd.synthetic.make_weights`` via ``load_state_dict`` and records
+inputs + outputs of every hot-path function as small .npz files.  Only data is written -- no
+reference source or bytecode enters the repository.
+"""
+import json
+import os
+import pickle
+import sys
+import tempfile
+import types
+
+import numpy as np
+import scipy.sparse
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+from mobileposer_amd import synthetic  # noqa: E402
+
+REFERENCE = "/root/reference"
+
+
+def install_stub_lightning():
+    L = types.ModuleType("lightning")
+
+    class LightningModule(torch.nn.Module):
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        def log(self, *a, **k):
+            pass
+
+        @property
+        def device(self):
+            return torch.device("cpu")
+
+    class LightningDataModule:
+        pass
+
+    L.LightningModule = LightningModule
+    L.LightningDataModule = LightningDataModule
+    sys.modules["lightning"] = L
+
+
+def to_torch_sd(sd):
+    return {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+
+
+def main():
+    torch.set_num_threads(4)
+    install_stub_lightning()
+    work = tempfile.mkdtemp(prefix="mp_golden_")
+    os.makedirs(os.path.join(work, "smpl"))
+    smpl = synthetic.synthetic_smpl()
+    pk = dict(smpl)
+    pk["J_regressor"] = scipy.sparse.csc_matrix(smpl["J_regressor"])
+    with open(os.path.join(work, "smpl", "basicmodel_m.pkl"), "wb") as f:
+        pickle.dump(pk, f)
+    os.chdir(work)
+    sys.path.insert(0, REFERENCE)
+    sys.dont_write_bytecode = True
+    from mobileposer.models import MobilePoserNet           # noqa: E402
+    from mobileposer.config import paths                    # noqa: E402
+    import mobileposer.articulate as art                    # noqa: E402
+
+    def new_model(seed=0):
+        m = MobilePoserNet()
+        m.load_state_dict(to_torch_sd(synthetic.make_weights(seed)))
+        m.eval()
+        return m
+
+    out = {}
+
+    # ---- G7 manifest ----------------------------------------------------------------------------
+    net = new_model()
+    manifest = [[k, list(v.shape)] for k, v in net.state_dict().items()]
+    with open(os.path.join(HERE, "g7_manifest.json"), "w") as f:
+        json.dump({"keys": manifest, "parent": [(-1 if p is None else int(p)) for p in net.bodymodel.parent],
+                   "floor_y": net.floor_y, "feet_pos": net.feet_pos.numpy().tolist()}, f, indent=0)
+
+    # ---- G1 per-module RNN, ragged lengths, with and without initial state ------------------------
+    lengths = [17, 9, 13, 17]
+    g1 = {"lengths": np.array(lengths)}
+    with torch.no_grad():
+        for name, mod, n_in in (("joints", net.joints.joints, 60), ("pose", net.pose.pose, 132),
+                                ("foot_contact", net.foot_contact.footcontact, 132), ("velocity", net.velocity.vel, 132)):
+            rng = np.random.Generator(np.random.PCG64(100 + n_in + len(name)))
+            x = rng.standard_normal((4, 17, n_in)).astype(np.float32) * 0.5
+            y, ol, (h, c) = mod(torch.from_numpy(x), lengths)
+            g1[f"{name}_x"], g1[f"{name}_y"], g1[f"{name}_h"], g1[f"{name}_c"] = x, y.numpy(), h.numpy(), c.numpy()
+            y2, _, (h2, c2) = mod(torch.from_numpy(x), lengths, (h, c))          # carry state in (velocity.py:47)
+            g1[f"{name}_y2"], g1[f"{name}_h2"], g1[f"{name}_c2"] = y2.numpy(), h2.numpy(), c2.numpy()
+    np.savez_compressed(os.path.join(HERE, "g1_rnn.npz"), **g1)
+
+    # ---- G2 full forward: equal lengths and ragged ------------------------------------------------
+    imu = synthetic.make_imu(3, 25, seed=11)
+    g2 = {"imu": imu}
+    with torch.no_grad():
+        for tag, lens in (("eq", [25, 25, 25]), ("rag", [25, 11, 18])):
+            m = new_model()
+            pose, joints, vel, contact = m.forward(torch.from_numpy(imu), lens)
+            g2[f"{tag}_lengths"] = np.array(lens)
+            g2[f"{tag}_pose"], g2[f"{tag}_joints"] = pose.numpy(), joints.numpy()
+            g2[f"{tag}_vel"], g2[f"{tag}_contact"] = vel.numpy(), contact.numpy()
+            h, c = m.velocity.rnn_state
+            g2[f"{tag}_vel_h"], g2[f"{tag}_vel_c"] = h.numpy(), c.numpy()
+            # raw 96-d r6d too (the quantity before Gram-Schmidt amplification)
+            x132 = torch.cat((joints, torch.from_numpy(imu)[:, :joints.shape[1]]), dim=-1)
+            g2[f"{tag}_r6d"] = m.pose(x132, lens).numpy()
+    np.savez_compressed(os.path.join(HERE, "g2_forward.npz"), **g2)
+
+    # ---- G3 r6d -> R -> full -> local, with degenerate rows (Q8) ----------------------------------
+    rng = np.random.Generator(np.random.PCG64(3))
+    r6d = rng.standard_normal((64, 96)).astype(np.float32)
+    r6d[5, 0:6] = 0.0                                   # zero vectors  -> NaN -> 0
+    r6d[6, 6:12] = [1, 2, 3, 2, 4, 6]                   # colinear      -> NaN -> 0 in columns 1,2
+    r6d[7, 12:18] = [0, 0, 0, 1, 0, 0]                  # zero first vector
+    with torch.no_grad():
+        full = net._reduced_global_to_full(torch.from_numpy(r6d))
+        rot = art.math.r6d_to_rotation_matrix(torch.from_numpy(r6d))
+    np.savez_compressed(os.path.join(HERE, "g3_r6d_ik.npz"), r6d=r6d, pose=full.numpy(), rot=rot.numpy())
+
+    # ---- G4 forward_offline: two consecutive sequences, stale velocity state (Q1) -----------------
+    T = 200
+    imu_a = synthetic.make_imu(1, T, seed=21)
+    imu_b = synthetic.make_imu(1, T, seed=22)
+    g4 = {"imu_a": imu_a, "imu_b": imu_b}
+    with torch.no_grad():
+        m = new_model()
+        for tag, x in (("a", imu_a), ("b", imu_b), ("a_again", imu_a)):
+            m.reset()
+            pose, joints, tran, contact = m.forward_offline(torch.from_numpy(x), [T])
+            g4[f"{tag}_pose"], g4[f"{tag}_joints"] = pose.numpy(), joints.numpy()
+            g4[f"{tag}_tran"], g4[f"{tag}_contact"] = tran.numpy(), contact.numpy()
+        m.reset()
+        m.velocity.rnn_state = None                      # explicit clear restores the first answer
+        pose, joints, tran, contact = m.forward_offline(torch.from_numpy(imu_a), [T])
+        g4["a_cleared_tran"] = tran.numpy()
+    np.savez_compressed(os.path.join(HERE, "g4_offline.npz"), **g4)
+
+    # ---- G5 forward_online: 60 consecutive frames from reset() (Q5, Q6) ---------------------------
+    n_on = 60
+    imu_on = synthetic.make_imu(1, n_on, seed=31)[0]
+    poses, jnts, trans, cons = [], [], [], []
+    with torch.no_grad():
+        m = new_model()
+        m.reset()
+        for f in torch.from_numpy(imu_on):
+            p, j, t, c = m.forward_online(f)
+            poses.append(p.numpy()); jnts.append(j.numpy()[40]); trans.append(t.numpy()); cons.append(c.numpy())
+        h, c = m.velocity.rnn_state
+    np.savez_compressed(os.path.join(HERE, "g5_online.npz"), imu=imu_on, pose=np.stack(poses), joints40=np.stack(jnts),
+                        tran=np.stack(trans), contact=np.stack(cons), vel_h=h.numpy(), vel_c=c.numpy(),
+                        current_root_y=np.float64(m.current_root_y))
+
+    # ---- G6 forward kinematics (joints, and the LBS mesh used by the evaluator) -------------------
+    rng = np.random.Generator(np.random.PCG64(6))
+    pose = synthetic._random_rotations(rng, 32 * 24).reshape(32, 24, 3, 3).astype(np.float32)
+    tran = rng.standard_normal((32, 3)).astype(np.float32)
+    with torch.no_grad():
+        Rg, jg = net.bodymodel.forward_kinematics(torch.from_numpy(pose))
+        Rg2, jg2, vg2 = net.bodymodel.forward_kinematics(torch.from_numpy(pose), tran=torch.from_numpy(tran), calc_mesh=True)
+    np.savez_compressed(os.path.join(HERE, "g6_fk.npz"), pose=pose, tran=tran, R_global=Rg.numpy(), joint=jg.numpy(),
+                        joint_tran=jg2.numpy(), vert_tran=vg2.numpy())
+    print("golden vectors written to", HERE)
+    for fn in sorted(os.listdir(HERE)):
+        print("  %-24s %8d B" % (fn, os.path.getsize(os.path.join(HERE, fn))))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,136 @@
+"""Pin the CPU oracle (oracle/mp_oracle.py) against golden vectors recorded from the reference itself
+(tests/golden/make_golden.py).  CPU only.  Tolerances: 1e-4 on joint angles / raw outputs, 1 mm on
+root translation (BASELINE.json north_star); the oracle actually agrees to ~1e-6."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, geodesic, load_golden
+from oracle import mp_oracle as O
+from mobileposer_amd.manifest import state_dict_manifest
+
+TOL = 1e-4
+TIGHT = 2e-5
+
+
+def test_g7_manifest_matches_reference():
+    with open(os.path.join(GOLDEN, "g7_manifest.json")) as f:
+        g = json.load(f)
+    ours = [[k, list(s)] for k, s in state_dict_manifest().items()]
+    assert ours == g["keys"]
+    assert g["parent"] == O.PARENT
+
+
+def test_g7_floor_and_feet(weights, smpl):
+    with open(os.path.join(GOLDEN, "g7_manifest.json")) as f:
+        g = json.load(f)
+    net = O.OracleNet(weights, smpl["J"])
+    assert abs(net.floor_y - g["floor_y"]) < 1e-7
+    np.testing.assert_allclose(net.feet_pos, np.array(g["feet_pos"], dtype=np.float32), atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["joints", "pose", "foot_contact", "velocity"])
+def test_g1_rnn_ragged(weights, name):
+    g = load_golden("g1_rnn.npz")
+    lengths = g["lengths"].tolist()
+    y, (h, c) = O.rnn_forward(weights, O.PREFIX[name], g[f"{name}_x"], lengths)
+    assert y.shape == g[f"{name}_y"].shape
+    assert np.abs(y - g[f"{name}_y"]).max() < TIGHT
+    assert np.abs(h - g[f"{name}_h"]).max() < TIGHT
+    assert np.abs(c - g[f"{name}_c"]).max() < TIGHT
+    # carried-in state (velocity.py:47)
+    y2, (h2, c2) = O.rnn_forward(weights, O.PREFIX[name], g[f"{name}_x"], lengths, (g[f"{name}_h"], g[f"{name}_c"]))
+    assert np.abs(y2 - g[f"{name}_y2"]).max() < TIGHT
+    assert np.abs(h2 - g[f"{name}_h2"]).max() < TIGHT
+    assert np.abs(c2 - g[f"{name}_c2"]).max() < TIGHT
+    # Q4: padded positions carry linear2.bias exactly
+    b2 = weights[O.PREFIX[name] + "linear2.bias"]
+    np.testing.assert_allclose(y[1, 9:], np.broadcast_to(b2, y[1, 9:].shape), atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["eq", "rag"])
+def test_g2_forward(weights, smpl, tag):
+    g = load_golden("g2_forward.npz")
+    net = O.OracleNet(weights, smpl["J"])
+    pose, joints, vel, contact = net.forward(g["imu"], g[f"{tag}_lengths"].tolist())
+    assert pose.shape == g[f"{tag}_pose"].shape           # [B*T,24,3,3] (Q8 flattening)
+    assert np.abs(net._last_r6d - g[f"{tag}_r6d"]).max() < TIGHT
+    assert np.abs(joints - g[f"{tag}_joints"]).max() < TIGHT
+    assert np.abs(vel - g[f"{tag}_vel"]).max() < TIGHT
+    assert np.abs(contact - g[f"{tag}_contact"]).max() < TIGHT
+    assert geodesic(pose, g[f"{tag}_pose"]).max() < TOL
+    assert np.abs(pose - g[f"{tag}_pose"]).max() < TOL
+    h, c = net.velocity_rnn_state
+    assert np.abs(h - g[f"{tag}_vel_h"]).max() < TIGHT and np.abs(c - g[f"{tag}_vel_c"]).max() < TIGHT
+
+
+def test_g3_r6d_ik_degenerate():
+    g = load_golden("g3_r6d_ik.npz")
+    rot = O.r6d_to_rotation_matrix(g["r6d"])
+    assert not np.isnan(rot).any()
+    assert np.abs(rot - g["rot"]).max() < TIGHT
+    pose = O.reduced_global_to_full(g["r6d"])
+    assert np.abs(pose - g["pose"]).max() < TIGHT
+    # the degenerate rows really are degenerate in the golden (NaN -> 0 path exercised)
+    assert np.abs(g["rot"].reshape(64, 16, 3, 3)[5, 0]).max() == 0.0
+
+
+def test_g4_offline_stale_velocity_state(weights, smpl):
+    g = load_golden("g4_offline.npz")
+    net = O.OracleNet(weights, smpl["J"])
+    res = {}
+    for tag, x in (("a", g["imu_a"]), ("b", g["imu_b"]), ("a_again", g["imu_a"])):
+        net.reset()
+        pose, joints, tran, contact = net.forward_offline(x, [x.shape[1]])
+        res[tag] = tran
+        assert geodesic(pose, g[f"{tag}_pose"]).max() < TOL
+        assert np.abs(joints - g[f"{tag}_joints"]).max() < TIGHT
+        assert np.abs(contact - g[f"{tag}_contact"]).max() < TIGHT
+        assert np.abs(tran - g[f"{tag}_tran"]).max() < 1e-3, tag        # 1 mm
+        assert np.abs(tran - g[f"{tag}_tran"]).max() < 5e-5, tag
+    # Q1: the same input gives a different translation the second time ...
+    assert np.abs(g["a_again_tran"] - g["a_tran"]).max() > 1e-5
+    # ... and clearing the velocity state restores it
+    net.reset()
+    net.velocity_rnn_state = None
+    _, _, tran, _ = net.forward_offline(g["imu_a"], [g["imu_a"].shape[1]])
+    assert np.abs(tran - g["a_cleared_tran"]).max() < 5e-5
+    assert np.abs(g["a_cleared_tran"] - g["a_tran"]).max() < 1e-6
+
+
+def test_g4_floor_clamp_is_exercised(weights, smpl):
+    """The golden sequence must actually hit the floor-penetration branch (net.py:151-152)."""
+    g = load_golden("g4_offline.npz")
+    net = O.OracleNet(weights, smpl["J"])
+    tran = g["a_tran"]
+    joints = g["a_joints"][0].reshape(-1, 24, 3)
+    foot_y = tran[:, 1] + joints[:, 10:12, 1].min(axis=1)
+    on_floor = np.abs(foot_y - net.floor_y) < 1e-4
+    assert on_floor.sum() > 10 and (~on_floor).sum() > 10
+
+
+def test_g5_online(weights, smpl):
+    g = load_golden("g5_online.npz")
+    net = O.OracleNet(weights, smpl["J"])
+    net.reset()
+    for k, f in enumerate(g["imu"]):
+        pose, joints, tran, contact = net.forward_online(f)
+        assert geodesic(pose.reshape(24, 3, 3), g["pose"][k].reshape(24, 3, 3)).max() < TOL
+        assert np.abs(joints[40] - g["joints40"][k]).max() < TIGHT
+        assert np.abs(contact - g["contact"][k]).max() < TIGHT
+        assert np.abs(tran - g["tran"][k]).max() < 1e-4, k
+    h, c = net.velocity_rnn_state
+    assert np.abs(h - g["vel_h"]).max() < TIGHT and np.abs(c - g["vel_c"]).max() < TIGHT
+    assert abs(net.current_root_y - float(g["current_root_y"])) < 1e-4
+
+
+def test_g6_fk(smpl):
+    g = load_golden("g6_fk.npz")
+    Rg, jg = O.forward_kinematics(g["pose"], smpl["J"])
+    assert np.abs(Rg - g["R_global"]).max() < TIGHT
+    assert np.abs(jg - g["joint"]).max() < TIGHT
+    Rg2, jg2, vg2 = O.forward_kinematics_mesh(g["pose"], smpl, tran=g["tran"])
+    assert np.abs(jg2 - g["joint_tran"]).max() < TIGHT
+    assert np.abs(vg2 - g["vert_tran"]).max() < TIGHT
