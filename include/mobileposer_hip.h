@@ -1,0 +1,143 @@
+/*
+ * mobileposer_hip.h -- C ABI of libmobileposer_hip.so, the MI355X (gfx950) implementation of the
+ * MobilePoser per-frame inference path.
+ *
+ * The reference (SPICExLAB/MobilePoser) is 100 % Python and has no FFI of its own; the boundary it
+ * offers is the method surface of MobilePoserNet.  Every entry point below therefore names the
+ * reference METHOD it replaces (paths relative to /root/reference/mobileposer).  The Python facade
+ * (mobileposer_amd/net.py) keeps those method signatures and calls these functions through ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every `*_dev` pointer is device (HBM) memory owned by the
+ *     caller, fp32 row-major; `*_host` pointers are host memory.
+ *   - every function returns MP_OK (0) or a negative mp_status; mp_last_error() gives the text.
+ *     No C++ exception crosses the ABI.
+ *   - a handle is bound to one device, is NOT thread-safe, and owns its weights, workspaces,
+ *     streams, captured hipGraphs and the carried state (velocity LSTM state, streaming windows).
+ *   - `stream` is the caller's HIP stream (void* = hipStream_t; NULL = the legacy default
+ *     stream).  Work is ordered after everything already enqueued on it and the caller's later
+ *     work on that stream is ordered after the call's results (event fork/join onto the
+ *     library's own streams); calls are asynchronous with respect to the host.
+ */
+#ifndef MOBILEPOSER_HIP_H
+#define MOBILEPOSER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mp_handle mp_handle;
+
+typedef enum mp_status {
+    MP_OK = 0,
+    MP_ERR_INVALID = -1,     /* bad argument (NULL pointer, non-positive size, unknown module ...)   */
+    MP_ERR_HIP = -2,         /* a HIP runtime call failed; text in mp_last_error()                   */
+    MP_ERR_STATE_SHAPE = -3, /* carried velocity state has another batch size (reference quirk Q2:   */
+                             /* nn.LSTM raises when h0's batch differs, models/velocity.py:45-48)    */
+    MP_ERR_NO_STREAMS = -4,  /* mp_stream_* called before mp_stream_create                           */
+    MP_ERR_LENGTHS = -5      /* lengths[] not in 1..T or max(lengths) != T (the reference's           */
+                             /* torch.cat at models/net.py:106 fails in that case)                    */
+} mp_status;
+
+/* module ids for mp_rnn_forward: the four RNN blocks built at models/net.py:40-43 */
+enum { MP_MOD_JOINTS = 0, MP_MOD_POSE = 1, MP_MOD_FOOT_CONTACT = 2, MP_MOD_VELOCITY = 3 };
+
+/* Number of fp32 values in the flat weight blob (6 674 994): the 72 state-dict tensors in the
+ * reference's registration order (pose.*, joints.*, foot_contact.*, velocity.*), each row-major.
+ * Replaces: the `.pth` state_dict written by combine_weights.py:53-56. */
+size_t mp_weight_count(void);
+
+/* i-th manifest entry (0 <= i < 72): key name, number of dims (1|2), shape, offset in the blob.
+ * Replaces: MobilePoserNet.state_dict() key/shape enumeration (utils/model_utils.py:11). */
+int mp_manifest_entry(int i, char* name, size_t name_cap, int* ndim, int64_t shape[2], size_t* offset);
+
+/* Create a model instance on `device` from a host weight blob and the SMPL constants the path uses.
+ * parent[24]: kinematic tree (parent[0] = -1); J[72]: raw SMPL joint positions (root-aligned inside).
+ * Replaces: MobilePoserNet.__init__ (models/net.py:28-74) + load_state_dict in load_model
+ * (utils/model_utils.py:6-15) + ParametricModel.__init__ (articulate/model.py:20-39). */
+int mp_create(mp_handle** out, int device, const float* weights_host, size_t n_floats,
+              const int32_t parent[24], const float J[72]);
+
+/* Same, from a blob that already lives in device memory (e.g. after the RCCL broadcast of the
+ * weights from rank 0).  The blob is only read during the call. */
+int mp_create_from_device(mp_handle** out, int device, const float* weights_dev, size_t n_floats,
+                          const int32_t parent[24], const float J[72]);
+
+void mp_destroy(mp_handle* h);
+const char* mp_last_error(const mp_handle* h);   /* h may be NULL: error of a failed mp_create */
+
+/* Read constants back: floor_y (models/net.py:49), feet_pos[2*3] (models/net.py:48). */
+int mp_get_constants(const mp_handle* h, float* floor_y, float feet_pos[6]);
+
+/* MobilePoserNet.forward (models/net.py:101-119).
+ *   imu_dev      [B,T,60]      in
+ *   lengths_host [B]           in   (1..T each, max == T; reference passes a Python list)
+ *   pose_dev     [B*T,24,3,3]  out  local rotations after _reduced_global_to_full (net.py:93-99)
+ *   joints_dev   [B,T,72]      out
+ *   vel_dev      [B,T,72]      out  (velocity LSTM state is carried across calls: velocity.py:45-48)
+ *   contact_dev  [B,T,2]       out  raw logits
+ *   r6d_dev      [B,T,96]      out, optional (NULL to skip): the Poser output before net.py:110 */
+int mp_forward(mp_handle* h, const float* imu_dev, const int32_t* lengths_host, int B, int T,
+               float* pose_dev, float* joints_dev, float* vel_dev, float* contact_dev,
+               float* r6d_dev, void* stream);
+
+/* RNN.forward of one module (models/rnn.py:20-33): Linear+ReLU -> 2-layer LSTM (packed-sequence
+ * semantics) -> Linear.  x_dev [B,T,n_in] -> y_dev [B,T,n_out].
+ * state_in_dev / state_out_dev: optional (h then c, each [layers*dirs, B, H] contiguous, nn.LSTM
+ * order l0, l0_reverse, l1, l1_reverse) -- the `h` argument / third return value of rnn.py:20,33. */
+int mp_rnn_forward(mp_handle* h, int module, const float* x_dev, const int32_t* lengths_host,
+                   int B, int T, float* y_dev, const float* state_in_dev, float* state_out_dev,
+                   void* stream);
+
+/* MobilePoserNet._reduced_global_to_full (models/net.py:93-99): r6d [N,96] -> pose [N,24,3,3]. */
+int mp_reduced_global_to_full(mp_handle* h, const float* r6d_dev, int64_t N, float* pose_dev, void* stream);
+
+/* The translation solver of forward_offline (models/net.py:130-154), batched over sequences.
+ * joints [B,T,72], vel [B,T,72], contact [B,T,2] (as returned by mp_forward) -> tran [B,T,3].
+ * Frames t >= lengths[b] get the last valid translation. */
+int mp_translate_offline(mp_handle* h, const float* joints_dev, const float* vel_dev,
+                         const float* contact_dev, const int32_t* lengths_host, int B, int T,
+                         float* tran_dev, void* stream);
+
+/* ParametricModel.forward_kinematics, calc_mesh=False, shape=None (articulate/model.py:208-232).
+ * pose [N,24,3,3] local, tran [N,3] optional (NULL) -> R_global [N,24,3,3], joint [N,24,3]. */
+int mp_fk(mp_handle* h, const float* pose_dev, const float* tran_dev, int64_t N,
+          float* rglobal_dev, float* joint_dev, void* stream);
+
+/* MobilePoserNet.reset (models/net.py:84-88) clears nothing this library owns for the batch path;
+ * clear_velocity != 0 additionally drops the carried velocity LSTM state (what setting
+ * `model.velocity.rnn_state = None` does in the reference). */
+int mp_reset_state(mp_handle* h, int clear_velocity);
+
+/* Carried velocity state, h then c, each [2,B,256] (velocity.py:30,47).  get: returns B (0 = none). */
+int mp_get_velocity_state(mp_handle* h, float* state_dev, int* batch);
+int mp_set_velocity_state(mp_handle* h, const float* state_dev, int batch);
+
+/* ---- streaming: MobilePoserNet.forward_online (models/net.py:173-219) for S concurrent streams --
+ * Each stream owns a 45-frame window (40 past + 5 future, config.py:52-54), last foot positions,
+ * current_root_y, last_root_pos and its rows of the velocity LSTM state.  One step consumes one
+ * new frame per stream and is replayed from a captured hipGraph. */
+int mp_stream_create(mp_handle* h, int S);
+/* frames [S,60] -> pose [S,24,9], joints [S,45,72] (optional NULL), root_pos [S,3], contact [S,2] */
+int mp_stream_step(mp_handle* h, const float* frames_dev, float* pose_dev, float* joints_dev,
+                   float* root_pos_dev, float* contact_dev, void* stream);
+/* reset(): all streams (mask_host == NULL) or those with mask_host[s] != 0.  Like the reference's
+ * reset() it leaves the velocity LSTM state alone unless clear_velocity != 0. */
+int mp_stream_reset(mp_handle* h, const uint8_t* mask_host, int clear_velocity);
+
+/* ---- measurement hooks (bench.py) ---------------------------------------------------------------
+ * With timing on, every mp_forward brackets its kernel classes with HIP events on the library's
+ * own streams.  mp_timing_read returns, for the last call, the number of launches and the summed
+ * event-measured milliseconds per class: 0 = MFMA GEMM, 1 = LSTM step, 2 = r6d/IK, 3 = whole call. */
+int mp_timing_enable(mp_handle* h, int on);
+int mp_timing_read(mp_handle* h, int cls, int* launches, float* ms);
+/* 0: eager launches, 1: replay captured hipGraphs (default; env MP_NO_GRAPH=1 flips the default). */
+int mp_set_graph_mode(mp_handle* h, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOBILEPOSER_HIP_H */

@@ -1,0 +1,73 @@
+"""ctypes binding of libmobileposer_hip.so (C ABI: include/mobileposer_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or lacks a symbol this module
+raises, and every facade method goes through it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmobileposer_hip.so")
+
+MP_OK = 0
+MP_ERR_INVALID, MP_ERR_HIP, MP_ERR_STATE_SHAPE, MP_ERR_NO_STREAMS, MP_ERR_LENGTHS = -1, -2, -3, -4, -5
+MOD_JOINTS, MOD_POSE, MOD_FOOT_CONTACT, MOD_VELOCITY = 0, 1, 2, 3
+
+_vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes): every symbol include/mobileposer_hip.h declares
+SIGNATURES = {
+    "mp_weight_count": (_sz, []),
+    "mp_manifest_entry": (_i, [_i, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_i64), C.POINTER(_sz)]),
+    "mp_create": (_i, [C.POINTER(_vp), _i, _fp, _sz, _ip, _fp]),
+    "mp_create_from_device": (_i, [C.POINTER(_vp), _i, _vp, _sz, _ip, _fp]),
+    "mp_destroy": (None, [_vp]),
+    "mp_last_error": (C.c_char_p, [_vp]),
+    "mp_get_constants": (_i, [_vp, _fp, _fp]),
+    "mp_forward": (_i, [_vp, _vp, _ip, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mp_rnn_forward": (_i, [_vp, _i, _vp, _ip, _i, _i, _vp, _vp, _vp, _vp]),
+    "mp_reduced_global_to_full": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "mp_translate_offline": (_i, [_vp, _vp, _vp, _vp, _ip, _i, _i, _vp, _vp]),
+    "mp_fk": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "mp_reset_state": (_i, [_vp, _i]),
+    "mp_get_velocity_state": (_i, [_vp, _vp, C.POINTER(_i)]),
+    "mp_set_velocity_state": (_i, [_vp, _vp, _i]),
+    "mp_stream_create": (_i, [_vp, _i]),
+    "mp_stream_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mp_stream_reset": (_i, [_vp, C.POINTER(C.c_uint8), _i]),
+    "mp_timing_enable": (_i, [_vp, _i]),
+    "mp_timing_read": (_i, [_vp, _i, C.POINTER(_i), _fp]),
+    "mp_set_graph_mode": (_i, [_vp, _i]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library and bind every symbol of the header; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "mobileposer_amd: %s not found -- build it with `python __graft_entry__.py` (hipcc, gfx950). "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error(handle=None):
+    msg = load().mp_last_error(handle)
+    return msg.decode() if msg else ""
+
+
+def check(rc, handle=None):
+    if rc != MP_OK:
+        raise RuntimeError("libmobileposer_hip: %s (status %d)" % (last_error(handle), rc))

@@ -1,0 +1,787 @@
+// Host runtime + C ABI of libmobileposer_hip.so (see include/mobileposer_hip.h).
+//
+// Orchestrates MobilePoserNet.forward (models/net.py:101-119) on one MI355X:
+//   joints RNN -> [pose RNN + r6d/IK] || velocity RNN || foot-contact RNN
+// on three library-owned HIP streams (fork/join by events), each RNN being
+//   GEMM(linear1+ReLU) -> GEMM(W_ih l0) -> T x lstm_step -> GEMM(W_ih l1) -> T x lstm_step -> GEMM(linear2),
+// captured once per (shape, buffer set) into a hipGraph and replayed.  Weights are re-laid-out once at load
+// time into MFMA fragment order; workspaces are sized per (B, T) plan and kept (288 GB of HBM: no reuse games).
+#include "../../include/mobileposer_hip.h"
+#include "mp_common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+std::string g_create_error;
+
+struct ModSpec { const char* prefix; int n_in, n_out, H, bi, id; };
+// registration order of the reference's state_dict (models/net.py:40-43)
+const ModSpec kSpecs[4] = {
+    {"pose.pose.", 132, 96, 256, 1, MP_MOD_POSE},
+    {"joints.joints.", 60, 72, 256, 1, MP_MOD_JOINTS},
+    {"foot_contact.footcontact.", 132, 2, 64, 1, MP_MOD_FOOT_CONTACT},
+    {"velocity.vel.", 132, 72, 256, 0, MP_MOD_VELOCITY},
+};
+
+enum Kind { K_WIH, K_WHH, K_BIH, K_BHH, K_L1W, K_L1B, K_L2W, K_L2B };
+struct Entry { std::string name; int ndim; int64_t shape[2]; size_t offset; int mod, kind, layer, dir; };
+
+std::vector<Entry> build_manifest() {
+    std::vector<Entry> v;
+    size_t off = 0;
+    auto add = [&](const std::string& name, int ndim, int64_t s0, int64_t s1, int mod, int kind, int layer, int dir) {
+        Entry e{name, ndim, {s0, s1}, off, mod, kind, layer, dir};
+        v.push_back(e);
+        off += (size_t)s0 * (ndim == 2 ? (size_t)s1 : 1);
+    };
+    for (const ModSpec& m : kSpecs) {
+        const int dirs = m.bi ? 2 : 1;
+        for (int l = 0; l < 2; ++l) {
+            const int in_l = l == 0 ? m.H : m.H * dirs;
+            for (int d = 0; d < dirs; ++d) {
+                const std::string sfx = "_l" + std::to_string(l) + (d ? "_reverse" : "");
+                add(std::string(m.prefix) + "rnn.weight_ih" + sfx, 2, 4 * m.H, in_l, m.id, K_WIH, l, d);
+                add(std::string(m.prefix) + "rnn.weight_hh" + sfx, 2, 4 * m.H, m.H, m.id, K_WHH, l, d);
+                add(std::string(m.prefix) + "rnn.bias_ih" + sfx, 1, 4 * m.H, 1, m.id, K_BIH, l, d);
+                add(std::string(m.prefix) + "rnn.bias_hh" + sfx, 1, 4 * m.H, 1, m.id, K_BHH, l, d);
+            }
+        }
+        add(std::string(m.prefix) + "linear1.weight", 2, m.H, m.n_in, m.id, K_L1W, 0, 0);
+        add(std::string(m.prefix) + "linear1.bias", 1, m.H, 1, m.id, K_L1B, 0, 0);
+        add(std::string(m.prefix) + "linear2.weight", 2, m.n_out, m.H * dirs, m.id, K_L2W, 0, 0);
+        add(std::string(m.prefix) + "linear2.bias", 1, m.n_out, 1, m.id, K_L2B, 0, 0);
+    }
+    return v;
+}
+const std::vector<Entry>& manifest() {
+    static const std::vector<Entry> m = build_manifest();
+    return m;
+}
+size_t manifest_floats() {
+    const Entry& e = manifest().back();
+    return e.offset + (size_t)e.shape[0] * (e.ndim == 2 ? (size_t)e.shape[1] : 1);
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct Packed { float* W = nullptr; float* bias = nullptr; int N = 0, K = 0, Kpad = 0, Npad = 0, bn = 0; };
+struct ModuleW {
+    int n_in = 0, n_out = 0, H = 0, dirs = 0;
+    Packed lin1, ih[2], lin2;
+    float* whh[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+};
+struct ModuleWS {
+    float *xproj = nullptr, *out0 = nullptr, *out1 = nullptr;   // X1 (linear1 output) aliases out1
+    float* hbuf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    float* cbuf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+};
+struct VelState { float* h = nullptr; float* c = nullptr; int B = 0; int cap = 0; };   // [2][B][256] each
+
+struct GraphKey {
+    int kind, B, T, flags;
+    const void* p[8];
+    bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
+};
+
+struct Plan {
+    int B = 0, T = 0;
+    ModuleWS ws[4];
+    float* r6d = nullptr;            // [B,T,96] when the caller does not ask for it
+    int* lengths_dev = nullptr;
+    int* lengths_pin = nullptr;      // pinned staging
+    std::vector<int> lengths_cache;
+    std::vector<void*> allocs;
+};
+
+struct Seg { int cls; hipEvent_t a, b; int launches; };
+
+struct StreamCtx {
+    int S = 0;
+    float* window = nullptr;         // [S,45,60]
+    uint8_t* fresh = nullptr;        // [S]
+    uint8_t* mask_dev = nullptr;     // [S]
+    OnlineState st;
+    float *joints = nullptr, *vel = nullptr, *contact = nullptr;
+};
+
+}  // namespace
+
+struct mp_handle {
+    int device = 0;
+    std::string err;
+    ModuleW mod[4];
+    int* parent_dev = nullptr;
+    int* depth_dev = nullptr;
+    float* bone_dev = nullptr;
+    float floor_y = 0.f;
+    float feet_pos[6] = {0, 0, 0, 0, 0, 0};
+    hipStream_t s_main = nullptr, s_vel = nullptr, s_foot = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_j = nullptr, ev_v = nullptr, ev_f = nullptr;
+    std::map<std::pair<int, int>, Plan*> plans;
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    VelState vstate;
+    StreamCtx sc;
+    bool use_graph = true;
+    bool timing = false;
+    std::vector<Seg> segs;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    bool capturing = false;
+};
+
+namespace {
+
+int fail(mp_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return fail(h, MP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int dev_alloc(mp_handle* h, void** p, size_t bytes, std::vector<void*>* track = nullptr) {
+    HIPCHK(h, hipMalloc(p, bytes ? bytes : 16));
+    if (track) track->push_back(*p);
+    return MP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ weights
+int alloc_packed(mp_handle* h, Packed& p, int N, int K) {
+    p.N = N; p.K = K; p.Kpad = round_up(K, 32); p.bn = mp_gemm_pick_bn(N); p.Npad = round_up(N, p.bn);
+    if (int rc = dev_alloc(h, (void**)&p.W, (size_t)p.Npad * p.Kpad * sizeof(float))) return rc;
+    if (int rc = dev_alloc(h, (void**)&p.bias, (size_t)p.Npad * sizeof(float))) return rc;
+    HIPCHK(h, hipMemsetAsync(p.W, 0, (size_t)p.Npad * p.Kpad * sizeof(float), h->s_main));
+    HIPCHK(h, hipMemsetAsync(p.bias, 0, (size_t)p.Npad * sizeof(float), h->s_main));
+    return MP_OK;
+}
+
+int pack_weights(mp_handle* h, const float* blob) {
+    for (const ModSpec& s : kSpecs) {
+        ModuleW& m = h->mod[s.id];
+        m.n_in = s.n_in; m.n_out = s.n_out; m.H = s.H; m.dirs = s.bi ? 2 : 1;
+        if (int rc = alloc_packed(h, m.lin1, m.H, m.n_in)) return rc;
+        if (int rc = alloc_packed(h, m.ih[0], m.dirs * 4 * m.H, m.H)) return rc;
+        if (int rc = alloc_packed(h, m.ih[1], m.dirs * 4 * m.H, m.dirs * m.H)) return rc;
+        if (int rc = alloc_packed(h, m.lin2, m.n_out, m.dirs * m.H)) return rc;
+        for (int l = 0; l < 2; ++l)
+            for (int d = 0; d < m.dirs; ++d)
+                if (int rc = dev_alloc(h, (void**)&m.whh[l][d], mp_whh_pack_floats(m.H) * sizeof(float))) return rc;
+    }
+    const std::vector<Entry>& man = manifest();
+    auto find = [&](int mod, int kind, int layer, int dir) -> const float* {
+        for (const Entry& e : man)
+            if (e.mod == mod && e.kind == kind && e.layer == layer && e.dir == dir) return blob + e.offset;
+        return nullptr;
+    };
+    for (const ModSpec& s : kSpecs) {
+        ModuleW& m = h->mod[s.id];
+        mp_launch_pack_linear(find(s.id, K_L1W, 0, 0), find(s.id, K_L1B, 0, 0), m.lin1.W, m.lin1.bias, m.lin1.N,
+                              m.lin1.K, m.lin1.Kpad, h->s_main);
+        mp_launch_pack_linear(find(s.id, K_L2W, 0, 0), find(s.id, K_L2B, 0, 0), m.lin2.W, m.lin2.bias, m.lin2.N,
+                              m.lin2.K, m.lin2.Kpad, h->s_main);
+        for (int l = 0; l < 2; ++l)
+            for (int d = 0; d < m.dirs; ++d) {
+                mp_launch_pack_wih(find(s.id, K_WIH, l, d), find(s.id, K_BIH, l, d), find(s.id, K_BHH, l, d),
+                                   m.ih[l].W, m.ih[l].bias, m.H, m.ih[l].K, m.ih[l].Kpad, d * 4 * m.H, h->s_main);
+                mp_launch_pack_whh(find(s.id, K_WHH, l, d), m.whh[l][d], m.H, h->s_main);
+            }
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->s_main));
+    return MP_OK;
+}
+
+int setup_smpl(mp_handle* h, const int32_t parent[24], const float J[72]) {
+    int par[24], depth[24];
+    float bone[72], j[72];
+    for (int i = 0; i < 24; ++i) {
+        par[i] = i == 0 ? -1 : parent[i];
+        if (i > 0 && (par[i] < 0 || par[i] >= i)) return fail(h, MP_ERR_INVALID, "parent[%d] = %d must be in [0,%d)", i, par[i], i);
+        for (int c = 0; c < 3; ++c) j[i * 3 + c] = J[i * 3 + c] - J[c];          // model.py:87
+    }
+    depth[0] = 0;
+    for (int c = 0; c < 3; ++c) bone[c] = j[c];
+    for (int i = 1; i < 24; ++i) {
+        depth[i] = depth[par[i]] + 1;
+        if (depth[i] > 8) return fail(h, MP_ERR_INVALID, "kinematic tree deeper than 8 levels");
+        for (int c = 0; c < 3; ++c) bone[i * 3 + c] = j[i * 3 + c] - j[par[i] * 3 + c];   // spatial.py:148-167
+    }
+    for (int c = 0; c < 6; ++c) h->feet_pos[c] = j[30 + c];                         // net.py:48
+    h->floor_y = j[31] < j[34] ? j[31] : j[34];                                     // net.py:49
+    if (int rc = dev_alloc(h, (void**)&h->parent_dev, sizeof(par))) return rc;
+    if (int rc = dev_alloc(h, (void**)&h->depth_dev, sizeof(depth))) return rc;
+    if (int rc = dev_alloc(h, (void**)&h->bone_dev, sizeof(bone))) return rc;
+    HIPCHK(h, hipMemcpy(h->parent_dev, par, sizeof(par), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->depth_dev, depth, sizeof(depth), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->bone_dev, bone, sizeof(bone), hipMemcpyHostToDevice));
+    return MP_OK;
+}
+
+int create_common(mp_handle** out, int device, const float* blob, bool blob_on_device, size_t n_floats,
+                  const int32_t parent[24], const float J[72]) {
+    if (!out || !blob || !parent || !J) return fail(nullptr, MP_ERR_INVALID, "mp_create: NULL argument");
+    if (n_floats != manifest_floats())
+        return fail(nullptr, MP_ERR_INVALID, "mp_create: weight blob has %zu floats, expected %zu", n_floats, manifest_floats());
+    mp_handle* h = new mp_handle();
+    h->device = device;
+    auto bail = [&](int rc) { g_create_error = h->err; mp_destroy(h); return rc; };
+    if (hipSetDevice(device) != hipSuccess) { h->err = "hipSetDevice failed"; return bail(MP_ERR_HIP); }
+    if (const char* e = getenv("MP_NO_GRAPH")) h->use_graph = !(e[0] && e[0] != '0');
+    hipError_t e = hipSuccess;
+    e = e ? e : hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking);
+    e = e ? e : hipStreamCreateWithFlags(&h->s_vel, hipStreamNonBlocking);
+    e = e ? e : hipStreamCreateWithFlags(&h->s_foot, hipStreamNonBlocking);
+    hipEvent_t* evs[5] = {&h->ev_in, &h->ev_out, &h->ev_j, &h->ev_v, &h->ev_f};
+    for (hipEvent_t* ev : evs) e = e ? e : hipEventCreateWithFlags(ev, hipEventDisableTiming);
+    if (e != hipSuccess) { h->err = std::string("stream/event creation failed: ") + hipGetErrorString(e); return bail(MP_ERR_HIP); }
+    float* staging = nullptr;
+    const float* dev_blob = blob;
+    if (!blob_on_device) {
+        if (hipMalloc((void**)&staging, n_floats * sizeof(float)) != hipSuccess ||
+            hipMemcpy(staging, blob, n_floats * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            h->err = "weight upload failed";
+            if (staging) (void)hipFree(staging);
+            return bail(MP_ERR_HIP);
+        }
+        dev_blob = staging;
+    }
+    int rc = pack_weights(h, dev_blob);
+    if (staging) (void)hipFree(staging);
+    if (rc) return bail(rc);
+    rc = setup_smpl(h, parent, J);
+    if (rc) return bail(rc);
+    *out = h;
+    return MP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ plans
+int get_plan(mp_handle* h, int B, int T, Plan** out) {
+    auto it = h->plans.find({B, T});
+    if (it != h->plans.end()) { *out = it->second; return MP_OK; }
+    Plan* p = new Plan();
+    p->B = B; p->T = T;
+    h->plans[{B, T}] = p;
+    const size_t M = (size_t)B * T;
+    for (int id = 0; id < 4; ++id) {
+        const ModuleW& m = h->mod[id];
+        ModuleWS& w = p->ws[id];
+        if (int rc = dev_alloc(h, (void**)&w.xproj, M * m.dirs * 4 * m.H * sizeof(float), &p->allocs)) return rc;
+        if (int rc = dev_alloc(h, (void**)&w.out0, M * m.dirs * m.H * sizeof(float), &p->allocs)) return rc;
+        if (int rc = dev_alloc(h, (void**)&w.out1, M * m.dirs * m.H * sizeof(float), &p->allocs)) return rc;
+        for (int l = 0; l < 2; ++l)
+            for (int d = 0; d < m.dirs; ++d) {
+                if (int rc = dev_alloc(h, (void**)&w.hbuf[l][d], (size_t)2 * B * m.H * sizeof(float), &p->allocs)) return rc;
+                if (int rc = dev_alloc(h, (void**)&w.cbuf[l][d], (size_t)B * m.H * sizeof(float), &p->allocs)) return rc;
+            }
+    }
+    if (int rc = dev_alloc(h, (void**)&p->r6d, M * 96 * sizeof(float), &p->allocs)) return rc;
+    if (int rc = dev_alloc(h, (void**)&p->lengths_dev, (size_t)B * sizeof(int), &p->allocs)) return rc;
+    HIPCHK(h, hipHostMalloc((void**)&p->lengths_pin, (size_t)B * sizeof(int), hipHostMallocDefault));
+    *out = p;
+    return MP_OK;
+}
+
+int upload_lengths(mp_handle* h, Plan* p, const int32_t* lengths) {
+    int mx = 0;
+    for (int b = 0; b < p->B; ++b) {
+        if (lengths[b] < 1 || lengths[b] > p->T) return fail(h, MP_ERR_LENGTHS, "lengths[%d] = %d outside 1..%d", b, lengths[b], p->T);
+        mx = lengths[b] > mx ? lengths[b] : mx;
+    }
+    if (mx != p->T)
+        return fail(h, MP_ERR_LENGTHS, "max(lengths) = %d but T = %d (the reference's torch.cat at net.py:106 fails)", mx, p->T);
+    if ((int)p->lengths_cache.size() == p->B && memcmp(p->lengths_cache.data(), lengths, p->B * sizeof(int)) == 0)
+        return MP_OK;
+    HIPCHK(h, hipStreamSynchronize(h->s_main));      // the staging buffer may still be in flight
+    memcpy(p->lengths_pin, lengths, p->B * sizeof(int));
+    HIPCHK(h, hipMemcpyAsync(p->lengths_dev, p->lengths_pin, p->B * sizeof(int), hipMemcpyHostToDevice, h->s_main));
+    p->lengths_cache.assign(lengths, lengths + p->B);
+    return MP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ timing
+hipEvent_t next_event(mp_handle* h) {
+    if (h->ev_used == h->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        h->ev_pool.push_back(e);
+    }
+    return h->ev_pool[h->ev_used++];
+}
+struct SegScope {
+    mp_handle* h; hipStream_t s; bool on; size_t idx;
+    SegScope(mp_handle* h_, hipStream_t s_, int cls, int launches) : h(h_), s(s_), on(false), idx(0) {
+        if (!h->timing || h->capturing || (cls != 3 && s != h->s_main)) return;
+        hipEvent_t a = next_event(h), b = next_event(h);
+        if (!a || !b) return;
+        on = true;
+        idx = h->segs.size();
+        h->segs.push_back({cls, a, b, launches});
+        (void)hipEventRecord(a, s);
+    }
+    ~SegScope() { if (on) (void)hipEventRecord(h->segs[idx].b, s); }
+};
+
+// ------------------------------------------------------------------------------------------ one RNN block
+enum StateMode { STATE_ZERO, STATE_FROM };
+
+RowMap internal_map(const float* base, int B, int width) { return RowMap{base, (long)width, (long)B * width, width}; }
+RowMap user_map(const float* base, int T, int width) { return RowMap{base, (long)T * width, (long)width, width}; }
+
+int run_gemm(mp_handle* h, hipStream_t s, RowMap a0, RowMap a1, const Packed& w, float* C, long cStrideB,
+             long cStrideT, int M, int B, int relu) {
+    SegScope seg(h, s, 0, 1);
+    GemmArgs g;
+    g.a0 = a0; g.a1 = a1; g.W = w.W; g.bias = w.bias; g.C = C; g.cStrideB = cStrideB; g.cStrideT = cStrideT;
+    g.M = M; g.N = w.N; g.K = w.K; g.Kpad = w.Kpad; g.B = B; g.relu = relu;
+    mp_launch_gemm(g, w.bn, s);
+    return MP_OK;
+}
+
+// x = [a0 | a1] rows (b,t); y rows (b,t) at y + b*yStrideB + t*yStrideT.
+// state_h/state_c: [layers*dirs][B][H] carried state (read when mode == STATE_FROM, written when out != null)
+int run_rnn(mp_handle* h, Plan* p, int id, RowMap a0, RowMap a1, float* y, long yStrideB, long yStrideT, StateMode mode,
+            const float* in_h, const float* in_c, float* out_h, float* out_c, hipStream_t s) {
+    const ModuleW& m = h->mod[id];
+    ModuleWS& w = p->ws[id];
+    const int B = p->B, T = p->T, M = B * T, H = m.H, dirs = m.dirs;
+    const RowMap none{nullptr, 0, 0, 0};
+    float* X1 = w.out1;
+    // linear1 + ReLU (rnn.py:22; dropout is identity in eval)
+    run_gemm(h, s, a0, a1, m.lin1, X1, H, (long)B * H, M, B, 1);
+    for (int l = 0; l < 2; ++l) {
+        // input projection of all frames, both directions, biases folded in (rnn.py:27)
+        if (l == 0) run_gemm(h, s, internal_map(X1, B, H), none, m.ih[0], w.xproj, dirs * 4 * H, (long)B * dirs * 4 * H, M, B, 0);
+        else run_gemm(h, s, internal_map(w.out0, B, dirs * H), none, m.ih[1], w.xproj, dirs * 4 * H, (long)B * dirs * 4 * H, M, B, 0);
+        for (int d = 0; d < dirs; ++d) {
+            const size_t n = (size_t)B * H * sizeof(float);
+            const int k = l * dirs + d;
+            if (mode == STATE_FROM) {
+                HIPCHK(h, hipMemcpyAsync(w.hbuf[l][d], in_h + (size_t)k * B * H, n, hipMemcpyDeviceToDevice, s));
+                HIPCHK(h, hipMemcpyAsync(w.cbuf[l][d], in_c + (size_t)k * B * H, n, hipMemcpyDeviceToDevice, s));
+            } else {
+                HIPCHK(h, hipMemsetAsync(w.hbuf[l][d], 0, n, s));
+                HIPCHK(h, hipMemsetAsync(w.cbuf[l][d], 0, n, s));
+            }
+        }
+        {
+            SegScope seg(h, s, 1, T);
+            LstmStepArgs a;
+            a.lengths = p->lengths_dev; a.ndir = dirs; a.B = B; a.T = T;
+            float* out = l == 0 ? w.out0 : w.out1;
+            for (int d = 0; d < dirs; ++d)
+                a.d[d] = LstmDir{m.whh[l][d], w.xproj + (size_t)d * 4 * H, out + (size_t)d * H, w.hbuf[l][d], w.cbuf[l][d],
+                                 dirs * 4 * H, dirs * H, d};
+            if (dirs == 1) a.d[1] = a.d[0];
+            for (int step = 0; step < T; ++step) {
+                a.step = step;
+                mp_launch_lstm_step(a, H, s);
+            }
+        }
+        if (out_h) {
+            for (int d = 0; d < dirs; ++d) {
+                const size_t n = (size_t)B * H * sizeof(float);
+                const int k = l * dirs + d;
+                HIPCHK(h, hipMemcpyAsync(out_h + (size_t)k * B * H, w.hbuf[l][d] + (size_t)(T & 1) * B * H, n, hipMemcpyDeviceToDevice, s));
+                HIPCHK(h, hipMemcpyAsync(out_c + (size_t)k * B * H, w.cbuf[l][d], n, hipMemcpyDeviceToDevice, s));
+            }
+        }
+    }
+    // linear2 (rnn.py:32) straight into the caller's layout
+    run_gemm(h, s, internal_map(w.out1, B, dirs * H), none, m.lin2, y, yStrideB, yStrideT, M, B, 0);
+    HIPCHK(h, hipGetLastError());
+    return MP_OK;
+}
+
+int ensure_vstate(mp_handle* h, VelState& v, int B) {
+    if (v.cap >= B) return MP_OK;
+    if (v.h) (void)hipFree(v.h);
+    if (v.c) (void)hipFree(v.c);
+    v.h = v.c = nullptr; v.cap = 0;
+    if (int rc = dev_alloc(h, (void**)&v.h, (size_t)2 * B * 256 * sizeof(float))) return rc;
+    if (int rc = dev_alloc(h, (void**)&v.c, (size_t)2 * B * 256 * sizeof(float))) return rc;
+    v.cap = B;
+    return MP_OK;
+}
+
+// models/net.py:101-119 on the library's streams (eager or under capture)
+int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long poseRows, long poseRowStride,
+                 long poseRowOffset, float* joints, float* vel, float* contact, float* r6d, VelState& vs,
+                 bool has_state) {
+    const int B = p->B, T = p->T;
+    const RowMap none{nullptr, 0, 0, 0};
+    // joints(batch)                                                                       net.py:103
+    if (int rc = run_rnn(h, p, MP_MOD_JOINTS, user_map(imu, T, 60), none, joints, (long)T * 72, 72, STATE_ZERO, nullptr,
+                         nullptr, nullptr, nullptr, h->s_main)) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_j, h->s_main));
+    HIPCHK(h, hipStreamWaitEvent(h->s_vel, h->ev_j, 0));
+    HIPCHK(h, hipStreamWaitEvent(h->s_foot, h->ev_j, 0));
+    // pose(cat(pred_joints, batch)) then global -> local                                   net.py:106-110
+    if (int rc = run_rnn(h, p, MP_MOD_POSE, user_map(joints, T, 72), user_map(imu, T, 60), r6d, (long)T * 96, 96,
+                         STATE_ZERO, nullptr, nullptr, nullptr, nullptr, h->s_main)) return rc;
+    {
+        SegScope seg(h, h->s_main, 2, 1);
+        mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, h->s_main);
+    }
+    // velocity.forward_online(cat(...)): carried state                                     net.py:117, velocity.py:45-48
+    if (int rc = run_rnn(h, p, MP_MOD_VELOCITY, user_map(joints, T, 72), user_map(imu, T, 60), vel, (long)T * 72, 72,
+                         has_state ? STATE_FROM : STATE_ZERO, vs.h, vs.c, vs.h, vs.c, h->s_vel)) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_v, h->s_vel));
+    // foot_contact(cat(...))                                                               net.py:113-114
+    if (int rc = run_rnn(h, p, MP_MOD_FOOT_CONTACT, user_map(joints, T, 72), user_map(imu, T, 60), contact, (long)T * 2, 2,
+                         STATE_ZERO, nullptr, nullptr, nullptr, nullptr, h->s_foot)) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_f, h->s_foot));
+    HIPCHK(h, hipStreamWaitEvent(h->s_main, h->ev_v, 0));
+    HIPCHK(h, hipStreamWaitEvent(h->s_main, h->ev_f, 0));
+    HIPCHK(h, hipGetLastError());
+    return MP_OK;
+}
+
+template <class Body>
+int run_maybe_graph(mp_handle* h, const GraphKey& key, Body body) {
+    if (!h->use_graph || h->timing) return body();
+    auto it = h->graphs.find(key);
+    if (it == h->graphs.end()) {
+        hipGraph_t graph = nullptr;
+        HIPCHK(h, hipStreamBeginCapture(h->s_main, hipStreamCaptureModeThreadLocal));
+        h->capturing = true;
+        int rc = body();
+        h->capturing = false;
+        hipError_t e = hipStreamEndCapture(h->s_main, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) return fail(h, MP_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) return fail(h, MP_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        it = h->graphs.emplace(key, exec).first;
+    }
+    HIPCHK(h, hipGraphLaunch(it->second, h->s_main));
+    return MP_OK;
+}
+
+int enter(mp_handle* h, void* stream) {
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventRecord(h->ev_in, (hipStream_t)stream));
+    HIPCHK(h, hipStreamWaitEvent(h->s_main, h->ev_in, 0));
+    return MP_OK;
+}
+int leave(mp_handle* h, void* stream) {
+    HIPCHK(h, hipEventRecord(h->ev_out, h->s_main));
+    HIPCHK(h, hipStreamWaitEvent((hipStream_t)stream, h->ev_out, 0));
+    return MP_OK;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+size_t mp_weight_count(void) { return manifest_floats(); }
+
+int mp_manifest_entry(int i, char* name, size_t name_cap, int* ndim, int64_t shape[2], size_t* offset) {
+    const std::vector<Entry>& m = manifest();
+    if (i < 0 || i >= (int)m.size()) return MP_ERR_INVALID;
+    const Entry& e = m[i];
+    if (name && name_cap) { strncpy(name, e.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (ndim) *ndim = e.ndim;
+    if (shape) { shape[0] = e.shape[0]; shape[1] = e.ndim == 2 ? e.shape[1] : 0; }
+    if (offset) *offset = e.offset;
+    return MP_OK;
+}
+
+int mp_create(mp_handle** out, int device, const float* weights_host, size_t n_floats, const int32_t parent[24],
+              const float J[72]) {
+    return create_common(out, device, weights_host, false, n_floats, parent, J);
+}
+
+int mp_create_from_device(mp_handle** out, int device, const float* weights_dev, size_t n_floats,
+                          const int32_t parent[24], const float J[72]) {
+    return create_common(out, device, weights_dev, true, n_floats, parent, J);
+}
+
+void mp_destroy(mp_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto& kv : h->plans) {
+        for (void* p : kv.second->allocs) (void)hipFree(p);
+        if (kv.second->lengths_pin) (void)hipHostFree(kv.second->lengths_pin);
+        delete kv.second;
+    }
+    for (ModuleW& m : h->mod) {
+        Packed* ps[4] = {&m.lin1, &m.ih[0], &m.ih[1], &m.lin2};
+        for (Packed* p : ps) { if (p->W) (void)hipFree(p->W); if (p->bias) (void)hipFree(p->bias); }
+        for (int l = 0; l < 2; ++l) for (int d = 0; d < 2; ++d) if (m.whh[l][d]) (void)hipFree(m.whh[l][d]);
+    }
+    void* misc[] = {h->parent_dev, h->depth_dev, h->bone_dev, h->vstate.h, h->vstate.c, h->sc.window, h->sc.fresh,
+                    h->sc.mask_dev, h->sc.st.last_foot, h->sc.st.root_y, h->sc.st.root_pos, h->sc.joints, h->sc.vel,
+                    h->sc.contact};
+    for (void* p : misc) if (p) (void)hipFree(p);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    hipEvent_t evs[5] = {h->ev_in, h->ev_out, h->ev_j, h->ev_v, h->ev_f};
+    for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+    hipStream_t ss[3] = {h->s_main, h->s_vel, h->s_foot};
+    for (hipStream_t s : ss) if (s) (void)hipStreamDestroy(s);
+    delete h;
+}
+
+const char* mp_last_error(const mp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mp_get_constants(const mp_handle* h, float* floor_y, float feet_pos[6]) {
+    if (!h) return MP_ERR_INVALID;
+    if (floor_y) *floor_y = h->floor_y;
+    if (feet_pos) memcpy(feet_pos, h->feet_pos, sizeof(h->feet_pos));
+    return MP_OK;
+}
+
+int mp_forward(mp_handle* h, const float* imu_dev, const int32_t* lengths_host, int B, int T, float* pose_dev,
+               float* joints_dev, float* vel_dev, float* contact_dev, float* r6d_dev, void* stream) {
+    if (!h) return MP_ERR_INVALID;
+    if (!imu_dev || !lengths_host || !pose_dev || !joints_dev || !vel_dev || !contact_dev || B < 1 || T < 1)
+        return fail(h, MP_ERR_INVALID, "mp_forward: NULL buffer or non-positive shape");
+    if (h->vstate.B != 0 && h->vstate.B != B)
+        return fail(h, MP_ERR_STATE_SHAPE, "carried velocity state has batch %d, call has batch %d (reset it first; "
+                    "the reference raises here too, velocity.py:45-48)", h->vstate.B, B);
+    if (int rc = enter(h, stream)) return rc;
+    Plan* p = nullptr;
+    if (int rc = get_plan(h, B, T, &p)) return rc;
+    if (int rc = upload_lengths(h, p, lengths_host)) return rc;
+    if (int rc = ensure_vstate(h, h->vstate, B)) return rc;
+    const bool has_state = h->vstate.B == B;
+    float* r6d = r6d_dev ? r6d_dev : p->r6d;
+    h->segs.clear(); h->ev_used = 0;
+    GraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.kind = 0; key.B = B; key.T = T; key.flags = has_state ? 1 : 0;
+    key.p[0] = imu_dev; key.p[1] = pose_dev; key.p[2] = joints_dev; key.p[3] = vel_dev; key.p[4] = contact_dev;
+    key.p[5] = r6d; key.p[6] = h->vstate.h;
+    int rc;
+    {
+        SegScope whole(h, h->s_main, 3, 1);
+        rc = run_maybe_graph(h, key, [&]() {
+            return forward_body(h, p, imu_dev, pose_dev, (long)B * T, 96, 0, joints_dev, vel_dev, contact_dev, r6d,
+                                h->vstate, has_state);
+        });
+    }
+    if (rc) return rc;
+    h->vstate.B = B;
+    return leave(h, stream);
+}
+
+int mp_rnn_forward(mp_handle* h, int module, const float* x_dev, const int32_t* lengths_host, int B, int T,
+                   float* y_dev, const float* state_in_dev, float* state_out_dev, void* stream) {
+    if (!h) return MP_ERR_INVALID;
+    if (module < 0 || module > 3 || !x_dev || !y_dev || !lengths_host || B < 1 || T < 1)
+        return fail(h, MP_ERR_INVALID, "mp_rnn_forward: bad argument");
+    if (int rc = enter(h, stream)) return rc;
+    Plan* p = nullptr;
+    if (int rc = get_plan(h, B, T, &p)) return rc;
+    if (int rc = upload_lengths(h, p, lengths_host)) return rc;
+    const ModuleW& m = h->mod[module];
+    const size_t half = (size_t)2 * m.dirs * B * m.H;
+    const RowMap none{nullptr, 0, 0, 0};
+    h->segs.clear(); h->ev_used = 0;
+    int rc = run_rnn(h, p, module, user_map(x_dev, T, m.n_in), none, y_dev, (long)T * m.n_out, m.n_out,
+                     state_in_dev ? STATE_FROM : STATE_ZERO, state_in_dev, state_in_dev ? state_in_dev + half : nullptr,
+                     state_out_dev, state_out_dev ? state_out_dev + half : nullptr, h->s_main);
+    if (rc) return rc;
+    return leave(h, stream);
+}
+
+int mp_reduced_global_to_full(mp_handle* h, const float* r6d_dev, int64_t N, float* pose_dev, void* stream) {
+    if (!h || !r6d_dev || !pose_dev || N < 0) return h ? fail(h, MP_ERR_INVALID, "mp_reduced_global_to_full: bad argument") : MP_ERR_INVALID;
+    if (int rc = enter(h, stream)) return rc;
+    mp_launch_r6d_ik(r6d_dev, (long)N, pose_dev, h->parent_dev, h->s_main);
+    HIPCHK(h, hipGetLastError());
+    return leave(h, stream);
+}
+
+int mp_translate_offline(mp_handle* h, const float* joints_dev, const float* vel_dev, const float* contact_dev,
+                         const int32_t* lengths_host, int B, int T, float* tran_dev, void* stream) {
+    if (!h || !joints_dev || !vel_dev || !contact_dev || !lengths_host || !tran_dev || B < 1 || T < 1)
+        return h ? fail(h, MP_ERR_INVALID, "mp_translate_offline: bad argument") : MP_ERR_INVALID;
+    if (int rc = enter(h, stream)) return rc;
+    Plan* p = nullptr;
+    if (int rc = get_plan(h, B, T, &p)) return rc;
+    if (int rc = upload_lengths(h, p, lengths_host)) return rc;
+    mp_launch_translate_offline(joints_dev, vel_dev, contact_dev, p->lengths_dev, B, T, h->floor_y, tran_dev, h->s_main);
+    HIPCHK(h, hipGetLastError());
+    return leave(h, stream);
+}
+
+int mp_fk(mp_handle* h, const float* pose_dev, const float* tran_dev, int64_t N, float* rglobal_dev, float* joint_dev,
+          void* stream) {
+    if (!h || !pose_dev || !rglobal_dev || !joint_dev || N < 0) return h ? fail(h, MP_ERR_INVALID, "mp_fk: bad argument") : MP_ERR_INVALID;
+    if (int rc = enter(h, stream)) return rc;
+    mp_launch_fk(pose_dev, tran_dev, (long)N, h->bone_dev, h->parent_dev, h->depth_dev, rglobal_dev, joint_dev, h->s_main);
+    HIPCHK(h, hipGetLastError());
+    return leave(h, stream);
+}
+
+int mp_reset_state(mp_handle* h, int clear_velocity) {
+    if (!h) return MP_ERR_INVALID;
+    if (clear_velocity) h->vstate.B = 0;
+    return MP_OK;
+}
+
+int mp_get_velocity_state(mp_handle* h, float* state_dev, int* batch) {
+    if (!h || !batch) return MP_ERR_INVALID;
+    *batch = h->vstate.B;
+    if (h->vstate.B && state_dev) {
+        const size_t n = (size_t)2 * h->vstate.B * 256;
+        HIPCHK(h, hipStreamSynchronize(h->s_main));
+        HIPCHK(h, hipMemcpy(state_dev, h->vstate.h, n * sizeof(float), hipMemcpyDeviceToDevice));
+        HIPCHK(h, hipMemcpy(state_dev + n, h->vstate.c, n * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    return MP_OK;
+}
+
+int mp_set_velocity_state(mp_handle* h, const float* state_dev, int batch) {
+    if (!h || batch < 0 || (batch > 0 && !state_dev)) return MP_ERR_INVALID;
+    if (batch == 0) { h->vstate.B = 0; return MP_OK; }
+    HIPCHK(h, hipStreamSynchronize(h->s_main));
+    if (int rc = ensure_vstate(h, h->vstate, batch)) return rc;
+    const size_t n = (size_t)2 * batch * 256;
+    HIPCHK(h, hipMemcpy(h->vstate.h, state_dev, n * sizeof(float), hipMemcpyDeviceToDevice));
+    HIPCHK(h, hipMemcpy(h->vstate.c, state_dev + n, n * sizeof(float), hipMemcpyDeviceToDevice));
+    h->vstate.B = batch;
+    return MP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ streaming
+int mp_stream_create(mp_handle* h, int S) {
+    if (!h || S < 1) return h ? fail(h, MP_ERR_INVALID, "mp_stream_create: S must be positive") : MP_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    StreamCtx& c = h->sc;
+    if (c.S) return fail(h, MP_ERR_INVALID, "streams already created (S = %d)", c.S);
+    const int W = 45;
+    if (int rc = dev_alloc(h, (void**)&c.window, (size_t)S * W * 60 * sizeof(float))) return rc;
+    if (int rc = dev_alloc(h, (void**)&c.fresh, S)) return rc;
+    if (int rc = dev_alloc(h, (void**)&c.mask_dev, S)) return rc;
+    if (int rc = dev_alloc(h, (void**)&c.st.last_foot, (size_t)S * 6 * sizeof(float))) return rc;
+    if (int rc = dev_alloc(h, (void**)&c.st.root_y, (size_t)S * sizeof(double))) return rc;
+    if (int rc = dev_alloc(h, (void**)&c.st.root_pos, (size_t)S * 3 * sizeof(float))) return rc;
+    if (int rc = dev_alloc(h, (void**)&c.joints, (size_t)S * W * 72 * sizeof(float))) return rc;
+    if (int rc = dev_alloc(h, (void**)&c.vel, (size_t)S * W * 72 * sizeof(float))) return rc;
+    if (int rc = dev_alloc(h, (void**)&c.contact, (size_t)S * W * 2 * sizeof(float))) return rc;
+    std::vector<float> lf((size_t)S * 6);
+    for (int s = 0; s < S; ++s) memcpy(&lf[(size_t)s * 6], h->feet_pos, sizeof(h->feet_pos));   // net.py:59
+    HIPCHK(h, hipMemcpy(c.st.last_foot, lf.data(), lf.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemset(c.fresh, 1, S));
+    HIPCHK(h, hipMemset(c.st.root_y, 0, (size_t)S * sizeof(double)));
+    HIPCHK(h, hipMemset(c.st.root_pos, 0, (size_t)S * 3 * sizeof(float)));
+    c.S = S;
+    Plan* p = nullptr;
+    if (int rc = get_plan(h, S, W, &p)) return rc;
+    std::vector<int32_t> len(S, W);
+    if (int rc = upload_lengths(h, p, len.data())) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->s_main));
+    return MP_OK;
+}
+
+int mp_stream_step(mp_handle* h, const float* frames_dev, float* pose_dev, float* joints_dev, float* root_pos_dev,
+                   float* contact_dev, void* stream) {
+    if (!h) return MP_ERR_INVALID;
+    StreamCtx& c = h->sc;
+    if (!c.S) return fail(h, MP_ERR_NO_STREAMS, "mp_stream_step before mp_stream_create");
+    if (!frames_dev || !pose_dev || !root_pos_dev || !contact_dev) return fail(h, MP_ERR_INVALID, "mp_stream_step: NULL buffer");
+    const int S = c.S, W = 45, PAST = 40;
+    // one velocity.rnn_state per model, shared by the batch and the online path (velocity.py:30)
+    if (h->vstate.B != 0 && h->vstate.B != S)
+        return fail(h, MP_ERR_STATE_SHAPE, "carried velocity state has batch %d, streaming has %d streams", h->vstate.B, S);
+    if (int rc = enter(h, stream)) return rc;
+    if (int rc = ensure_vstate(h, h->vstate, S)) return rc;
+    Plan* p = nullptr;
+    if (int rc = get_plan(h, S, W, &p)) return rc;
+    {   // the (S,45) plan may have been used by mp_forward with other lengths in between
+        std::vector<int32_t> len(S, W);
+        if (int rc = upload_lengths(h, p, len.data())) return rc;
+    }
+    float* joints = joints_dev ? joints_dev : c.joints;
+    const bool has_state = h->vstate.B == S;
+    h->segs.clear(); h->ev_used = 0;
+    GraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.kind = 1; key.B = S; key.T = W; key.flags = has_state ? 1 : 0;
+    key.p[0] = frames_dev; key.p[1] = pose_dev; key.p[2] = joints; key.p[3] = root_pos_dev; key.p[4] = contact_dev;
+    key.p[6] = h->vstate.h;
+    int rc;
+    {
+        SegScope whole(h, h->s_main, 3, 1);
+        rc = run_maybe_graph(h, key, [&]() {
+            mp_launch_window_push(c.window, frames_dev, c.fresh, S, W, h->s_main);               // net.py:175
+            // forward on the 45-frame window (net.py:178); pose only for index 40 (net.py:181)
+            if (int r = forward_body(h, p, c.window, pose_dev, S, (long)W * 96, (long)PAST * 96, joints, c.vel, c.contact,
+                                     p->r6d, h->vstate, has_state)) return r;
+            mp_launch_translate_online(joints, c.vel, c.contact, S, W, PAST, h->floor_y, c.st, root_pos_dev, contact_dev,
+                                       h->s_main);                                                // net.py:186-208
+            HIPCHK(h, hipGetLastError());
+            return (int)MP_OK;
+        });
+    }
+    if (rc) return rc;
+    h->vstate.B = S;
+    return leave(h, stream);
+}
+
+int mp_stream_reset(mp_handle* h, const uint8_t* mask_host, int clear_velocity) {
+    if (!h) return MP_ERR_INVALID;
+    StreamCtx& c = h->sc;
+    if (!c.S) return fail(h, MP_ERR_NO_STREAMS, "mp_stream_reset before mp_stream_create");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->s_main));
+    if (mask_host) HIPCHK(h, hipMemcpy(c.mask_dev, mask_host, c.S, hipMemcpyHostToDevice));
+    const bool vel = clear_velocity && h->vstate.B == c.S;
+    mp_launch_stream_reset(mask_host ? c.mask_dev : nullptr, c.fresh, c.st.root_y, c.st.root_pos, vel ? h->vstate.h : nullptr,
+                           vel ? h->vstate.c : nullptr, c.S, h->s_main);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->s_main));
+    return MP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ measurement
+int mp_timing_enable(mp_handle* h, int on) {
+    if (!h) return MP_ERR_INVALID;
+    h->timing = on != 0;
+    h->segs.clear(); h->ev_used = 0;
+    return MP_OK;
+}
+
+int mp_timing_read(mp_handle* h, int cls, int* launches, float* ms) {
+    if (!h || !launches || !ms) return MP_ERR_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->s_main));
+    *launches = 0; *ms = 0.f;
+    for (const Seg& s : h->segs) {
+        if (s.cls != cls) continue;
+        float t = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&t, s.a, s.b));
+        *ms += t;
+        *launches += s.launches;
+    }
+    return MP_OK;
+}
+
+int mp_set_graph_mode(mp_handle* h, int on) {
+    if (!h) return MP_ERR_INVALID;
+    h->use_graph = on != 0;
+    return MP_OK;
+}
+
+}  // extern "C"

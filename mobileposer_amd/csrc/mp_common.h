@@ -1,0 +1,81 @@
+// Shared declarations of the gfx950 kernels behind libmobileposer_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Address of logical row m = t*B + b (time-major row index) of an activation matrix:
+// base + b*strideB + t*strideT.  Internal buffers are time-major ([T][B][C]: strideB = C,
+// strideT = B*C); caller buffers are batch-major ([B][T][C]: strideB = T*C, strideT = C).
+struct RowMap {
+    const float* base;
+    long strideB;
+    long strideT;
+    int width;       // number of valid K columns supplied by this segment
+};
+
+// ---------------------------------------------------------------- K1/K3: fp32 MFMA GEMM
+// C[m][n] = act( sum_k A[m][k] * W[n][k] + bias[n] ),  A = [a0 | a1] (concat fused), W packed
+// [Npad][Kpad] zero padded (Kpad % 32 == 0, Npad % BN == 0).
+struct GemmArgs {
+    RowMap a0, a1;
+    const float* W;
+    const float* bias;
+    float* C;
+    long cStrideB, cStrideT;
+    int M, N, K, Kpad, B, relu;
+};
+// bn: 128, 96 or 32 (chosen by the caller from N)
+void mp_launch_gemm(const GemmArgs& g, int bn, hipStream_t s);
+int mp_gemm_pick_bn(int N);
+
+// ---------------------------------------------------------------- K2: LSTM recurrence step
+struct LstmDir {
+    const float* wpack;   // W_hh in MFMA B-fragment order (see mp_lstm.hip)
+    const float* xproj;   // [T*B][xprojStride] gate-interleaved (4*j+g), bias folded in; column offset applied
+    float* out;           // [T*B][outStride], column offset applied
+    float* hbuf;          // [2][B][H] ping-pong hidden state
+    float* cbuf;          // [B][H]
+    int xprojStride, outStride, reverse;
+};
+struct LstmStepArgs {
+    LstmDir d[2];
+    const int* lengths;   // [B] device
+    int ndir, B, T, step;
+};
+void mp_launch_lstm_step(const LstmStepArgs& a, int H, hipStream_t s);
+size_t mp_whh_pack_floats(int H);   // H*4H
+void mp_launch_pack_whh(const float* whh, float* dst, int H, hipStream_t s);
+// W_ih rows -> gate-interleaved rows of a [Npad][Kpad] matrix at row offset dirOff; bias = b_ih+b_hh
+void mp_launch_pack_wih(const float* wih, const float* bih, const float* bhh, float* dstW, float* dstBias,
+                        int H, int K, int Kpad, int dirOff, hipStream_t s);
+void mp_launch_pack_linear(const float* w, const float* b, float* dstW, float* dstBias, int N, int K, int Kpad,
+                           hipStream_t s);
+
+// ---------------------------------------------------------------- K4/K5: kinematics
+void mp_launch_r6d_ik(const float* r6d, long N, float* pose, const int* parent_dev, hipStream_t s);
+// frame n reads its 96 numbers at r6d + n*rowStride + rowOffset
+void mp_launch_r6d_ik_strided(const float* r6d, long N, long rowStride, long rowOffset, float* pose,
+                              const int* parent_dev, hipStream_t s);
+void mp_launch_fk(const float* pose, const float* tran, long N, const float* bone_dev, const int* parent_dev,
+                  const int* depth_dev, float* rglobal, float* joint, hipStream_t s);
+
+// ---------------------------------------------------------------- K6: translation solver
+void mp_launch_translate_offline(const float* joints, const float* vel, const float* contact, const int* lengths,
+                                 int B, int T, float floor_y, float* tran, hipStream_t s);
+struct OnlineState {       // per-stream state of forward_online (net.py:59-64,205-208)
+    float* last_foot;      // [S][2][3]
+    double* root_y;        // [S]
+    float* root_pos;       // [S][3]
+};
+// streaming window maintenance (net.py:175): window[s] = fresh[s] ? frame x45 : cat(window[s][1:], frame)
+void mp_launch_window_push(float* window, const float* frames, uint8_t* fresh, int S, int W, hipStream_t s);
+// reset() for the masked streams (mask == nullptr: all): fresh = 1, root_y = 0, root_pos = 0 (net.py:84-88);
+// velH/velC (optional) rows of the carried velocity state [2][S][256] are zeroed as well
+void mp_launch_stream_reset(const uint8_t* mask, uint8_t* fresh, double* root_y, float* root_pos, float* velH,
+                            float* velC, int S, hipStream_t s);
+void mp_launch_translate_online(const float* joints, const float* vel, const float* contact, int S, int T, int idx,
+                                float floor_y, OnlineState st, float* root_pos_out, float* contact_out,
+                                hipStream_t s);

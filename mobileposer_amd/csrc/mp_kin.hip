@@ -1,0 +1,157 @@
+// K4 -- fused 6D -> SO(3) (Gram-Schmidt), 16 -> 24 joint scatter and global -> local rotations:
+//   MobilePoserNet._reduced_global_to_full (models/net.py:93-99)
+//     = r6d_to_rotation_matrix (articulate/math/angular.py:167-182, normalize_tensor general.py:27-39)
+//     + reduced_pose_to_full   (utils/model_utils.py:18-25)
+//     + inverse_kinematics_R   (articulate/math/spatial.py:197-221, _inverse_tree :115-123)
+//     + identity on joint_set.ignored and root = global root (net.py:97-98).
+// K5 -- SMPL forward kinematics without mesh: ParametricModel.forward_kinematics
+//   (articulate/model.py:208-232; spatial.py:60-75 transformation_matrix, :104-112 _forward_tree).
+//
+// Both are HBM-bound elementwise-class kernels (K4: 384 B in, 864 B out per frame; K5: 864(+12) B in,
+// 1152 B out).  K4 runs one thread per (frame, joint): the parent's global rotation is recomputed from
+// its 6 numbers instead of being exchanged, so there is no dependency chain at all (IK on rotations only
+// needs the parent's INPUT) and a wave's 64 x 36-byte outputs are one contiguous 2304-byte run.
+// K5 has a real chain (tree depth 8): lanes are joints, two frames per wave (32-lane halves), the tree is
+// walked level by level and a lane fetches its parent's global transform with wavefront shuffles
+// (ds_bpermute) -- the kinematic reduction never touches LDS or HBM.
+#include "mp_common.h"
+
+namespace {
+
+// joint -> slot in the 16-joint reduced set (config.py:134), -1 = not predicted (identity)
+__constant__ int c_slot[24] = {0, 1, 2, 3, 4, 5, 6, -1, -1, 7, -1, -1, 8, 9, 10, 11, 12, 13, 14, 15, -1, -1, -1, -1};
+// joint_set.ignored (config.py:135) as a bit mask
+constexpr unsigned IGNORED_MASK = (1u << 0) | (1u << 7) | (1u << 8) | (1u << 10) | (1u << 11) | (1u << 20) |
+                                  (1u << 21) | (1u << 22) | (1u << 23);
+
+__device__ __forceinline__ float nan0(float x) { return x != x ? 0.f : x; }
+
+// R (row-major 3x3) from 6 numbers = first two COLUMNS of R (angular.py:180); NaN -> 0 (angular.py:181)
+__device__ __forceinline__ void gram_schmidt(const float* __restrict__ p, float R[9]) {
+    const float ax = p[0], ay = p[1], az = p[2], bx = p[3], by = p[4], bz = p[5];
+    const float na = sqrtf(ax * ax + ay * ay + az * az);
+    const float c0x = ax / na, c0y = ay / na, c0z = az / na;
+    const float d = c0x * bx + c0y * by + c0z * bz;
+    const float ux = bx - d * c0x, uy = by - d * c0y, uz = bz - d * c0z;
+    const float nu = sqrtf(ux * ux + uy * uy + uz * uz);
+    const float c1x = ux / nu, c1y = uy / nu, c1z = uz / nu;
+    const float c2x = c0y * c1z - c0z * c1y, c2y = c0z * c1x - c0x * c1z, c2z = c0x * c1y - c0y * c1x;
+    R[0] = nan0(c0x); R[1] = nan0(c1x); R[2] = nan0(c2x);
+    R[3] = nan0(c0y); R[4] = nan0(c1y); R[5] = nan0(c2y);
+    R[6] = nan0(c0z); R[7] = nan0(c1z); R[8] = nan0(c2z);
+}
+
+__device__ __forceinline__ void global_rot(const float* __restrict__ row96, int joint, float R[9]) {
+    const int s = joint >= 0 ? c_slot[joint] : -1;
+    if (s >= 0) {
+        gram_schmidt(row96 + 6 * s, R);
+    } else {
+        R[0] = 1.f; R[1] = 0.f; R[2] = 0.f; R[3] = 0.f; R[4] = 1.f; R[5] = 0.f; R[6] = 0.f; R[7] = 0.f; R[8] = 1.f;
+    }
+}
+
+// frame n reads its 96 numbers at r6d + n*rowStride + rowOffset (lets the streaming step convert only
+// window index 40 of every stream); writes pose[n][24][9]
+__global__ __launch_bounds__(256) void mp_r6d_ik(const float* __restrict__ r6d, long N, long rowStride,
+                                                  long rowOffset, float* __restrict__ pose,
+                                                  const int* __restrict__ parent) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= N * 24) return;
+    const long n = gid / 24;
+    const int i = (int)(gid - n * 24);
+    const float* row = r6d + n * rowStride + rowOffset;
+    float G[9], out[9];
+    global_rot(row, i, G);
+    if (i == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) out[k] = G[k];
+    } else if ((IGNORED_MASK >> i) & 1u) {
+        out[0] = 1.f; out[1] = 0.f; out[2] = 0.f; out[3] = 0.f; out[4] = 1.f; out[5] = 0.f; out[6] = 0.f; out[7] = 0.f; out[8] = 1.f;
+    } else {
+        float P[9];
+        global_rot(row, parent[i], P);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                out[r * 3 + c] = P[0 * 3 + r] * G[0 * 3 + c] + P[1 * 3 + r] * G[1 * 3 + c] + P[2 * 3 + r] * G[2 * 3 + c];
+    }
+    float* o = pose + gid * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = out[k];
+}
+
+// lanes = joints, 2 frames per wave; bone[24][3] = j_i - j_parent(i) (bone[0] = j_0 = 0), depth[24]
+__global__ __launch_bounds__(256) void mp_fk(const float* __restrict__ pose, const float* __restrict__ tran, long N,
+                                              const float* __restrict__ bone, const int* __restrict__ parent,
+                                              const int* __restrict__ depth, float* __restrict__ rglobal,
+                                              float* __restrict__ joint) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 31;                       // joint
+    const long n = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    const bool live = (i < 24) && (n < N);
+    float G[9], p[3], L[9], bv[3];
+    int par = 0, dep = -1;
+    if (live) {
+        const float* src = pose + (n * 24 + i) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { L[k] = src[k]; G[k] = L[k]; }
+        bv[0] = bone[i * 3 + 0]; bv[1] = bone[i * 3 + 1]; bv[2] = bone[i * 3 + 2];
+        p[0] = bv[0]; p[1] = bv[1]; p[2] = bv[2];
+        par = i > 0 ? parent[i] : 0;
+        dep = depth[i];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { L[k] = 0.f; G[k] = 0.f; }
+        bv[0] = bv[1] = bv[2] = 0.f; p[0] = p[1] = p[2] = 0.f;
+    }
+    const int srcLane = (lane & 32) + par;
+#pragma unroll 1
+    for (int level = 1; level <= 8; ++level) {
+        float Pg[9], pp[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Pg[k] = __shfl(G[k], srcLane, 64);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pp[k] = __shfl(p[k], srcLane, 64);
+        if (dep == level) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    G[r * 3 + c] = Pg[r * 3 + 0] * L[0 * 3 + c] + Pg[r * 3 + 1] * L[1 * 3 + c] + Pg[r * 3 + 2] * L[2 * 3 + c];
+                p[r] = Pg[r * 3 + 0] * bv[0] + Pg[r * 3 + 1] * bv[1] + Pg[r * 3 + 2] * bv[2] + pp[r];
+            }
+        }
+    }
+    if (live) {
+        float* og = rglobal + (n * 24 + i) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) og[k] = G[k];
+        float tx = 0.f, ty = 0.f, tz = 0.f;
+        if (tran) { tx = tran[n * 3 + 0]; ty = tran[n * 3 + 1]; tz = tran[n * 3 + 2]; }
+        float* oj = joint + (n * 24 + i) * 3;
+        oj[0] = p[0] + tx; oj[1] = p[1] + ty; oj[2] = p[2] + tz;
+    }
+}
+
+}  // namespace
+
+void mp_launch_r6d_ik_strided(const float* r6d, long N, long rowStride, long rowOffset, float* pose,
+                              const int* parent_dev, hipStream_t s) {
+    if (N <= 0) return;
+    const long threads = N * 24;
+    hipLaunchKernelGGL(mp_r6d_ik, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, r6d, N, rowStride,
+                       rowOffset, pose, parent_dev);
+}
+
+void mp_launch_r6d_ik(const float* r6d, long N, float* pose, const int* parent_dev, hipStream_t s) {
+    mp_launch_r6d_ik_strided(r6d, N, 96, 0, pose, parent_dev, s);
+}
+
+void mp_launch_fk(const float* pose, const float* tran, long N, const float* bone_dev, const int* parent_dev,
+                  const int* depth_dev, float* rglobal, float* joint, hipStream_t s) {
+    if (N <= 0) return;
+    const long blocks = (N + 7) / 8;   // 4 waves x 2 frames per block
+    hipLaunchKernelGGL(mp_fk, dim3((unsigned)blocks), dim3(256), 0, s, pose, tran, N, bone_dev, parent_dev, depth_dev,
+                       rglobal, joint);
+}

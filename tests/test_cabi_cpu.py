@@ -1,0 +1,77 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/mobileposer_hip.h declares,
+and its host-only entry points (manifest) agree with the reference's state-dict layout.  No GPU calls."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO
+from mobileposer_amd import _lib
+from mobileposer_amd.manifest import n_params, state_dict_manifest
+from mobileposer_amd.model_utils import blob_to_state_dict, state_dict_to_blob
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.load()
+
+
+def test_header_symbols_all_exported(lib):
+    hdr = open(os.path.join(REPO, "include", "mobileposer_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mp_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_weight_count_and_manifest(lib):
+    assert lib.mp_weight_count() == n_params() == 6674994
+    with open(os.path.join(GOLDEN, "g7_manifest.json")) as f:
+        ref_keys = json.load(f)["keys"]
+    off_expect = 0
+    for i, (key, shape) in enumerate(state_dict_manifest().items()):
+        name = C.create_string_buffer(128)
+        ndim, off = C.c_int(), C.c_size_t()
+        shp = (C.c_int64 * 2)()
+        assert lib.mp_manifest_entry(i, name, 128, C.byref(ndim), shp, C.byref(off)) == 0
+        assert name.value.decode() == key == ref_keys[i][0]
+        assert list(shp)[:ndim.value] == list(shape) == ref_keys[i][1]
+        assert off.value == off_expect
+        off_expect += int(np.prod(shape))
+    assert lib.mp_manifest_entry(72, None, 0, None, None, None) == _lib.MP_ERR_INVALID
+
+
+def test_create_rejects_bad_blob_without_touching_gpu(lib):
+    h = C.c_void_p()
+    blob = np.zeros(10, dtype=np.float32)
+    parent = (C.c_int32 * 24)(*([-1] + list(range(23))))
+    J = (C.c_float * 72)()
+    rc = lib.mp_create(C.byref(h), 0, blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, parent, J)
+    assert rc == _lib.MP_ERR_INVALID
+    assert "6674994" in _lib.last_error(None)
+
+
+def test_blob_round_trip(weights):
+    blob = state_dict_to_blob(weights)
+    assert blob.size == 6674994
+    back = blob_to_state_dict(blob)
+    for k, v in weights.items():
+        assert np.array_equal(back[k], v)
+    with pytest.raises(KeyError):
+        state_dict_to_blob({k: v for k, v in list(weights.items())[:-1]})
+
+
+def test_facade_requires_gpu_and_library():
+    import torch
+    from mobileposer_amd.net import MobilePoserNet
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            MobilePoserNet(device="cpu")

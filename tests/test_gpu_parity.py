@@ -1,0 +1,260 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes facade), against
+  (1) golden vectors recorded from the reference itself (tests/golden/*.npz),
+  (2) the CPU oracle on seeded inputs, at sizes the oracle finishes in seconds,
+  (3) size-independent properties at BASELINE.json's full size (256 x 125).
+Tolerances (BASELINE.json north_star): 1e-4 on joint angles and raw network outputs, 1 mm on root translation.
+"""
+import numpy as np
+import pytest
+
+from conftest import geodesic, load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+TOL_TRAN = 1e-3
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
+    return torch
+
+
+@pytest.fixture()
+def net(torch_mod, weights, smpl):
+    from mobileposer_amd.net import MobilePoserNet
+    return MobilePoserNet.from_numpy(weights, smpl, device="cuda:0")
+
+
+def cu(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def test_native_library_is_what_runs(net):
+    import ctypes
+    assert net._h is not None and isinstance(net._lib, ctypes.CDLL)
+    assert abs(net.floor_y - float(net.j[10:12, 1].min())) < 1e-7
+
+
+@pytest.mark.parametrize("name", ["joints", "pose", "foot_contact", "velocity"])
+def test_g1_rnn_ragged_golden(torch_mod, net, name):
+    g = load_golden("g1_rnn.npz")
+    lengths = g["lengths"].tolist()
+    y, (h, c) = net.rnn_forward(name, cu(torch_mod, g[f"{name}_x"]), lengths)
+    assert np.abs(npy(y) - g[f"{name}_y"]).max() < TOL
+    assert np.abs(npy(h) - g[f"{name}_h"]).max() < TOL
+    assert np.abs(npy(c) - g[f"{name}_c"]).max() < TOL
+    y2, (h2, c2) = net.rnn_forward(name, cu(torch_mod, g[f"{name}_x"]), lengths, (h, c))
+    assert np.abs(npy(y2) - g[f"{name}_y2"]).max() < TOL
+    assert np.abs(npy(h2) - g[f"{name}_h2"]).max() < TOL
+    assert np.abs(npy(c2) - g[f"{name}_c2"]).max() < TOL
+
+
+@pytest.mark.parametrize("tag", ["eq", "rag"])
+def test_g2_forward_golden(torch_mod, net, tag):
+    g = load_golden("g2_forward.npz")
+    pose, joints, vel, contact = net.forward(cu(torch_mod, g["imu"]), g[f"{tag}_lengths"].tolist())
+    assert tuple(pose.shape) == g[f"{tag}_pose"].shape
+    assert np.abs(npy(joints) - g[f"{tag}_joints"]).max() < TOL
+    assert np.abs(npy(vel) - g[f"{tag}_vel"]).max() < TOL
+    assert np.abs(npy(contact) - g[f"{tag}_contact"]).max() < TOL
+    assert np.abs(npy(net._io[(3, 25)]["r6d"]) - g[f"{tag}_r6d"]).max() < TOL
+    assert geodesic(npy(pose), g[f"{tag}_pose"]).max() < TOL
+    h, c = net.velocity.rnn_state
+    assert np.abs(npy(h) - g[f"{tag}_vel_h"]).max() < TOL and np.abs(npy(c) - g[f"{tag}_vel_c"]).max() < TOL
+
+
+def test_g3_r6d_ik_golden_with_degenerate_rows(torch_mod, net):
+    g = load_golden("g3_r6d_ik.npz")
+    pose = npy(net._reduced_global_to_full(cu(torch_mod, g["r6d"])))
+    assert not np.isnan(pose).any()
+    assert np.abs(pose - g["pose"]).max() < 1e-5
+
+
+def test_g4_offline_golden_and_stale_velocity_state(torch_mod, net):
+    g = load_golden("g4_offline.npz")
+    for tag, x in (("a", g["imu_a"]), ("b", g["imu_b"]), ("a_again", g["imu_a"])):
+        net.reset()
+        pose, joints, tran, contact = net.forward_offline(cu(torch_mod, x), [x.shape[1]])
+        assert tuple(pose.shape) == g[f"{tag}_pose"].shape and tuple(tran.shape) == g[f"{tag}_tran"].shape
+        assert geodesic(npy(pose), g[f"{tag}_pose"]).max() < TOL, tag
+        assert np.abs(npy(joints) - g[f"{tag}_joints"]).max() < TOL
+        assert np.abs(npy(contact) - g[f"{tag}_contact"]).max() < TOL
+        assert np.abs(npy(tran) - g[f"{tag}_tran"]).max() < TOL_TRAN, tag
+    # Q1: clearing the velocity state restores the first answer
+    net.reset()
+    net.velocity.rnn_state = None
+    _, _, tran, _ = net.forward_offline(cu(torch_mod, g["imu_a"]), [g["imu_a"].shape[1]])
+    assert np.abs(npy(tran) - g["a_cleared_tran"]).max() < TOL_TRAN
+    assert np.abs(npy(tran) - g["a_again_tran"]).max() > 1e-5
+
+
+def test_g5_online_golden(torch_mod, net):
+    g = load_golden("g5_online.npz")
+    net.reset()
+    for k, f in enumerate(g["imu"]):
+        pose, joints, tran, contact = net.forward_online(cu(torch_mod, f))
+        assert tuple(pose.shape) == (24, 9) and tuple(joints.shape) == (45, 72)
+        assert geodesic(npy(pose).reshape(24, 3, 3), g["pose"][k].reshape(24, 3, 3)).max() < TOL, k
+        assert np.abs(npy(joints)[40] - g["joints40"][k]).max() < TOL
+        assert np.abs(npy(contact) - g["contact"][k]).max() < TOL
+        assert np.abs(npy(tran) - g["tran"][k]).max() < TOL_TRAN, k
+    h, c = net.velocity.rnn_state
+    assert np.abs(npy(h) - g["vel_h"]).max() < TOL and np.abs(npy(c) - g["vel_c"]).max() < TOL
+
+
+def test_g6_fk_golden(torch_mod, net):
+    g = load_golden("g6_fk.npz")
+    Rg, jg = net.forward_kinematics(cu(torch_mod, g["pose"]))
+    assert np.abs(npy(Rg) - g["R_global"]).max() < 1e-5
+    assert np.abs(npy(jg) - g["joint"]).max() < 1e-5
+    _, jg2 = net.bodymodel.forward_kinematics(cu(torch_mod, g["pose"]), tran=cu(torch_mod, g["tran"]))
+    assert np.abs(npy(jg2) - g["joint_tran"]).max() < 1e-5
+
+
+def test_translate_offline_vs_oracle_ragged(torch_mod, net):
+    """K6 alone on crafted inputs: both feet take turns, the floor clamp fires, ragged lengths."""
+    from oracle import mp_oracle as O
+    rng = np.random.Generator(np.random.PCG64(77))
+    B, T = 5, 300
+    joints = (rng.standard_normal((B, T, 72)) * 0.05).astype(np.float32)
+    joints[:, :, 31] -= 0.9
+    joints[:, :, 34] -= 0.9
+    vel = (rng.standard_normal((B, T, 72)) * 0.3).astype(np.float32)
+    contact = (rng.standard_normal((B, T, 2)) * 2.0).astype(np.float32)
+    lengths = [300, 1, 17, 300, 123]
+    tran = torch_mod.empty(B, T, 3, device="cuda")
+    import ctypes as C
+    net.translate_offline_into(cu(torch_mod, joints), cu(torch_mod, vel), cu(torch_mod, contact), (C.c_int32 * B)(*lengths), tran)
+    tran = npy(tran)
+    clamped = 0
+    for b in range(B):
+        L = lengths[b]
+        ref = O.translate_offline(joints[b, :L].reshape(L, 24, 3), vel[b, :L], contact[b, :L], net.floor_y)
+        assert np.abs(tran[b, :L] - ref).max() < 1e-4, b
+        assert np.abs(tran[b, L:] - ref[-1]).max() < 1e-4
+        foot = ref[:, 1] + joints[b, :L].reshape(L, 24, 3)[:, 10:12, 1].min(axis=1)
+        clamped += int((np.abs(foot - net.floor_y) < 1e-5).sum())
+    assert clamped > 20
+
+
+def test_forward_vs_oracle_medium(torch_mod, net, weights, smpl):
+    """Seeded 24 x 60 batch with ragged lengths against the oracle (all four outputs + translation)."""
+    from mobileposer_amd import synthetic
+    from oracle import mp_oracle as O
+    B, T = 24, 60
+    imu = synthetic.make_imu(B, T, seed=3)
+    lengths = [T] * B
+    for b, L in ((1, 7), (5, 59), (17, 1), (23, 33)):
+        lengths[b] = L
+    pose, joints, vel, contact = net.forward(cu(torch_mod, imu), lengths)
+    ref = O.OracleNet(weights, smpl["J"])
+    rpose, rjoints, rvel, rcontact = ref.forward(imu, lengths)
+    assert np.abs(npy(joints) - rjoints).max() < TOL
+    assert np.abs(npy(vel) - rvel).max() < TOL
+    assert np.abs(npy(contact) - rcontact).max() < TOL
+    assert np.abs(npy(net._io[(B, T)]["r6d"]) - ref._last_r6d).max() < TOL
+    assert geodesic(npy(pose), rpose).max() < TOL
+
+
+def test_full_size_vs_oracle_and_properties(torch_mod, net, weights, smpl):
+    """BASELINE config: 256 x 125.  Oracle comparison on the whole batch plus size-independent properties:
+    batch-permutation equivariance (sequences are independent), graph replay == eager, determinism."""
+    import ctypes as C
+    from mobileposer_amd import synthetic
+    from oracle import mp_oracle as O
+    B, T = 256, 125
+    imu = synthetic.make_imu(B, T, seed=1)
+    x = cu(torch_mod, imu)
+    lengths = [T] * B
+    net.reset_all()
+    pose, joints, vel, contact = net.forward(x, lengths)
+    ref = O.OracleNet(weights, smpl["J"])
+    rpose, rjoints, rvel, rcontact = ref.forward(imu, lengths)
+    assert np.abs(npy(joints) - rjoints).max() < TOL
+    assert np.abs(npy(vel) - rvel).max() < TOL
+    assert np.abs(npy(contact) - rcontact).max() < TOL
+    assert geodesic(npy(pose), rpose).max() < TOL
+    # translation at full size through the batched solver
+    tran = torch_mod.empty(B, T, 3, device="cuda")
+    net.translate_offline_into(joints, vel.reshape(B, T, 72), contact, (C.c_int32 * B)(*lengths), tran)
+    for b in (0, 100, 255):
+        rt = O.translate_offline(rjoints[b].reshape(T, 24, 3), rvel[b], rcontact[b], ref.floor_y)
+        assert np.abs(npy(tran[b]) - rt).max() < TOL_TRAN
+    # determinism + graph replay: same call again (state cleared) is bitwise identical
+    net.reset_all()
+    pose2, joints2, vel2, contact2 = net.forward(x, lengths)
+    assert torch_mod.equal(pose, pose2) and torch_mod.equal(joints, joints2) and torch_mod.equal(vel, vel2)
+    # eager launches == graph replay, bitwise
+    net.reset_all()
+    net.set_graph_mode(False)
+    pose3, joints3, vel3, contact3 = net.forward(x, lengths)
+    net.set_graph_mode(True)
+    assert torch_mod.equal(pose, pose3) and torch_mod.equal(vel, vel3) and torch_mod.equal(contact, contact3)
+    # permutation equivariance: sequences never interact
+    perm = torch_mod.randperm(B, generator=torch_mod.Generator().manual_seed(0)).cuda()
+    net.reset_all()
+    pose4, joints4, vel4, contact4 = net.forward(x[perm], lengths)
+    assert torch_mod.equal(joints4, joints[perm]) and torch_mod.equal(vel4, vel[perm])
+    assert torch_mod.equal(pose4.reshape(B, T, 24, 9), pose.reshape(B, T, 24, 9)[perm])
+
+
+def test_ragged_equals_truncated(torch_mod, net):
+    """Packed-sequence semantics (Q4): a short sequence inside a padded batch == the same sequence alone."""
+    from mobileposer_amd import synthetic
+    B, T, L = 4, 50, 23
+    imu = synthetic.make_imu(B, T, seed=9)
+    net.reset_all()
+    _, joints, vel, contact = net.forward(cu(torch_mod, imu), [T, L, T, T])
+    r6d = net._io[(B, T)]["r6d"].clone()
+    net.reset_all()
+    _, joints1, vel1, contact1 = net.forward(cu(torch_mod, imu[1:2, :L]), [L])
+    r6d1 = net._io[(1, L)]["r6d"]
+    assert np.abs(npy(joints[1, :L]) - npy(joints1[0])).max() < 1e-6
+    assert np.abs(npy(r6d[1, :L]) - npy(r6d1[0])).max() < 1e-6
+    assert np.abs(npy(vel[1, :L]) - npy(vel1)).max() < 1e-6
+    # padded frames carry linear2.bias exactly
+    b2 = net.state_dict()["joints.joints.linear2.bias"].numpy()
+    assert np.abs(npy(joints[1, L:]) - b2).max() < 1e-7
+
+
+def test_error_behaviour(torch_mod, net):
+    from mobileposer_amd import synthetic
+    x = cu(torch_mod, synthetic.make_imu(2, 10, seed=2))
+    with pytest.raises(ValueError):
+        net.forward(x, None)                       # Q3
+    with pytest.raises(RuntimeError):
+        net.forward(x, [10, 11])                   # length > T
+    with pytest.raises(RuntimeError):
+        net.forward(x, [9, 9])                     # max(lengths) != T: the reference's cat fails
+    net.forward(x, [10, 10])
+    x3 = cu(torch_mod, synthetic.make_imu(3, 10, seed=2))
+    with pytest.raises(RuntimeError):
+        net.forward(x3, [10, 10, 10])              # Q2: carried velocity state has another batch size
+    net.velocity.rnn_state = None
+    net.forward(x3, [10, 10, 10])
+
+
+def test_multi_stream_equals_single_streams(torch_mod, weights, smpl):
+    """K7: S concurrent streams ticked together == each stream run alone through forward_online."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    S, n = 3, 8
+    frames = synthetic.make_imu(S, n, seed=41)
+    multi = MobilePoserNet.from_numpy(weights, smpl, device="cuda:0")
+    multi.stream_create(S)
+    outs = [multi.stream_step(cu(torch_mod, frames[:, k])) for k in range(n)]
+    for s in range(S):
+        single = MobilePoserNet.from_numpy(weights, smpl, device="cuda:0")
+        single.reset()
+        for k in range(n):
+            pose, joints, root, contact = single.forward_online(cu(torch_mod, frames[s, k]))
+            assert np.abs(npy(outs[k][0][s]) - npy(pose)).max() < 1e-5
+            assert np.abs(npy(outs[k][2][s]) - npy(root)).max() < 1e-5
+            assert np.abs(npy(outs[k][3][s]) - npy(contact)).max() < 1e-5
