@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- IMU frames/s of the MobilePoser inference path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one synthetic batch of 256 IMU windows x 125 frames that is
+already resident in HBM:  mp_forward (4 stacked-LSTM modules + 6D->SO(3) + global->local)
+ -> mp_fk (SMPL forward kinematics of the predicted pose) -> mp_translate_offline (foot-contact/velocity
+translation solver).  With N > 1 every rank (one process per GPU, launched by torch.distributed.run) runs
+the same per-GPU workload on its own seeded batch (weak scaling); the only collective is the RCCL broadcast
+of the weight blob from rank 0 at start-up.
+
+Prints ONE JSON line on rank 0 (see the field list in README / DESIGN.md section "Measurement").
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+B_PER_GPU, T_WIN = 256, 125
+FLOP_PER_FRAME = 2 * 6651392            # 13.30 MFLOP / frame for the 4 modules
+BYTES_PER_FRAME = 1688                  # compulsory HBM bytes / frame (240 in + 1448 out)
+PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def gemm_flops_main_stream(M):
+    """FLOPs of the GEMM launches timed on the main stream (joints + pose modules)."""
+    fl = 0
+    for n_in, n_out in ((60, 72), (132, 96)):
+        fl += 2 * M * (256 * n_in + 2048 * 256 + 2048 * 512 + n_out * 512)
+    return fl
+
+
+def lstm_flops_main_stream(M):
+    """Recurrent FLOPs (h W_hh^T) of the step launches on the main stream: 2 modules x 2 layers x 2 dirs."""
+    return 2 * M * 256 * 1024 * 8
+
+
+def cpu_baseline(seconds=12.0):
+    """The numpy oracle (a port of the reference's CPU path) on a bounded sample of the same workload."""
+    from mobileposer_amd import synthetic
+    from oracle import mp_oracle as O
+    sd = synthetic.make_weights(0)
+    smpl = synthetic.synthetic_smpl()
+    Bs = 32
+    imu = synthetic.make_imu(Bs, T_WIN, seed=1)[:Bs]
+    ref = O.OracleNet(sd, smpl["J"])
+
+    def one():
+        ref.velocity_rnn_state = None
+        pose, joints, vel, contact = ref.forward(imu, [T_WIN] * Bs)
+        O.forward_kinematics(pose, smpl["J"])
+        for b in range(Bs):
+            O.translate_offline(joints[b].reshape(T_WIN, 24, 3), vel[b], contact[b], ref.floor_y)
+
+    one()                                   # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or reps >= 50:
+            break
+    return {"value": round(reps * Bs * T_WIN / dt, 1), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d reps of %d sequences x %d frames (numpy oracle: forward + FK + translation), %.1f s"
+                      % (reps, Bs, T_WIN, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    dev = torch.device("cuda", local_rank)
+
+    import __graft_entry__
+    if not os.path.exists(__graft_entry__.LIB):
+        if rank == 0:
+            __graft_entry__.build()
+        if dist is not None:
+            dist.barrier()
+
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.dist import broadcast_weights
+    from mobileposer_amd.net import MobilePoserNet
+
+    smpl = synthetic.synthetic_smpl()
+    if dist is not None:
+        blob = broadcast_weights(synthetic.make_weights(0) if rank == 0 else None, dev, src=0)
+        net = MobilePoserNet.from_device_blob(blob, smpl, device=dev)
+    else:
+        net = MobilePoserNet.from_numpy(synthetic.make_weights(0), smpl, device=dev)
+    if args.no_graph:
+        net.set_graph_mode(False)
+
+    B, T = B_PER_GPU, T_WIN
+    imu = torch.from_numpy(synthetic.make_imu(B, T, seed=1 + rank)).to(dev)
+    f32 = torch.float32
+    pose = torch.empty(B * T, 24, 3, 3, device=dev, dtype=f32)
+    joints = torch.empty(B, T, 72, device=dev, dtype=f32)
+    vel = torch.empty(B, T, 72, device=dev, dtype=f32)
+    contact = torch.empty(B, T, 2, device=dev, dtype=f32)
+    tran = torch.empty(B, T, 3, device=dev, dtype=f32)
+    rglob = torch.empty(B * T, 24, 3, 3, device=dev, dtype=f32)
+    jglob = torch.empty(B * T, 24, 3, device=dev, dtype=f32)
+    lens = (C.c_int32 * B)(*([T] * B))
+    lib, h = net._lib, net._h
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+
+    def step():
+        lib.mp_reset_state(h, 1)            # every step is a fresh, independent batch
+        rc = lib.mp_forward(h, vp(imu), lens, B, T, vp(pose), vp(joints), vp(vel), vp(contact), None, stream)
+        rc = rc or lib.mp_fk(h, vp(pose), None, B * T, vp(rglob), vp(jglob), stream)
+        rc = rc or lib.mp_translate_offline(h, vp(joints), vp(vel), vp(contact), lens, B, T, vp(tran), stream)
+        if rc:
+            raise RuntimeError(lib.mp_last_error(h).decode())
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- per-kernel-class timing with HIP events on the library's own stream (eager launches) ----
+    kern = {}
+    if rank == 0:
+        net.timing_enable(True)
+        acc = {0: [0, 0.0], 1: [0, 0.0], 2: [0, 0.0], 3: [0, 0.0]}
+        reps = 3
+        for _ in range(reps):
+            lib.mp_reset_state(h, 1)
+            lib.mp_forward(h, vp(imu), lens, B, T, vp(pose), vp(joints), vp(vel), vp(contact), None, stream)
+            torch.cuda.synchronize(dev)
+            for cls in acc:
+                n, ms = net.timing_read(cls)
+                acc[cls][0] += n
+                acc[cls][1] += ms
+        net.timing_enable(False)
+        M = B * T
+        g_n, g_ms = acc[0]
+        s_n, s_ms = acc[1]
+        kern = {
+            "mp_gemm_f32": {"launches_per_forward_main_stream": g_n // reps, "avg_ms": g_ms / max(g_n, 1),
+                            "tflops": gemm_flops_main_stream(M) * reps / (g_ms * 1e-3) / 1e12 if g_ms else None},
+            "mp_lstm_step": {"launches_per_forward_main_stream": s_n // reps, "avg_us_eager": 1e3 * s_ms / max(s_n, 1),
+                             "tflops_eager": lstm_flops_main_stream(M) * reps / (s_ms * 1e-3) / 1e12 if s_ms else None},
+            "mp_r6d_ik": {"avg_ms": acc[2][1] / max(acc[2][0], 1)},
+            "forward_eager_ms": acc[3][1] / reps,
+        }
+    if dist is not None:
+        dist.barrier()
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    frames = world * B * T * args.steps
+    value = frames / elapsed
+    g = kern["mp_gemm_f32"]
+    achieved = g["tflops"] or 0.0
+    out = {
+        "metric": "imu_frames_per_sec (MobilePoserNet fwd + FK + translation solver, batch 256 x window 125 per GPU)",
+        "value": round(value, 1), "unit": "frames/s", "per_gpu": round(value / world, 1),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[2]+solver: full MobilePoserNet (4 LSTM modules) + r6d/IK + SMPL FK + offline "
+                               "translation solver, B=256 x T=125 per GPU, seeded synthetic IMU (lw_rp combo), "
+                               "seeded random weights, synthetic SMPL constants",
+                   "batch_per_gpu": B, "window": T, "global_batch": world * B,
+                   "parallelism": "independent sequences sharded, dp%d" % world,
+                   "graph": not args.no_graph},
+        "end_to_end": {"tflops": round(value * FLOP_PER_FRAME / 1e12, 3),
+                       "frac_of_fp32_mfma_peak": round(value / world * FLOP_PER_FRAME / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                       "hbm_gbps_compulsory": round(value / world * BYTES_PER_FRAME / 1e9, 2)},
+        "roofline": {"kernel": "mp_gemm_f32<2,2,2,2> (fp32 MFMA GEMM: linear1 / W_ih projections / linear2)",
+                     "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None},
+        "kernels": kern,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,13 +27,17 @@ constexpr unsigned IGNORED_MASK = (1u << 0) | (1u << 7) | (1u << 8) | (1u << 10)
 __device__ __forceinline__ float nan0(float x) { return x != x ? 0.f : x; }
 
 // R (row-major 3x3) from 6 numbers = first two COLUMNS of R (angular.py:180); NaN -> 0 (angular.py:181)
+// Every product and sum is rounded separately (no FMA contraction) and summed left to right, as the
+// reference's elementwise torch ops do: for (near-)colinear inputs the second column is normalised rounding
+// noise, and only the same operation sequence reproduces the reference's NaN/0 pattern there.
 __device__ __forceinline__ void gram_schmidt(const float* __restrict__ p, float R[9]) {
+#pragma clang fp contract(off)
     const float ax = p[0], ay = p[1], az = p[2], bx = p[3], by = p[4], bz = p[5];
-    const float na = sqrtf(ax * ax + ay * ay + az * az);
+    const float na = sqrtf((ax * ax + ay * ay) + az * az);
     const float c0x = ax / na, c0y = ay / na, c0z = az / na;
-    const float d = c0x * bx + c0y * by + c0z * bz;
+    const float d = (c0x * bx + c0y * by) + c0z * bz;
     const float ux = bx - d * c0x, uy = by - d * c0y, uz = bz - d * c0z;
-    const float nu = sqrtf(ux * ux + uy * uy + uz * uz);
+    const float nu = sqrtf((ux * ux + uy * uy) + uz * uz);
     const float c1x = ux / nu, c1y = uy / nu, c1z = uz / nu;
     const float c2x = c0y * c1z - c0z * c1y, c2y = c0z * c1x - c0x * c1z, c2z = c0x * c1y - c0y * c1x;
     R[0] = nan0(c0x); R[1] = nan0(c1x); R[2] = nan0(c2x);

@@ -138,7 +138,8 @@ def test_translate_offline_vs_oracle_ragged(torch_mod, net):
         L = lengths[b]
         ref = O.translate_offline(joints[b, :L].reshape(L, 24, 3), vel[b, :L], contact[b, :L], net.floor_y)
         assert np.abs(tran[b, :L] - ref).max() < 1e-4, b
-        assert np.abs(tran[b, L:] - ref[-1]).max() < 1e-4
+        if L < T:
+            assert np.abs(tran[b, L:] - ref[-1]).max() < 1e-4
         foot = ref[:, 1] + joints[b, :L].reshape(L, 24, 3)[:, 10:12, 1].min(axis=1)
         clamped += int((np.abs(foot - net.floor_y) < 1e-5).sum())
     assert clamped > 20
