@@ -40,6 +40,8 @@ SIGNATURES = {
     "mp_timing_enable": (_i, [_vp, _i]),
     "mp_timing_read": (_i, [_vp, _i, C.POINTER(_i), _fp]),
     "mp_set_graph_mode": (_i, [_vp, _i]),
+    "mp_set_lstm_mode": (_i, [_vp, _i]),
+    "mp_device_error": (_i, [_vp, C.POINTER(_i)]),
 }
 
 _lib = None

@@ -75,12 +75,15 @@ struct Packed { float* W = nullptr; float* bias = nullptr; int N = 0, K = 0, Kpa
 struct ModuleW {
     int n_in = 0, n_out = 0, H = 0, dirs = 0;
     Packed lin1, ih[2], lin2;
-    float* whh[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    float* whh[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};    // per-step kernel layout
+    float* whhP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // persistent kernel layout
 };
 struct ModuleWS {
     float *xproj = nullptr, *out0 = nullptr, *out1 = nullptr;   // X1 (linear1 output) aliases out1
     float* hbuf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     float* cbuf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    unsigned long long* hx = nullptr;   // granule exchange buffer of the persistent kernel
+    size_t hx_bytes = 0;
 };
 struct VelState { float* h = nullptr; float* c = nullptr; int B = 0; int cap = 0; };   // [2][B][256] each
 
@@ -122,8 +125,11 @@ struct mp_handle {
     float* bone_dev = nullptr;
     float floor_y = 0.f;
     float feet_pos[6] = {0, 0, 0, 0, 0, 0};
-    hipStream_t s_main = nullptr, s_vel = nullptr, s_foot = nullptr;
+    hipStream_t s_main = nullptr, s_vel = nullptr, s_foot = nullptr, s_gp = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_j = nullptr, ev_v = nullptr, ev_f = nullptr;
+    hipEvent_t ev_x[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int* err_dev = nullptr;          // device error word of the persistent kernels
+    bool persist = true;             // LSTM recurrence: persistent kernel (default) or per-step launches
     std::map<std::pair<int, int>, Plan*> plans;
     std::map<GraphKey, hipGraphExec_t> graphs;
     VelState vstate;
@@ -181,7 +187,10 @@ int pack_weights(mp_handle* h, const float* blob) {
         if (int rc = alloc_packed(h, m.lin2, m.n_out, m.dirs * m.H)) return rc;
         for (int l = 0; l < 2; ++l)
             for (int d = 0; d < m.dirs; ++d)
+            {
                 if (int rc = dev_alloc(h, (void**)&m.whh[l][d], mp_whh_pack_floats(m.H) * sizeof(float))) return rc;
+                if (int rc = dev_alloc(h, (void**)&m.whhP[l][d], mp_whh_pack_floats(m.H) * sizeof(float))) return rc;
+            }
     }
     const std::vector<Entry>& man = manifest();
     auto find = [&](int mod, int kind, int layer, int dir) -> const float* {
@@ -200,6 +209,7 @@ int pack_weights(mp_handle* h, const float* blob) {
                 mp_launch_pack_wih(find(s.id, K_WIH, l, d), find(s.id, K_BIH, l, d), find(s.id, K_BHH, l, d),
                                    m.ih[l].W, m.ih[l].bias, m.H, m.ih[l].K, m.ih[l].Kpad, d * 4 * m.H, h->s_main);
                 mp_launch_pack_whh(find(s.id, K_WHH, l, d), m.whh[l][d], m.H, h->s_main);
+                mp_launch_pack_whh_persist(find(s.id, K_WHH, l, d), m.whhP[l][d], m.H, h->s_main);
             }
     }
     HIPCHK(h, hipGetLastError());
@@ -243,10 +253,15 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     auto bail = [&](int rc) { g_create_error = h->err; mp_destroy(h); return rc; };
     if (hipSetDevice(device) != hipSuccess) { h->err = "hipSetDevice failed"; return bail(MP_ERR_HIP); }
     if (const char* e = getenv("MP_NO_GRAPH")) h->use_graph = !(e[0] && e[0] != '0');
+    if (const char* e = getenv("MP_LSTM_MODE")) h->persist = strcmp(e, "step") != 0;
     hipError_t e = hipSuccess;
     e = e ? e : hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking);
     e = e ? e : hipStreamCreateWithFlags(&h->s_vel, hipStreamNonBlocking);
     e = e ? e : hipStreamCreateWithFlags(&h->s_foot, hipStreamNonBlocking);
+    e = e ? e : hipStreamCreateWithFlags(&h->s_gp, hipStreamNonBlocking);
+    for (hipEvent_t& ev : h->ev_x) e = e ? e : hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (!e) e = hipMalloc((void**)&h->err_dev, sizeof(int));
+    if (!e) e = hipMemset(h->err_dev, 0, sizeof(int));
     hipEvent_t* evs[5] = {&h->ev_in, &h->ev_out, &h->ev_j, &h->ev_v, &h->ev_f};
     for (hipEvent_t* ev : evs) e = e ? e : hipEventCreateWithFlags(ev, hipEventDisableTiming);
     if (e != hipSuccess) { h->err = std::string("stream/event creation failed: ") + hipGetErrorString(e); return bail(MP_ERR_HIP); }
@@ -289,6 +304,8 @@ int get_plan(mp_handle* h, int B, int T, Plan** out) {
                 if (int rc = dev_alloc(h, (void**)&w.hbuf[l][d], (size_t)2 * B * m.H * sizeof(float), &p->allocs)) return rc;
                 if (int rc = dev_alloc(h, (void**)&w.cbuf[l][d], (size_t)B * m.H * sizeof(float), &p->allocs)) return rc;
             }
+        w.hx_bytes = (size_t)m.dirs * ((B + 15) / 16) * 2 * 16 * m.H * sizeof(unsigned long long);
+        if (int rc = dev_alloc(h, (void**)&w.hx, w.hx_bytes, &p->allocs)) return rc;
     }
     if (int rc = dev_alloc(h, (void**)&p->r6d, M * 96 * sizeof(float), &p->allocs)) return rc;
     if (int rc = dev_alloc(h, (void**)&p->lengths_dev, (size_t)B * sizeof(int), &p->allocs)) return rc;
@@ -326,7 +343,7 @@ hipEvent_t next_event(mp_handle* h) {
 struct SegScope {
     mp_handle* h; hipStream_t s; bool on; size_t idx;
     SegScope(mp_handle* h_, hipStream_t s_, int cls, int launches) : h(h_), s(s_), on(false), idx(0) {
-        if (!h->timing || h->capturing || (cls != 3 && s != h->s_main)) return;
+        if (!h->timing || h->capturing || (cls != 3 && s != h->s_main && s != h->s_gp)) return;
         hipEvent_t a = next_event(h), b = next_event(h);
         if (!a || !b) return;
         on = true;
@@ -353,59 +370,125 @@ int run_gemm(mp_handle* h, hipStream_t s, RowMap a0, RowMap a1, const Packed& w,
     return MP_OK;
 }
 
+// One RNN block (models/rnn.py:20-33) as five phases so that the orchestrator can put the GEMM phases and the
+// recurrences of different modules on different streams:
+//   g0: linear1+ReLU, W_ih(l0) projection, initial (h,c) of both layers      rec(0): layer-0 recurrence
+//   g1: W_ih(l1) projection                                                   rec(1): layer-1 recurrence
+//   g2: final (h,c) copy-out, linear2 into the caller's layout
 // x = [a0 | a1] rows (b,t); y rows (b,t) at y + b*yStrideB + t*yStrideT.
-// state_h/state_c: [layers*dirs][B][H] carried state (read when mode == STATE_FROM, written when out != null)
-int run_rnn(mp_handle* h, Plan* p, int id, RowMap a0, RowMap a1, float* y, long yStrideB, long yStrideT, StateMode mode,
-            const float* in_h, const float* in_c, float* out_h, float* out_c, hipStream_t s) {
-    const ModuleW& m = h->mod[id];
-    ModuleWS& w = p->ws[id];
-    const int B = p->B, T = p->T, M = B * T, H = m.H, dirs = m.dirs;
+// in_h/in_c, out_h/out_c: [layers*dirs][B][H] carried state (read when mode == STATE_FROM, written when out != null)
+struct RnnJob {
+    mp_handle* h; Plan* p; int id;
+    RowMap a0, a1;
+    float* y; long yStrideB, yStrideT;
+    StateMode mode;
+    const float *in_h, *in_c;
+    float *out_h, *out_c;
+};
+
+int rnn_g0(const RnnJob& j, hipStream_t s) {
+    mp_handle* h = j.h;
+    const ModuleW& m = h->mod[j.id];
+    ModuleWS& w = j.p->ws[j.id];
+    const int B = j.p->B, T = j.p->T, M = B * T, H = m.H, dirs = m.dirs;
     const RowMap none{nullptr, 0, 0, 0};
     float* X1 = w.out1;
-    // linear1 + ReLU (rnn.py:22; dropout is identity in eval)
-    run_gemm(h, s, a0, a1, m.lin1, X1, H, (long)B * H, M, B, 1);
-    for (int l = 0; l < 2; ++l) {
-        // input projection of all frames, both directions, biases folded in (rnn.py:27)
-        if (l == 0) run_gemm(h, s, internal_map(X1, B, H), none, m.ih[0], w.xproj, dirs * 4 * H, (long)B * dirs * 4 * H, M, B, 0);
-        else run_gemm(h, s, internal_map(w.out0, B, dirs * H), none, m.ih[1], w.xproj, dirs * 4 * H, (long)B * dirs * 4 * H, M, B, 0);
+    run_gemm(h, s, j.a0, j.a1, m.lin1, X1, H, (long)B * H, M, B, 1);                       // rnn.py:22
+    run_gemm(h, s, internal_map(X1, B, H), none, m.ih[0], w.xproj, dirs * 4 * H, (long)B * dirs * 4 * H, M, B, 0);
+    for (int l = 0; l < 2; ++l)
         for (int d = 0; d < dirs; ++d) {
             const size_t n = (size_t)B * H * sizeof(float);
             const int k = l * dirs + d;
-            if (mode == STATE_FROM) {
-                HIPCHK(h, hipMemcpyAsync(w.hbuf[l][d], in_h + (size_t)k * B * H, n, hipMemcpyDeviceToDevice, s));
-                HIPCHK(h, hipMemcpyAsync(w.cbuf[l][d], in_c + (size_t)k * B * H, n, hipMemcpyDeviceToDevice, s));
+            if (j.mode == STATE_FROM) {
+                HIPCHK(h, hipMemcpyAsync(w.hbuf[l][d], j.in_h + (size_t)k * B * H, n, hipMemcpyDeviceToDevice, s));
+                HIPCHK(h, hipMemcpyAsync(w.cbuf[l][d], j.in_c + (size_t)k * B * H, n, hipMemcpyDeviceToDevice, s));
             } else {
                 HIPCHK(h, hipMemsetAsync(w.hbuf[l][d], 0, n, s));
                 HIPCHK(h, hipMemsetAsync(w.cbuf[l][d], 0, n, s));
             }
         }
-        {
-            SegScope seg(h, s, 1, T);
-            LstmStepArgs a;
-            a.lengths = p->lengths_dev; a.ndir = dirs; a.B = B; a.T = T;
-            float* out = l == 0 ? w.out0 : w.out1;
+    HIPCHK(h, hipGetLastError());
+    return MP_OK;
+}
+
+int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
+    mp_handle* h = j.h;
+    const ModuleW& m = h->mod[j.id];
+    ModuleWS& w = j.p->ws[j.id];
+    const int B = j.p->B, T = j.p->T, H = m.H, dirs = m.dirs;
+    float* out = l == 0 ? w.out0 : w.out1;
+    if (h->persist) {
+        HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));     // every polled word is re-zeroed before every launch
+        SegScope seg(h, s, 1, T);
+        const int nslab = (B + 15) / 16;
+        const int chunk = 256 / (dirs * mp_persist_nslice(H));  // slabs per launch: grid <= 256 workgroups, 1 per CU
+        for (int s0 = 0; s0 < nslab; s0 += chunk) {
+            LstmPersistArgs a;
+            a.lengths = j.p->lengths_dev; a.ndir = dirs; a.B = B; a.T = T;
+            a.slab0 = s0; a.nslab = nslab - s0 < chunk ? nslab - s0 : chunk;
+            a.hx = w.hx + (size_t)dirs * s0 * 2 * 16 * H;
+            a.err = h->err_dev; a.max_spin = 1u << 18;
             for (int d = 0; d < dirs; ++d)
-                a.d[d] = LstmDir{m.whh[l][d], w.xproj + (size_t)d * 4 * H, out + (size_t)d * H, w.hbuf[l][d], w.cbuf[l][d],
+                a.d[d] = LstmDir{m.whhP[l][d], w.xproj + (size_t)d * 4 * H, out + (size_t)d * H, w.hbuf[l][d], w.cbuf[l][d],
                                  dirs * 4 * H, dirs * H, d};
             if (dirs == 1) a.d[1] = a.d[0];
-            for (int step = 0; step < T; ++step) {
-                a.step = step;
-                mp_launch_lstm_step(a, H, s);
-            }
+            mp_launch_lstm_persist(a, H, s);
         }
-        if (out_h) {
+    } else {
+        SegScope seg(h, s, 1, T);
+        LstmStepArgs a;
+        a.lengths = j.p->lengths_dev; a.ndir = dirs; a.B = B; a.T = T;
+        for (int d = 0; d < dirs; ++d)
+            a.d[d] = LstmDir{m.whh[l][d], w.xproj + (size_t)d * 4 * H, out + (size_t)d * H, w.hbuf[l][d], w.cbuf[l][d],
+                             dirs * 4 * H, dirs * H, d};
+        if (dirs == 1) a.d[1] = a.d[0];
+        for (int step = 0; step < T; ++step) {
+            a.step = step;
+            mp_launch_lstm_step(a, H, s);
+        }
+    }
+    HIPCHK(h, hipGetLastError());
+    return MP_OK;
+}
+
+int rnn_g1(const RnnJob& j, hipStream_t s) {
+    mp_handle* h = j.h;
+    const ModuleW& m = h->mod[j.id];
+    ModuleWS& w = j.p->ws[j.id];
+    const int B = j.p->B, T = j.p->T, M = B * T, H = m.H, dirs = m.dirs;
+    const RowMap none{nullptr, 0, 0, 0};
+    run_gemm(h, s, internal_map(w.out0, B, dirs * H), none, m.ih[1], w.xproj, dirs * 4 * H, (long)B * dirs * 4 * H, M, B, 0);
+    HIPCHK(h, hipGetLastError());
+    return MP_OK;
+}
+
+int rnn_g2(const RnnJob& j, hipStream_t s) {
+    mp_handle* h = j.h;
+    const ModuleW& m = h->mod[j.id];
+    ModuleWS& w = j.p->ws[j.id];
+    const int B = j.p->B, T = j.p->T, M = B * T, H = m.H, dirs = m.dirs;
+    const RowMap none{nullptr, 0, 0, 0};
+    if (j.out_h) {
+        const size_t fin = h->persist ? 0 : (size_t)(T & 1) * B * H;   // where the recurrence left h_n
+        for (int l = 0; l < 2; ++l)
             for (int d = 0; d < dirs; ++d) {
                 const size_t n = (size_t)B * H * sizeof(float);
                 const int k = l * dirs + d;
-                HIPCHK(h, hipMemcpyAsync(out_h + (size_t)k * B * H, w.hbuf[l][d] + (size_t)(T & 1) * B * H, n, hipMemcpyDeviceToDevice, s));
-                HIPCHK(h, hipMemcpyAsync(out_c + (size_t)k * B * H, w.cbuf[l][d], n, hipMemcpyDeviceToDevice, s));
+                HIPCHK(h, hipMemcpyAsync(j.out_h + (size_t)k * B * H, w.hbuf[l][d] + fin, n, hipMemcpyDeviceToDevice, s));
+                HIPCHK(h, hipMemcpyAsync(j.out_c + (size_t)k * B * H, w.cbuf[l][d], n, hipMemcpyDeviceToDevice, s));
             }
-        }
     }
-    // linear2 (rnn.py:32) straight into the caller's layout
-    run_gemm(h, s, internal_map(w.out1, B, dirs * H), none, m.lin2, y, yStrideB, yStrideT, M, B, 0);
+    run_gemm(h, s, internal_map(w.out1, B, dirs * H), none, m.lin2, j.y, j.yStrideB, j.yStrideT, M, B, 0);   // rnn.py:32
     HIPCHK(h, hipGetLastError());
     return MP_OK;
+}
+
+int run_rnn(const RnnJob& j, hipStream_t s) {
+    if (int rc = rnn_g0(j, s)) return rc;
+    if (int rc = rnn_rec(j, 0, s)) return rc;
+    if (int rc = rnn_g1(j, s)) return rc;
+    if (int rc = rnn_rec(j, 1, s)) return rc;
+    return rnn_g2(j, s);
 }
 
 int ensure_vstate(mp_handle* h, VelState& v, int B) {
@@ -419,35 +502,67 @@ int ensure_vstate(mp_handle* h, VelState& v, int B) {
     return MP_OK;
 }
 
-// models/net.py:101-119 on the library's streams (eager or under capture)
+// models/net.py:101-119 on the library's streams (eager or under capture).
+// Stream plan (persistent mode): the multi-workgroup persistent recurrences must never run concurrently
+// (their workgroups wait on each other, so two such grids that are each only partly resident could starve
+// one another), hence ALL H = 256 recurrences are serialised on s_main; the GEMM phases of pose / velocity
+// run beside them on s_gp / s_vel, and the foot-contact block (H = 64: one workgroup per slab, waits on
+// nobody) runs whole on s_foot.
 int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long poseRows, long poseRowStride,
                  long poseRowOffset, float* joints, float* vel, float* contact, float* r6d, VelState& vs,
                  bool has_state) {
-    const int B = p->B, T = p->T;
+    const int T = p->T;
     const RowMap none{nullptr, 0, 0, 0};
+    const RowMap xj = user_map(joints, T, 72), xi = user_map(imu, T, 60);
+    RnnJob J{h, p, MP_MOD_JOINTS, xi, none, joints, (long)T * 72, 72, STATE_ZERO, nullptr, nullptr, nullptr, nullptr};
+    RnnJob P{h, p, MP_MOD_POSE, xj, xi, r6d, (long)T * 96, 96, STATE_ZERO, nullptr, nullptr, nullptr, nullptr};
+    RnnJob V{h, p, MP_MOD_VELOCITY, xj, xi, vel, (long)T * 72, 72, has_state ? STATE_FROM : STATE_ZERO, vs.h, vs.c, vs.h, vs.c};
+    RnnJob F{h, p, MP_MOD_FOOT_CONTACT, xj, xi, contact, (long)T * 2, 2, STATE_ZERO, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t sm = h->s_main, sp = h->s_gp, sv = h->s_vel, sf = h->s_foot;
+    auto link = [&](hipEvent_t ev, hipStream_t from, hipStream_t to) -> int {
+        HIPCHK(h, hipEventRecord(ev, from));
+        HIPCHK(h, hipStreamWaitEvent(to, ev, 0));
+        return MP_OK;
+    };
+#define RC(x) do { if (int rc_ = (x)) return rc_; } while (0)
     // joints(batch)                                                                       net.py:103
-    if (int rc = run_rnn(h, p, MP_MOD_JOINTS, user_map(imu, T, 60), none, joints, (long)T * 72, 72, STATE_ZERO, nullptr,
-                         nullptr, nullptr, nullptr, h->s_main)) return rc;
-    HIPCHK(h, hipEventRecord(h->ev_j, h->s_main));
-    HIPCHK(h, hipStreamWaitEvent(h->s_vel, h->ev_j, 0));
-    HIPCHK(h, hipStreamWaitEvent(h->s_foot, h->ev_j, 0));
-    // pose(cat(pred_joints, batch)) then global -> local                                   net.py:106-110
-    if (int rc = run_rnn(h, p, MP_MOD_POSE, user_map(joints, T, 72), user_map(imu, T, 60), r6d, (long)T * 96, 96,
-                         STATE_ZERO, nullptr, nullptr, nullptr, nullptr, h->s_main)) return rc;
-    {
-        SegScope seg(h, h->s_main, 2, 1);
-        mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, h->s_main);
+    RC(run_rnn(J, sm));
+    HIPCHK(h, hipEventRecord(h->ev_j, sm));
+    HIPCHK(h, hipStreamWaitEvent(sv, h->ev_j, 0));
+    HIPCHK(h, hipStreamWaitEvent(sf, h->ev_j, 0));
+    // foot_contact(cat(pred_joints, batch))                                               net.py:113-114
+    RC(run_rnn(F, sf));
+    HIPCHK(h, hipEventRecord(h->ev_f, sf));
+    if (!h->persist) {
+        // per-step kernels have no cross-workgroup waits: pose and velocity simply run side by side
+        RC(run_rnn(P, sm));                                                               // net.py:106-107
+        { SegScope seg(h, sm, 2, 1);
+          mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sm); }   // net.py:110
+        RC(run_rnn(V, sv));                                                               // net.py:117
+        HIPCHK(h, hipEventRecord(h->ev_v, sv));
+    } else {
+        auto rec = [&](int i, hipStream_t on) -> int { HIPCHK(h, hipEventRecord(h->ev_x[i], on)); return MP_OK; };
+        auto wait = [&](int i, hipStream_t on) -> int { HIPCHK(h, hipStreamWaitEvent(on, h->ev_x[i], 0)); return MP_OK; };
+        HIPCHK(h, hipStreamWaitEvent(sp, h->ev_j, 0));
+        RC(rnn_g0(P, sp));      RC(rec(0, sp));                  // pose GEMMs      | s_gp
+        RC(rnn_g0(V, sv));      RC(rec(1, sv));                  // velocity GEMMs  | s_vel
+        RC(wait(0, sm)); RC(rnn_rec(P, 0, sm)); RC(rec(2, sm));  // recurrences     | s_main, strictly serial
+        RC(wait(2, sp)); RC(rnn_g1(P, sp));     RC(rec(3, sp));
+        RC(wait(1, sm)); RC(rnn_rec(V, 0, sm)); RC(rec(4, sm));  // overlaps pose's W_ih(l1) GEMM
+        RC(wait(4, sv)); RC(rnn_g1(V, sv));     RC(rec(5, sv));
+        RC(wait(3, sm)); RC(rnn_rec(P, 1, sm)); RC(rec(6, sm));  // overlaps velocity's W_ih(l1) GEMM
+        RC(wait(6, sp)); RC(rnn_g2(P, sp));                                               // net.py:107
+        { SegScope seg(h, sp, 2, 1);
+          mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sp); }   // net.py:110
+        RC(rec(7, sp));
+        RC(wait(5, sm)); RC(rnn_rec(V, 1, sm)); RC(rec(8, sm));
+        RC(wait(8, sv)); RC(rnn_g2(V, sv));                                               // net.py:117
+        RC(wait(7, sm));
+        HIPCHK(h, hipEventRecord(h->ev_v, sv));
     }
-    // velocity.forward_online(cat(...)): carried state                                     net.py:117, velocity.py:45-48
-    if (int rc = run_rnn(h, p, MP_MOD_VELOCITY, user_map(joints, T, 72), user_map(imu, T, 60), vel, (long)T * 72, 72,
-                         has_state ? STATE_FROM : STATE_ZERO, vs.h, vs.c, vs.h, vs.c, h->s_vel)) return rc;
-    HIPCHK(h, hipEventRecord(h->ev_v, h->s_vel));
-    // foot_contact(cat(...))                                                               net.py:113-114
-    if (int rc = run_rnn(h, p, MP_MOD_FOOT_CONTACT, user_map(joints, T, 72), user_map(imu, T, 60), contact, (long)T * 2, 2,
-                         STATE_ZERO, nullptr, nullptr, nullptr, nullptr, h->s_foot)) return rc;
-    HIPCHK(h, hipEventRecord(h->ev_f, h->s_foot));
-    HIPCHK(h, hipStreamWaitEvent(h->s_main, h->ev_v, 0));
-    HIPCHK(h, hipStreamWaitEvent(h->s_main, h->ev_f, 0));
+#undef RC
+    HIPCHK(h, hipStreamWaitEvent(sm, h->ev_v, 0));
+    HIPCHK(h, hipStreamWaitEvent(sm, h->ev_f, 0));
     HIPCHK(h, hipGetLastError());
     return MP_OK;
 }
@@ -528,16 +643,20 @@ void mp_destroy(mp_handle* h) {
     for (ModuleW& m : h->mod) {
         Packed* ps[4] = {&m.lin1, &m.ih[0], &m.ih[1], &m.lin2};
         for (Packed* p : ps) { if (p->W) (void)hipFree(p->W); if (p->bias) (void)hipFree(p->bias); }
-        for (int l = 0; l < 2; ++l) for (int d = 0; d < 2; ++d) if (m.whh[l][d]) (void)hipFree(m.whh[l][d]);
+        for (int l = 0; l < 2; ++l) for (int d = 0; d < 2; ++d) {
+            if (m.whh[l][d]) (void)hipFree(m.whh[l][d]);
+            if (m.whhP[l][d]) (void)hipFree(m.whhP[l][d]);
+        }
     }
     void* misc[] = {h->parent_dev, h->depth_dev, h->bone_dev, h->vstate.h, h->vstate.c, h->sc.window, h->sc.fresh,
                     h->sc.mask_dev, h->sc.st.last_foot, h->sc.st.root_y, h->sc.st.root_pos, h->sc.joints, h->sc.vel,
-                    h->sc.contact};
+                    h->sc.contact, h->err_dev};
     for (void* p : misc) if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     hipEvent_t evs[5] = {h->ev_in, h->ev_out, h->ev_j, h->ev_v, h->ev_f};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
-    hipStream_t ss[3] = {h->s_main, h->s_vel, h->s_foot};
+    for (hipEvent_t e : h->ev_x) if (e) (void)hipEventDestroy(e);
+    hipStream_t ss[4] = {h->s_main, h->s_vel, h->s_foot, h->s_gp};
     for (hipStream_t s : ss) if (s) (void)hipStreamDestroy(s);
     delete h;
 }
@@ -569,7 +688,7 @@ int mp_forward(mp_handle* h, const float* imu_dev, const int32_t* lengths_host, 
     h->segs.clear(); h->ev_used = 0;
     GraphKey key;
     memset(&key, 0, sizeof(key));
-    key.kind = 0; key.B = B; key.T = T; key.flags = has_state ? 1 : 0;
+    key.kind = 0; key.B = B; key.T = T; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0);
     key.p[0] = imu_dev; key.p[1] = pose_dev; key.p[2] = joints_dev; key.p[3] = vel_dev; key.p[4] = contact_dev;
     key.p[5] = r6d; key.p[6] = h->vstate.h;
     int rc;
@@ -598,9 +717,10 @@ int mp_rnn_forward(mp_handle* h, int module, const float* x_dev, const int32_t* 
     const size_t half = (size_t)2 * m.dirs * B * m.H;
     const RowMap none{nullptr, 0, 0, 0};
     h->segs.clear(); h->ev_used = 0;
-    int rc = run_rnn(h, p, module, user_map(x_dev, T, m.n_in), none, y_dev, (long)T * m.n_out, m.n_out,
-                     state_in_dev ? STATE_FROM : STATE_ZERO, state_in_dev, state_in_dev ? state_in_dev + half : nullptr,
-                     state_out_dev, state_out_dev ? state_out_dev + half : nullptr, h->s_main);
+    RnnJob job{h, p, module, user_map(x_dev, T, m.n_in), none, y_dev, (long)T * m.n_out, m.n_out,
+               state_in_dev ? STATE_FROM : STATE_ZERO, state_in_dev, state_in_dev ? state_in_dev + half : nullptr,
+               state_out_dev, state_out_dev ? state_out_dev + half : nullptr};
+    int rc = run_rnn(job, h->s_main);
     if (rc) return rc;
     return leave(h, stream);
 }
@@ -719,7 +839,7 @@ int mp_stream_step(mp_handle* h, const float* frames_dev, float* pose_dev, float
     h->segs.clear(); h->ev_used = 0;
     GraphKey key;
     memset(&key, 0, sizeof(key));
-    key.kind = 1; key.B = S; key.T = W; key.flags = has_state ? 1 : 0;
+    key.kind = 1; key.B = S; key.T = W; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0);
     key.p[0] = frames_dev; key.p[1] = pose_dev; key.p[2] = joints; key.p[3] = root_pos_dev; key.p[4] = contact_dev;
     key.p[6] = h->vstate.h;
     int rc;
@@ -775,6 +895,21 @@ int mp_timing_read(mp_handle* h, int cls, int* launches, float* ms) {
         *ms += t;
         *launches += s.launches;
     }
+    return MP_OK;
+}
+
+int mp_device_error(mp_handle* h, int* code) {
+    if (!h || !code) return MP_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->s_main));
+    HIPCHK(h, hipMemcpy(code, h->err_dev, sizeof(int), hipMemcpyDeviceToHost));
+    if (*code) HIPCHK(h, hipMemset(h->err_dev, 0, sizeof(int)));
+    return MP_OK;
+}
+
+int mp_set_lstm_mode(mp_handle* h, int persistent) {
+    if (!h) return MP_ERR_INVALID;
+    h->persist = persistent != 0;
     return MP_OK;
 }
 

@@ -54,6 +54,20 @@ void mp_launch_pack_wih(const float* wih, const float* bih, const float* bhh, fl
 void mp_launch_pack_linear(const float* w, const float* b, float* dstW, float* dstBias, int N, int K, int Kpad,
                            hipStream_t s);
 
+// persistent variant (mp_lstm_persist.hip): one launch = all T steps of <= 2 directions for `nslab` slabs
+// of 16 sequences starting at slab `slab0`; grid = nslab * NSLICE x ndir workgroups, all co-resident.
+struct LstmPersistArgs {
+    LstmDir d[2];                 // wpack in the persistent layout; hbuf = [B][H] initial/final state (parity 0)
+    const int* lengths;
+    unsigned long long* hx;       // granules [ndir][nslab][2][16][H], zeroed before every launch
+    int* err;                     // device error word (0 = ok, 1+step = a gather timed out)
+    int ndir, B, T, slab0, nslab;
+    unsigned max_spin;
+};
+void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, hipStream_t s);
+void mp_launch_pack_whh_persist(const float* whh, float* dst, int H, hipStream_t s);
+int mp_persist_nslice(int H);
+
 // ---------------------------------------------------------------- K4/K5: kinematics
 void mp_launch_r6d_ik(const float* r6d, long N, float* pose, const int* parent_dev, hipStream_t s);
 // frame n reads its 96 numbers at r6d + n*rowStride + rowOffset

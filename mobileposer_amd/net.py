@@ -361,6 +361,15 @@ class MobilePoserNet:
         _lib.check(self._lib.mp_timing_read(self._h, cls, C.byref(n), C.byref(ms)), self._h)
         return n.value, ms.value
 
+    def set_lstm_mode(self, persistent):
+        _lib.check(self._lib.mp_set_lstm_mode(self._h, int(bool(persistent))), self._h)
+
+    def device_error(self):
+        """0 = ok; otherwise 1+step at which a persistent-kernel wait timed out (synchronises)."""
+        code = C.c_int(0)
+        _lib.check(self._lib.mp_device_error(self._h, C.byref(code)), self._h)
+        return code.value
+
     def set_graph_mode(self, on):
         _lib.check(self._lib.mp_set_graph_mode(self._h, int(bool(on))), self._h)
 

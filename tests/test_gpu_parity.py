@@ -259,3 +259,31 @@ def test_multi_stream_equals_single_streams(torch_mod, weights, smpl):
             assert np.abs(npy(outs[k][0][s]) - npy(pose)).max() < 1e-5
             assert np.abs(npy(outs[k][2][s]) - npy(root)).max() < 1e-5
             assert np.abs(npy(outs[k][3][s]) - npy(contact)).max() < 1e-5
+
+
+def test_persistent_and_step_recurrence_agree(torch_mod, net):
+    """The persistent kernel (granule exchange) and the per-step kernels compute the same recurrence;
+    only the fp32 summation order over K differs.  Also checks that no bounded wait timed out."""
+    from mobileposer_amd import synthetic
+    B, T = 40, 50
+    imu = cu(torch_mod, synthetic.make_imu(B, T, seed=12))
+    lengths = [T] * B
+    lengths[3], lengths[17], lengths[39] = 5, 49, 1
+    outs = {}
+    for mode in (True, False):
+        net.set_lstm_mode(mode)
+        net.reset_all()
+        outs[mode] = [t.clone() for t in net.forward(imu, lengths)]
+        assert net.device_error() == 0
+    net.set_lstm_mode(True)
+    for a, b in zip(outs[True], outs[False]):
+        assert float((a - b).abs().max()) < 2e-5
+
+
+def test_no_device_error_after_full_size(torch_mod, net):
+    from mobileposer_amd import synthetic
+    x = cu(torch_mod, synthetic.make_imu(256, 125, seed=1))
+    for _ in range(3):
+        net.reset_all()
+        net.forward(x, [125] * 256)
+    assert net.device_error() == 0
