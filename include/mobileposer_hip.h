@@ -142,6 +142,9 @@ int mp_set_lstm_mode(mp_handle* h, int persistent);
 /* Synchronises the library's stream and returns the device error word of the persistent kernels:
  * 0 = ok, 1+step = a bounded wait for another workgroup's hidden state timed out (results invalid). */
 int mp_device_error(mp_handle* h, int* code);
+/* Debug (env MP_PERSIST_PROF=1 at mp_create): per-workgroup cycle sums [grid][6] of the phases of the last
+ * persistent-kernel launch: wait, sweep, mfma, reduce, cell+publish, steps. */
+int mp_debug_read_prof(mp_handle* h, long long* out, int n_words);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,7 @@ SIGNATURES = {
     "mp_set_graph_mode": (_i, [_vp, _i]),
     "mp_set_lstm_mode": (_i, [_vp, _i]),
     "mp_device_error": (_i, [_vp, C.POINTER(_i)]),
+    "mp_debug_read_prof": (_i, [_vp, C.POINTER(C.c_longlong), _i]),
 }
 
 _lib = None

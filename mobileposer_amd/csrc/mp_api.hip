@@ -129,6 +129,7 @@ struct mp_handle {
     hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_j = nullptr, ev_v = nullptr, ev_f = nullptr;
     hipEvent_t ev_x[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int* err_dev = nullptr;          // device error word of the persistent kernels
+    long long* prof_dev = nullptr;   // debug: per-workgroup phase cycle sums of the last persistent launch
     bool persist = true;             // LSTM recurrence: persistent kernel (default) or per-step launches
     std::map<std::pair<int, int>, Plan*> plans;
     std::map<GraphKey, hipGraphExec_t> graphs;
@@ -254,6 +255,10 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     if (hipSetDevice(device) != hipSuccess) { h->err = "hipSetDevice failed"; return bail(MP_ERR_HIP); }
     if (const char* e = getenv("MP_NO_GRAPH")) h->use_graph = !(e[0] && e[0] != '0');
     if (const char* e = getenv("MP_LSTM_MODE")) h->persist = strcmp(e, "step") != 0;
+    if (getenv("MP_PERSIST_PROF")) {
+        if (hipMalloc((void**)&h->prof_dev, 512 * 6 * sizeof(long long)) != hipSuccess) h->prof_dev = nullptr;
+        else (void)hipMemset(h->prof_dev, 0, 512 * 6 * sizeof(long long));
+    }
     hipError_t e = hipSuccess;
     e = e ? e : hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking);
     e = e ? e : hipStreamCreateWithFlags(&h->s_vel, hipStreamNonBlocking);
@@ -304,7 +309,7 @@ int get_plan(mp_handle* h, int B, int T, Plan** out) {
                 if (int rc = dev_alloc(h, (void**)&w.hbuf[l][d], (size_t)2 * B * m.H * sizeof(float), &p->allocs)) return rc;
                 if (int rc = dev_alloc(h, (void**)&w.cbuf[l][d], (size_t)B * m.H * sizeof(float), &p->allocs)) return rc;
             }
-        w.hx_bytes = (size_t)m.dirs * ((B + 15) / 16) * 2 * 16 * m.H * sizeof(unsigned long long);
+        w.hx_bytes = (size_t)m.dirs * ((B + 15) / 16) * ((size_t)4 * 16 * m.H + 8) * sizeof(unsigned long long);
         if (int rc = dev_alloc(h, (void**)&w.hx, w.hx_bytes, &p->allocs)) return rc;
     }
     if (int rc = dev_alloc(h, (void**)&p->r6d, M * 96 * sizeof(float), &p->allocs)) return rc;
@@ -426,8 +431,8 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             LstmPersistArgs a;
             a.lengths = j.p->lengths_dev; a.ndir = dirs; a.B = B; a.T = T;
             a.slab0 = s0; a.nslab = nslab - s0 < chunk ? nslab - s0 : chunk;
-            a.hx = w.hx + (size_t)dirs * s0 * 2 * 16 * H;
-            a.err = h->err_dev; a.max_spin = 1u << 18;
+            a.hx = w.hx + (size_t)dirs * s0 * ((size_t)4 * 16 * H + 8);
+            a.err = h->err_dev; a.max_spin = 1u << 18; a.prof = h->prof_dev;
             for (int d = 0; d < dirs; ++d)
                 a.d[d] = LstmDir{m.whhP[l][d], w.xproj + (size_t)d * 4 * H, out + (size_t)d * H, w.hbuf[l][d], w.cbuf[l][d],
                                  dirs * 4 * H, dirs * H, d};
@@ -904,6 +909,13 @@ int mp_device_error(mp_handle* h, int* code) {
     HIPCHK(h, hipStreamSynchronize(h->s_main));
     HIPCHK(h, hipMemcpy(code, h->err_dev, sizeof(int), hipMemcpyDeviceToHost));
     if (*code) HIPCHK(h, hipMemset(h->err_dev, 0, sizeof(int)));
+    return MP_OK;
+}
+
+int mp_debug_read_prof(mp_handle* h, long long* out, int n_words) {
+    if (!h || !out || !h->prof_dev || n_words > 512 * 6) return MP_ERR_INVALID;
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(out, h->prof_dev, (size_t)n_words * sizeof(long long), hipMemcpyDeviceToHost));
     return MP_OK;
 }
 

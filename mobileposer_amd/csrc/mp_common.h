@@ -59,10 +59,11 @@ void mp_launch_pack_linear(const float* w, const float* b, float* dstW, float* d
 struct LstmPersistArgs {
     LstmDir d[2];                 // wpack in the persistent layout; hbuf = [B][H] initial/final state (parity 0)
     const int* lengths;
-    unsigned long long* hx;       // granules [ndir][nslab][2][16][H], zeroed before every launch
+    unsigned long long* hx;       // granules [ndir][nslab][4*16*H + 8], zeroed before every launch
     int* err;                     // device error word (0 = ok, 1+step = a gather timed out)
     int ndir, B, T, slab0, nslab;
     unsigned max_spin;
+    long long* prof;              // optional [grid][6] cycle sums per phase (debug), else nullptr
 };
 void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, hipStream_t s);
 void mp_launch_pack_whh_persist(const float* whh, float* dst, int H, hipStream_t s);
