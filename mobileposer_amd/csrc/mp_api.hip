@@ -77,6 +77,7 @@ struct ModuleW {
     Packed lin1, ih[2], lin2;
     float* whh[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};    // per-step kernel layout
     float* whhP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // persistent kernel layout
+    float* wihP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // W_ih, persistent kernel layout
 };
 struct ModuleWS {
     float *xproj = nullptr, *out0 = nullptr, *out1 = nullptr;   // X1 (linear1 output) aliases out1
@@ -191,6 +192,8 @@ int pack_weights(mp_handle* h, const float* blob) {
             {
                 if (int rc = dev_alloc(h, (void**)&m.whh[l][d], mp_whh_pack_floats(m.H) * sizeof(float))) return rc;
                 if (int rc = dev_alloc(h, (void**)&m.whhP[l][d], mp_whh_pack_floats(m.H) * sizeof(float))) return rc;
+                const int kin = l == 0 ? m.H : m.dirs * m.H;
+                if (int rc = dev_alloc(h, (void**)&m.wihP[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
             }
     }
     const std::vector<Entry>& man = manifest();
@@ -211,6 +214,7 @@ int pack_weights(mp_handle* h, const float* blob) {
                                    m.ih[l].W, m.ih[l].bias, m.H, m.ih[l].K, m.ih[l].Kpad, d * 4 * m.H, h->s_main);
                 mp_launch_pack_whh(find(s.id, K_WHH, l, d), m.whh[l][d], m.H, h->s_main);
                 mp_launch_pack_whh_persist(find(s.id, K_WHH, l, d), m.whhP[l][d], m.H, h->s_main);
+                mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP[l][d], m.H, m.ih[l].K, h->s_main);
             }
     }
     HIPCHK(h, hipGetLastError());
@@ -399,7 +403,9 @@ int rnn_g0(const RnnJob& j, hipStream_t s) {
     const RowMap none{nullptr, 0, 0, 0};
     float* X1 = w.out1;
     run_gemm(h, s, j.a0, j.a1, m.lin1, X1, H, (long)B * H, M, B, 1);                       // rnn.py:22
-    run_gemm(h, s, internal_map(X1, B, H), none, m.ih[0], w.xproj, dirs * 4 * H, (long)B * dirs * 4 * H, M, B, 0);
+    // the per-step kernels take the input projection from a GEMM; the persistent kernel computes it itself
+    if (!h->persist)
+        run_gemm(h, s, internal_map(X1, B, H), none, m.ih[0], w.xproj, dirs * 4 * H, (long)B * dirs * 4 * H, M, B, 0);
     for (int l = 0; l < 2; ++l)
         for (int d = 0; d < dirs; ++d) {
             const size_t n = (size_t)B * H * sizeof(float);
@@ -407,7 +413,7 @@ int rnn_g0(const RnnJob& j, hipStream_t s) {
             if (j.mode == STATE_FROM) {
                 HIPCHK(h, hipMemcpyAsync(w.hbuf[l][d], j.in_h + (size_t)k * B * H, n, hipMemcpyDeviceToDevice, s));
                 HIPCHK(h, hipMemcpyAsync(w.cbuf[l][d], j.in_c + (size_t)k * B * H, n, hipMemcpyDeviceToDevice, s));
-            } else {
+            } else if (!h->persist) {                                      // persistent kernel: zero_state flag
                 HIPCHK(h, hipMemsetAsync(w.hbuf[l][d], 0, n, s));
                 HIPCHK(h, hipMemsetAsync(w.cbuf[l][d], 0, n, s));
             }
@@ -427,17 +433,26 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         SegScope seg(h, s, 1, T);
         const int nslab = (B + 15) / 16;
         const int chunk = 256 / (dirs * mp_persist_nslice(H));  // slabs per launch: grid <= 256 workgroups, 1 per CU
+        const int kin = l == 0 ? H : dirs * H;
+        const float* xin = l == 0 ? w.out1 /* X1 */ : w.out0;
+        float* outp = l == 0 ? w.out0 : w.out1;
+        // layer 1 overwrites out1, which still holds X1 while layer 0 runs -- layer 0 has finished by then
         for (int s0 = 0; s0 < nslab; s0 += chunk) {
             LstmPersistArgs a;
             a.lengths = j.p->lengths_dev; a.ndir = dirs; a.B = B; a.T = T;
             a.slab0 = s0; a.nslab = nslab - s0 < chunk ? nslab - s0 : chunk;
             a.hx = w.hx + (size_t)dirs * s0 * ((size_t)4 * 16 * H + 8);
             a.err = h->err_dev; a.max_spin = 1u << 18; a.prof = h->prof_dev;
-            for (int d = 0; d < dirs; ++d)
-                a.d[d] = LstmDir{m.whhP[l][d], w.xproj + (size_t)d * 4 * H, out + (size_t)d * H, w.hbuf[l][d], w.cbuf[l][d],
-                                 dirs * 4 * H, dirs * H, d};
+            a.zero_state = j.mode == STATE_ZERO ? 1 : 0;
+            for (int d = 0; d < dirs; ++d) {
+                LstmDir& dd = a.d[d];
+                dd.wpack = m.whhP[l][d]; dd.xproj = nullptr; dd.out = outp + (size_t)d * H;
+                dd.hbuf = w.hbuf[l][d]; dd.cbuf = w.cbuf[l][d];
+                dd.xprojStride = 0; dd.outStride = dirs * H; dd.reverse = d;
+                dd.wihpack = m.wihP[l][d]; dd.bias = m.ih[l].bias + (size_t)d * 4 * H; dd.xin = xin;
+            }
             if (dirs == 1) a.d[1] = a.d[0];
-            mp_launch_lstm_persist(a, H, s);
+            mp_launch_lstm_persist(a, H, kin, s);
         }
     } else {
         SegScope seg(h, s, 1, T);
@@ -445,7 +460,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         a.lengths = j.p->lengths_dev; a.ndir = dirs; a.B = B; a.T = T;
         for (int d = 0; d < dirs; ++d)
             a.d[d] = LstmDir{m.whh[l][d], w.xproj + (size_t)d * 4 * H, out + (size_t)d * H, w.hbuf[l][d], w.cbuf[l][d],
-                             dirs * 4 * H, dirs * H, d};
+                             dirs * 4 * H, dirs * H, d, nullptr, nullptr, nullptr};
         if (dirs == 1) a.d[1] = a.d[0];
         for (int step = 0; step < T; ++step) {
             a.step = step;
@@ -462,7 +477,8 @@ int rnn_g1(const RnnJob& j, hipStream_t s) {
     ModuleWS& w = j.p->ws[j.id];
     const int B = j.p->B, T = j.p->T, M = B * T, H = m.H, dirs = m.dirs;
     const RowMap none{nullptr, 0, 0, 0};
-    run_gemm(h, s, internal_map(w.out0, B, dirs * H), none, m.ih[1], w.xproj, dirs * 4 * H, (long)B * dirs * 4 * H, M, B, 0);
+    if (!h->persist)
+        run_gemm(h, s, internal_map(w.out0, B, dirs * H), none, m.ih[1], w.xproj, dirs * 4 * H, (long)B * dirs * 4 * H, M, B, 0);
     HIPCHK(h, hipGetLastError());
     return MP_OK;
 }
@@ -524,46 +540,44 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
     RnnJob V{h, p, MP_MOD_VELOCITY, xj, xi, vel, (long)T * 72, 72, has_state ? STATE_FROM : STATE_ZERO, vs.h, vs.c, vs.h, vs.c};
     RnnJob F{h, p, MP_MOD_FOOT_CONTACT, xj, xi, contact, (long)T * 2, 2, STATE_ZERO, nullptr, nullptr, nullptr, nullptr};
     hipStream_t sm = h->s_main, sp = h->s_gp, sv = h->s_vel, sf = h->s_foot;
-    auto link = [&](hipEvent_t ev, hipStream_t from, hipStream_t to) -> int {
-        HIPCHK(h, hipEventRecord(ev, from));
-        HIPCHK(h, hipStreamWaitEvent(to, ev, 0));
-        return MP_OK;
-    };
 #define RC(x) do { if (int rc_ = (x)) return rc_; } while (0)
     // joints(batch)                                                                       net.py:103
     RC(run_rnn(J, sm));
     HIPCHK(h, hipEventRecord(h->ev_j, sm));
     HIPCHK(h, hipStreamWaitEvent(sv, h->ev_j, 0));
     HIPCHK(h, hipStreamWaitEvent(sf, h->ev_j, 0));
-    // foot_contact(cat(pred_joints, batch))                                               net.py:113-114
-    RC(run_rnn(F, sf));
-    HIPCHK(h, hipEventRecord(h->ev_f, sf));
     if (!h->persist) {
-        // per-step kernels have no cross-workgroup waits: pose and velocity simply run side by side
+        // per-step kernels have no cross-workgroup waits: the three remaining blocks simply run side by side
+        RC(run_rnn(F, sf));                                                               // net.py:113-114
+        HIPCHK(h, hipEventRecord(h->ev_f, sf));
         RC(run_rnn(P, sm));                                                               // net.py:106-107
         { SegScope seg(h, sm, 2, 1);
           mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sm); }   // net.py:110
         RC(run_rnn(V, sv));                                                               // net.py:117
         HIPCHK(h, hipEventRecord(h->ev_v, sv));
     } else {
+        // Persistent fused layers: the H = 256 grids are made of clusters of 8 workgroups that wait on each
+        // other and want a whole CU each (160 KB LDS), so they run strictly one after another on s_main;
+        // pose fills the chip (256 workgroups), velocity only half of it, and the foot-contact layers (H = 64:
+        // one workgroup per slab, waits on nobody) run beside velocity on the free CUs.  linear1 / linear2
+        // GEMMs and the r6d/IK kernel go to side streams.
         auto rec = [&](int i, hipStream_t on) -> int { HIPCHK(h, hipEventRecord(h->ev_x[i], on)); return MP_OK; };
         auto wait = [&](int i, hipStream_t on) -> int { HIPCHK(h, hipStreamWaitEvent(on, h->ev_x[i], 0)); return MP_OK; };
         HIPCHK(h, hipStreamWaitEvent(sp, h->ev_j, 0));
-        RC(rnn_g0(P, sp));      RC(rec(0, sp));                  // pose GEMMs      | s_gp
-        RC(rnn_g0(V, sv));      RC(rec(1, sv));                  // velocity GEMMs  | s_vel
-        RC(wait(0, sm)); RC(rnn_rec(P, 0, sm)); RC(rec(2, sm));  // recurrences     | s_main, strictly serial
-        RC(wait(2, sp)); RC(rnn_g1(P, sp));     RC(rec(3, sp));
-        RC(wait(1, sm)); RC(rnn_rec(V, 0, sm)); RC(rec(4, sm));  // overlaps pose's W_ih(l1) GEMM
-        RC(wait(4, sv)); RC(rnn_g1(V, sv));     RC(rec(5, sv));
-        RC(wait(3, sm)); RC(rnn_rec(P, 1, sm)); RC(rec(6, sm));  // overlaps velocity's W_ih(l1) GEMM
-        RC(wait(6, sp)); RC(rnn_g2(P, sp));                                               // net.py:107
+        RC(rnn_g0(P, sp)); RC(rec(0, sp));                       // linear1 of the three blocks, concurrently
+        RC(rnn_g0(V, sv)); RC(rec(1, sv));
+        RC(rnn_g0(F, sf));
+        RC(wait(0, sm)); RC(rnn_rec(P, 0, sm)); RC(rnn_rec(P, 1, sm)); RC(rec(2, sm));      // net.py:106-107
+        RC(wait(2, sp)); RC(rnn_g2(P, sp));
         { SegScope seg(h, sp, 2, 1);
           mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sp); }   // net.py:110
-        RC(rec(7, sp));
-        RC(wait(5, sm)); RC(rnn_rec(V, 1, sm)); RC(rec(8, sm));
-        RC(wait(8, sv)); RC(rnn_g2(V, sv));                                               // net.py:117
-        RC(wait(7, sm));
+        RC(rec(3, sp));
+        RC(wait(1, sm)); RC(rnn_rec(V, 0, sm)); RC(rnn_rec(V, 1, sm)); RC(rec(4, sm));      // net.py:117
+        RC(wait(4, sv)); RC(rnn_g2(V, sv));
         HIPCHK(h, hipEventRecord(h->ev_v, sv));
+        RC(wait(2, sf)); RC(rnn_rec(F, 0, sf)); RC(rnn_rec(F, 1, sf)); RC(rnn_g2(F, sf));   // net.py:113-114
+        HIPCHK(h, hipEventRecord(h->ev_f, sf));
+        RC(wait(3, sm));
     }
 #undef RC
     HIPCHK(h, hipStreamWaitEvent(sm, h->ev_v, 0));
@@ -651,6 +665,7 @@ void mp_destroy(mp_handle* h) {
         for (int l = 0; l < 2; ++l) for (int d = 0; d < 2; ++d) {
             if (m.whh[l][d]) (void)hipFree(m.whh[l][d]);
             if (m.whhP[l][d]) (void)hipFree(m.whhP[l][d]);
+            if (m.wihP[l][d]) (void)hipFree(m.wihP[l][d]);
         }
     }
     void* misc[] = {h->parent_dev, h->depth_dev, h->bone_dev, h->vstate.h, h->vstate.c, h->sc.window, h->sc.fresh,

@@ -33,12 +33,16 @@ int mp_gemm_pick_bn(int N);
 
 // ---------------------------------------------------------------- K2: LSTM recurrence step
 struct LstmDir {
-    const float* wpack;   // W_hh in MFMA B-fragment order (see mp_lstm.hip)
-    const float* xproj;   // [T*B][xprojStride] gate-interleaved (4*j+g), bias folded in; column offset applied
+    const float* wpack;   // W_hh in MFMA B-fragment order (per-step layout: mp_lstm.hip; persistent: mp_lstm_persist.hip)
+    const float* xproj;   // per-step kernel: [T*B][xprojStride] gate-interleaved (4*j+g) pre-activations, bias folded in
     float* out;           // [T*B][outStride], column offset applied
-    float* hbuf;          // [2][B][H] ping-pong hidden state
+    float* hbuf;          // per-step: [2][B][H] ping-pong hidden state; persistent: [B][H] initial/final state
     float* cbuf;          // [B][H]
     int xprojStride, outStride, reverse;
+    // fused persistent kernel only
+    const float* wihpack; // W_ih in B-fragment order (mp_pack_wih_persist)
+    const float* bias;    // [4H] gate-interleaved b_ih + b_hh of this direction
+    const float* xin;     // layer input, time-major [T][B][K_in]
 };
 struct LstmStepArgs {
     LstmDir d[2];
@@ -57,16 +61,18 @@ void mp_launch_pack_linear(const float* w, const float* b, float* dstW, float* d
 // persistent variant (mp_lstm_persist.hip): one launch = all T steps of <= 2 directions for `nslab` slabs
 // of 16 sequences starting at slab `slab0`; grid = nslab * NSLICE x ndir workgroups, all co-resident.
 struct LstmPersistArgs {
-    LstmDir d[2];                 // wpack in the persistent layout; hbuf = [B][H] initial/final state (parity 0)
+    LstmDir d[2];
     const int* lengths;
     unsigned long long* hx;       // granules [ndir][nslab][4*16*H + 8], zeroed before every launch
     int* err;                     // device error word (0 = ok, 1+step = a gather timed out)
     int ndir, B, T, slab0, nslab;
+    int zero_state;               // 1: start from h = c = 0 without reading hbuf / cbuf
     unsigned max_spin;
     long long* prof;              // optional [grid][6] cycle sums per phase (debug), else nullptr
 };
-void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, hipStream_t s);
+void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, hipStream_t s);
 void mp_launch_pack_whh_persist(const float* whh, float* dst, int H, hipStream_t s);
+void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, hipStream_t s);
 int mp_persist_nslice(int H);
 
 // ---------------------------------------------------------------- K4/K5: kinematics

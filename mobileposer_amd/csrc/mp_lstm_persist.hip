@@ -1,24 +1,32 @@
-// K2p -- persistent nn.LSTM recurrence (models/rnn.py:27): ONE launch walks all T time steps of up to two
-// (layer, direction) instances.  Same arithmetic, gate order and packed-sequence semantics as the per-step
-// kernel in mp_lstm.hip (which stays as the reference implementation / fallback); what changes is where
-// the data lives between steps:
+// K2 -- persistent, fused nn.LSTM layer (models/rnn.py:27): ONE launch computes, for all T time steps of up to
+// two directions,   gates_t = x_t W_ih^T + (b_ih + b_hh) + h_{t-1} W_hh^T ;  i,f,g,o = s,s,tanh,s ;
+//                   c_t = f c_{t-1} + i g ;  h_t = o tanh(c_t)            (PyTorch gate order i,f,g,o)
+// with packed-sequence semantics (rnn.py:25-31): sequence b is active for steps s < len_b, forward
+// visits t = s, reverse t = len_b-1-s, inactive rows keep (h,c) and the padded output position is written 0.
 //
-//   * W_hh never leaves the register file.  A workgroup owns (direction, slab of 16 sequences, slice of
-//     U hidden units); its 4 waves split K = H four ways, so a lane holds 4U/16 * H/16 weight values
-//     (128 VGPRs for H = 256, U = 32; 64 for H = 64, U = 64), loaded once in B-fragment order.
-//   * c_t, and h_t of the lane's own (sequence, unit), stay in registers for all T steps.
-//   * h_t crosses workgroups (the 8 slices of a slab need each other's units every step) as 8-byte
-//     {epoch, value} granules: one relaxed agent-scope (sc1) store per value, and the consumer lane that
-//     needs the value as an MFMA A operand re-reads its 16 granules until every tag equals the step's
-//     epoch -- the data is its own flag, so there is no fence, no barrier and no separate flag word
-//     (cdna_hip_programming.md Guideline 16, form R2; placement independent).  Two parities suffice: a
-//     producer can only be one step ahead of its slowest peer.  Gathered values feed
-//     v_mfma_f32_16x16x4_f32 straight from the load registers (no LDS staging).
-//   * The 4 K-partials meet in LDS; each wave finishes a quarter of the (sequence, unit) pairs, so the
-//     cell update is spread over all lanes.
+// Why fused and persistent (gfx950): the recurrence is a chain of T dependent steps, each a tiny GEMM, so
+// a step is latency-bound (hidden state must cross workgroups) while the input projection is a big
+// MFMA-bound GEMM with no dependence on h.  Doing both in one persistent kernel lets the x_t W_ih^T MFMAs
+// of step t run exactly where the kernel would otherwise sit waiting for h_{t-1} from its peers, and
+// removes the [B*T, 4H] gate pre-activation round trip through HBM (2 KB/frame/direction written + read).
 //
-// Per step the critical path is: granule visibility (~1 us) -> 128 MFMAs per wave (1.7 us) -> LDS
-// reduction + cell update (~0.3 us) instead of a kernel boundary + a full 128 KB weight re-read.
+// Mapping: a workgroup owns (direction, slab of 16 sequences = the M of v_mfma_f32_16x16x4_f32, slice of
+// U hidden units); its 4 waves split every K range four ways.  Everything a step needs stays on chip:
+//   * W_hh slice: registers (H=256, U=32: 128 VGPRs per lane), loaded once in B-fragment order;
+//   * W_ih slice: LDS (up to 128 KB as 16-byte B-fragment groups) and, when K_in = 2H, the rest in registers;
+//   * c_t and the lane's own h_t: registers for all T steps;
+//   * x_{t+1}: prefetched from HBM into registers while step t finishes (16-byte loads, 64-byte segments).
+// h_t crosses workgroups (the NSLICE slices of a slab need each other's units every step) as 8-byte
+// {epoch, value} granules -- the data is its own flag, no fence / barrier / flag word (cdna_hip_programming.md
+// Guideline 16, form R2).  Two transports, chosen per PRODUCER from where it really runs (its XCC id,
+// published once at kernel start), so the result never depends on placement, only the speed does:
+//   R: write-through (sc1) stores + sc1 loads -- coherent for any placement (fabric round trip, ~1 us);
+//   L: ordinary stores + L1-bypassing (sc1) loads -- producer and consumer share an XCD (one L2), ~4x faster.
+// Granules are laid out [unit/4][row][unit%4] so a consumer wave's 64 lanes (16 rows x 4 consecutive units)
+// read 512 contiguous bytes per instruction and feed the MFMA A operand straight from the load registers.
+// They are requested half-way through the x-projection MFMAs and validated before use, so their latency is
+// normally hidden; a stale granule falls back to a bounded poll (cheap gate + sweep).  The 4 K-partials
+// meet in LDS and every wave finishes a quarter of the (sequence, unit) pairs.
 // All workgroups of a launch must be co-resident (grid <= 256, one per CU); every spin is bounded and a
 // timeout raises a device-side error word instead of hanging the GPU.
 #include "mp_common.h"
@@ -26,7 +34,6 @@
 namespace {
 
 typedef unsigned long long u64;
-typedef __attribute__((address_space(1))) u64 gu64;
 
 // v_exp_f32 / v_rcp_f32 are 1-ulp instructions: sigma and tanh come out within ~2e-7 absolute of libm
 __device__ __forceinline__ float sigmoidf_(float x) {
@@ -36,8 +43,7 @@ __device__ __forceinline__ float tanhf_(float x) {
     const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * x);
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
-// granule index of (row, hidden unit j) inside one [16][H] slab-parity block: [j/4][row][j%4], so that the
-// 64 lanes of a consumer wave (16 rows x 4 consecutive units) read 512 contiguous bytes per instruction
+// granule index of (row, hidden unit j) inside one [16][H] slab-parity block
 __device__ __forceinline__ int granule_index(int row, int j) { return (((j >> 2) * 16 + row) << 2) + (j & 3); }
 
 __device__ __forceinline__ u64 granule_load(const u64* p) {
@@ -46,8 +52,7 @@ __device__ __forceinline__ u64 granule_load(const u64* p) {
 __device__ __forceinline__ void granule_store(u64* p, unsigned epoch, float v) {
     __hip_atomic_store(p, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// same 8-byte granule as an ordinary store: it goes through the (write-through) L1 into THIS XCD's L2 and stays
-// there, where a consumer on the same XCD finds it with an L1-bypassing (sc1) load at L2-hit latency
+// same granule as an ordinary store: through the write-through L1 into THIS XCD's L2, where it stays
 __device__ __forceinline__ void granule_store_l2(u64* p, unsigned epoch, float v) {
     __hip_atomic_store(p, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -56,23 +61,39 @@ __device__ __forceinline__ unsigned xcc_id() {
 }
 constexpr unsigned XCC_TAG = 0x7fffffffu;
 
-// H: hidden size; NSLICE: workgroups sharing one slab (8 for H = 256, 1 for H = 64)
-template <int H, int NSLICE>
-__global__ __launch_bounds__(256, 1) void mp_lstm_persist(LstmPersistArgs a) {
-    constexpr int U = H / NSLICE;              // hidden units per workgroup (32 | 64)
-    constexpr int NUB = U / 16;                // 16-unit blocks per workgroup (2 | 4)
-    constexpr int NT = 4 * NUB;                // MFMA tiles per wave: gates x unit blocks (8 | 16)
-    constexpr int KW = H / 4;                  // K range of one wave (64 | 16)
-    constexpr int NKS = KW / 4;                // k-steps per wave (16 | 4)
-    constexpr int NOWN = NUB == 2 ? 2 : 4;     // accumulator regs a lane finishes
-    // reduction scratch: red[parity][dst wave][src wave][o][lane] of float4 (i,f,g,o partial sums)
-    __shared__ __attribute__((aligned(16))) float red[2 * 4 * 4 * 4 * NOWN * 64];
+template <int H, int NSLICE, int KIN>
+struct Cfg {
+    static constexpr int U = H / NSLICE;              // hidden units per workgroup (32 | 64)
+    static constexpr int NUB = U / 16;                // 16-unit blocks per workgroup (2 | 4)
+    static constexpr int NT = 4 * NUB;                // MFMA tiles per wave: gates x unit blocks (8 | 16)
+    static constexpr int NTG = NT / 4;                // 16-byte groups of 4 tiles (2 | 4)
+    static constexpr int KW = H / 4;                  // h: K range of one wave (64 | 16)
+    static constexpr int NKS = KW / 4;                // h: k-steps per wave (16 | 4)
+    static constexpr int KQ = KIN / 4;                // x: K range of one wave
+    static constexpr int NXS = KQ / 4;                // x: k-steps per wave (16|32 for H=256, 4|8 for H=64)
+    static constexpr int NXJ = KQ / 16;               // x: 16-byte loads per lane per step
+    static constexpr int NOWN = NUB == 2 ? 2 : 4;     // accumulator regs a lane finishes
+    static constexpr int RED_F4 = 4 * 4 * NOWN * 64;  // float4 slots of the reduction scratch
+    // LDS budget 160 KB: reduction scratch + as many x k-steps of W_ih as fit; the rest lives in registers
+    static constexpr int STEP_BYTES = 4 * NTG * 64 * 16;                      // all 4 waves, one k-step
+    static constexpr int LDS_STEPS_MAX = (160 * 1024 - RED_F4 * 16) / STEP_BYTES;
+    static constexpr int XL = NXS <= LDS_STEPS_MAX ? NXS : (LDS_STEPS_MAX / 4) * 4;  // x k-steps served from LDS
+    static constexpr int XR = NXS - XL;                                        // x k-steps served from registers
+};
+
+template <int H, int NSLICE, int KIN, bool PROF>
+__global__ __launch_bounds__(256, 1) void mp_lstm_fused(LstmPersistArgs a) {
+    using C = Cfg<H, NSLICE, KIN>;
+    constexpr int U = C::U, NUB = C::NUB, NT = C::NT, NTG = C::NTG, KW = C::KW, NKS = C::NKS, KQ = C::KQ;
+    constexpr int NXS = C::NXS, NXJ = C::NXJ, NOWN = C::NOWN, XL = C::XL, XR = C::XR;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* red = reinterpret_cast<f32x4*>(smem);                       // [dst wave][src wave][o][lane]
+    f32x4* wxl = reinterpret_cast<f32x4*>(smem) + C::RED_F4;           // [wave][x-step < XL][tile group][lane]
 
     const LstmDir d = a.d[blockIdx.y];
     int slab, slice;
     if (NSLICE == 8 && (a.nslab & 7) == 0) {
-        // keep the 8 slices of a slab on one XCD (block b runs on XCD b % 8): faster hand-off, never needed
-        // for correctness
+        // keep the 8 slices of a slab on one XCD (block b runs on XCD b % 8): speed only, never correctness
         const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
         slab = (i >> 3) * 8 + xcd;
         slice = i & 7;
@@ -85,7 +106,21 @@ __global__ __launch_bounds__(256, 1) void mp_lstm_persist(LstmPersistArgs a) {
     const int B = a.B, T = a.T;
     const int brow0 = (a.slab0 + slab) * 16;
 
-    // ---- W_hh slice -> registers (once).  wv[ks][t]: tile t = g*NUB + ub
+    // ---- W_ih slice: k-steps [0, XL) -> LDS, [XL, NXS) -> registers; W_hh slice -> registers
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(d.wihpack) + (size_t)slice * 4 * NXS * NTG * 64;
+        for (int w = 0; w < 4; ++w)
+            for (int i = threadIdx.x; i < XL * NTG * 64; i += 256)
+                wxl[(size_t)w * XL * NTG * 64 + i] = src[(size_t)w * NXS * NTG * 64 + i];
+    }
+    f32x4 wxr[XR > 0 ? XR : 1][NTG];
+    if (XR > 0) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(d.wihpack) + ((size_t)(slice * 4 + wave) * NXS + XL) * NTG * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < XR; ++s)
+#pragma unroll
+            for (int tg = 0; tg < NTG; ++tg) wxr[s][tg] = src[(size_t)(s * NTG + tg) * 64];
+    }
     float wv[NKS][NT];
     {
         const float* wp = d.wpack + ((size_t)(slice * 4 + wave) * NKS * NT) * 64 + lane;
@@ -99,6 +134,7 @@ __global__ __launch_bounds__(256, 1) void mp_lstm_persist(LstmPersistArgs a) {
     const int ubo = NUB == 2 ? (wave & 1) : wave;          // unit block this wave finishes
     const int reg0 = NUB == 2 ? 2 * (wave >> 1) : 0;       // first accumulator reg it finishes
     const int jown = slice * U + ubo * 16 + r16;           // hidden unit
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(d.bias + 4 * jown);
     float cst[NOWN], hst[NOWN];
     int blen[NOWN], bidx[NOWN];
 #pragma unroll
@@ -107,25 +143,26 @@ __global__ __launch_bounds__(256, 1) void mp_lstm_persist(LstmPersistArgs a) {
         bidx[o] = b;
         const bool inb = b < B;
         blen[o] = inb ? a.lengths[b] : 0;
-        cst[o] = inb ? d.cbuf[(size_t)b * H + jown] : 0.f;
-        hst[o] = inb ? d.hbuf[(size_t)b * H + jown] : 0.f;
+        cst[o] = (inb && !a.zero_state) ? d.cbuf[(size_t)b * H + jown] : 0.f;
+        hst[o] = (inb && !a.zero_state) ? d.hbuf[(size_t)b * H + jown] : 0.f;
     }
 
-    // ---- A operand for step 0 from the initial state: h0[row r16][k = wave*KW + 4*ks + q]
+    // ---- A-operand row of this lane (row r16 of the slab): its sequence, length, x pointer pieces
+    const int arow = brow0 + r16;
+    const bool arow_in = arow < B;
+    const int alen = arow_in ? a.lengths[arow] : 0;
+    const float* xbase = d.xin + (size_t)(arow_in ? arow : 0) * KIN + wave * KQ + q * 4;
+    const size_t xtstride = (size_t)B * KIN;
+
+    // A operand of the recurrent part for step 0 from the initial state: h0[row r16][k = wave*KW + 4*ks + q]
     float av[NKS];
     {
-        const int b = brow0 + r16;
-        const float* p = d.hbuf + (size_t)(b < B ? b : 0) * H + wave * KW + q;
+        const float* p = d.hbuf + (size_t)(arow_in ? arow : 0) * H + wave * KW + q;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) av[ks] = b < B ? p[4 * ks] : 0.f;
+        for (int ks = 0; ks < NKS; ++ks) av[ks] = (arow_in && !a.zero_state) ? p[4 * ks] : 0.f;
     }
 
-    // granules of this slab: hx[dir][slab] = { L[2 parities][16*H], R[2 parities][16*H], xcc[8] }.
-    // Two transports, chosen per PRODUCER from where it really runs (its XCC id, published once):
-    //   R: write-through (sc1) stores + sc1 loads -- coherent for any placement, a fabric round trip (~1 us);
-    //   L: ordinary stores + sc1 loads -- only when producer and consumer share an XCD (one L2), ~4x faster.
-    // A producer always fills L and fills R unless every slice of its slab is on its own XCD, so the result
-    // never depends on placement -- only the speed does (cdna_hip_programming.md Guideline 16).
+    // granules of this slab: hx[dir][slab] = { L[2 parities][16*H], R[2 parities][16*H], xcc[8] }
     constexpr size_t SLABW = (size_t)4 * 16 * H + 8;
     u64* hxL = a.hx + (size_t)(blockIdx.y * a.nslab + slab) * SLABW;
     u64* hxR = hxL + (size_t)2 * 16 * H;
@@ -150,94 +187,123 @@ __global__ __launch_bounds__(256, 1) void mp_lstm_persist(LstmPersistArgs a) {
         all_local = (same & ((1ull << NSLICE) - 1)) == ((1ull << NSLICE) - 1);
         src_local[0] = (same >> (2 * wave)) & 1;           // k-steps 0..NKS/2-1 come from slice 2*wave
         src_local[1] = (same >> (2 * wave + 1)) & 1;       // the rest from slice 2*wave+1
-        if (peer == ~0u) spin_budget = 0;
+        if (__ballot(peer == ~0u)) spin_budget = 0;
     }
 
+    // ---- x_0: this lane's A values of the input projection, k = wave*KQ + j*16 + q*4 + i  (x-step s = 4j+i)
+    f32x4 xa[NXJ];
+    auto load_x = [&](int step) {
+        const bool on = step < alen;
+        const int t = on ? (d.reverse ? alen - 1 - step : step) : 0;
+        const float* p = xbase + (size_t)t * xtstride;
+#pragma unroll
+        for (int j = 0; j < NXJ; ++j) xa[j] = on ? *reinterpret_cast<const f32x4*>(p + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    load_x(0);
+    __syncthreads();                                          // W_ih LDS image complete
+
     long long pt[6] = {0, 0, 0, 0, 0, 0};
-    const bool prof = a.prof != nullptr && threadIdx.x == 0;
-#define PROF_T(i) do { if (prof) pt[i] -= (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#define PROF_E(i) do { if (prof) pt[i] += (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    const bool prof = PROF && a.prof != nullptr && threadIdx.x == 0;
+#define PROF_T(i) do { if (PROF && prof) pt[i] -= (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define PROF_E(i) do { if (PROF && prof) pt[i] += (long long)__builtin_amdgcn_s_memtime(); } while (0)
+
+    const f32x4* wxw = wxl + (size_t)wave * XL * NTG * 64 + lane;
+
     for (int step = 0; step < T; ++step) {
         PROF_T(0);
-        // ---- gate pre-activations from the input projection (issued early; consumed after the MFMAs)
-        f32x4 xp[NOWN];
-        int tt[NOWN];
-        bool act[NOWN];
+        f32x4 acc[NT];
 #pragma unroll
-        for (int o = 0; o < NOWN; ++o) {
-            act[o] = step < blen[o];
-            tt[o] = act[o] ? (d.reverse ? blen[o] - 1 - step : step) : step;
-            xp[o] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (act[o])
-                xp[o] = *reinterpret_cast<const f32x4*>(d.xproj + ((size_t)tt[o] * B + bidx[o]) * d.xprojStride + 4 * jown);
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ---- first half of x_t W_ih^T (independent of h: this is what fills the wait for the peers)
+#pragma unroll
+        for (int s = 0; s < NXS / 2; ++s) {
+            const float a_s = xa[s >> 2][s & 3];
+#pragma unroll
+            for (int tg = 0; tg < NTG; ++tg) {
+                const f32x4 w4 = s < XL ? wxw[(size_t)(s * NTG + tg) * 64] : wxr[s >= XL ? s - XL : 0][tg];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[tg * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, w4[i], acc[tg * 4 + i], 0, 0, 0);
+            }
         }
 
-        // ---- gather h_{step-1} and multiply.  The lane's A value for k-step ks is granule
-        //      (row r16, unit wave*KW + 4*ks + q): one coalesced 512-byte read per instruction.
-        f32x4 acc[NT];
+        // ---- request h_{step-1}: granule (row r16, unit wave*KW + 4*ks + q), 512 contiguous bytes per instruction
+        u64 gr[NKS];
+        const unsigned epoch = (unsigned)step;                 // written by the producers at the end of step-1
+        const size_t goff = (size_t)((step + 1) & 1) * 16 * H + (size_t)wave * NKS * 64 + r16 * 4 + q;
+        const u64* src0 = (src_local[0] ? hxL : hxR) + goff;
+        const u64* src1 = NSLICE > 1 ? (src_local[1] ? hxL : hxR) + goff : src0;
         if (step > 0) {
-            const unsigned epoch = (unsigned)step;            // written by the producers at the end of step-1
-            const size_t goff = (size_t)((step - 1) & 1) * 16 * H + (size_t)wave * NKS * 64 + r16 * 4 + q;
-            const u64* src0 = (src_local[0] ? hxL : hxR) + goff;
-            const u64* src1 = NSLICE > 1 ? (src_local[1] ? hxL : hxR) + goff : src0;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) gr[ks] = granule_load((ks < NKS / 2 ? src0 : src1) + (size_t)ks * 64);
+        }
+        // ---- second half of the input projection
+#pragma unroll
+        for (int s = NXS / 2; s < NXS; ++s) {
+            const float a_s = xa[s >> 2][s & 3];
+#pragma unroll
+            for (int tg = 0; tg < NTG; ++tg) {
+                const f32x4 w4 = s < XL ? wxw[(size_t)(s * NTG + tg) * 64] : wxr[s >= XL ? s - XL : 0][tg];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[tg * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, w4[i], acc[tg * 4 + i], 0, 0, 0);
+            }
+        }
+        load_x(step + 1);                                      // prefetch next step's x (lands during this step)
+        PROF_E(0); PROF_T(1);
+
+        // ---- validate the granules; the slow path (cheap gate, then sweep) only runs when some were stale
+        if (step > 0) {
+            bool ok = true;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) ok = ok && ((unsigned)(gr[ks] >> 32) == epoch);
             unsigned spins = 0;
             bool timed_out = false;
-            // (1) cheap gate: 4 lanes per wave watch ONE granule each (all lanes x all granules would flood the
-            //     fabric with sc1 loads and slow every hand-off on the chip: MI355X_MICROARCH "polling-cost")
-            while (true) {
-                bool ready = true;
-                if (r16 == 0) ready = (unsigned)(granule_load(src0) >> 32) == epoch;
-                if (r16 == 1) ready = (unsigned)(granule_load(src1 + (size_t)(NKS / 2) * 64) >> 32) == epoch;
-                if (__all(ready)) break;
-                if (++spins > spin_budget) { timed_out = true; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            PROF_E(0); PROF_T(1);
-            // (2) speculative sweep: issue all loads, run the MFMAs as the values land, validate the tags last;
-            //     a stale granule (rare once the gate has opened) just repeats the sweep
-            while (true) {
-                u64 gr[NKS];
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) gr[ks] = granule_load((ks < NKS / 2 ? src0 : src1) + (size_t)ks * 64);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                bool ok = true;
+            while (!__all(ok) && !timed_out) {
+                // gate: 2 lanes per wave watch ONE granule of each producer (polling with everything floods the
+                // fabric with sc1 loads and slows every hand-off on the chip: MI355X_MICROARCH "polling-cost")
+                while (true) {
+                    bool ready = true;
+                    if (lane == 0) ready = (unsigned)(granule_load(src0) >> 32) == epoch;
+                    if (lane == 1) ready = (unsigned)(granule_load(src1 + (size_t)(NKS / 2) * 64) >> 32) == epoch;
+                    if (__all(ready)) break;
+                    if (++spins > spin_budget) { timed_out = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                ok = true;
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
-                    const float a_s = __uint_as_float((unsigned)gr[ks]);
+                    gr[ks] = granule_load((ks < NKS / 2 ? src0 : src1) + (size_t)ks * 64);
                     ok = ok && ((unsigned)(gr[ks] >> 32) == epoch);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, wv[ks][t], acc[t], 0, 0, 0);
                 }
-                if (__all(ok) || timed_out) break;
-                if (++spins > spin_budget) { timed_out = true; break; }
-                __builtin_amdgcn_s_sleep(1);
+                if (++spins > spin_budget) timed_out = true;
             }
-            if (timed_out) {                                  // bounded: flag the error and never wait again
+            if (timed_out) {                                   // bounded: flag the error and never wait again
                 if (lane == 0) atomicExch(a.err, 1 + step);
                 spin_budget = 0;
             }
-        } else {
-            PROF_E(0); PROF_T(1);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], wv[ks][t], acc[t], 0, 0, 0);
+            for (int ks = 0; ks < NKS; ++ks) av[ks] = __uint_as_float((unsigned)gr[ks]);
         }
         PROF_E(1); PROF_T(2);
-        // ---- K reduction through LDS (double-buffered by step parity: one barrier per step).  Every wave
-        // drops, for each finishing wave dw (itself included, so that all register indices stay compile-time
-        // constants), the 4 gate values of the accumulator regs dw finishes as one 16-byte store.
-        f32x4* redp = reinterpret_cast<f32x4*>(red) + (size_t)(step & 1) * (4 * 4 * NOWN * 64);
+
+        // ---- recurrent part: h_{t-1} W_hh^T on top of the input projection
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], wv[ks][t], acc[t], 0, 0, 0);
+        PROF_E(2); PROF_T(3);
+
+        // ---- K reduction through LDS.  Every wave drops, for each finishing wave dw (itself included, so that
+        // all register indices stay compile-time constants), the 4 gate values of the regs dw finishes.
+        __syncthreads();                                       // previous step's reads of `red` are done
 #pragma unroll
         for (int dw = 0; dw < 4; ++dw) {
             const int dub = NUB == 2 ? (dw & 1) : dw;
             const int dreg0 = NUB == 2 ? 2 * (dw >> 1) : 0;
 #pragma unroll
             for (int o = 0; o < NOWN; ++o)
-                redp[((dw * 4 + wave) * NOWN + o) * 64 + lane] =
+                red[((dw * 4 + wave) * NOWN + o) * 64 + lane] =
                     f32x4{acc[0 * NUB + dub][dreg0 + o], acc[1 * NUB + dub][dreg0 + o], acc[2 * NUB + dub][dreg0 + o],
                           acc[3 * NUB + dub][dreg0 + o]};
         }
@@ -245,23 +311,25 @@ __global__ __launch_bounds__(256, 1) void mp_lstm_persist(LstmPersistArgs a) {
         f32x4 gate[NOWN];
 #pragma unroll
         for (int o = 0; o < NOWN; ++o) {
-            f32x4 v = redp[((wave * 4 + 0) * NOWN + o) * 64 + lane];
+            f32x4 v = red[((wave * 4 + 0) * NOWN + o) * 64 + lane];
 #pragma unroll
-            for (int sw = 1; sw < 4; ++sw) v += redp[((wave * 4 + sw) * NOWN + o) * 64 + lane];
-            gate[o] = v;
+            for (int sw = 1; sw < 4; ++sw) v += red[((wave * 4 + sw) * NOWN + o) * 64 + lane];
+            gate[o] = v + bias4;
         }
-
         PROF_E(3); PROF_T(4);
+
         // ---- cell update (register-local), publish h_step, write the layer output
         const size_t doff = (size_t)(step & 1) * 16 * H;
 #pragma unroll
         for (int o = 0; o < NOWN; ++o) {
+            const bool act = step < blen[o];
+            const int tt = act ? (d.reverse ? blen[o] - 1 - step : step) : step;
             float oval = 0.f;
-            if (act[o]) {
-                const float ig = sigmoidf_(gate[o][0] + xp[o][0]);
-                const float fg = sigmoidf_(gate[o][1] + xp[o][1]);
-                const float gg = tanhf_(gate[o][2] + xp[o][2]);
-                const float og = sigmoidf_(gate[o][3] + xp[o][3]);
+            if (act) {
+                const float ig = sigmoidf_(gate[o][0]);
+                const float fg = sigmoidf_(gate[o][1]);
+                const float gg = tanhf_(gate[o][2]);
+                const float og = sigmoidf_(gate[o][3]);
                 cst[o] = fg * cst[o] + ig * gg;
                 hst[o] = og * tanhf_(cst[o]);
                 oval = hst[o];
@@ -269,17 +337,17 @@ __global__ __launch_bounds__(256, 1) void mp_lstm_persist(LstmPersistArgs a) {
             const int gi = granule_index(q * 4 + reg0 + o, jown);
             granule_store_l2(hxL + doff + gi, (unsigned)(step + 1), hst[o]);
             if (!all_local) granule_store(hxR + doff + gi, (unsigned)(step + 1), hst[o]);
-            if (bidx[o] < B) d.out[((size_t)tt[o] * B + bidx[o]) * d.outStride + jown] = oval;
+            if (bidx[o] < B) d.out[((size_t)tt * B + bidx[o]) * d.outStride + jown] = oval;
         }
         PROF_E(4);
     }
-    if (prof) {
+    if (PROF && prof) {
         long long* o = a.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 6;
         for (int i = 0; i < 5; ++i) o[i] = pt[i];
         o[5] = T;
     }
 
-    // ---- final state (h_n, c_n of models/rnn.py:33) back to hbuf parity 0 / cbuf
+    // ---- final state (h_n, c_n of models/rnn.py:33) back to hbuf / cbuf
 #pragma unroll
     for (int o = 0; o < NOWN; ++o) {
         if (bidx[o] < B) {
@@ -308,6 +376,46 @@ __global__ void mp_pack_whh_persist(const float* __restrict__ whh, float* __rest
     dst[idx] = whh[(size_t)row * H + col];
 }
 
+// dst[((((slice*4 + wave)*NXS + s)*NTG + tg)*64 + lane)*4 + i]
+//   = W_ih[g*H + slice*U + ub*16 + (lane&15)][wave*KQ + (s/4)*16 + (lane>>4)*4 + (s%4)],  tile tg*4+i = g*NUB + ub
+template <int H, int NSLICE>
+__global__ void mp_pack_wih_persist(const float* __restrict__ wih, float* __restrict__ dst, int KIN) {
+    constexpr int U = H / NSLICE, NUB = U / 16, NT = 4 * NUB, NTG = NT / 4;
+    const int KQ = KIN / 4, NXS = KQ / 4;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)4 * H * KIN) return;
+    const int i = idx & 3;
+    const int lane = (idx >> 2) & 63;
+    size_t rest = idx >> 8;
+    const int tg = rest % NTG; rest /= NTG;
+    const int s = rest % NXS; rest /= NXS;
+    const int wave = rest % 4; rest /= 4;
+    const int slice = (int)rest;
+    const int t = tg * 4 + i;
+    const int g = t / NUB, ub = t % NUB;
+    const int row = g * H + slice * U + ub * 16 + (lane & 15);
+    const int col = wave * KQ + (s >> 2) * 16 + (lane >> 4) * 4 + (s & 3);
+    dst[idx] = wih[(size_t)row * KIN + col];
+}
+
+template <int H, int NSLICE, int KIN>
+void launch_fused(const LstmPersistArgs& a, hipStream_t s) {
+    using C = Cfg<H, NSLICE, KIN>;
+    const size_t lds = (size_t)C::RED_F4 * 16 + (size_t)4 * C::XL * C::NTG * 64 * 16;
+    const dim3 grid(a.nslab * NSLICE, a.ndir);
+    if (a.prof) {
+        static bool once = (hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, true>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+        (void)once;
+        hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, true>), grid, dim3(256), lds, s, a);
+    } else {
+        static bool once = (hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, false>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+        (void)once;
+        hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, false>), grid, dim3(256), lds, s, a);
+    }
+}
+
 }  // namespace
 
 void mp_launch_pack_whh_persist(const float* whh, float* dst, int H, hipStream_t s) {
@@ -317,9 +425,18 @@ void mp_launch_pack_whh_persist(const float* whh, float* dst, int H, hipStream_t
     else hipLaunchKernelGGL((mp_pack_whh_persist<64, 1>), dim3(grid), dim3(256), 0, s, whh, dst);
 }
 
+void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, hipStream_t s) {
+    const size_t n = (size_t)4 * H * KIN;
+    const int grid = (int)((n + 255) / 256);
+    if (H == 256) hipLaunchKernelGGL((mp_pack_wih_persist<256, 8>), dim3(grid), dim3(256), 0, s, wih, dst, KIN);
+    else hipLaunchKernelGGL((mp_pack_wih_persist<64, 1>), dim3(grid), dim3(256), 0, s, wih, dst, KIN);
+}
+
 int mp_persist_nslice(int H) { return H == 256 ? 8 : 1; }
 
-void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, hipStream_t s) {
-    if (H == 256) hipLaunchKernelGGL((mp_lstm_persist<256, 8>), dim3(a.nslab * 8, a.ndir), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((mp_lstm_persist<64, 1>), dim3(a.nslab, a.ndir), dim3(256), 0, s, a);
+void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, hipStream_t s) {
+    if (H == 256 && KIN == 256) launch_fused<256, 8, 256>(a, s);
+    else if (H == 256 && KIN == 512) launch_fused<256, 8, 512>(a, s);
+    else if (H == 64 && KIN == 64) launch_fused<64, 1, 64>(a, s);
+    else if (H == 64 && KIN == 128) launch_fused<64, 1, 128>(a, s);
 }

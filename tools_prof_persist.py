@@ -17,7 +17,7 @@ buf = (C.c_longlong * (512 * 6))()
 net._lib.mp_debug_read_prof(net._h, buf, 512 * 6)
 a = np.array(buf[:]).reshape(512, 6)
 a = a[a[:, 5] > 0]
-names = ["wait(gate)", "sweep+mfma", "-", "reduce", "cell+publish"]
+names = ["x-proj mfma", "validate/wait", "h mfma", "reduce", "cell+publish"]
 print("workgroups:", len(a), "steps:", a[0, 5])
 for i, n in enumerate(names):
     per = a[:, i] / a[:, 5]
