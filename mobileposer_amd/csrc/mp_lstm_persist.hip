@@ -61,33 +61,41 @@ __device__ __forceinline__ unsigned xcc_id() {
 }
 constexpr unsigned XCC_TAG = 0x7fffffffu;
 
-template <int H, int NSLICE, int KIN>
+// Wave layout: 4*TW waves.  Wave w takes K quarter kq = w & 3 of both GEMM parts and tile group tw = w >> 2:
+//   TW = 1  : every wave computes all 4*NUB gate tiles                          (H = 64:  4 waves)
+//   TW = NUB: wave (kq, tw) computes the 4 gate tiles of unit block ub = tw     (H = 256: 8 waves, 2 per SIMD,
+//             so no wave needs more than 256 registers and the MFMA pipe always has a second wave to issue)
+template <int H, int NSLICE, int KIN, int TW>
 struct Cfg {
     static constexpr int U = H / NSLICE;              // hidden units per workgroup (32 | 64)
     static constexpr int NUB = U / 16;                // 16-unit blocks per workgroup (2 | 4)
-    static constexpr int NT = 4 * NUB;                // MFMA tiles per wave: gates x unit blocks (8 | 16)
-    static constexpr int NTG = NT / 4;                // 16-byte groups of 4 tiles (2 | 4)
+    static constexpr int NWV = 4 * TW;                // waves per workgroup
+    static constexpr int NTW = 4 * NUB / TW;          // MFMA tiles per wave
+    static constexpr int NTG = NTW / 4;               // 16-byte groups of 4 tiles per wave
     static constexpr int KW = H / 4;                  // h: K range of one wave (64 | 16)
     static constexpr int NKS = KW / 4;                // h: k-steps per wave (16 | 4)
     static constexpr int KQ = KIN / 4;                // x: K range of one wave
-    static constexpr int NXS = KQ / 4;                // x: k-steps per wave (16|32 for H=256, 4|8 for H=64)
+    static constexpr int NXS = KQ / 4;                // x: k-steps per wave
     static constexpr int NXJ = KQ / 16;               // x: 16-byte loads per lane per step
-    static constexpr int NOWN = NUB == 2 ? 2 : 4;     // accumulator regs a lane finishes
-    static constexpr int RED_F4 = 4 * 4 * NOWN * 64;  // float4 slots of the reduction scratch
+    // a lane finishes NOWN accumulator regs (sequences) of one unit block
+    static constexpr int NOWN = TW == 1 ? (NUB == 2 ? 2 : 4) : 1;
+    static constexpr int RED_F4 = NWV * 4 * NOWN * 64;   // float4 slots: [finishing wave][source kq][o][lane]
     // LDS budget 160 KB: reduction scratch + as many x k-steps of W_ih as fit; the rest lives in registers
-    static constexpr int STEP_BYTES = 4 * NTG * 64 * 16;                      // all 4 waves, one k-step
+    static constexpr int STEP_BYTES = NWV * NTG * 64 * 16;                     // all waves, one k-step
     static constexpr int LDS_STEPS_MAX = (160 * 1024 - RED_F4 * 16) / STEP_BYTES;
     static constexpr int XL = NXS <= LDS_STEPS_MAX ? NXS : (LDS_STEPS_MAX / 4) * 4;  // x k-steps served from LDS
     static constexpr int XR = NXS - XL;                                        // x k-steps served from registers
+    static_assert(TW == 1 || TW == NUB, "tile groups are whole unit blocks");
 };
 
-template <int H, int NSLICE, int KIN, bool PROF>
-__global__ __launch_bounds__(256, 1) void mp_lstm_fused(LstmPersistArgs a) {
-    using C = Cfg<H, NSLICE, KIN>;
-    constexpr int U = C::U, NUB = C::NUB, NT = C::NT, NTG = C::NTG, KW = C::KW, NKS = C::NKS, KQ = C::KQ;
+template <int H, int NSLICE, int KIN, int TW, bool PROF>
+__global__ __launch_bounds__(256 * TW, 1) void mp_lstm_fused(LstmPersistArgs a) {
+    using C = Cfg<H, NSLICE, KIN, TW>;
+    constexpr int U = C::U, NUB = C::NUB, NWV = C::NWV, NTW = C::NTW, NTG = C::NTG, KW = C::KW, NKS = C::NKS, KQ = C::KQ;
     constexpr int NXS = C::NXS, NXJ = C::NXJ, NOWN = C::NOWN, XL = C::XL, XR = C::XR;
+    constexpr int NTHREADS = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    f32x4* red = reinterpret_cast<f32x4*>(smem);                       // [dst wave][src wave][o][lane]
+    f32x4* red = reinterpret_cast<f32x4*>(smem);                       // [finishing wave][source kq][o][lane]
     f32x4* wxl = reinterpret_cast<f32x4*>(smem) + C::RED_F4;           // [wave][x-step < XL][tile group][lane]
 
     const LstmDir d = a.d[blockIdx.y];
@@ -102,38 +110,39 @@ __global__ __launch_bounds__(256, 1) void mp_lstm_fused(LstmPersistArgs a) {
         slice = blockIdx.x % NSLICE;
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kq = wave & 3, tw = wave >> 2;
     const int q = lane >> 4, r16 = lane & 15;
     const int B = a.B, T = a.T;
     const int brow0 = (a.slab0 + slab) * 16;
 
     // ---- W_ih slice: k-steps [0, XL) -> LDS, [XL, NXS) -> registers; W_hh slice -> registers
     {
-        const f32x4* src = reinterpret_cast<const f32x4*>(d.wihpack) + (size_t)slice * 4 * NXS * NTG * 64;
-        for (int w = 0; w < 4; ++w)
-            for (int i = threadIdx.x; i < XL * NTG * 64; i += 256)
+        const f32x4* src = reinterpret_cast<const f32x4*>(d.wihpack) + (size_t)slice * NWV * NXS * NTG * 64;
+        for (int w = 0; w < NWV; ++w)
+            for (int i = threadIdx.x; i < XL * NTG * 64; i += NTHREADS)
                 wxl[(size_t)w * XL * NTG * 64 + i] = src[(size_t)w * NXS * NTG * 64 + i];
     }
     f32x4 wxr[XR > 0 ? XR : 1][NTG];
     if (XR > 0) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(d.wihpack) + ((size_t)(slice * 4 + wave) * NXS + XL) * NTG * 64 + lane;
+        const f32x4* src = reinterpret_cast<const f32x4*>(d.wihpack) + ((size_t)(slice * NWV + wave) * NXS + XL) * NTG * 64 + lane;
 #pragma unroll
         for (int s = 0; s < XR; ++s)
 #pragma unroll
             for (int tg = 0; tg < NTG; ++tg) wxr[s][tg] = src[(size_t)(s * NTG + tg) * 64];
     }
-    float wv[NKS][NT];
+    float wv[NKS][NTW];
     {
-        const float* wp = d.wpack + ((size_t)(slice * 4 + wave) * NKS * NT) * 64 + lane;
+        const float* wp = d.wpack + ((size_t)(slice * NWV + wave) * NKS * NTW) * 64 + lane;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) wv[ks][t] = wp[(size_t)(ks * NT + t) * 64];
+            for (int t = 0; t < NTW; ++t) wv[ks][t] = wp[(size_t)(ks * NTW + t) * 64];
     }
 
     // ---- the (sequence, unit) pairs this lane finishes: accumulator regs of tile column r16
-    const int ubo = NUB == 2 ? (wave & 1) : wave;          // unit block this wave finishes
-    const int reg0 = NUB == 2 ? 2 * (wave >> 1) : 0;       // first accumulator reg it finishes
-    const int jown = slice * U + ubo * 16 + r16;           // hidden unit
+    const int ubo = TW == 1 ? (NUB == 2 ? (kq & 1) : kq) : tw;             // unit block this wave finishes
+    const int reg0 = TW == 1 ? (NUB == 2 ? 2 * (kq >> 1) : 0) : kq;        // first accumulator reg it finishes
+    const int jown = slice * U + ubo * 16 + r16;                           // hidden unit
     const f32x4 bias4 = *reinterpret_cast<const f32x4*>(d.bias + 4 * jown);
     float cst[NOWN], hst[NOWN];
     int blen[NOWN], bidx[NOWN];
@@ -151,13 +160,13 @@ __global__ __launch_bounds__(256, 1) void mp_lstm_fused(LstmPersistArgs a) {
     const int arow = brow0 + r16;
     const bool arow_in = arow < B;
     const int alen = arow_in ? a.lengths[arow] : 0;
-    const float* xbase = d.xin + (size_t)(arow_in ? arow : 0) * KIN + wave * KQ + q * 4;
+    const float* xbase = d.xin + (size_t)(arow_in ? arow : 0) * KIN + kq * KQ + q * 4;
     const size_t xtstride = (size_t)B * KIN;
 
-    // A operand of the recurrent part for step 0 from the initial state: h0[row r16][k = wave*KW + 4*ks + q]
+    // A operand of the recurrent part for step 0 from the initial state: h0[row r16][k = kq*KW + 4*ks + q]
     float av[NKS];
     {
-        const float* p = d.hbuf + (size_t)(arow_in ? arow : 0) * H + wave * KW + q;
+        const float* p = d.hbuf + (size_t)(arow_in ? arow : 0) * H + kq * KW + q;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) av[ks] = (arow_in && !a.zero_state) ? p[4 * ks] : 0.f;
     }
@@ -185,12 +194,12 @@ __global__ __launch_bounds__(256, 1) void mp_lstm_fused(LstmPersistArgs a) {
         }
         const unsigned long long same = __ballot(peer == my_xcc);
         all_local = (same & ((1ull << NSLICE) - 1)) == ((1ull << NSLICE) - 1);
-        src_local[0] = (same >> (2 * wave)) & 1;           // k-steps 0..NKS/2-1 come from slice 2*wave
-        src_local[1] = (same >> (2 * wave + 1)) & 1;       // the rest from slice 2*wave+1
+        src_local[0] = (same >> (2 * kq)) & 1;             // k-steps 0..NKS/2-1 come from slice 2*kq
+        src_local[1] = (same >> (2 * kq + 1)) & 1;         // the rest from slice 2*kq+1
         if (__ballot(peer == ~0u)) spin_budget = 0;
     }
 
-    // ---- x_0: this lane's A values of the input projection, k = wave*KQ + j*16 + q*4 + i  (x-step s = 4j+i)
+    // ---- x_0: this lane's A values of the input projection, k = kq*KQ + j*16 + q*4 + i  (x-step s = 4j+i)
     f32x4 xa[NXJ];
     auto load_x = [&](int step) {
         const bool on = step < alen;
@@ -211,9 +220,9 @@ __global__ __launch_bounds__(256, 1) void mp_lstm_fused(LstmPersistArgs a) {
 
     for (int step = 0; step < T; ++step) {
         PROF_T(0);
-        f32x4 acc[NT];
+        f32x4 acc[NTW];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         // ---- first half of x_t W_ih^T (independent of h: this is what fills the wait for the peers)
 #pragma unroll
         for (int s = 0; s < NXS / 2; ++s) {
@@ -227,10 +236,10 @@ __global__ __launch_bounds__(256, 1) void mp_lstm_fused(LstmPersistArgs a) {
             }
         }
 
-        // ---- request h_{step-1}: granule (row r16, unit wave*KW + 4*ks + q), 512 contiguous bytes per instruction
+        // ---- request h_{step-1}: granule (row r16, unit kq*KW + 4*ks + q), 512 contiguous bytes per instruction
         u64 gr[NKS];
         const unsigned epoch = (unsigned)step;                 // written by the producers at the end of step-1
-        const size_t goff = (size_t)((step + 1) & 1) * 16 * H + (size_t)wave * NKS * 64 + r16 * 4 + q;
+        const size_t goff = (size_t)((step + 1) & 1) * 16 * H + (size_t)kq * NKS * 64 + r16 * 4 + q;
         const u64* src0 = (src_local[0] ? hxL : hxR) + goff;
         const u64* src1 = NSLICE > 1 ? (src_local[1] ? hxL : hxR) + goff : src0;
         if (step > 0) {
@@ -249,7 +258,6 @@ __global__ __launch_bounds__(256, 1) void mp_lstm_fused(LstmPersistArgs a) {
                     acc[tg * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, w4[i], acc[tg * 4 + i], 0, 0, 0);
             }
         }
-        load_x(step + 1);                                      // prefetch next step's x (lands during this step)
         PROF_E(0); PROF_T(1);
 
         // ---- validate the granules; the slow path (cheap gate, then sweep) only runs when some were stale
@@ -285,27 +293,36 @@ __global__ __launch_bounds__(256, 1) void mp_lstm_fused(LstmPersistArgs a) {
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) av[ks] = __uint_as_float((unsigned)gr[ks]);
         }
+        load_x(step + 1);                // next step's x: issued only now so that the granule wait above does not
+                                         // also drain these HBM loads; they land under the MFMAs / cell update below
         PROF_E(1); PROF_T(2);
 
         // ---- recurrent part: h_{t-1} W_hh^T on top of the input projection
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], wv[ks][t], acc[t], 0, 0, 0);
+            for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], wv[ks][t], acc[t], 0, 0, 0);
         PROF_E(2); PROF_T(3);
 
-        // ---- K reduction through LDS.  Every wave drops, for each finishing wave dw (itself included, so that
-        // all register indices stay compile-time constants), the 4 gate values of the regs dw finishes.
+        // ---- K reduction through LDS: the 4 K-quarter waves of a tile group hand each finishing wave the 4 gate
+        // values of the accumulator regs it finishes (own share included: register indices stay compile-time)
         __syncthreads();                                       // previous step's reads of `red` are done
+        if (TW == 1) {
 #pragma unroll
-        for (int dw = 0; dw < 4; ++dw) {
-            const int dub = NUB == 2 ? (dw & 1) : dw;
-            const int dreg0 = NUB == 2 ? 2 * (dw >> 1) : 0;
+            for (int dw = 0; dw < 4; ++dw) {
+                const int dub = NUB == 2 ? (dw & 1) : dw;
+                const int dreg0 = NUB == 2 ? 2 * (dw >> 1) : 0;
 #pragma unroll
-            for (int o = 0; o < NOWN; ++o)
-                red[((dw * 4 + wave) * NOWN + o) * 64 + lane] =
-                    f32x4{acc[0 * NUB + dub][dreg0 + o], acc[1 * NUB + dub][dreg0 + o], acc[2 * NUB + dub][dreg0 + o],
-                          acc[3 * NUB + dub][dreg0 + o]};
+                for (int o = 0; o < NOWN; ++o)
+                    red[((dw * 4 + kq) * NOWN + o) * 64 + lane] =
+                        f32x4{acc[(0 * NUB + dub) % NTW][dreg0 + o], acc[(1 * NUB + dub) % NTW][dreg0 + o],
+                              acc[(2 * NUB + dub) % NTW][dreg0 + o], acc[(3 * NUB + dub) % NTW][dreg0 + o]};
+            }
+        } else {
+#pragma unroll
+            for (int dk = 0; dk < 4; ++dk)                     // finishing wave (dk, tw) takes accumulator reg dk
+                red[(((tw * 4 + dk) * 4 + kq)) * 64 + lane] =
+                    f32x4{acc[0][dk], acc[1 % NTW][dk], acc[2 % NTW][dk], acc[3 % NTW][dk]};
         }
         __syncthreads();
         f32x4 gate[NOWN];
@@ -357,30 +374,32 @@ __global__ __launch_bounds__(256, 1) void mp_lstm_fused(LstmPersistArgs a) {
     }
 }
 
-// dst[(((slice*4 + wave)*NKS + ks)*NT + t)*64 + lane] = W_hh[g*H + slice*U + ub*16 + (lane&15)][wave*KW + 4*ks + (lane>>4)]
-// with t = g*NUB + ub
-template <int H, int NSLICE>
+// tile lt of wave w = (kq = w & 3, tw = w >> 2):  TW == 1: g = lt / NUB, ub = lt % NUB;   TW == NUB: g = lt, ub = tw
+// W_hh: dst[(((slice*NWV + w)*NKS + ks)*NTW + lt)*64 + lane]
+//         = W_hh[g*H + slice*U + ub*16 + (lane&15)][kq*KW + 4*ks + (lane>>4)]
+template <int H, int NSLICE, int TW>
 __global__ void mp_pack_whh_persist(const float* __restrict__ whh, float* __restrict__ dst) {
-    constexpr int U = H / NSLICE, NUB = U / 16, NT = 4 * NUB, KW = H / 4, NKS = KW / 4;
+    constexpr int U = H / NSLICE, NUB = U / 16, NWV = 4 * TW, NTW = 4 * NUB / TW, KW = H / 4, NKS = KW / 4;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)4 * H * H) return;
     const int lane = idx & 63;
     size_t rest = idx >> 6;
-    const int t = rest % NT; rest /= NT;
+    const int lt = rest % NTW; rest /= NTW;
     const int ks = rest % NKS; rest /= NKS;
-    const int wave = rest % 4; rest /= 4;
+    const int w = rest % NWV; rest /= NWV;
     const int slice = (int)rest;
-    const int g = t / NUB, ub = t % NUB;
+    const int kq = w & 3, tw = w >> 2;
+    const int g = TW == 1 ? lt / NUB : lt, ub = TW == 1 ? lt % NUB : tw;
     const int row = g * H + slice * U + ub * 16 + (lane & 15);
-    const int col = wave * KW + 4 * ks + (lane >> 4);
+    const int col = kq * KW + 4 * ks + (lane >> 4);
     dst[idx] = whh[(size_t)row * H + col];
 }
 
-// dst[((((slice*4 + wave)*NXS + s)*NTG + tg)*64 + lane)*4 + i]
-//   = W_ih[g*H + slice*U + ub*16 + (lane&15)][wave*KQ + (s/4)*16 + (lane>>4)*4 + (s%4)],  tile tg*4+i = g*NUB + ub
-template <int H, int NSLICE>
+// W_ih: dst[((((slice*NWV + w)*NXS + s)*NTG + tg)*64 + lane)*4 + i]   (tile lt = tg*4 + i)
+//         = W_ih[g*H + slice*U + ub*16 + (lane&15)][kq*KQ + (s/4)*16 + (lane>>4)*4 + (s%4)]
+template <int H, int NSLICE, int TW>
 __global__ void mp_pack_wih_persist(const float* __restrict__ wih, float* __restrict__ dst, int KIN) {
-    constexpr int U = H / NSLICE, NUB = U / 16, NT = 4 * NUB, NTG = NT / 4;
+    constexpr int U = H / NSLICE, NUB = U / 16, NWV = 4 * TW, NTW = 4 * NUB / TW, NTG = NTW / 4;
     const int KQ = KIN / 4, NXS = KQ / 4;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)4 * H * KIN) return;
@@ -389,30 +408,31 @@ __global__ void mp_pack_wih_persist(const float* __restrict__ wih, float* __rest
     size_t rest = idx >> 8;
     const int tg = rest % NTG; rest /= NTG;
     const int s = rest % NXS; rest /= NXS;
-    const int wave = rest % 4; rest /= 4;
+    const int w = rest % NWV; rest /= NWV;
     const int slice = (int)rest;
-    const int t = tg * 4 + i;
-    const int g = t / NUB, ub = t % NUB;
+    const int kq = w & 3, tw = w >> 2;
+    const int lt = tg * 4 + i;
+    const int g = TW == 1 ? lt / NUB : lt, ub = TW == 1 ? lt % NUB : tw;
     const int row = g * H + slice * U + ub * 16 + (lane & 15);
-    const int col = wave * KQ + (s >> 2) * 16 + (lane >> 4) * 4 + (s & 3);
+    const int col = kq * KQ + (s >> 2) * 16 + (lane >> 4) * 4 + (s & 3);
     dst[idx] = wih[(size_t)row * KIN + col];
 }
 
-template <int H, int NSLICE, int KIN>
+template <int H, int NSLICE, int KIN, int TW>
 void launch_fused(const LstmPersistArgs& a, hipStream_t s) {
-    using C = Cfg<H, NSLICE, KIN>;
-    const size_t lds = (size_t)C::RED_F4 * 16 + (size_t)4 * C::XL * C::NTG * 64 * 16;
+    using C = Cfg<H, NSLICE, KIN, TW>;
+    const size_t lds = (size_t)C::RED_F4 * 16 + (size_t)C::NWV * C::XL * C::NTG * 64 * 16;
     const dim3 grid(a.nslab * NSLICE, a.ndir);
     if (a.prof) {
-        static bool once = (hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, true>,
+        static bool once = (hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, TW, true>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
         (void)once;
-        hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, true>), grid, dim3(256), lds, s, a);
+        hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, TW, true>), grid, dim3(64 * C::NWV), lds, s, a);
     } else {
-        static bool once = (hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, false>,
+        static bool once = (hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, TW, false>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
         (void)once;
-        hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, false>), grid, dim3(256), lds, s, a);
+        hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, TW, false>), grid, dim3(64 * C::NWV), lds, s, a);
     }
 }
 
@@ -421,22 +441,22 @@ void launch_fused(const LstmPersistArgs& a, hipStream_t s) {
 void mp_launch_pack_whh_persist(const float* whh, float* dst, int H, hipStream_t s) {
     const size_t n = (size_t)4 * H * H;
     const int grid = (int)((n + 255) / 256);
-    if (H == 256) hipLaunchKernelGGL((mp_pack_whh_persist<256, 8>), dim3(grid), dim3(256), 0, s, whh, dst);
-    else hipLaunchKernelGGL((mp_pack_whh_persist<64, 1>), dim3(grid), dim3(256), 0, s, whh, dst);
+    if (H == 256) hipLaunchKernelGGL((mp_pack_whh_persist<256, 8, 2>), dim3(grid), dim3(256), 0, s, whh, dst);
+    else hipLaunchKernelGGL((mp_pack_whh_persist<64, 1, 1>), dim3(grid), dim3(256), 0, s, whh, dst);
 }
 
 void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, hipStream_t s) {
     const size_t n = (size_t)4 * H * KIN;
     const int grid = (int)((n + 255) / 256);
-    if (H == 256) hipLaunchKernelGGL((mp_pack_wih_persist<256, 8>), dim3(grid), dim3(256), 0, s, wih, dst, KIN);
-    else hipLaunchKernelGGL((mp_pack_wih_persist<64, 1>), dim3(grid), dim3(256), 0, s, wih, dst, KIN);
+    if (H == 256) hipLaunchKernelGGL((mp_pack_wih_persist<256, 8, 2>), dim3(grid), dim3(256), 0, s, wih, dst, KIN);
+    else hipLaunchKernelGGL((mp_pack_wih_persist<64, 1, 1>), dim3(grid), dim3(256), 0, s, wih, dst, KIN);
 }
 
 int mp_persist_nslice(int H) { return H == 256 ? 8 : 1; }
 
 void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, hipStream_t s) {
-    if (H == 256 && KIN == 256) launch_fused<256, 8, 256>(a, s);
-    else if (H == 256 && KIN == 512) launch_fused<256, 8, 512>(a, s);
-    else if (H == 64 && KIN == 64) launch_fused<64, 1, 64>(a, s);
-    else if (H == 64 && KIN == 128) launch_fused<64, 1, 128>(a, s);
+    if (H == 256 && KIN == 256) launch_fused<256, 8, 256, 2>(a, s);
+    else if (H == 256 && KIN == 512) launch_fused<256, 8, 512, 2>(a, s);
+    else if (H == 64 && KIN == 64) launch_fused<64, 1, 64, 1>(a, s);
+    else if (H == 64 && KIN == 128) launch_fused<64, 1, 128, 1>(a, s);
 }
