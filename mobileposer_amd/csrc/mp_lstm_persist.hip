@@ -201,14 +201,19 @@ __global__ __launch_bounds__(256 * TW, 1) void mp_lstm_fused(LstmPersistArgs a) 
 
     // ---- x_0: this lane's A values of the input projection, k = kq*KQ + j*16 + q*4 + i  (x-step s = 4j+i)
     f32x4 xa[NXJ];
-    auto load_x = [&](int step) {
+    // With part of W_ih in registers (XR > 0) there is no room for a whole prefetched x row beside the
+    // granules: the second half of x_t is then fetched at the top of step t (it is first used ~2000 cycles later).
+    constexpr bool SPLIT_X = XR > 0;
+    constexpr int XJ_PRE = SPLIT_X ? NXJ / 2 : NXJ;        // 16-byte pieces prefetched one step ahead
+    auto load_x = [&](int step, int j0, int j1) {
         const bool on = step < alen;
         const int t = on ? (d.reverse ? alen - 1 - step : step) : 0;
         const float* p = xbase + (size_t)t * xtstride;
 #pragma unroll
-        for (int j = 0; j < NXJ; ++j) xa[j] = on ? *reinterpret_cast<const f32x4*>(p + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NXJ; ++j)
+            if (j >= j0 && j < j1) xa[j] = on ? *reinterpret_cast<const f32x4*>(p + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    load_x(0);
+    load_x(0, 0, XJ_PRE);
     __syncthreads();                                          // W_ih LDS image complete
 
     long long pt[6] = {0, 0, 0, 0, 0, 0};
@@ -220,20 +225,33 @@ __global__ __launch_bounds__(256 * TW, 1) void mp_lstm_fused(LstmPersistArgs a) 
 
     for (int step = 0; step < T; ++step) {
         PROF_T(0);
+        if (SPLIT_X) load_x(step, XJ_PRE, NXJ);
         f32x4 acc[NTW];
 #pragma unroll
         for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         // ---- first half of x_t W_ih^T (independent of h: this is what fills the wait for the peers)
+        // (LDS-resident weights are fetched exactly one k-step ahead; the scheduling barriers keep the compiler
+        //  from hoisting dozens of ds_reads -- and their 4 destination registers each -- to the top of the loop)
+        f32x4 wl[NTG], wn[NTG];
+#pragma unroll
+        for (int tg = 0; tg < NTG; ++tg) wl[tg] = wxw[(size_t)tg * 64];
 #pragma unroll
         for (int s = 0; s < NXS / 2; ++s) {
             const float a_s = xa[s >> 2][s & 3];
+            if (s + 1 < XL) {
+#pragma unroll
+                for (int tg = 0; tg < NTG; ++tg) wn[tg] = wxw[(size_t)((s + 1) * NTG + tg) * 64];
+            }
 #pragma unroll
             for (int tg = 0; tg < NTG; ++tg) {
-                const f32x4 w4 = s < XL ? wxw[(size_t)(s * NTG + tg) * 64] : wxr[s >= XL ? s - XL : 0][tg];
+                const f32x4 w4 = s < XL ? wl[tg] : wxr[s >= XL ? s - XL : 0][tg];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     acc[tg * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, w4[i], acc[tg * 4 + i], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tg = 0; tg < NTG; ++tg) wl[tg] = wn[tg];
         }
 
         // ---- request h_{step-1}: granule (row r16, unit kq*KW + 4*ks + q), 512 contiguous bytes per instruction
@@ -242,7 +260,10 @@ __global__ __launch_bounds__(256 * TW, 1) void mp_lstm_fused(LstmPersistArgs a) 
         const size_t goff = (size_t)((step + 1) & 1) * 16 * H + (size_t)kq * NKS * 64 + r16 * 4 + q;
         const u64* src0 = (src_local[0] ? hxL : hxR) + goff;
         const u64* src1 = NSLICE > 1 ? (src_local[1] ? hxL : hxR) + goff : src0;
-        if (step > 0) {
+        // (when part of W_ih lives in registers there is no room to hold 16 granules in flight beside it:
+        //  request them after the projection instead; the second wave on the SIMD covers the L2 latency)
+        constexpr bool EARLY_GATHER = XR == 0;
+        if (EARLY_GATHER && step > 0) {
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) gr[ks] = granule_load((ks < NKS / 2 ? src0 : src1) + (size_t)ks * 64);
         }
@@ -250,18 +271,29 @@ __global__ __launch_bounds__(256 * TW, 1) void mp_lstm_fused(LstmPersistArgs a) 
 #pragma unroll
         for (int s = NXS / 2; s < NXS; ++s) {
             const float a_s = xa[s >> 2][s & 3];
+            if (s + 1 < XL) {
+#pragma unroll
+                for (int tg = 0; tg < NTG; ++tg) wn[tg] = wxw[(size_t)((s + 1) * NTG + tg) * 64];
+            }
 #pragma unroll
             for (int tg = 0; tg < NTG; ++tg) {
-                const f32x4 w4 = s < XL ? wxw[(size_t)(s * NTG + tg) * 64] : wxr[s >= XL ? s - XL : 0][tg];
+                const f32x4 w4 = s < XL ? wl[tg] : wxr[s >= XL ? s - XL : 0][tg];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     acc[tg * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, w4[i], acc[tg * 4 + i], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tg = 0; tg < NTG; ++tg) wl[tg] = wn[tg];
         }
         PROF_E(0); PROF_T(1);
 
         // ---- validate the granules; the slow path (cheap gate, then sweep) only runs when some were stale
         if (step > 0) {
+            if (!EARLY_GATHER) {
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) gr[ks] = granule_load((ks < NKS / 2 ? src0 : src1) + (size_t)ks * 64);
+            }
             bool ok = true;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) ok = ok && ((unsigned)(gr[ks] >> 32) == epoch);
@@ -293,7 +325,7 @@ __global__ __launch_bounds__(256 * TW, 1) void mp_lstm_fused(LstmPersistArgs a) 
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) av[ks] = __uint_as_float((unsigned)gr[ks]);
         }
-        load_x(step + 1);                // next step's x: issued only now so that the granule wait above does not
+        load_x(step + 1, 0, XJ_PRE);     // next step's x: issued only now so that the granule wait above does not
                                          // also drain these HBM loads; they land under the MFMAs / cell update below
         PROF_E(1); PROF_T(2);
 
