@@ -29,17 +29,15 @@ BYTES_PER_FRAME = 1688                  # compulsory HBM bytes / frame (240 in +
 PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
-def gemm_flops_main_stream(M):
-    """FLOPs of the GEMM launches timed on the main stream (joints + pose modules)."""
-    fl = 0
-    for n_in, n_out in ((60, 72), (132, 96)):
-        fl += 2 * M * (256 * n_in + 2048 * 256 + 2048 * 512 + n_out * 512)
-    return fl
-
-
-def lstm_flops_main_stream(M):
-    """Recurrent FLOPs (h W_hh^T) of the step launches on the main stream: 2 modules x 2 layers x 2 dirs."""
-    return 2 * M * 256 * 1024 * 8
+KERNEL_CLASSES = {   # timing classes of the C ABI (include/mobileposer_hip.h, mp_timing_read)
+    0: "mp_gemm_f32 (linear1 / linear2)",
+    1: "mp_lstm_fused<256,8,256,2> bidirectional layer 0 (joints, pose)",
+    4: "mp_lstm_fused<256,8,512,2> bidirectional layer 1 (joints, pose)",
+    5: "mp_lstm_fused<256,8,256,2> unidirectional layers (velocity)",
+    6: "mp_lstm_fused<64,1,*,1> (foot contact)",
+    7: "mp_lstm_step (per-step fallback)",
+    2: "mp_r6d_ik",
+}
 
 
 def cpu_baseline(seconds=12.0):
@@ -156,32 +154,32 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # ---- per-kernel-class timing with HIP events on the library's own stream (eager launches) ----
-    kern = {}
+    # ---- per-kernel-class timing: HIP events around every launch, on the library stream that launches it ----
+    kern, dominant = {}, None
     if rank == 0:
         net.timing_enable(True)
-        acc = {0: [0, 0.0], 1: [0, 0.0], 2: [0, 0.0], 3: [0, 0.0]}
+        acc = {c: [0, 0.0, 0.0] for c in list(KERNEL_CLASSES) + [3]}
         reps = 3
         for _ in range(reps):
             lib.mp_reset_state(h, 1)
             lib.mp_forward(h, vp(imu), lens, B, T, vp(pose), vp(joints), vp(vel), vp(contact), None, stream)
             torch.cuda.synchronize(dev)
             for cls in acc:
-                n, ms = net.timing_read(cls)
+                n, ms, gf = net.timing_read(cls)
                 acc[cls][0] += n
                 acc[cls][1] += ms
+                acc[cls][2] += gf
         net.timing_enable(False)
-        M = B * T
-        g_n, g_ms = acc[0]
-        s_n, s_ms = acc[1]
-        kern = {
-            "mp_gemm_f32": {"launches_per_forward_main_stream": g_n // reps, "avg_ms": g_ms / max(g_n, 1),
-                            "tflops": gemm_flops_main_stream(M) * reps / (g_ms * 1e-3) / 1e12 if g_ms else None},
-            "mp_lstm_step": {"launches_per_forward_main_stream": s_n // reps, "avg_us_eager": 1e3 * s_ms / max(s_n, 1),
-                             "tflops_eager": lstm_flops_main_stream(M) * reps / (s_ms * 1e-3) / 1e12 if s_ms else None},
-            "mp_r6d_ik": {"avg_ms": acc[2][1] / max(acc[2][0], 1)},
-            "forward_eager_ms": acc[3][1] / reps,
-        }
+        for cls, name in KERNEL_CLASSES.items():
+            n, ms, gf = acc[cls]
+            if n == 0:
+                continue
+            kern[name] = {"launches_per_forward": n // reps, "avg_launch_ms": round(ms / n, 4),
+                          "ms_per_forward": round(ms / reps, 4), "gflop_per_launch": round(gf / n, 3),
+                          "tflops": round(gf / ms, 2) if ms > 0 else None}
+        kern["forward_eager_ms"] = round(acc[3][1] / reps, 4)
+        # the kernel class with the largest share of the forward is the one the roofline line describes
+        dominant = max((c for c in KERNEL_CLASSES if acc[c][0]), key=lambda c: acc[c][1])
     if dist is not None:
         dist.barrier()
 
@@ -192,8 +190,8 @@ def main():
 
     frames = world * B * T * args.steps
     value = frames / elapsed
-    g = kern["mp_gemm_f32"]
-    achieved = g["tflops"] or 0.0
+    dn, dms, dgf = acc[dominant]
+    achieved = dgf / dms if dms > 0 else 0.0              # GFLOP / ms = TFLOP/s
     out = {
         "metric": "imu_frames_per_sec (MobilePoserNet fwd + FK + translation solver, batch 256 x window 125 per GPU)",
         "value": round(value, 1), "unit": "frames/s", "per_gpu": round(value / world, 1),
@@ -209,9 +207,12 @@ def main():
         "end_to_end": {"tflops": round(value * FLOP_PER_FRAME / 1e12, 3),
                        "frac_of_fp32_mfma_peak": round(value / world * FLOP_PER_FRAME / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                        "hbm_gbps_compulsory": round(value / world * BYTES_PER_FRAME / 1e9, 2)},
-        "roofline": {"kernel": "mp_gemm_f32<2,2,2,2> (fp32 MFMA GEMM: linear1 / W_ih projections / linear2)",
-                     "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None},
+        "roofline": {"kernel": KERNEL_CLASSES[dominant], "bound": "mfma",
+                     "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                     "flop_per_launch": round(dgf / dn * 1e9), "avg_launch_ms": round(dms / dn, 4),
+                     "note": "algorithmic FLOPs of the launch (input projection + recurrence, SURVEY.md 8(d)) / "
+                             "HIP-event duration of the launch, v_mfma_f32_16x16x4_f32 dense peak"},
         "kernels": kern,
     }
     if not args.no_cpu_baseline:

@@ -129,11 +129,14 @@ int mp_stream_step(mp_handle* h, const float* frames_dev, float* pose_dev, float
 int mp_stream_reset(mp_handle* h, const uint8_t* mask_host, int clear_velocity);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------------
- * With timing on, every mp_forward brackets its kernel classes with HIP events on the library's
- * own streams.  mp_timing_read returns, for the last call, the number of launches and the summed
- * event-measured milliseconds per class: 0 = MFMA GEMM, 1 = LSTM step, 2 = r6d/IK, 3 = whole call. */
+ * With timing on, every call runs eagerly (no hipGraph) and brackets each kernel launch of the classes below
+ * with HIP events on the library stream that launches it.  mp_timing_read returns, for the last call, the
+ * number of launches, the summed event-measured milliseconds and the algorithmic GFLOP of a class:
+ *   0 = MFMA GEMM (linear1 / linear2),   1 = fused LSTM layer H=256 bidirectional K_in=256,
+ *   4 = fused LSTM layer H=256 bidirectional K_in=512,   5 = fused LSTM layer H=256 unidirectional,
+ *   6 = fused LSTM layer H=64,   7 = per-step LSTM kernels (fallback mode),   2 = r6d/IK,   3 = whole call. */
 int mp_timing_enable(mp_handle* h, int on);
-int mp_timing_read(mp_handle* h, int cls, int* launches, float* ms);
+int mp_timing_read(mp_handle* h, int cls, int* launches, float* ms, double* gflop);
 /* 0: eager launches, 1: replay captured hipGraphs (default; env MP_NO_GRAPH=1 flips the default). */
 int mp_set_graph_mode(mp_handle* h, int on);
 /* LSTM recurrence implementation: 1 = persistent kernel, all T steps in one launch, hidden state exchanged

@@ -38,7 +38,7 @@ SIGNATURES = {
     "mp_stream_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_stream_reset": (_i, [_vp, C.POINTER(C.c_uint8), _i]),
     "mp_timing_enable": (_i, [_vp, _i]),
-    "mp_timing_read": (_i, [_vp, _i, C.POINTER(_i), _fp]),
+    "mp_timing_read": (_i, [_vp, _i, C.POINTER(_i), _fp, C.POINTER(C.c_double)]),
     "mp_set_graph_mode": (_i, [_vp, _i]),
     "mp_set_lstm_mode": (_i, [_vp, _i]),
     "mp_device_error": (_i, [_vp, C.POINTER(_i)]),

@@ -104,7 +104,7 @@ struct Plan {
     std::vector<void*> allocs;
 };
 
-struct Seg { int cls; hipEvent_t a, b; int launches; };
+struct Seg { int cls; hipEvent_t a, b; int launches; double flop; };
 
 struct StreamCtx {
     int S = 0;
@@ -351,13 +351,13 @@ hipEvent_t next_event(mp_handle* h) {
 }
 struct SegScope {
     mp_handle* h; hipStream_t s; bool on; size_t idx;
-    SegScope(mp_handle* h_, hipStream_t s_, int cls, int launches) : h(h_), s(s_), on(false), idx(0) {
-        if (!h->timing || h->capturing || (cls != 3 && s != h->s_main && s != h->s_gp)) return;
+    SegScope(mp_handle* h_, hipStream_t s_, int cls, int launches, double flop = 0.0) : h(h_), s(s_), on(false), idx(0) {
+        if (!h->timing || h->capturing) return;
         hipEvent_t a = next_event(h), b = next_event(h);
         if (!a || !b) return;
         on = true;
         idx = h->segs.size();
-        h->segs.push_back({cls, a, b, launches});
+        h->segs.push_back({cls, a, b, launches, flop});
         (void)hipEventRecord(a, s);
     }
     ~SegScope() { if (on) (void)hipEventRecord(h->segs[idx].b, s); }
@@ -371,7 +371,7 @@ RowMap user_map(const float* base, int T, int width) { return RowMap{base, (long
 
 int run_gemm(mp_handle* h, hipStream_t s, RowMap a0, RowMap a1, const Packed& w, float* C, long cStrideB,
              long cStrideT, int M, int B, int relu) {
-    SegScope seg(h, s, 0, 1);
+    SegScope seg(h, s, 0, 1, 2.0 * M * (double)w.N * w.K);
     GemmArgs g;
     g.a0 = a0; g.a1 = a1; g.W = w.W; g.bias = w.bias; g.C = C; g.cStrideB = cStrideB; g.cStrideT = cStrideT;
     g.M = M; g.N = w.N; g.K = w.K; g.Kpad = w.Kpad; g.B = B; g.relu = relu;
@@ -430,10 +430,12 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
     float* out = l == 0 ? w.out0 : w.out1;
     if (h->persist) {
         HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));     // every polled word is re-zeroed before every launch
-        SegScope seg(h, s, 1, T);
         const int nslab = (B + 15) / 16;
         const int chunk = 256 / (dirs * mp_persist_nslice(H));  // slabs per launch: grid <= 256 workgroups, 1 per CU
         const int kin = l == 0 ? H : dirs * H;
+        // timing classes: 1 = H256 bidirectional K_in=256, 4 = H256 bidirectional K_in=512, 5 = H256 unidirectional
+        const int cls = H != 256 ? 6 : (dirs == 1 ? 5 : (kin == 256 ? 1 : 4));
+        SegScope seg(h, s, cls, (nslab + chunk - 1) / chunk, 2.0 * dirs * (double)B * T * 4.0 * H * (kin + H));
         const float* xin = l == 0 ? w.out1 /* X1 */ : w.out0;
         float* outp = l == 0 ? w.out0 : w.out1;
         // layer 1 overwrites out1, which still holds X1 while layer 0 runs -- layer 0 has finished by then
@@ -455,7 +457,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             mp_launch_lstm_persist(a, H, kin, s);
         }
     } else {
-        SegScope seg(h, s, 1, T);
+        SegScope seg(h, s, 7, T, 2.0 * dirs * (double)B * T * 4.0 * H * H);
         LstmStepArgs a;
         a.lengths = j.p->lengths_dev; a.ndir = dirs; a.B = B; a.T = T;
         for (int d = 0; d < dirs; ++d)
@@ -904,17 +906,20 @@ int mp_timing_enable(mp_handle* h, int on) {
     return MP_OK;
 }
 
-int mp_timing_read(mp_handle* h, int cls, int* launches, float* ms) {
+int mp_timing_read(mp_handle* h, int cls, int* launches, float* ms, double* gflop) {
     if (!h || !launches || !ms) return MP_ERR_INVALID;
-    HIPCHK(h, hipStreamSynchronize(h->s_main));
+    HIPCHK(h, hipDeviceSynchronize());
     *launches = 0; *ms = 0.f;
+    double fl = 0.0;
     for (const Seg& s : h->segs) {
         if (s.cls != cls) continue;
         float t = 0.f;
         HIPCHK(h, hipEventElapsedTime(&t, s.a, s.b));
         *ms += t;
         *launches += s.launches;
+        fl += s.flop;
     }
+    if (gflop) *gflop = fl * 1e-9;
     return MP_OK;
 }
 

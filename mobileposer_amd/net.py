@@ -357,9 +357,10 @@ class MobilePoserNet:
         _lib.check(self._lib.mp_timing_enable(self._h, int(bool(on))), self._h)
 
     def timing_read(self, cls):
-        n, ms = C.c_int(0), C.c_float(0)
-        _lib.check(self._lib.mp_timing_read(self._h, cls, C.byref(n), C.byref(ms)), self._h)
-        return n.value, ms.value
+        """(launches, event-measured ms, algorithmic GFLOP) of a kernel class in the last timed call."""
+        n, ms, gf = C.c_int(0), C.c_float(0), C.c_double(0)
+        _lib.check(self._lib.mp_timing_read(self._h, cls, C.byref(n), C.byref(ms), C.byref(gf)), self._h)
+        return n.value, ms.value, gf.value
 
     def set_lstm_mode(self, persistent):
         _lib.check(self._lib.mp_set_lstm_mode(self._h, int(bool(persistent))), self._h)
