@@ -174,6 +174,31 @@ def main():
         Rg2, jg2, vg2 = net.bodymodel.forward_kinematics(torch.from_numpy(pose), tran=torch.from_numpy(tran), calc_mesh=True)
     np.savez_compressed(os.path.join(HERE, "g6_fk.npz"), pose=pose, tran=tran, R_global=Rg.numpy(), joint=jg.numpy(),
                         joint_tran=jg2.numpy(), vert_tran=vg2.numpy())
+    # ---- G8 PoseDataset eval-mode input formation (data.py:57-85,94-107) on a synthetic dip_test.pt -------
+    rng = np.random.Generator(np.random.PCG64(8))
+    seqs = []
+    for n in (30, 20):
+        seqs.append({
+            "acc": (rng.standard_normal((n, 6, 3)) * 5.0).astype(np.float32),
+            "ori": synthetic._random_rotations(rng, n * 6).reshape(n, 6, 3, 3).astype(np.float32),
+            "pose": synthetic._random_rotations(rng, n * 24).reshape(n, 24, 3, 3).astype(np.float32),
+            "tran": rng.standard_normal((n, 3)).astype(np.float32),
+        })
+    os.makedirs(os.path.join(work, "data", "processed_datasets", "eval"))
+    torch.save({k: [torch.from_numpy(sq[k]) for sq in seqs] for k in ("acc", "ori", "pose", "tran")},
+               os.path.join(work, "data", "processed_datasets", "eval", "dip_test.pt"))
+    from mobileposer.data import PoseDataset            # noqa: E402
+    ds = PoseDataset(fold="test", evaluate="dip")
+    g8 = {"n_items": np.int64(len(ds))}
+    for k, sq in enumerate(seqs):
+        for name, v in sq.items():
+            g8[f"in{k}_{name}"] = v
+    for idx in range(len(ds)):
+        imu, pose, joint, tran = ds[idx]
+        g8[f"item{idx}_imu"], g8[f"item{idx}_pose"] = imu.numpy(), pose.numpy()
+        g8[f"item{idx}_joint"], g8[f"item{idx}_tran"] = joint.numpy(), tran.numpy()
+    np.savez_compressed(os.path.join(HERE, "g8_dataset.npz"), **g8)
+
     print("golden vectors written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         print("  %-24s %8d B" % (fn, os.path.getsize(os.path.join(HERE, fn))))

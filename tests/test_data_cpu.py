@@ -1,0 +1,28 @@
+"""PoseDataset eval-mode input formation against the reference's own PoseDataset output (golden G8). CPU only."""
+import numpy as np
+import torch
+
+from conftest import load_golden
+from mobileposer_amd.data import PoseDataset
+from oracle import mp_oracle as O
+
+
+def test_g8_dataset_formation(smpl):
+    g = load_golden("g8_dataset.npz")
+    data = {k: [torch.from_numpy(g[f"in{i}_{k}"]) for i in range(2)] for k in ("acc", "ori", "pose", "tran")}
+
+    def fk(pose):                       # test-side FK (oracle) standing in for the GPU kernel
+        Rg, jg = O.forward_kinematics(pose.numpy(), smpl["J"])
+        return torch.from_numpy(Rg), torch.from_numpy(jg)
+
+    ds = PoseDataset(data, fk=fk)
+    assert len(ds) == int(g["n_items"]) == 24                      # 2 sequences x 12 combos
+    for idx in range(len(ds)):
+        imu, pose, joint, tran = ds[idx]
+        assert np.array_equal(imu.numpy(), g[f"item{idx}_imu"])
+        assert np.abs(pose.numpy() - g[f"item{idx}_pose"]).max() == 0
+        assert np.abs(joint.numpy() - g[f"item{idx}_joint"]).max() < 1e-5
+        assert np.array_equal(tran.numpy(), g[f"item{idx}_tran"])
+    # combo masks: item 0 is 'lw_rp_h' = devices [0,3,4]; the other two devices are zero
+    imu0 = ds[0][0]
+    assert float(imu0[:, 3:9].abs().max()) == 0 and float(imu0[:, 0:3].abs().max()) > 0

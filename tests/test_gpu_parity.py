@@ -287,3 +287,23 @@ def test_no_device_error_after_full_size(torch_mod, net):
         net.reset_all()
         net.forward(x, [125] * 256)
     assert net.device_error() == 0
+
+
+def test_evaluate_harness_offline_and_online(torch_mod, net, monkeypatch):
+    """evaluate.py flow on a synthetic dataset: runs end to end, FK-consistent metrics, ONLINE branch included."""
+    from mobileposer_amd.data import PoseDataset
+    from mobileposer_amd.evaluate import PoseEvaluator, evaluate_pose, synthetic_dataset
+    from mobileposer_amd.config import amass
+    data = synthetic_dataset(n_seq=1, frames=40, seed=3)
+    ds = PoseDataset(data, fk=net.forward_kinematics, combos=dict(list(amass.combos.items())[:2]))
+    assert len(ds) == 2 and tuple(ds[0][0].shape) == (40, 60) and tuple(ds[0][2].shape) == (40, 24, 3)
+    monkeypatch.setenv("ONLINE", "1")
+    out = evaluate_pose(net, ds, verbose=False)
+    assert tuple(out["offline"].shape) == (8, 2) and tuple(out["online"].shape) == (8, 2)
+    assert torch_mod.isfinite(out["offline"][[0, 1, 3, 6]]).all()
+    # identical prediction and ground truth -> zero errors
+    ev = PoseEvaluator(net)
+    pose = data["pose"][0].cuda()
+    e = ev.eval(pose, pose, tran_p=data["tran"][0], tran_t=data["tran"][0])
+    assert float(e[[0, 1, 3, 4], 0].abs().max()) < 1e-3
+    assert net.device_error() == 0
