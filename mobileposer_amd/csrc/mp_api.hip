@@ -131,7 +131,8 @@ struct mp_handle {
     hipEvent_t ev_x[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int* err_dev = nullptr;          // device error word of the persistent kernels
     long long* prof_dev = nullptr;   // debug: per-workgroup phase cycle sums of the last persistent launch
-    bool persist = true;             // LSTM recurrence: persistent kernel (default) or per-step launches
+    bool persist = true;
+    int nslice = 16;                 // decomposition of the H = 256 persistent layers (env MP_LSTM_SLICES=8|16)             // LSTM recurrence: persistent kernel (default) or per-step launches
     std::map<std::pair<int, int>, Plan*> plans;
     std::map<GraphKey, hipGraphExec_t> graphs;
     VelState vstate;
@@ -213,8 +214,8 @@ int pack_weights(mp_handle* h, const float* blob) {
                 mp_launch_pack_wih(find(s.id, K_WIH, l, d), find(s.id, K_BIH, l, d), find(s.id, K_BHH, l, d),
                                    m.ih[l].W, m.ih[l].bias, m.H, m.ih[l].K, m.ih[l].Kpad, d * 4 * m.H, h->s_main);
                 mp_launch_pack_whh(find(s.id, K_WHH, l, d), m.whh[l][d], m.H, h->s_main);
-                mp_launch_pack_whh_persist(find(s.id, K_WHH, l, d), m.whhP[l][d], m.H, h->s_main);
-                mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP[l][d], m.H, m.ih[l].K, h->s_main);
+                mp_launch_pack_whh_persist(find(s.id, K_WHH, l, d), m.whhP[l][d], m.H, h->nslice, h->s_main);
+                mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP[l][d], m.H, m.ih[l].K, h->nslice, h->s_main);
             }
     }
     HIPCHK(h, hipGetLastError());
@@ -259,6 +260,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     if (hipSetDevice(device) != hipSuccess) { h->err = "hipSetDevice failed"; return bail(MP_ERR_HIP); }
     if (const char* e = getenv("MP_NO_GRAPH")) h->use_graph = !(e[0] && e[0] != '0');
     if (const char* e = getenv("MP_LSTM_MODE")) h->persist = strcmp(e, "step") != 0;
+    if (const char* e = getenv("MP_LSTM_SLICES")) h->nslice = atoi(e) == 8 ? 8 : 16;
     if (getenv("MP_PERSIST_PROF")) {
         if (hipMalloc((void**)&h->prof_dev, 512 * 6 * sizeof(long long)) != hipSuccess) h->prof_dev = nullptr;
         else (void)hipMemset(h->prof_dev, 0, 512 * 6 * sizeof(long long));
@@ -313,7 +315,7 @@ int get_plan(mp_handle* h, int B, int T, Plan** out) {
                 if (int rc = dev_alloc(h, (void**)&w.hbuf[l][d], (size_t)2 * B * m.H * sizeof(float), &p->allocs)) return rc;
                 if (int rc = dev_alloc(h, (void**)&w.cbuf[l][d], (size_t)B * m.H * sizeof(float), &p->allocs)) return rc;
             }
-        w.hx_bytes = (size_t)m.dirs * ((B + 15) / 16) * ((size_t)4 * 16 * m.H + 8) * sizeof(unsigned long long);
+        w.hx_bytes = (size_t)m.dirs * ((B + 15) / 16) * ((size_t)4 * 16 * m.H + 16) * sizeof(unsigned long long);
         if (int rc = dev_alloc(h, (void**)&w.hx, w.hx_bytes, &p->allocs)) return rc;
     }
     if (int rc = dev_alloc(h, (void**)&p->r6d, M * 96 * sizeof(float), &p->allocs)) return rc;
@@ -431,7 +433,8 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
     if (h->persist) {
         HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));     // every polled word is re-zeroed before every launch
         const int nslab = (B + 15) / 16;
-        const int chunk = 256 / (dirs * mp_persist_nslice(H));  // slabs per launch: grid <= 256 workgroups, 1 per CU
+        const int nsl = H == 256 ? h->nslice : 4;
+        const int chunk = mp_persist_max_wg(H, nsl) / (dirs * nsl);   // slabs per launch: the whole grid is co-resident
         const int kin = l == 0 ? H : dirs * H;
         // timing classes: 1 = H256 bidirectional K_in=256, 4 = H256 bidirectional K_in=512, 5 = H256 unidirectional
         const int cls = H != 256 ? 6 : (dirs == 1 ? 5 : (kin == 256 ? 1 : 4));
@@ -443,7 +446,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             LstmPersistArgs a;
             a.lengths = j.p->lengths_dev; a.ndir = dirs; a.B = B; a.T = T;
             a.slab0 = s0; a.nslab = nslab - s0 < chunk ? nslab - s0 : chunk;
-            a.hx = w.hx + (size_t)dirs * s0 * ((size_t)4 * 16 * H + 8);
+            a.hx = w.hx + (size_t)dirs * s0 * ((size_t)4 * 16 * H + 16);
             a.err = h->err_dev; a.max_spin = 1u << 18; a.prof = h->prof_dev;
             a.zero_state = j.mode == STATE_ZERO ? 1 : 0;
             for (int d = 0; d < dirs; ++d) {
@@ -454,7 +457,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
                 dd.wihpack = m.wihP[l][d]; dd.bias = m.ih[l].bias + (size_t)d * 4 * H; dd.xin = xin;
             }
             if (dirs == 1) a.d[1] = a.d[0];
-            mp_launch_lstm_persist(a, H, kin, s);
+            mp_launch_lstm_persist(a, H, kin, nsl, s);
         }
     } else {
         SegScope seg(h, s, 7, T, 2.0 * dirs * (double)B * T * 4.0 * H * H);
@@ -558,11 +561,11 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         RC(run_rnn(V, sv));                                                               // net.py:117
         HIPCHK(h, hipEventRecord(h->ev_v, sv));
     } else {
-        // Persistent fused layers: the H = 256 grids are made of clusters of 8 workgroups that wait on each
-        // other and want a whole CU each (160 KB LDS), so they run strictly one after another on s_main;
-        // pose fills the chip (256 workgroups), velocity only half of it, and the foot-contact layers (H = 64:
-        // one workgroup per slab, waits on nobody) run beside velocity on the free CUs.  linear1 / linear2
-        // GEMMs and the r6d/IK kernel go to side streams.
+        // Persistent fused layers are grids of clusters of workgroups that wait on each other; joints and pose
+        // need every CU (2 workgroups x 80 KB LDS each), so nothing that also waits may run beside them: they
+        // are serialised on s_main.  Velocity (unidirectional) leaves half the slots free, and the small
+        // foot-contact layers (H = 64, 48 KB) are started only then, beside it.  linear1 / linear2 GEMMs and
+        // the r6d/IK kernel go to side streams.
         auto rec = [&](int i, hipStream_t on) -> int { HIPCHK(h, hipEventRecord(h->ev_x[i], on)); return MP_OK; };
         auto wait = [&](int i, hipStream_t on) -> int { HIPCHK(h, hipStreamWaitEvent(on, h->ev_x[i], 0)); return MP_OK; };
         HIPCHK(h, hipStreamWaitEvent(sp, h->ev_j, 0));

@@ -63,17 +63,18 @@ void mp_launch_pack_linear(const float* w, const float* b, float* dstW, float* d
 struct LstmPersistArgs {
     LstmDir d[2];
     const int* lengths;
-    unsigned long long* hx;       // granules [ndir][nslab][4*16*H + 8], zeroed before every launch
+    unsigned long long* hx;       // granules [ndir][nslab][4*16*H + 16], zeroed before every launch
     int* err;                     // device error word (0 = ok, 1+step = a gather timed out)
     int ndir, B, T, slab0, nslab;
     int zero_state;               // 1: start from h = c = 0 without reading hbuf / cbuf
     unsigned max_spin;
     long long* prof;              // optional [grid][6] cycle sums per phase (debug), else nullptr
 };
-void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, hipStream_t s);
-void mp_launch_pack_whh_persist(const float* whh, float* dst, int H, hipStream_t s);
-void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, hipStream_t s);
-int mp_persist_nslice(int H);
+// nslice: workgroups sharing one slab of an H = 256 layer: 16 (4-wave workgroups, two per CU) or 8 (8-wave, one per CU)
+void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice, hipStream_t s);
+void mp_launch_pack_whh_persist(const float* whh, float* dst, int H, int nslice, hipStream_t s);
+void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, int nslice, hipStream_t s);
+int mp_persist_max_wg(int H, int nslice);    // largest grid that is co-resident
 
 // ---------------------------------------------------------------- K4/K5: kinematics
 void mp_launch_r6d_ik(const float* r6d, long N, float* pose, const int* parent_dev, hipStream_t s);

@@ -77,38 +77,49 @@ struct Cfg {
     static constexpr int KQ = KIN / 4;                // x: K range of one wave
     static constexpr int NXS = KQ / 4;                // x: k-steps per wave
     static constexpr int NXJ = KQ / 16;               // x: 16-byte loads per lane per step
-    // a lane finishes NOWN accumulator regs (sequences) of one unit block
-    static constexpr int NOWN = TW == 1 ? (NUB == 2 ? 2 : 4) : 1;
+    // PER_UB: every wave's tiles are the 4 gates of ONE unit block -> finishing wave (kq, tw) takes accumulator
+    // reg kq of unit block tw; otherwise (TW = 1, several unit blocks per wave) a wave finishes NOWN regs of one block
+    static constexpr bool PER_UB = TW == NUB;
+    static constexpr int NOWN = PER_UB ? 1 : (NUB == 2 ? 2 : 4);
+    static constexpr int NPW = NSLICE >= 4 ? NSLICE / 4 : 1;   // producer slices inside one wave's K quarter
     static constexpr int RED_F4 = NWV * 4 * NOWN * 64;   // float4 slots: [finishing wave][source kq][o][lane]
     // LDS budget 160 KB: reduction scratch + as many x k-steps of W_ih as fit; the rest lives in registers
     static constexpr int STEP_BYTES = NWV * NTG * 64 * 16;                     // all waves, one k-step
-    static constexpr int LDS_STEPS_MAX = (160 * 1024 - RED_F4 * 16) / STEP_BYTES;
+    static constexpr int LDS_BUDGET = (NWV == 4 && NSLICE == 16) ? 80 * 1024 : 160 * 1024;   // 2 workgroups per CU
+    static constexpr int LDS_STEPS_MAX = (LDS_BUDGET - RED_F4 * 16) / STEP_BYTES;
     static constexpr int XL = NXS <= LDS_STEPS_MAX ? NXS : (LDS_STEPS_MAX / 4) * 4;  // x k-steps served from LDS
     static constexpr int XR = NXS - XL;                                        // x k-steps served from registers
+    static constexpr bool BIG = KIN > H;              // part of W_ih in registers: late gather, split x prefetch
+    static constexpr int WG_PER_CU = NWV == 4 && NSLICE == 16 ? 2 : 1;         // co-resident workgroups wanted
     static_assert(TW == 1 || TW == NUB, "tile groups are whole unit blocks");
 };
 
 template <int H, int NSLICE, int KIN, int TW, bool PROF>
-__global__ __launch_bounds__(256 * TW, 1) void mp_lstm_fused(LstmPersistArgs a) {
+__global__ __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void mp_lstm_fused(LstmPersistArgs a) {
     using C = Cfg<H, NSLICE, KIN, TW>;
     constexpr int U = C::U, NUB = C::NUB, NWV = C::NWV, NTW = C::NTW, NTG = C::NTG, KW = C::KW, NKS = C::NKS, KQ = C::KQ;
-    constexpr int NXS = C::NXS, NXJ = C::NXJ, NOWN = C::NOWN, XL = C::XL, XR = C::XR;
+    constexpr int NXS = C::NXS, NXJ = C::NXJ, NOWN = C::NOWN, XL = C::XL, XR = C::XR, NPW = C::NPW;
+    constexpr bool PER_UB = C::PER_UB;
     constexpr int NTHREADS = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* red = reinterpret_cast<f32x4*>(smem);                       // [finishing wave][source kq][o][lane]
     f32x4* wxl = reinterpret_cast<f32x4*>(smem) + C::RED_F4;           // [wave][x-step < XL][tile group][lane]
 
-    const LstmDir d = a.d[blockIdx.y];
-    int slab, slice;
-    if (NSLICE == 8 && (a.nslab & 7) == 0) {
-        // keep the 8 slices of a slab on one XCD (block b runs on XCD b % 8): speed only, never correctness
+    // 1-D grid over (direction, slab, slice).  When the number of (direction, slab) clusters is a multiple of 8
+    // the NSLICE workgroups of a cluster are given block ids that are congruent mod 8, i.e. (observed dispatch,
+    // block b -> XCD b % 8) they share an XCD and its L2: speed only, never correctness.
+    const int ncl = a.ndir * a.nslab;
+    int cl, slice;
+    if ((ncl & 7) == 0) {
         const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-        slab = (i >> 3) * 8 + xcd;
-        slice = i & 7;
+        cl = (i / NSLICE) * 8 + xcd;
+        slice = i % NSLICE;
     } else {
-        slab = blockIdx.x / NSLICE;
+        cl = blockIdx.x / NSLICE;
         slice = blockIdx.x % NSLICE;
     }
+    const int dir = cl / a.nslab, slab = cl % a.nslab;
+    const LstmDir d = a.d[dir];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kq = wave & 3, tw = wave >> 2;
     const int q = lane >> 4, r16 = lane & 15;
@@ -140,8 +151,8 @@ __global__ __launch_bounds__(256 * TW, 1) void mp_lstm_fused(LstmPersistArgs a) 
     }
 
     // ---- the (sequence, unit) pairs this lane finishes: accumulator regs of tile column r16
-    const int ubo = TW == 1 ? (NUB == 2 ? (kq & 1) : kq) : tw;             // unit block this wave finishes
-    const int reg0 = TW == 1 ? (NUB == 2 ? 2 * (kq >> 1) : 0) : kq;        // first accumulator reg it finishes
+    const int ubo = PER_UB ? tw : (NUB == 2 ? (kq & 1) : kq);              // unit block this wave finishes
+    const int reg0 = PER_UB ? kq : (NUB == 2 ? 2 * (kq >> 1) : 0);         // first accumulator reg it finishes
     const int jown = slice * U + ubo * 16 + r16;                           // hidden unit
     const f32x4 bias4 = *reinterpret_cast<const f32x4*>(d.bias + 4 * jown);
     float cst[NOWN], hst[NOWN];
@@ -172,13 +183,15 @@ __global__ __launch_bounds__(256 * TW, 1) void mp_lstm_fused(LstmPersistArgs a) 
     }
 
     // granules of this slab: hx[dir][slab] = { L[2 parities][16*H], R[2 parities][16*H], xcc[8] }
-    constexpr size_t SLABW = (size_t)4 * 16 * H + 8;
-    u64* hxL = a.hx + (size_t)(blockIdx.y * a.nslab + slab) * SLABW;
+    constexpr size_t SLABW = (size_t)4 * 16 * H + 16;
+    u64* hxL = a.hx + (size_t)cl * SLABW;
     u64* hxR = hxL + (size_t)2 * 16 * H;
     u64* xtab = hxL + (size_t)4 * 16 * H;
     unsigned spin_budget = a.max_spin;
     const unsigned my_xcc = xcc_id();
-    bool src_local[2] = {true, true};      // is the producer of this wave's first / second k-half on my XCD?
+    bool src_local[NPW];                   // is the producer slice of each part of this wave's K quarter on my XCD?
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) src_local[i] = true;
     bool all_local = true;
     if (NSLICE > 1) {
         if (threadIdx.x == 0) granule_store(xtab + slice, XCC_TAG, __uint_as_float(my_xcc));
@@ -194,8 +207,8 @@ __global__ __launch_bounds__(256 * TW, 1) void mp_lstm_fused(LstmPersistArgs a) 
         }
         const unsigned long long same = __ballot(peer == my_xcc);
         all_local = (same & ((1ull << NSLICE) - 1)) == ((1ull << NSLICE) - 1);
-        src_local[0] = (same >> (2 * kq)) & 1;             // k-steps 0..NKS/2-1 come from slice 2*kq
-        src_local[1] = (same >> (2 * kq + 1)) & 1;         // the rest from slice 2*kq+1
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) src_local[i] = (same >> (NPW * kq + i)) & 1;   // k-steps of part i come from slice NPW*kq+i
         if (__ballot(peer == ~0u)) spin_budget = 0;
     }
 
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(256 * TW, 1) void mp_lstm_fused(LstmPersistArgs a) 
     f32x4 xa[NXJ];
     // With part of W_ih in registers (XR > 0) there is no room for a whole prefetched x row beside the
     // granules: the second half of x_t is then fetched at the top of step t (it is first used ~2000 cycles later).
-    constexpr bool SPLIT_X = XR > 0;
+    constexpr bool SPLIT_X = C::BIG;
     constexpr int XJ_PRE = SPLIT_X ? NXJ / 2 : NXJ;        // 16-byte pieces prefetched one step ahead
     auto load_x = [&](int step, int j0, int j1) {
         const bool on = step < alen;
@@ -258,14 +271,16 @@ __global__ __launch_bounds__(256 * TW, 1) void mp_lstm_fused(LstmPersistArgs a) 
         u64 gr[NKS];
         const unsigned epoch = (unsigned)step;                 // written by the producers at the end of step-1
         const size_t goff = (size_t)((step + 1) & 1) * 16 * H + (size_t)kq * NKS * 64 + r16 * 4 + q;
-        const u64* src0 = (src_local[0] ? hxL : hxR) + goff;
-        const u64* src1 = NSLICE > 1 ? (src_local[1] ? hxL : hxR) + goff : src0;
+        const u64* srcp[NPW];
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) srcp[i] = (src_local[i] ? hxL : hxR) + goff;
+        constexpr int KSP = NKS / NPW;                          // k-steps per producer slice
         // (when part of W_ih lives in registers there is no room to hold 16 granules in flight beside it:
         //  request them after the projection instead; the second wave on the SIMD covers the L2 latency)
-        constexpr bool EARLY_GATHER = XR == 0;
+        constexpr bool EARLY_GATHER = !C::BIG;
         if (EARLY_GATHER && step > 0) {
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) gr[ks] = granule_load((ks < NKS / 2 ? src0 : src1) + (size_t)ks * 64);
+            for (int ks = 0; ks < NKS; ++ks) gr[ks] = granule_load(srcp[ks / KSP] + (size_t)ks * 64);
         }
         // ---- second half of the input projection
 #pragma unroll
@@ -292,7 +307,7 @@ __global__ __launch_bounds__(256 * TW, 1) void mp_lstm_fused(LstmPersistArgs a) 
         if (step > 0) {
             if (!EARLY_GATHER) {
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) gr[ks] = granule_load((ks < NKS / 2 ? src0 : src1) + (size_t)ks * 64);
+                for (int ks = 0; ks < NKS; ++ks) gr[ks] = granule_load(srcp[ks / KSP] + (size_t)ks * 64);
             }
             bool ok = true;
 #pragma unroll
@@ -300,12 +315,13 @@ __global__ __launch_bounds__(256 * TW, 1) void mp_lstm_fused(LstmPersistArgs a) 
             unsigned spins = 0;
             bool timed_out = false;
             while (!__all(ok) && !timed_out) {
-                // gate: 2 lanes per wave watch ONE granule of each producer (polling with everything floods the
+                // gate: NPW lanes per wave watch ONE granule of each producer (polling with everything floods the
                 // fabric with sc1 loads and slows every hand-off on the chip: MI355X_MICROARCH "polling-cost")
                 while (true) {
                     bool ready = true;
-                    if (lane == 0) ready = (unsigned)(granule_load(src0) >> 32) == epoch;
-                    if (lane == 1) ready = (unsigned)(granule_load(src1 + (size_t)(NKS / 2) * 64) >> 32) == epoch;
+#pragma unroll
+                    for (int i = 0; i < NPW; ++i)
+                        if (lane == i) ready = (unsigned)(granule_load(srcp[i] + (size_t)(i * KSP) * 64) >> 32) == epoch;
                     if (__all(ready)) break;
                     if (++spins > spin_budget) { timed_out = true; break; }
                     __builtin_amdgcn_s_sleep(1);
@@ -313,7 +329,7 @@ __global__ __launch_bounds__(256 * TW, 1) void mp_lstm_fused(LstmPersistArgs a) 
                 ok = true;
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
-                    gr[ks] = granule_load((ks < NKS / 2 ? src0 : src1) + (size_t)ks * 64);
+                    gr[ks] = granule_load(srcp[ks / KSP] + (size_t)ks * 64);
                     ok = ok && ((unsigned)(gr[ks] >> 32) == epoch);
                 }
                 if (++spins > spin_budget) timed_out = true;
@@ -339,7 +355,7 @@ __global__ __launch_bounds__(256 * TW, 1) void mp_lstm_fused(LstmPersistArgs a) 
         // ---- K reduction through LDS: the 4 K-quarter waves of a tile group hand each finishing wave the 4 gate
         // values of the accumulator regs it finishes (own share included: register indices stay compile-time)
         __syncthreads();                                       // previous step's reads of `red` are done
-        if (TW == 1) {
+        if (!PER_UB) {
 #pragma unroll
             for (int dw = 0; dw < 4; ++dw) {
                 const int dub = NUB == 2 ? (dw & 1) : dw;
@@ -391,7 +407,7 @@ __global__ __launch_bounds__(256 * TW, 1) void mp_lstm_fused(LstmPersistArgs a) 
         PROF_E(4);
     }
     if (PROF && prof) {
-        long long* o = a.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 6;
+        long long* o = a.prof + (size_t)blockIdx.x * 6;
         for (int i = 0; i < 5; ++i) o[i] = pt[i];
         o[5] = T;
     }
@@ -454,7 +470,7 @@ template <int H, int NSLICE, int KIN, int TW>
 void launch_fused(const LstmPersistArgs& a, hipStream_t s) {
     using C = Cfg<H, NSLICE, KIN, TW>;
     const size_t lds = (size_t)C::RED_F4 * 16 + (size_t)C::NWV * C::XL * C::NTG * 64 * 16;
-    const dim3 grid(a.nslab * NSLICE, a.ndir);
+    const dim3 grid(a.nslab * NSLICE * a.ndir);
     if (a.prof) {
         static bool once = (hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, TW, true>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
@@ -470,25 +486,32 @@ void launch_fused(const LstmPersistArgs& a, hipStream_t s) {
 
 }  // namespace
 
-void mp_launch_pack_whh_persist(const float* whh, float* dst, int H, hipStream_t s) {
+// nslice selects the decomposition of the H = 256 layers: 16 (4-wave workgroups, two per CU) or 8 (8-wave, one per CU)
+void mp_launch_pack_whh_persist(const float* whh, float* dst, int H, int nslice, hipStream_t s) {
     const size_t n = (size_t)4 * H * H;
     const int grid = (int)((n + 255) / 256);
-    if (H == 256) hipLaunchKernelGGL((mp_pack_whh_persist<256, 8, 2>), dim3(grid), dim3(256), 0, s, whh, dst);
-    else hipLaunchKernelGGL((mp_pack_whh_persist<64, 1, 1>), dim3(grid), dim3(256), 0, s, whh, dst);
+    if (H == 256 && nslice == 16) hipLaunchKernelGGL((mp_pack_whh_persist<256, 16, 1>), dim3(grid), dim3(256), 0, s, whh, dst);
+    else if (H == 256) hipLaunchKernelGGL((mp_pack_whh_persist<256, 8, 2>), dim3(grid), dim3(256), 0, s, whh, dst);
+    else hipLaunchKernelGGL((mp_pack_whh_persist<64, 4, 1>), dim3(grid), dim3(256), 0, s, whh, dst);
 }
 
-void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, hipStream_t s) {
+void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, int nslice, hipStream_t s) {
     const size_t n = (size_t)4 * H * KIN;
     const int grid = (int)((n + 255) / 256);
-    if (H == 256) hipLaunchKernelGGL((mp_pack_wih_persist<256, 8, 2>), dim3(grid), dim3(256), 0, s, wih, dst, KIN);
-    else hipLaunchKernelGGL((mp_pack_wih_persist<64, 1, 1>), dim3(grid), dim3(256), 0, s, wih, dst, KIN);
+    if (H == 256 && nslice == 16) hipLaunchKernelGGL((mp_pack_wih_persist<256, 16, 1>), dim3(grid), dim3(256), 0, s, wih, dst, KIN);
+    else if (H == 256) hipLaunchKernelGGL((mp_pack_wih_persist<256, 8, 2>), dim3(grid), dim3(256), 0, s, wih, dst, KIN);
+    else hipLaunchKernelGGL((mp_pack_wih_persist<64, 4, 1>), dim3(grid), dim3(256), 0, s, wih, dst, KIN);
 }
 
-int mp_persist_nslice(int H) { return H == 256 ? 8 : 1; }
+int mp_persist_max_wg(int H, int nslice) { return H == 256 && nslice == 16 ? 512 : 256; }
 
-void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, hipStream_t s) {
-    if (H == 256 && KIN == 256) launch_fused<256, 8, 256, 2>(a, s);
-    else if (H == 256 && KIN == 512) launch_fused<256, 8, 512, 2>(a, s);
-    else if (H == 64 && KIN == 64) launch_fused<64, 1, 64, 1>(a, s);
-    else if (H == 64 && KIN == 128) launch_fused<64, 1, 128, 1>(a, s);
+void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice, hipStream_t s) {
+    if (H == 256 && nslice == 16) {
+        if (KIN == 256) launch_fused<256, 16, 256, 1>(a, s);
+        else launch_fused<256, 16, 512, 1>(a, s);
+    } else if (H == 256) {
+        if (KIN == 256) launch_fused<256, 8, 256, 2>(a, s);
+        else launch_fused<256, 8, 512, 2>(a, s);
+    } else if (KIN == 64) launch_fused<64, 4, 64, 1>(a, s);      // H = 64 (foot contact): 4 slices of 16 units, small
+    else launch_fused<64, 4, 128, 1>(a, s);                       // footprint so that it fits beside the velocity layers
 }
