@@ -73,7 +73,7 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 struct Packed { float* W = nullptr; float* bias = nullptr; int N = 0, K = 0, Kpad = 0, Npad = 0, bn = 0; };
 struct ModuleW {
-    int n_in = 0, n_out = 0, H = 0, dirs = 0;
+    int n_in = 0, n_out = 0, H = 0, dirs = 0, nslice = 0;
     Packed lin1, ih[2], lin2;
     float* whh[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};    // per-step kernel layout
     float* whhP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // persistent kernel layout
@@ -132,7 +132,8 @@ struct mp_handle {
     int* err_dev = nullptr;          // device error word of the persistent kernels
     long long* prof_dev = nullptr;   // debug: per-workgroup phase cycle sums of the last persistent launch
     bool persist = true;
-    int nslice = 16;                 // decomposition of the H = 256 persistent layers (env MP_LSTM_SLICES=8|16)             // LSTM recurrence: persistent kernel (default) or per-step launches
+    int nslice_env = 0;              // 0: pick per module (8 slices / 8 waves for bidirectional layers that fill the
+                                     // chip, 16 slices / 4 waves for unidirectional ones); env MP_LSTM_SLICES=8|16 forces one             // LSTM recurrence: persistent kernel (default) or per-step launches
     std::map<std::pair<int, int>, Plan*> plans;
     std::map<GraphKey, hipGraphExec_t> graphs;
     VelState vstate;
@@ -184,6 +185,10 @@ int pack_weights(mp_handle* h, const float* blob) {
     for (const ModSpec& s : kSpecs) {
         ModuleW& m = h->mod[s.id];
         m.n_in = s.n_in; m.n_out = s.n_out; m.H = s.H; m.dirs = s.bi ? 2 : 1;
+        // B = 256 bidirectional = 2 x 16 slabs x 8 slices = 256 workgroups (one per CU); a unidirectional layer
+        // reaches the same 256 with 16 slices.  (Two 4-wave workgroups per CU were measured slower: the
+        // lock-step of a cluster turns any contention between co-resident workgroups into waiting for everyone.)
+        m.nslice = m.H != 256 ? 4 : (h->nslice_env ? h->nslice_env : (m.dirs == 2 ? 8 : 16));
         if (int rc = alloc_packed(h, m.lin1, m.H, m.n_in)) return rc;
         if (int rc = alloc_packed(h, m.ih[0], m.dirs * 4 * m.H, m.H)) return rc;
         if (int rc = alloc_packed(h, m.ih[1], m.dirs * 4 * m.H, m.dirs * m.H)) return rc;
@@ -214,8 +219,8 @@ int pack_weights(mp_handle* h, const float* blob) {
                 mp_launch_pack_wih(find(s.id, K_WIH, l, d), find(s.id, K_BIH, l, d), find(s.id, K_BHH, l, d),
                                    m.ih[l].W, m.ih[l].bias, m.H, m.ih[l].K, m.ih[l].Kpad, d * 4 * m.H, h->s_main);
                 mp_launch_pack_whh(find(s.id, K_WHH, l, d), m.whh[l][d], m.H, h->s_main);
-                mp_launch_pack_whh_persist(find(s.id, K_WHH, l, d), m.whhP[l][d], m.H, h->nslice, h->s_main);
-                mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP[l][d], m.H, m.ih[l].K, h->nslice, h->s_main);
+                mp_launch_pack_whh_persist(find(s.id, K_WHH, l, d), m.whhP[l][d], m.H, m.nslice, h->s_main);
+                mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP[l][d], m.H, m.ih[l].K, m.nslice, h->s_main);
             }
     }
     HIPCHK(h, hipGetLastError());
@@ -260,10 +265,10 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     if (hipSetDevice(device) != hipSuccess) { h->err = "hipSetDevice failed"; return bail(MP_ERR_HIP); }
     if (const char* e = getenv("MP_NO_GRAPH")) h->use_graph = !(e[0] && e[0] != '0');
     if (const char* e = getenv("MP_LSTM_MODE")) h->persist = strcmp(e, "step") != 0;
-    if (const char* e = getenv("MP_LSTM_SLICES")) h->nslice = atoi(e) == 8 ? 8 : 16;
+    if (const char* e = getenv("MP_LSTM_SLICES")) h->nslice_env = atoi(e) == 8 ? 8 : (atoi(e) == 16 ? 16 : 0);
     if (getenv("MP_PERSIST_PROF")) {
-        if (hipMalloc((void**)&h->prof_dev, 512 * 6 * sizeof(long long)) != hipSuccess) h->prof_dev = nullptr;
-        else (void)hipMemset(h->prof_dev, 0, 512 * 6 * sizeof(long long));
+        if (hipMalloc((void**)&h->prof_dev, 512 * 8 * sizeof(long long)) != hipSuccess) h->prof_dev = nullptr;
+        else (void)hipMemset(h->prof_dev, 0, 512 * 8 * sizeof(long long));
     }
     hipError_t e = hipSuccess;
     e = e ? e : hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking);
@@ -433,8 +438,8 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
     if (h->persist) {
         HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));     // every polled word is re-zeroed before every launch
         const int nslab = (B + 15) / 16;
-        const int nsl = H == 256 ? h->nslice : 4;
-        const int chunk = mp_persist_max_wg(H, nsl) / (dirs * nsl);   // slabs per launch: the whole grid is co-resident
+        const int nsl = m.nslice;
+        const int chunk = 256 / (dirs * nsl);                         // slabs per launch: grid <= 256 workgroups, one per CU
         const int kin = l == 0 ? H : dirs * H;
         // timing classes: 1 = H256 bidirectional K_in=256, 4 = H256 bidirectional K_in=512, 5 = H256 unidirectional
         const int cls = H != 256 ? 6 : (dirs == 1 ? 5 : (kin == 256 ? 1 : 4));
@@ -936,7 +941,7 @@ int mp_device_error(mp_handle* h, int* code) {
 }
 
 int mp_debug_read_prof(mp_handle* h, long long* out, int n_words) {
-    if (!h || !out || !h->prof_dev || n_words > 512 * 6) return MP_ERR_INVALID;
+    if (!h || !out || !h->prof_dev || n_words > 512 * 8) return MP_ERR_INVALID;
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipMemcpy(out, h->prof_dev, (size_t)n_words * sizeof(long long), hipMemcpyDeviceToHost));
     return MP_OK;

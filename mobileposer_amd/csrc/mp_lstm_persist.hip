@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) voi
 
     long long pt[6] = {0, 0, 0, 0, 0, 0};
     const bool prof = PROF && a.prof != nullptr && threadIdx.x == 0;
+    const long long t_start = PROF ? (long long)__builtin_amdgcn_s_memtime() : 0;
 #define PROF_T(i) do { if (PROF && prof) pt[i] -= (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #define PROF_E(i) do { if (PROF && prof) pt[i] += (long long)__builtin_amdgcn_s_memtime(); } while (0)
 
@@ -407,9 +408,11 @@ __global__ __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) voi
         PROF_E(4);
     }
     if (PROF && prof) {
-        long long* o = a.prof + (size_t)blockIdx.x * 6;
+        long long* o = a.prof + (size_t)blockIdx.x * 8;
         for (int i = 0; i < 5; ++i) o[i] = pt[i];
         o[5] = T;
+        o[6] = t_start;
+        o[7] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8) | my_xcc;   // HW_REG_HW_ID, XCC id
     }
 
     // ---- final state (h_n, c_n of models/rnn.py:33) back to hbuf / cbuf

@@ -13,9 +13,9 @@ xin = x if mod == "joints" else torch.randn(B, T, 132, device="cuda") * 0.3
 for _ in range(3):
     net.rnn_forward(mod, xin, [T] * B)
 torch.cuda.synchronize()
-buf = (C.c_longlong * (512 * 6))()
-net._lib.mp_debug_read_prof(net._h, buf, 512 * 6)
-a = np.array(buf[:]).reshape(512, 6)
+buf = (C.c_longlong * (512 * 8))()
+net._lib.mp_debug_read_prof(net._h, buf, 512 * 8)
+a = np.array(buf[:]).reshape(512, 8)
 a = a[a[:, 5] > 0]
 names = ["x-proj mfma", "validate/wait", "h mfma", "reduce", "cell+publish"]
 print("workgroups:", len(a), "steps:", a[0, 5])
@@ -24,3 +24,12 @@ for i, n in enumerate(names):
     print("%-13s mean %8.1f  min %8.1f  max %8.1f  (memtime ticks / step; 100 MHz => x10 ns)" % (n, per.mean(), per.min(), per.max()))
 tot = a[:, :5].sum(axis=1) / a[:, 5]
 print("total/step    mean %8.1f" % tot.mean())
+
+st = a[:, 6] - a[:, 6].min()
+print("start offsets (ticks): first 8 blocks", st[:8], " blocks 256..263", st[256:264] if len(a) > 256 else "-")
+print("late starters (> 100k ticks):", int((st > 100000).sum()), "of", len(a))
+hw = a[:, 7]
+cu = [(int(x) & 0xF, (int(x) >> 8 >> 8) & 0xF, (int(x) >> 8 >> 13) & 0x7, (int(x) >> 8 >> 16) & 0xF) for x in hw]   # xcc, cu_id, sh, se
+from collections import Counter
+cnt = Counter(cu)
+print("distinct (xcc,cu,sh,se):", len(cnt), " max WGs on one CU:", max(cnt.values()), " histogram:", Counter(cnt.values()))
