@@ -2,9 +2,8 @@
 """bench.py -- IMU frames/s of the MobilePoser inference path on MI355X (BASELINE.json metric).
 
 One "step" = one pass of the hot path over one synthetic batch of 256 IMU windows x 125 frames that is
-already resident in HBM:  mp_forward (4 stacked-LSTM modules + 6D->SO(3) + global->local)
- -> mp_fk (SMPL forward kinematics of the predicted pose) -> mp_translate_offline (foot-contact/velocity
-translation solver).  With N > 1 every rank (one process per GPU, launched by torch.distributed.run) runs
+already resident in HBM:  mp_forward_offline = forward (4 stacked-LSTM modules + 6D->SO(3) + global->local)
+ + SMPL forward kinematics of the predicted pose + foot-contact/velocity translation solver, one captured graph.  With N > 1 every rank (one process per GPU, launched by torch.distributed.run) runs
 the same per-GPU workload on its own seeded batch (weak scaling); the only collective is the RCCL broadcast
 of the weight blob from rank 0 at start-up.
 
@@ -130,9 +129,8 @@ def main():
 
     def step():
         lib.mp_reset_state(h, 1)            # every step is a fresh, independent batch
-        rc = lib.mp_forward(h, vp(imu), lens, B, T, vp(pose), vp(joints), vp(vel), vp(contact), None, stream)
-        rc = rc or lib.mp_fk(h, vp(pose), None, B * T, vp(rglob), vp(jglob), stream)
-        rc = rc or lib.mp_translate_offline(h, vp(joints), vp(vel), vp(contact), lens, B, T, vp(tran), stream)
+        rc = lib.mp_forward_offline(h, vp(imu), lens, B, T, vp(pose), vp(joints), vp(vel), vp(contact), vp(tran),
+                                    vp(rglob), vp(jglob), stream)       # forward + FK + translation solver, one graph
         if rc:
             raise RuntimeError(lib.mp_last_error(h).decode())
 

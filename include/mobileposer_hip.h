@@ -84,6 +84,14 @@ int mp_forward(mp_handle* h, const float* imu_dev, const int32_t* lengths_host, 
                float* pose_dev, float* joints_dev, float* vel_dev, float* contact_dev,
                float* r6d_dev, void* stream);
 
+/* MobilePoserNet.forward_offline (models/net.py:121-171, PHYSICS off) batched over sequences, as ONE captured
+ * graph: mp_forward + the translation solver (tran_dev [B,T,3]) and, when rglobal_dev / joint_dev are given
+ * (both or neither), the SMPL forward kinematics of the predicted pose that the evaluator applies next
+ * (articulate/evaluator.py:319; R_global [B*T,24,3,3], joint [B*T,24,3], no translation added). */
+int mp_forward_offline(mp_handle* h, const float* imu_dev, const int32_t* lengths_host, int B, int T,
+                       float* pose_dev, float* joints_dev, float* vel_dev, float* contact_dev, float* tran_dev,
+                       float* rglobal_dev, float* joint_dev, void* stream);
+
 /* RNN.forward of one module (models/rnn.py:20-33): Linear+ReLU -> 2-layer LSTM (packed-sequence
  * semantics) -> Linear.  x_dev [B,T,n_in] -> y_dev [B,T,n_out].
  * state_in_dev / state_out_dev: optional (h then c, each [layers*dirs, B, H] contiguous, nn.LSTM

@@ -27,6 +27,7 @@ SIGNATURES = {
     "mp_last_error": (C.c_char_p, [_vp]),
     "mp_get_constants": (_i, [_vp, _fp, _fp]),
     "mp_forward": (_i, [_vp, _vp, _ip, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mp_forward_offline": (_i, [_vp, _vp, _ip, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_rnn_forward": (_i, [_vp, _i, _vp, _ip, _i, _i, _vp, _vp, _vp, _vp]),
     "mp_reduced_global_to_full": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "mp_translate_offline": (_i, [_vp, _vp, _vp, _vp, _ip, _i, _i, _vp, _vp]),

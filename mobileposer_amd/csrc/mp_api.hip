@@ -417,7 +417,10 @@ int rnn_g0(const RnnJob& j, hipStream_t s) {
         for (int d = 0; d < dirs; ++d) {
             const size_t n = (size_t)B * H * sizeof(float);
             const int k = l * dirs + d;
-            if (j.mode == STATE_FROM) {
+            if (h->persist && j.out_h == j.in_h && j.out_h) {
+                // the persistent kernel reads its initial and writes its final (h,c) in place: carried state
+                // (velocity.rnn_state) needs no staging copies at all
+            } else if (j.mode == STATE_FROM) {
                 HIPCHK(h, hipMemcpyAsync(w.hbuf[l][d], j.in_h + (size_t)k * B * H, n, hipMemcpyDeviceToDevice, s));
                 HIPCHK(h, hipMemcpyAsync(w.cbuf[l][d], j.in_c + (size_t)k * B * H, n, hipMemcpyDeviceToDevice, s));
             } else if (!h->persist) {                                      // persistent kernel: zero_state flag
@@ -457,7 +460,9 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             for (int d = 0; d < dirs; ++d) {
                 LstmDir& dd = a.d[d];
                 dd.wpack = m.whhP[l][d]; dd.xproj = nullptr; dd.out = outp + (size_t)d * H;
-                dd.hbuf = w.hbuf[l][d]; dd.cbuf = w.cbuf[l][d];
+                const bool inplace = j.out_h == j.in_h && j.out_h;
+                dd.hbuf = inplace ? j.out_h + (size_t)(l * dirs + d) * B * H : w.hbuf[l][d];
+                dd.cbuf = inplace ? j.out_c + (size_t)(l * dirs + d) * B * H : w.cbuf[l][d];
                 dd.xprojStride = 0; dd.outStride = dirs * H; dd.reverse = d;
                 dd.wihpack = m.wihP[l][d]; dd.bias = m.ih[l].bias + (size_t)d * 4 * H; dd.xin = xin;
             }
@@ -499,7 +504,7 @@ int rnn_g2(const RnnJob& j, hipStream_t s) {
     ModuleWS& w = j.p->ws[j.id];
     const int B = j.p->B, T = j.p->T, M = B * T, H = m.H, dirs = m.dirs;
     const RowMap none{nullptr, 0, 0, 0};
-    if (j.out_h) {
+    if (j.out_h && !(h->persist && j.out_h == j.in_h)) {
         const size_t fin = h->persist ? 0 : (size_t)(T & 1) * B * H;   // where the recurrence left h_n
         for (int l = 0; l < 2; ++l)
             for (int d = 0; d < dirs; ++d) {
@@ -541,7 +546,7 @@ int ensure_vstate(mp_handle* h, VelState& v, int B) {
 // nobody) runs whole on s_foot.
 int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long poseRows, long poseRowStride,
                  long poseRowOffset, float* joints, float* vel, float* contact, float* r6d, VelState& vs,
-                 bool has_state) {
+                 bool has_state, float* fk_rglobal = nullptr, float* fk_joint = nullptr) {
     const int T = p->T;
     const RowMap none{nullptr, 0, 0, 0};
     const RowMap xj = user_map(joints, T, 72), xi = user_map(imu, T, 60);
@@ -563,6 +568,7 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         RC(run_rnn(P, sm));                                                               // net.py:106-107
         { SegScope seg(h, sm, 2, 1);
           mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sm); }   // net.py:110
+        if (fk_rglobal) mp_launch_fk(pose, nullptr, poseRows, h->bone_dev, h->parent_dev, h->depth_dev, fk_rglobal, fk_joint, sm);
         RC(run_rnn(V, sv));                                                               // net.py:117
         HIPCHK(h, hipEventRecord(h->ev_v, sv));
     } else {
@@ -581,6 +587,7 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         RC(wait(2, sp)); RC(rnn_g2(P, sp));
         { SegScope seg(h, sp, 2, 1);
           mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sp); }   // net.py:110
+        if (fk_rglobal) mp_launch_fk(pose, nullptr, poseRows, h->bone_dev, h->parent_dev, h->depth_dev, fk_rglobal, fk_joint, sp);
         RC(rec(3, sp));
         RC(wait(1, sm)); RC(rnn_rec(V, 0, sm)); RC(rnn_rec(V, 1, sm)); RC(rec(4, sm));      // net.py:117
         RC(wait(4, sv)); RC(rnn_g2(V, sv));
@@ -727,6 +734,44 @@ int mp_forward(mp_handle* h, const float* imu_dev, const int32_t* lengths_host, 
         rc = run_maybe_graph(h, key, [&]() {
             return forward_body(h, p, imu_dev, pose_dev, (long)B * T, 96, 0, joints_dev, vel_dev, contact_dev, r6d,
                                 h->vstate, has_state);
+        });
+    }
+    if (rc) return rc;
+    h->vstate.B = B;
+    return leave(h, stream);
+}
+
+int mp_forward_offline(mp_handle* h, const float* imu_dev, const int32_t* lengths_host, int B, int T, float* pose_dev,
+                       float* joints_dev, float* vel_dev, float* contact_dev, float* tran_dev, float* rglobal_dev,
+                       float* joint_dev, void* stream) {
+    if (!h) return MP_ERR_INVALID;
+    if (!imu_dev || !lengths_host || !pose_dev || !joints_dev || !vel_dev || !contact_dev || !tran_dev || B < 1 || T < 1 ||
+        ((rglobal_dev == nullptr) != (joint_dev == nullptr)))
+        return fail(h, MP_ERR_INVALID, "mp_forward_offline: NULL buffer or non-positive shape");
+    if (h->vstate.B != 0 && h->vstate.B != B)
+        return fail(h, MP_ERR_STATE_SHAPE, "carried velocity state has batch %d, call has batch %d", h->vstate.B, B);
+    if (int rc = enter(h, stream)) return rc;
+    Plan* p = nullptr;
+    if (int rc = get_plan(h, B, T, &p)) return rc;
+    if (int rc = upload_lengths(h, p, lengths_host)) return rc;
+    if (int rc = ensure_vstate(h, h->vstate, B)) return rc;
+    const bool has_state = h->vstate.B == B;
+    h->segs.clear(); h->ev_used = 0;
+    GraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.kind = 2; key.B = B; key.T = T; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0);
+    key.p[0] = imu_dev; key.p[1] = pose_dev; key.p[2] = joints_dev; key.p[3] = vel_dev; key.p[4] = contact_dev;
+    key.p[5] = tran_dev; key.p[6] = h->vstate.h; key.p[7] = rglobal_dev;
+    int rc;
+    {
+        SegScope whole(h, h->s_main, 3, 1);
+        rc = run_maybe_graph(h, key, [&]() {
+            if (int r = forward_body(h, p, imu_dev, pose_dev, (long)B * T, 96, 0, joints_dev, vel_dev, contact_dev, p->r6d,
+                                     h->vstate, has_state, rglobal_dev, joint_dev)) return r;
+            mp_launch_translate_offline(joints_dev, vel_dev, contact_dev, p->lengths_dev, B, T, h->floor_y, tran_dev,
+                                        h->s_main);                                       // net.py:130-154
+            HIPCHK(h, hipGetLastError());
+            return (int)MP_OK;
         });
     }
     if (rc) return rc;

@@ -259,9 +259,15 @@ class MobilePoserNet:
         (pose [T,24,3,3], pred_joints [1,T,72], tran [T,3], contact [T,2]).
         With a batch B > 1 (a generalisation the reference does not have) the leading dims are kept:
         pose [B*T,24,3,3], pred_joints [B,T,72], tran [B,T,3], contact [B,T,2]."""
-        io, lens, B, T = self._forward_buffers(imu, input_lengths)
-        rc = self._lib.mp_translate_offline(self._h, _ptr(io["joints"]), _ptr(io["vel"]), _ptr(io["contact"]), lens,
-                                            B, T, _ptr(io["tran"]), self._stream())
+        self._require_weights()
+        if imu.dim() != 3 or imu.shape[-1] != model_config.n_imu:
+            raise RuntimeError("expected imu of shape [B, T, 60], got %s" % (tuple(imu.shape),))
+        B, T = int(imu.shape[0]), int(imu.shape[1])
+        lens = self._lengths(input_lengths, B, T)
+        io = self._buffers(B, T)
+        io["imu"].copy_(imu.to(device=self.device, dtype=torch.float32))
+        rc = self._lib.mp_forward_offline(self._h, _ptr(io["imu"]), lens, B, T, _ptr(io["pose"]), _ptr(io["joints"]),
+                                          _ptr(io["vel"]), _ptr(io["contact"]), _ptr(io["tran"]), None, None, self._stream())
         _lib.check(rc, self._h)
         pose, joints = io["pose"].clone(), io["joints"].clone()
         tran, contact = io["tran"].clone(), io["contact"].clone()
