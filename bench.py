@@ -32,8 +32,8 @@ KERNEL_CLASSES = {   # timing classes of the C ABI (include/mobileposer_hip.h, m
     0: "mp_gemm_f32 (linear1 / linear2)",
     1: "mp_lstm_fused<256,8,256,2> bidirectional layer 0 (joints, pose)",
     4: "mp_lstm_fused<256,8,512,2> bidirectional layer 1 (joints, pose)",
-    5: "mp_lstm_fused<256,8,256,2> unidirectional layers (velocity)",
-    6: "mp_lstm_fused<64,1,*,1> (foot contact)",
+    5: "mp_lstm_fused<256,16,256,1> unidirectional layers (velocity)",
+    6: "mp_lstm_fused<64,4,*,1> (foot contact)",
     7: "mp_lstm_step (per-step fallback)",
     2: "mp_r6d_ik",
 }
@@ -190,6 +190,16 @@ def main():
     value = frames / elapsed
     dn, dms, dgf = acc[dominant]
     achieved = dgf / dms if dms > 0 else 0.0              # GFLOP / ms = TFLOP/s
+    # HBM bytes per launch of that kernel from the separate rocprofv3 --pmc passes (profiles/r01_pmc_summary.json):
+    # (2*FETCH_SIZE + WRITE_SIZE)*1024, corrected as MI355X_MICROARCH.md prescribes; null when no profile is present
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_summary.json")))["kernels"]
+        key = {1: "mp_lstm_fused<256, 8, 256, 2, false>", 4: "mp_lstm_fused<256, 8, 512, 2, false>",
+               5: "mp_lstm_fused<256, 16, 256, 1, false>", 0: "mp_gemm_f32<2, 2, 2, 2>"}.get(dominant)
+        traffic = pmc[key]["hbm_bytes_per_launch_corrected"] if key in pmc else None
+    except Exception:
+        traffic = None
     out = {
         "metric": "imu_frames_per_sec (MobilePoserNet fwd + FK + translation solver, batch 256 x window 125 per GPU)",
         "value": round(value, 1), "unit": "frames/s", "per_gpu": round(value / world, 1),
@@ -207,7 +217,7 @@ def main():
                        "hbm_gbps_compulsory": round(value / world * BYTES_PER_FRAME / 1e9, 2)},
         "roofline": {"kernel": KERNEL_CLASSES[dominant], "bound": "mfma",
                      "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                      "flop_per_launch": round(dgf / dn * 1e9), "avg_launch_ms": round(dms / dn, 4),
                      "note": "algorithmic FLOPs of the launch (input projection + recurrence, SURVEY.md 8(d)) / "
                              "HIP-event duration of the launch, v_mfma_f32_16x16x4_f32 dense peak"},
