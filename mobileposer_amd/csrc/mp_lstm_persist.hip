@@ -315,6 +315,7 @@ __global__ __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) voi
             for (int ks = 0; ks < NKS; ++ks) ok = ok && ((unsigned)(gr[ks] >> 32) == epoch);
             unsigned spins = 0;
             bool timed_out = false;
+            if (PROF && prof && !__all(ok)) pt[5] += 1;      // slow-path entries
             while (!__all(ok) && !timed_out) {
                 // gate: NPW lanes per wave watch ONE granule of each producer (polling with everything floods the
                 // fabric with sc1 loads and slows every hand-off on the chip: MI355X_MICROARCH "polling-cost")
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) voi
         long long* o = a.prof + (size_t)blockIdx.x * 8;
         for (int i = 0; i < 5; ++i) o[i] = pt[i];
         o[5] = T;
-        o[6] = t_start;
+        o[6] = pt[5];
         o[7] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8) | my_xcc;   // HW_REG_HW_ID, XCC id
     }
 

@@ -134,3 +134,17 @@ def test_g6_fk(smpl):
     Rg2, jg2, vg2 = O.forward_kinematics_mesh(g["pose"], smpl, tran=g["tran"])
     assert np.abs(jg2 - g["joint_tran"]).max() < TIGHT
     assert np.abs(vg2 - g["vert_tran"]).max() < TIGHT
+
+
+@pytest.mark.parametrize("tag", ["eq", "rag"])
+def test_torch_baseline_restatement_matches_golden(weights, smpl, tag):
+    """oracle/torch_ref.py (the torch-CPU leg of bench.py's cpu_baseline) against the reference's own outputs."""
+    from oracle.torch_ref import TorchNet
+    g = load_golden("g2_forward.npz")
+    net = TorchNet(weights, smpl["J"])
+    pose, joints, vel, contact, r6d = net.forward(g["imu"], g[f"{tag}_lengths"].tolist())
+    assert np.abs(joints - g[f"{tag}_joints"]).max() < TIGHT
+    assert np.abs(r6d - g[f"{tag}_r6d"]).max() < TIGHT
+    assert np.abs(vel - g[f"{tag}_vel"]).max() < TIGHT
+    assert np.abs(contact - g[f"{tag}_contact"]).max() < TIGHT
+    assert geodesic(pose, g[f"{tag}_pose"]).max() < TOL

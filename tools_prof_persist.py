@@ -25,11 +25,4 @@ for i, n in enumerate(names):
 tot = a[:, :5].sum(axis=1) / a[:, 5]
 print("total/step    mean %8.1f" % tot.mean())
 
-st = a[:, 6] - a[:, 6].min()
-print("start offsets (ticks): first 8 blocks", st[:8], " blocks 256..263", st[256:264] if len(a) > 256 else "-")
-print("late starters (> 100k ticks):", int((st > 100000).sum()), "of", len(a))
-hw = a[:, 7]
-cu = [(int(x) & 0xF, (int(x) >> 8 >> 8) & 0xF, (int(x) >> 8 >> 13) & 0x7, (int(x) >> 8 >> 16) & 0xF) for x in hw]   # xcc, cu_id, sh, se
-from collections import Counter
-cnt = Counter(cu)
-print("distinct (xcc,cu,sh,se):", len(cnt), " max WGs on one CU:", max(cnt.values()), " histogram:", Counter(cnt.values()))
+print("slow-path (stale granules at first look) steps per workgroup: mean %.1f of %d" % (a[:, 6].mean(), a[0, 5]))
