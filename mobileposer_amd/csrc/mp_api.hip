@@ -78,6 +78,7 @@ struct ModuleW {
     float* whh[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};    // per-step kernel layout
     float* whhP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // persistent kernel layout
     float* wihP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // W_ih, persistent kernel layout
+    float* wihG1 = nullptr;          // unidirectional H=256 block: layer-1 W_ih in granule k-order (wavefront kernel)
 };
 struct ModuleWS {
     float *xproj = nullptr, *out0 = nullptr, *out1 = nullptr;   // X1 (linear1 output) aliases out1
@@ -132,6 +133,7 @@ struct mp_handle {
     int* err_dev = nullptr;          // device error word of the persistent kernels
     long long* prof_dev = nullptr;   // debug: per-workgroup phase cycle sums of the last persistent launch
     bool persist = true;
+    bool uni2 = true;                // velocity block: both layers as one wavefront launch (env MP_LSTM_UNI2=0 disables)
     int nslice_env = 0;              // 0: pick per module (8 slices / 8 waves for bidirectional layers that fill the
                                      // chip, 16 slices / 4 waves for unidirectional ones); env MP_LSTM_SLICES=8|16 forces one             // LSTM recurrence: persistent kernel (default) or per-step launches
     std::map<std::pair<int, int>, Plan*> plans;
@@ -220,7 +222,11 @@ int pack_weights(mp_handle* h, const float* blob) {
                                    m.ih[l].W, m.ih[l].bias, m.H, m.ih[l].K, m.ih[l].Kpad, d * 4 * m.H, h->s_main);
                 mp_launch_pack_whh(find(s.id, K_WHH, l, d), m.whh[l][d], m.H, h->s_main);
                 mp_launch_pack_whh_persist(find(s.id, K_WHH, l, d), m.whhP[l][d], m.H, m.nslice, h->s_main);
-                mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP[l][d], m.H, m.ih[l].K, m.nslice, h->s_main);
+                mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP[l][d], m.H, m.ih[l].K, m.nslice, 0, h->s_main);
+                if (l == 1 && m.dirs == 1 && m.H == 256 && m.nslice == 16) {
+                    if (int rc = dev_alloc(h, (void**)&m.wihG1, (size_t)4 * m.H * m.ih[1].K * sizeof(float))) return rc;
+                    mp_launch_pack_wih_persist(find(s.id, K_WIH, 1, 0), m.wihG1, m.H, m.ih[1].K, 16, 1, h->s_main);
+                }
             }
     }
     HIPCHK(h, hipGetLastError());
@@ -265,6 +271,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     if (hipSetDevice(device) != hipSuccess) { h->err = "hipSetDevice failed"; return bail(MP_ERR_HIP); }
     if (const char* e = getenv("MP_NO_GRAPH")) h->use_graph = !(e[0] && e[0] != '0');
     if (const char* e = getenv("MP_LSTM_MODE")) h->persist = strcmp(e, "step") != 0;
+    if (const char* e = getenv("MP_LSTM_UNI2")) h->uni2 = !(e[0] == '0');
     if (const char* e = getenv("MP_LSTM_SLICES")) h->nslice_env = atoi(e) == 8 ? 8 : (atoi(e) == 16 ? 16 : 0);
     if (getenv("MP_PERSIST_PROF")) {
         if (hipMalloc((void**)&h->prof_dev, 512 * 8 * sizeof(long long)) != hipSuccess) h->prof_dev = nullptr;
@@ -320,7 +327,7 @@ int get_plan(mp_handle* h, int B, int T, Plan** out) {
                 if (int rc = dev_alloc(h, (void**)&w.hbuf[l][d], (size_t)2 * B * m.H * sizeof(float), &p->allocs)) return rc;
                 if (int rc = dev_alloc(h, (void**)&w.cbuf[l][d], (size_t)B * m.H * sizeof(float), &p->allocs)) return rc;
             }
-        w.hx_bytes = (size_t)m.dirs * ((B + 15) / 16) * ((size_t)4 * 16 * m.H + 16) * sizeof(unsigned long long);
+        w.hx_bytes = (size_t)2 * ((B + 15) / 16) * ((size_t)4 * 16 * m.H + 16) * sizeof(unsigned long long);
         if (int rc = dev_alloc(h, (void**)&w.hx, w.hx_bytes, &p->allocs)) return rc;
     }
     if (int rc = dev_alloc(h, (void**)&p->r6d, M * 96 * sizeof(float), &p->allocs)) return rc;
@@ -402,13 +409,19 @@ struct RnnJob {
     float *out_h, *out_c;
 };
 
+// linear1's output X1 normally lives in out1's memory (dead until layer 1 writes it); the two-layer wavefront
+// kernel writes out1 while layer 0 is still reading X1, so there X1 goes to the (otherwise unused) out0
+float* x1_buffer(const mp_handle* h, const ModuleW& m, ModuleWS& w) {
+    return (h->persist && h->uni2 && m.wihG1) ? w.out0 : w.out1;
+}
+
 int rnn_g0(const RnnJob& j, hipStream_t s) {
     mp_handle* h = j.h;
     const ModuleW& m = h->mod[j.id];
     ModuleWS& w = j.p->ws[j.id];
     const int B = j.p->B, T = j.p->T, M = B * T, H = m.H, dirs = m.dirs;
     const RowMap none{nullptr, 0, 0, 0};
-    float* X1 = w.out1;
+    float* X1 = x1_buffer(h, m, w);
     run_gemm(h, s, j.a0, j.a1, m.lin1, X1, H, (long)B * H, M, B, 1);                       // rnn.py:22
     // the per-step kernels take the input projection from a GEMM; the persistent kernel computes it itself
     if (!h->persist)
@@ -438,7 +451,31 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
     ModuleWS& w = j.p->ws[j.id];
     const int B = j.p->B, T = j.p->T, H = m.H, dirs = m.dirs;
     float* out = l == 0 ? w.out0 : w.out1;
-    if (h->persist) {
+    if (h->persist && h->uni2 && m.wihG1) {
+        // two-layer wavefront launch: layer 0 and layer 1 together when asked for layer 0, nothing for layer 1
+        if (l == 1) return MP_OK;
+        HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
+        const int nslab = (B + 15) / 16, chunk = 16;            // 16 slabs x 16 slices = 256 workgroups, one per CU
+        SegScope seg(h, s, 5, (nslab + chunk - 1) / chunk, 2.0 * (double)B * T * 4.0 * H * (4.0 * H));
+        const bool inplace = j.out_h == j.in_h && j.out_h;
+        for (int s0 = 0; s0 < nslab; s0 += chunk) {
+            LstmPersistArgs a;
+            a.lengths = j.p->lengths_dev; a.ndir = 2; a.B = B; a.T = T;
+            a.slab0 = s0; a.nslab = nslab - s0 < chunk ? nslab - s0 : chunk;
+            a.hx = w.hx + (size_t)2 * s0 * ((size_t)4 * 16 * H + 16);
+            a.err = h->err_dev; a.max_spin = 1u << 18; a.prof = nullptr;
+            a.zero_state = j.mode == STATE_ZERO ? 1 : 0;
+            for (int ll = 0; ll < 2; ++ll) {
+                LstmDir& dd = a.d[ll];
+                dd.wpack = m.whhP[ll][0]; dd.xproj = nullptr; dd.out = w.out1;
+                dd.hbuf = inplace ? j.out_h + (size_t)ll * B * H : w.hbuf[ll][0];
+                dd.cbuf = inplace ? j.out_c + (size_t)ll * B * H : w.cbuf[ll][0];
+                dd.xprojStride = 0; dd.outStride = H; dd.reverse = 0;
+                dd.wihpack = ll == 0 ? m.wihP[0][0] : m.wihG1; dd.bias = m.ih[ll].bias; dd.xin = x1_buffer(h, m, w);
+            }
+            mp_launch_lstm_uni2(a, s);
+        }
+    } else if (h->persist) {
         HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));     // every polled word is re-zeroed before every launch
         const int nslab = (B + 15) / 16;
         const int nsl = m.nslice;
@@ -684,6 +721,7 @@ void mp_destroy(mp_handle* h) {
             if (m.whhP[l][d]) (void)hipFree(m.whhP[l][d]);
             if (m.wihP[l][d]) (void)hipFree(m.wihP[l][d]);
         }
+        if (m.wihG1) (void)hipFree(m.wihG1);
     }
     void* misc[] = {h->parent_dev, h->depth_dev, h->bone_dev, h->vstate.h, h->vstate.c, h->sc.window, h->sc.fresh,
                     h->sc.mask_dev, h->sc.st.last_foot, h->sc.st.root_y, h->sc.st.root_pos, h->sc.joints, h->sc.vel,

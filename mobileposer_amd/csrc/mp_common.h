@@ -73,8 +73,10 @@ struct LstmPersistArgs {
 // nslice: workgroups sharing one slab of an H = 256 layer: 16 (4-wave workgroups, two per CU) or 8 (8-wave, one per CU)
 void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice, hipStream_t s);
 void mp_launch_pack_whh_persist(const float* whh, float* dst, int H, int nslice, hipStream_t s);
-void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, int nslice, hipStream_t s);
+void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, int nslice, int korder, hipStream_t s);
 int mp_persist_max_wg(int H, int nslice);    // largest grid that is co-resident
+// both layers of a unidirectional 2-layer H = 256 LSTM as one wavefront launch (d[0] = layer 0, d[1] = layer 1)
+void mp_launch_lstm_uni2(const LstmPersistArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- K4/K5: kinematics
 void mp_launch_r6d_ik(const float* r6d, long N, float* pose, const int* parent_dev, hipStream_t s);

@@ -426,6 +426,231 @@ __global__ __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Two stacked UNIDIRECTIONAL layers in one launch (the velocity block, models/velocity.py:29: nn.LSTM(256, 256,
+// 2 layers)).  Layer 1 at time t needs only h0_t, so the layers form a wavefront: at step s a workgroup
+// advances layer 0 to time s and layer 1 to time s-1.  h0_{s-1}, which is exchanged anyway for layer 0's
+// recurrence, IS layer 1's input x1_{s-1}.  T+1 steps instead of 2T, twice the MFMA work per step (the two
+// layers cover each other's latencies on every SIMD), no layer-0 output round trip through HBM, one launch.
+// 16 slices x 16 units; 8 waves: wave (kq, layer) takes K quarter kq of layer `layer` (2 waves per SIMD, <= 256
+// VGPRs each).  W_hh0 / W_hh1 in VGPRs, W_ih0 / W_ih1 as two 64 KB LDS images, 32 KB reduction scratch = 160 KB.
+// d[0] / d[1] describe layer 0 / layer 1.
+template <int H>
+__global__ __launch_bounds__(512, 1) void mp_lstm_fused_uni2(LstmPersistArgs a) {
+    constexpr int NSLICE = 16, U = 16, KW = H / 4, NKS = KW / 4, KQ = H / 4, NXS = KQ / 4, NXJ = KQ / 16, NPW = 4;
+    constexpr int KSP = NKS / NPW;
+    constexpr int IMG_F4 = 4 * NXS * 64;                                // one W_ih LDS image, in float4
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* red = reinterpret_cast<f32x4*>(smem);                        // [layer][finishing wave][source kq][lane]
+    f32x4* wximg = reinterpret_cast<f32x4*>(smem) + 2 * 4 * 4 * 64;     // [layer][wave kq][k-step][lane]
+
+    const int ncl = a.nslab;
+    int slab, slice;
+    if ((ncl & 7) == 0) {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        slab = (i / NSLICE) * 8 + xcd;
+        slice = i % NSLICE;
+    } else {
+        slab = blockIdx.x / NSLICE;
+        slice = blockIdx.x % NSLICE;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kq = wave & 3, layer = wave >> 2;
+    const LstmDir d = a.d[layer];
+    const int q = lane >> 4, r16 = lane & 15;
+    const int B = a.B, T = a.T;
+    const int brow0 = (a.slab0 + slab) * 16;
+
+    {   // LDS images (the k-steps of a slice's 4 K-quarter waves are contiguous in the packed arrays)
+        const f32x4* s0 = reinterpret_cast<const f32x4*>(a.d[0].wihpack) + (size_t)slice * IMG_F4;
+        const f32x4* s1 = reinterpret_cast<const f32x4*>(a.d[1].wihpack) + (size_t)slice * IMG_F4;
+        for (int i = threadIdx.x; i < IMG_F4; i += 512) { wximg[i] = s0[i]; wximg[IMG_F4 + i] = s1[i]; }
+    }
+    float wv[NKS][4];
+    {
+        const float* p = d.wpack + ((size_t)(slice * 4 + kq) * NKS * 4) * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wv[ks][t] = p[(size_t)(ks * 4 + t) * 64];
+    }
+
+    // the (sequence, unit) this lane finishes in its layer: accumulator reg kq of tile column r16
+    const int jown = slice * U + r16;
+    const int bown = brow0 + q * 4 + kq;
+    const bool inb = bown < B;
+    const int blen = inb ? a.lengths[bown] : 0;
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(d.bias + 4 * jown);
+    float cst = (inb && !a.zero_state) ? d.cbuf[(size_t)bown * H + jown] : 0.f;
+    float hst = (inb && !a.zero_state) ? d.hbuf[(size_t)bown * H + jown] : 0.f;
+
+    const int arow = brow0 + r16;
+    const bool arow_in = arow < B;
+    const int alen = arow_in ? a.lengths[arow] : 0;
+    const float* xbase = a.d[0].xin + (size_t)(arow_in ? arow : 0) * H + kq * KQ + q * 4;
+    const size_t xtstride = (size_t)B * H;
+    // A operands at step 0: h0_init for the layer-0 recurrence; layer 1 is idle at step 0 (its inputs are zeroed)
+    float av[NKS];
+    {
+        const float* p = d.hbuf + (size_t)(arow_in ? arow : 0) * H + kq * KW + q;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) av[ks] = (arow_in && !a.zero_state) ? p[4 * ks] : 0.f;
+    }
+
+    constexpr size_t SLABW = (size_t)4 * 16 * H + 16;
+    u64* hx0L = a.hx + (size_t)slab * SLABW;                 // layer 0: cluster index = slab
+    u64* hx1L = a.hx + (size_t)(a.nslab + slab) * SLABW;     // layer 1: cluster index = nslab + slab
+    u64* hx0R = hx0L + (size_t)2 * 16 * H;
+    u64* hx1R = hx1L + (size_t)2 * 16 * H;
+    u64* hxoL = layer ? hx1L : hx0L;                         // where this wave publishes
+    u64* hxoR = layer ? hx1R : hx0R;
+    u64* xtab = hx0L + (size_t)4 * 16 * H;
+    unsigned spin_budget = a.max_spin;
+    const unsigned my_xcc = xcc_id();
+    bool src_local[NPW];
+    bool all_local = true;
+    {
+        if (threadIdx.x == 0) granule_store(xtab + slice, XCC_TAG, __uint_as_float(my_xcc));
+        unsigned peer = my_xcc;
+        if (lane < NSLICE) {
+            unsigned spins = 0;
+            while (true) {
+                const u64 g = granule_load(xtab + lane);
+                if ((unsigned)(g >> 32) == XCC_TAG) { peer = (unsigned)g; break; }
+                if (++spins > spin_budget) { atomicExch(a.err, 1000000); peer = ~0u; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        const unsigned long long same = __ballot(peer == my_xcc);
+        all_local = (same & 0xFFFFull) == 0xFFFFull;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) src_local[i] = (same >> (NPW * kq + i)) & 1;
+        if (__ballot(peer == ~0u)) spin_budget = 0;
+    }
+
+    f32x4 xa[NXJ];
+    auto load_x = [&](int step) {
+        const bool on = layer == 0 && step < alen;
+        const float* p = xbase + (size_t)(on ? step : 0) * xtstride;
+#pragma unroll
+        for (int j = 0; j < NXJ; ++j) xa[j] = on ? *reinterpret_cast<const f32x4*>(p + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    load_x(0);
+    __syncthreads();
+
+    const f32x4* wxw = wximg + (size_t)layer * IMG_F4 + (size_t)kq * NXS * 64 + lane;
+
+    // gather the 16 granules of this lane from buffers (bufL|bufR) published with tag `epoch`; bounded wait
+    auto gather = [&](u64* bufL, u64* bufR, unsigned epoch, int step, float (&out)[NKS]) {
+        const size_t goff = (size_t)((step + 1) & 1) * 16 * H + (size_t)kq * NKS * 64 + r16 * 4 + q;
+        const u64* sp[NPW];
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) sp[i] = (src_local[i] ? bufL : bufR) + goff;
+        u64 g[NKS];
+        bool ok = true;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) g[ks] = granule_load(sp[ks / KSP] + (size_t)ks * 64);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) ok = ok && ((unsigned)(g[ks] >> 32) == epoch);
+        unsigned spins = 0;
+        bool timed_out = false;
+        while (!__all(ok) && !timed_out) {
+            while (true) {                                            // cheap gate: one granule per producer
+                bool ready = true;
+#pragma unroll
+                for (int i = 0; i < NPW; ++i)
+                    if (lane == i) ready = (unsigned)(granule_load(sp[i] + (size_t)(i * KSP) * 64) >> 32) == epoch;
+                if (__all(ready)) break;
+                if (++spins > spin_budget) { timed_out = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            ok = true;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                g[ks] = granule_load(sp[ks / KSP] + (size_t)ks * 64);
+                ok = ok && ((unsigned)(g[ks] >> 32) == epoch);
+            }
+            if (++spins > spin_budget) timed_out = true;
+        }
+        if (timed_out) {
+            if (lane == 0) atomicExch(a.err, 1 + step);
+            spin_budget = 0;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) out[ks] = __uint_as_float((unsigned)g[ks]);
+    };
+
+    for (int step = 0; step <= T; ++step) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned epoch = (unsigned)step;               // everything consumed now was published at the end of step-1
+        // ---- input projection.  Layer 0: x_s (prefetched from HBM).  Layer 1: x1_{s-1} = h0_{s-1} (granules).
+        float xin[NKS];
+        if (layer == 1) {
+            if (step > 0) gather(hx0L, hx0R, epoch, step, xin);
+            else {
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) xin[ks] = 0.f;
+            }
+        }
+        {
+            f32x4 wl = wxw[0];
+#pragma unroll
+            for (int s = 0; s < NXS; ++s) {
+                // k mapping of the LDS image: x-step s <-> k = kq*KQ + (s/4)*16 + q*4 + (s%4)   (HBM rows, layer 0)
+                // granules arrive as k = kq*KW + 4*ks + q                                          (layer 1)
+                // -> layer 1 walks the image in granule order: ks = 4*(s%4) + s/4 has k = kq*64 + 16*(s%4) + 4*(s/4) + q
+                const float a_s = layer == 0 ? xa[s >> 2][s & 3] : xin[s];
+                f32x4 wn = wl;
+                if (s + 1 < NXS) wn = wxw[(size_t)(s + 1) * 64];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, wl[i], acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                wl = wn;
+            }
+        }
+        // ---- recurrence: layer 0 uses h0_{s-1}, layer 1 uses h1_{s-2}; both published at the end of step s-1
+        if (step > 0) gather(layer ? hx1L : hx0L, layer ? hx1R : hx0R, epoch, step, av);
+        load_x(step + 1);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], wv[ks][t], acc[t], 0, 0, 0);
+
+        // ---- K reduction (per layer) through LDS
+        __syncthreads();
+#pragma unroll
+        for (int dk = 0; dk < 4; ++dk)
+            red[((layer * 4 + dk) * 4 + kq) * 64 + lane] = f32x4{acc[0][dk], acc[1][dk], acc[2][dk], acc[3][dk]};
+        __syncthreads();
+        f32x4 gt = red[((layer * 4 + kq) * 4 + 0) * 64 + lane];
+#pragma unroll
+        for (int sw = 1; sw < 4; ++sw) gt += red[((layer * 4 + kq) * 4 + sw) * 64 + lane];
+        gt += bias4;
+
+        // ---- cell: layer 0 at time s, layer 1 at time s-1
+        const int tcur = step - layer;
+        const bool act = tcur >= 0 && tcur < blen;
+        float oval = 0.f;
+        if (act) {
+            const float ig = sigmoidf_(gt[0]), fg = sigmoidf_(gt[1]), gg = tanhf_(gt[2]), og = sigmoidf_(gt[3]);
+            cst = fg * cst + ig * gg;
+            hst = og * tanhf_(cst);
+            oval = hst;
+        }
+        const size_t doff = (size_t)(step & 1) * 16 * H;
+        const int gi = granule_index(q * 4 + kq, jown);
+        granule_store_l2(hxoL + doff + gi, (unsigned)(step + 1), hst);
+        if (!all_local) granule_store(hxoR + doff + gi, (unsigned)(step + 1), hst);
+        if (layer == 1 && inb && tcur >= 0 && tcur < T) d.out[((size_t)tcur * B + bown) * d.outStride + jown] = oval;
+    }
+    if (inb) {
+        d.hbuf[(size_t)bown * H + jown] = hst;
+        d.cbuf[(size_t)bown * H + jown] = cst;
+    }
+}
+
 // tile lt of wave w = (kq = w & 3, tw = w >> 2):  TW == 1: g = lt / NUB, ub = lt % NUB;   TW == NUB: g = lt, ub = tw
 // W_hh: dst[(((slice*NWV + w)*NKS + ks)*NTW + lt)*64 + lane]
 //         = W_hh[g*H + slice*U + ub*16 + (lane&15)][kq*KW + 4*ks + (lane>>4)]
@@ -449,8 +674,10 @@ __global__ void mp_pack_whh_persist(const float* __restrict__ whh, float* __rest
 
 // W_ih: dst[((((slice*NWV + w)*NXS + s)*NTG + tg)*64 + lane)*4 + i]   (tile lt = tg*4 + i)
 //         = W_ih[g*H + slice*U + ub*16 + (lane&15)][kq*KQ + (s/4)*16 + (lane>>4)*4 + (s%4)]
+// korder != 0: k-steps in granule order, k = kq*KQ + 4*s + (lane>>4) (layer 1 of the two-layer wavefront kernel,
+// whose input arrives as granules rather than as 16-byte row pieces)
 template <int H, int NSLICE, int TW>
-__global__ void mp_pack_wih_persist(const float* __restrict__ wih, float* __restrict__ dst, int KIN) {
+__global__ void mp_pack_wih_persist(const float* __restrict__ wih, float* __restrict__ dst, int KIN, int korder) {
     constexpr int U = H / NSLICE, NUB = U / 16, NWV = 4 * TW, NTW = 4 * NUB / TW, NTG = NTW / 4;
     const int KQ = KIN / 4, NXS = KQ / 4;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -466,7 +693,7 @@ __global__ void mp_pack_wih_persist(const float* __restrict__ wih, float* __rest
     const int lt = tg * 4 + i;
     const int g = TW == 1 ? lt / NUB : lt, ub = TW == 1 ? lt % NUB : tw;
     const int row = g * H + slice * U + ub * 16 + (lane & 15);
-    const int col = kq * KQ + (s >> 2) * 16 + (lane >> 4) * 4 + (s & 3);
+    const int col = korder ? kq * KQ + 4 * s + (lane >> 4) : kq * KQ + (s >> 2) * 16 + (lane >> 4) * 4 + (s & 3);
     dst[idx] = wih[(size_t)row * KIN + col];
 }
 
@@ -499,15 +726,24 @@ void mp_launch_pack_whh_persist(const float* whh, float* dst, int H, int nslice,
     else hipLaunchKernelGGL((mp_pack_whh_persist<64, 4, 1>), dim3(grid), dim3(256), 0, s, whh, dst);
 }
 
-void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, int nslice, hipStream_t s) {
+void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, int nslice, int korder, hipStream_t s) {
     const size_t n = (size_t)4 * H * KIN;
     const int grid = (int)((n + 255) / 256);
-    if (H == 256 && nslice == 16) hipLaunchKernelGGL((mp_pack_wih_persist<256, 16, 1>), dim3(grid), dim3(256), 0, s, wih, dst, KIN);
-    else if (H == 256) hipLaunchKernelGGL((mp_pack_wih_persist<256, 8, 2>), dim3(grid), dim3(256), 0, s, wih, dst, KIN);
-    else hipLaunchKernelGGL((mp_pack_wih_persist<64, 4, 1>), dim3(grid), dim3(256), 0, s, wih, dst, KIN);
+    if (H == 256 && nslice == 16) hipLaunchKernelGGL((mp_pack_wih_persist<256, 16, 1>), dim3(grid), dim3(256), 0, s, wih, dst, KIN, korder);
+    else if (H == 256) hipLaunchKernelGGL((mp_pack_wih_persist<256, 8, 2>), dim3(grid), dim3(256), 0, s, wih, dst, KIN, korder);
+    else hipLaunchKernelGGL((mp_pack_wih_persist<64, 4, 1>), dim3(grid), dim3(256), 0, s, wih, dst, KIN, korder);
 }
 
 int mp_persist_max_wg(int H, int nslice) { return H == 256 && nslice == 16 ? 512 : 256; }
+
+// both layers of a unidirectional 2-layer LSTM (H = 256, 16-slice packing) as one wavefront launch
+void mp_launch_lstm_uni2(const LstmPersistArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)(2 * 4 * 4 * 64 + 2 * 4 * (256 / 16) * 64) * 16;    // 32 KB + 2 x 64 KB
+    static bool once = (hipFuncSetAttribute((const void*)mp_lstm_fused_uni2<256>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    hipLaunchKernelGGL((mp_lstm_fused_uni2<256>), dim3(a.nslab * 16), dim3(512), lds, s, a);
+}
 
 void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice, hipStream_t s) {
     if (H == 256 && nslice == 16) {
