@@ -147,9 +147,10 @@ int mp_timing_enable(mp_handle* h, int on);
 int mp_timing_read(mp_handle* h, int cls, int* launches, float* ms, double* gflop);
 /* 0: eager launches, 1: replay captured hipGraphs (default; env MP_NO_GRAPH=1 flips the default). */
 int mp_set_graph_mode(mp_handle* h, int on);
-/* LSTM recurrence implementation: 1 = persistent kernel, all T steps in one launch, hidden state exchanged
- * between workgroups as tagged granules (default); 0 = one launch per time step (env MP_LSTM_MODE=step). */
-int mp_set_lstm_mode(mp_handle* h, int persistent);
+/* LSTM implementation: 1 = fused persistent layer kernels, one launch per layer, hidden state exchanged between
+ * workgroups as tagged granules (default); 2 = same, and the unidirectional velocity block as ONE two-layer
+ * wavefront launch; 0 = input-projection GEMM + one launch per time step (env MP_LSTM_MODE=step). */
+int mp_set_lstm_mode(mp_handle* h, int mode);
 /* Synchronises the library's stream and returns the device error word of the persistent kernels:
  * 0 = ok, 1+step = a bounded wait for another workgroup's hidden state timed out (results invalid). */
 int mp_device_error(mp_handle* h, int* code);

@@ -133,7 +133,10 @@ struct mp_handle {
     int* err_dev = nullptr;          // device error word of the persistent kernels
     long long* prof_dev = nullptr;   // debug: per-workgroup phase cycle sums of the last persistent launch
     bool persist = true;
-    bool uni2 = true;                // velocity block: both layers as one wavefront launch (env MP_LSTM_UNI2=0 disables)
+    bool uni2 = false;               // velocity block as ONE two-layer wavefront launch (mp_set_lstm_mode(h, 2) / env
+                                     // MP_LSTM_UNI2=1).  Off by default: it is 20 % faster than two launches but fills every
+                                     // CU's registers and LDS, so the foot-contact layers and pose's linear2 / IK / FK can no
+                                     // longer run beside the velocity block and the forward as a whole gets slower.
     int nslice_env = 0;              // 0: pick per module (8 slices / 8 waves for bidirectional layers that fill the
                                      // chip, 16 slices / 4 waves for unidirectional ones); env MP_LSTM_SLICES=8|16 forces one             // LSTM recurrence: persistent kernel (default) or per-step launches
     std::map<std::pair<int, int>, Plan*> plans;
@@ -271,7 +274,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     if (hipSetDevice(device) != hipSuccess) { h->err = "hipSetDevice failed"; return bail(MP_ERR_HIP); }
     if (const char* e = getenv("MP_NO_GRAPH")) h->use_graph = !(e[0] && e[0] != '0');
     if (const char* e = getenv("MP_LSTM_MODE")) h->persist = strcmp(e, "step") != 0;
-    if (const char* e = getenv("MP_LSTM_UNI2")) h->uni2 = !(e[0] == '0');
+    if (const char* e = getenv("MP_LSTM_UNI2")) h->uni2 = e[0] == '1';
     if (const char* e = getenv("MP_LSTM_SLICES")) h->nslice_env = atoi(e) == 8 ? 8 : (atoi(e) == 16 ? 16 : 0);
     if (getenv("MP_PERSIST_PROF")) {
         if (hipMalloc((void**)&h->prof_dev, 512 * 8 * sizeof(long long)) != hipSuccess) h->prof_dev = nullptr;
@@ -763,7 +766,7 @@ int mp_forward(mp_handle* h, const float* imu_dev, const int32_t* lengths_host, 
     h->segs.clear(); h->ev_used = 0;
     GraphKey key;
     memset(&key, 0, sizeof(key));
-    key.kind = 0; key.B = B; key.T = T; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0);
+    key.kind = 0; key.B = B; key.T = T; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0) | (h->uni2 ? 4 : 0);
     key.p[0] = imu_dev; key.p[1] = pose_dev; key.p[2] = joints_dev; key.p[3] = vel_dev; key.p[4] = contact_dev;
     key.p[5] = r6d; key.p[6] = h->vstate.h;
     int rc;
@@ -797,7 +800,7 @@ int mp_forward_offline(mp_handle* h, const float* imu_dev, const int32_t* length
     h->segs.clear(); h->ev_used = 0;
     GraphKey key;
     memset(&key, 0, sizeof(key));
-    key.kind = 2; key.B = B; key.T = T; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0);
+    key.kind = 2; key.B = B; key.T = T; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0) | (h->uni2 ? 4 : 0);
     key.p[0] = imu_dev; key.p[1] = pose_dev; key.p[2] = joints_dev; key.p[3] = vel_dev; key.p[4] = contact_dev;
     key.p[5] = tran_dev; key.p[6] = h->vstate.h; key.p[7] = rglobal_dev;
     int rc;
@@ -952,7 +955,7 @@ int mp_stream_step(mp_handle* h, const float* frames_dev, float* pose_dev, float
     h->segs.clear(); h->ev_used = 0;
     GraphKey key;
     memset(&key, 0, sizeof(key));
-    key.kind = 1; key.B = S; key.T = W; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0);
+    key.kind = 1; key.B = S; key.T = W; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0) | (h->uni2 ? 4 : 0);
     key.p[0] = frames_dev; key.p[1] = pose_dev; key.p[2] = joints; key.p[3] = root_pos_dev; key.p[4] = contact_dev;
     key.p[6] = h->vstate.h;
     int rc;
@@ -1030,9 +1033,11 @@ int mp_debug_read_prof(mp_handle* h, long long* out, int n_words) {
     return MP_OK;
 }
 
-int mp_set_lstm_mode(mp_handle* h, int persistent) {
-    if (!h) return MP_ERR_INVALID;
-    h->persist = persistent != 0;
+int mp_set_lstm_mode(mp_handle* h, int mode) {
+    if (!h || mode < 0 || mode > 2) return MP_ERR_INVALID;
+    HIPCHK(h, hipDeviceSynchronize());
+    h->persist = mode != 0;
+    h->uni2 = mode == 2;
     return MP_OK;
 }
 

@@ -368,8 +368,9 @@ class MobilePoserNet:
         _lib.check(self._lib.mp_timing_read(self._h, cls, C.byref(n), C.byref(ms), C.byref(gf)), self._h)
         return n.value, ms.value, gf.value
 
-    def set_lstm_mode(self, persistent):
-        _lib.check(self._lib.mp_set_lstm_mode(self._h, int(bool(persistent))), self._h)
+    def set_lstm_mode(self, mode):
+        """0/False: per-step kernels; 1/True: fused persistent layers (default); 2: + two-layer wavefront velocity kernel."""
+        _lib.check(self._lib.mp_set_lstm_mode(self._h, int(mode)), self._h)
 
     def device_error(self):
         """0 = ok; otherwise 1+step at which a persistent-kernel wait timed out (synchronises)."""

@@ -270,14 +270,17 @@ def test_persistent_and_step_recurrence_agree(torch_mod, net):
     lengths = [T] * B
     lengths[3], lengths[17], lengths[39] = 5, 49, 1
     outs = {}
-    for mode in (True, False):
+    for mode in (1, 0, 2):          # fused persistent layers | per-step kernels | + two-layer wavefront velocity kernel
         net.set_lstm_mode(mode)
         net.reset_all()
         outs[mode] = [t.clone() for t in net.forward(imu, lengths)]
+        # carried velocity state must survive the mode as well (second call starts from the first call's state)
+        outs[mode] += [t.clone() for t in net.forward(imu, lengths)]
         assert net.device_error() == 0
-    net.set_lstm_mode(True)
-    for a, b in zip(outs[True], outs[False]):
-        assert float((a - b).abs().max()) < 2e-5
+    net.set_lstm_mode(1)
+    for other in (0, 2):
+        for a, b in zip(outs[1], outs[other]):
+            assert float((a - b).abs().max()) < 2e-5, other
 
 
 def test_no_device_error_after_full_size(torch_mod, net):
