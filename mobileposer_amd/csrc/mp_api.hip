@@ -97,6 +97,7 @@ struct GraphKey {
 
 struct Plan {
     int B = 0, T = 0;
+    unsigned long long last_use = 0;   // LRU stamp (plans and their graphs are evicted when shapes keep changing)
     ModuleWS ws[4];
     float* r6d = nullptr;            // [B,T,96] when the caller does not ask for it
     int* lengths_dev = nullptr;
@@ -141,6 +142,7 @@ struct mp_handle {
                                      // chip, 16 slices / 4 waves for unidirectional ones); env MP_LSTM_SLICES=8|16 forces one             // LSTM recurrence: persistent kernel (default) or per-step launches
     std::map<std::pair<int, int>, Plan*> plans;
     std::map<GraphKey, hipGraphExec_t> graphs;
+    unsigned long long use_clock = 0;
     VelState vstate;
     StreamCtx sc;
     bool use_graph = true;
@@ -312,17 +314,39 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
 }
 
 // ------------------------------------------------------------------------------------------ plans
+void free_plan(mp_handle* h, Plan* p) {
+    // graphs captured for this shape reference its workspaces
+    for (auto it = h->graphs.begin(); it != h->graphs.end();) {
+        if (it->first.B == p->B && it->first.T == p->T) { (void)hipGraphExecDestroy(it->second); it = h->graphs.erase(it); }
+        else ++it;
+    }
+    for (void* q : p->allocs) (void)hipFree(q);
+    if (p->lengths_pin) (void)hipHostFree(p->lengths_pin);
+    delete p;
+}
+
+constexpr size_t kMaxPlans = 8;     // evaluate.py feeds one sequence length after another: keep only recent shapes
+
 int get_plan(mp_handle* h, int B, int T, Plan** out) {
     auto it = h->plans.find({B, T});
-    if (it != h->plans.end()) { *out = it->second; return MP_OK; }
+    if (it != h->plans.end()) { it->second->last_use = ++h->use_clock; *out = it->second; return MP_OK; }
+    if (h->plans.size() >= kMaxPlans) {
+        HIPCHK(h, hipDeviceSynchronize());
+        auto victim = h->plans.end();
+        for (auto jt = h->plans.begin(); jt != h->plans.end(); ++jt) {
+            if (h->sc.S && jt->first == std::make_pair(h->sc.S, 45)) continue;      // the streaming plan stays
+            if (victim == h->plans.end() || jt->second->last_use < victim->second->last_use) victim = jt;
+        }
+        if (victim != h->plans.end()) { free_plan(h, victim->second); h->plans.erase(victim); }
+    }
     Plan* p = new Plan();
-    p->B = B; p->T = T;
+    p->B = B; p->T = T; p->last_use = ++h->use_clock;
     h->plans[{B, T}] = p;
     const size_t M = (size_t)B * T;
     for (int id = 0; id < 4; ++id) {
         const ModuleW& m = h->mod[id];
         ModuleWS& w = p->ws[id];
-        if (int rc = dev_alloc(h, (void**)&w.xproj, M * m.dirs * 4 * m.H * sizeof(float), &p->allocs)) return rc;
+        w.xproj = nullptr;                                   // gate pre-activations: per-step mode only, allocated on demand
         if (int rc = dev_alloc(h, (void**)&w.out0, M * m.dirs * m.H * sizeof(float), &p->allocs)) return rc;
         if (int rc = dev_alloc(h, (void**)&w.out1, M * m.dirs * m.H * sizeof(float), &p->allocs)) return rc;
         for (int l = 0; l < 2; ++l)
@@ -340,7 +364,20 @@ int get_plan(mp_handle* h, int B, int T, Plan** out) {
     return MP_OK;
 }
 
+// per-step mode keeps the [B*T, dirs*4H] gate pre-activations in HBM; allocate them outside of any graph capture
+int ensure_step_ws(mp_handle* h, Plan* p) {
+    if (h->persist) return MP_OK;
+    for (int id = 0; id < 4; ++id) {
+        const ModuleW& m = h->mod[id];
+        ModuleWS& w = p->ws[id];
+        if (!w.xproj)
+            if (int rc = dev_alloc(h, (void**)&w.xproj, (size_t)p->B * p->T * m.dirs * 4 * m.H * sizeof(float), &p->allocs)) return rc;
+    }
+    return MP_OK;
+}
+
 int upload_lengths(mp_handle* h, Plan* p, const int32_t* lengths) {
+    if (int rc = ensure_step_ws(h, p)) return rc;
     int mx = 0;
     for (int b = 0; b < p->B; ++b) {
         if (lengths[b] < 1 || lengths[b] > p->T) return fail(h, MP_ERR_LENGTHS, "lengths[%d] = %d outside 1..%d", b, lengths[b], p->T);
@@ -427,6 +464,7 @@ int rnn_g0(const RnnJob& j, hipStream_t s) {
     float* X1 = x1_buffer(h, m, w);
     run_gemm(h, s, j.a0, j.a1, m.lin1, X1, H, (long)B * H, M, B, 1);                       // rnn.py:22
     // the per-step kernels take the input projection from a GEMM; the persistent kernel computes it itself
+    if (!h->persist && !w.xproj) return fail(h, MP_ERR_INVALID, "internal: per-step workspace missing");
     if (!h->persist)
         run_gemm(h, s, internal_map(X1, B, H), none, m.ih[0], w.xproj, dirs * 4 * H, (long)B * dirs * 4 * H, M, B, 0);
     for (int l = 0; l < 2; ++l)
@@ -648,6 +686,11 @@ int run_maybe_graph(mp_handle* h, const GraphKey& key, Body body) {
     if (!h->use_graph || h->timing) return body();
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
+        if (h->graphs.size() >= 64) {                      // callers that keep changing buffers: start over
+            HIPCHK(h, hipDeviceSynchronize());
+            for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+            h->graphs.clear();
+        }
         hipGraph_t graph = nullptr;
         HIPCHK(h, hipStreamBeginCapture(h->s_main, hipStreamCaptureModeThreadLocal));
         h->capturing = true;
@@ -716,6 +759,7 @@ void mp_destroy(mp_handle* h) {
         if (kv.second->lengths_pin) (void)hipHostFree(kv.second->lengths_pin);
         delete kv.second;
     }
+    h->plans.clear();
     for (ModuleW& m : h->mod) {
         Packed* ps[4] = {&m.lin1, &m.ih[0], &m.ih[1], &m.lin2};
         for (Packed* p : ps) { if (p->W) (void)hipFree(p->W); if (p->bias) (void)hipFree(p->bias); }

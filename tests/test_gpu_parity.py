@@ -310,3 +310,40 @@ def test_evaluate_harness_offline_and_online(torch_mod, net, monkeypatch):
     e = ev.eval(pose, pose, tran_p=data["tran"][0], tran_t=data["tran"][0])
     assert float(e[[0, 1, 3, 4], 0].abs().max()) < 1e-3
     assert net.device_error() == 0
+
+
+def test_large_ragged_batch_chunked_launches(torch_mod, net, weights, smpl):
+    """B = 300 (> 256 and not a multiple of 16): the persistent layers run as several co-resident launches with a
+    partial last slab; spot-check rows against the oracle."""
+    from mobileposer_amd import synthetic
+    from oracle import mp_oracle as O
+    B, T = 300, 20
+    imu = synthetic.make_imu(B, T, seed=17)
+    lengths = [T] * B
+    lengths[0], lengths[255], lengths[256], lengths[299] = 3, 11, 20, 7
+    net.reset_all()
+    pose, joints, vel, contact = net.forward(cu(torch_mod, imu), lengths)
+    assert net.device_error() == 0
+    rows = [0, 15, 16, 255, 256, 288, 299]
+    for r in rows:                                   # one sequence at a time: lengths differ
+        L = lengths[r]
+        ro = O.OracleNet(weights, smpl["J"])
+        _, rj, rv, rc = ro.forward(imu[r:r + 1, :L], [L])
+        assert np.abs(npy(joints[r, :L]) - rj[0]).max() < TOL, r
+        assert np.abs(npy(vel[r, :L]) - rv[0]).max() < TOL, r
+        assert np.abs(npy(contact[r, :L]) - rc[0]).max() < TOL, r
+
+
+def test_many_shapes_evict_plans(torch_mod, net):
+    """evaluate.py-style stream of different sequence lengths: plans and graphs are evicted, results stay right."""
+    from mobileposer_amd import synthetic
+    imu = synthetic.make_imu(1, 40, seed=23)
+    net.reset_all()
+    first = net.forward(cu(torch_mod, imu[:, :12]), [12])[1].clone()
+    for T in range(13, 26):                          # 13 more shapes > kMaxPlans
+        net.reset_all()
+        net.forward(cu(torch_mod, imu[:, :T]), [T])
+    net.reset_all()
+    again = net.forward(cu(torch_mod, imu[:, :12]), [12])[1]
+    assert torch_mod.equal(first, again)
+    assert net.device_error() == 0
