@@ -67,16 +67,20 @@ def cpu_baseline(seconds=10.0):
     out = {"value": round(reps * Bs * T_WIN / dt, 1), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
            "sample": "%d reps of %d sequences x %d frames (numpy oracle: forward + FK + translation), %.1f s"
                      % (reps, Bs, T_WIN, dt)}
-    # the same sample through torch's own CPU nn.LSTM / nn.Linear (what the reference calls), all host threads
+    # the same workload through torch's own CPU nn.LSTM / nn.Linear (what the reference calls): the full 256 x 125
+    # batch, a thread count ATen scales to (more threads than that are slower on these small GEMMs)
     try:
         from oracle.torch_ref import TorchNet
+        nthr = max(1, min(32, os.cpu_count() or 1))
+        torch.set_num_threads(nthr)
         tnet = TorchNet(sd, smpl["J"])
+        imu_full = synthetic.make_imu(B_PER_GPU, T_WIN, seed=1)
 
         def one_t():
             tnet.vel_state = None
-            pose, joints, vel, contact, _ = tnet.forward(imu, [T_WIN] * Bs)
+            pose, joints, vel, contact, _ = tnet.forward(imu_full, [T_WIN] * B_PER_GPU)
             O.forward_kinematics(pose, smpl["J"])
-            for b in range(Bs):
+            for b in range(B_PER_GPU):
                 O.translate_offline(joints[b].reshape(T_WIN, 24, 3), vel[b], contact[b], tnet.floor_y)
 
         one_t()
@@ -85,14 +89,20 @@ def cpu_baseline(seconds=10.0):
             one_t()
             reps_t += 1
             dt_t = time.perf_counter() - t0
-            if dt_t >= seconds or reps_t >= 200:
+            if dt_t >= seconds or reps_t >= 50:
                 break
-        out["torch_cpu"] = {"value": round(reps_t * Bs * T_WIN / dt_t, 1), "unit": "frames/s",
-                            "threads": torch.get_num_threads(),
-                            "sample": "%d reps of the same sample through torch CPU nn.LSTM (oracle/torch_ref.py), %.1f s"
-                                      % (reps_t, dt_t)}
-    except Exception as e:                                  # the numpy figure above is the contractual one
+        out["torch_cpu"] = {"value": round(reps_t * B_PER_GPU * T_WIN / dt_t, 1), "unit": "frames/s", "threads": nthr,
+                            "sample": "%d reps of %d sequences x %d frames through torch CPU nn.LSTM "
+                                      "(oracle/torch_ref.py) + numpy FK / translation, %.1f s"
+                                      % (reps_t, B_PER_GPU, T_WIN, dt_t)}
+    except Exception as e:
         out["torch_cpu"] = {"error": str(e)}
+    # report the stronger CPU figure as the baseline proper, keep the other one beside it
+    t = out.get("torch_cpu", {})
+    if "value" in t and t["value"] > out["value"]:
+        numpy_leg = {k: out[k] for k in ("value", "unit", "cores", "sample")}
+        out = {"value": t["value"], "unit": "frames/s", "cores": t["threads"], "kind": "port", "sample": t["sample"],
+               "numpy_oracle": numpy_leg}
     return out
 
 
@@ -153,11 +163,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:           # launched by torch.distributed.run: one process per GPU over RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
         local_rank = 0
