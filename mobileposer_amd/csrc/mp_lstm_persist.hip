@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) voi
         for (int i = 0; i < 5; ++i) o[i] = pt[i];
         o[5] = T;
         o[6] = pt[5];
-        o[7] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8) | my_xcc;   // HW_REG_HW_ID, XCC id
+        o[7] = (all_local ? 256 : 0) | my_xcc;                                     // placement: all slices on my XCD?, XCC id
     }
 
     // ---- final state (h_n, c_n of models/rnn.py:33) back to hbuf / cbuf

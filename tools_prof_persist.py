@@ -26,3 +26,6 @@ tot = a[:, :5].sum(axis=1) / a[:, 5]
 print("total/step    mean %8.1f" % tot.mean())
 
 print("slow-path (stale granules at first look) steps per workgroup: mean %.1f of %d" % (a[:, 6].mean(), a[0, 5]))
+
+print("workgroups whose whole slab is on their own XCD (fast L2 transport):", int((a[:, 7] >= 256).sum()), "of", len(a),
+      " XCC ids seen:", sorted(set(int(x) & 0xFF for x in a[:, 7])))
