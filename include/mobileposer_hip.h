@@ -115,6 +115,16 @@ int mp_translate_offline(mp_handle* h, const float* joints_dev, const float* vel
 int mp_fk(mp_handle* h, const float* pose_dev, const float* tran_dev, int64_t N,
           float* rglobal_dev, float* joint_dev, void* stream);
 
+/* Mesh part of ParametricModel (articulate/model.py:28-35): v_template [V,3] (raw; root-aligned inside) and
+ * skinning weights [V,24], both host pointers.  Needed only by mp_fk_mesh. */
+int mp_set_mesh(mp_handle* h, const float* v_template_host, const float* weights_host, int n_vertex);
+
+/* ParametricModel.forward_kinematics with calc_mesh=True, shape=None, no pose blendshape
+ * (articulate/model.py:208-240): as mp_fk, plus vert [N,V,3] by linear blend skinning.  This is what
+ * FullMotionEvaluator.__call__ runs on prediction and ground truth (articulate/evaluator.py:319-320). */
+int mp_fk_mesh(mp_handle* h, const float* pose_dev, const float* tran_dev, int64_t N,
+               float* rglobal_dev, float* joint_dev, float* vert_dev, void* stream);
+
 /* MobilePoserNet.reset (models/net.py:84-88) clears nothing this library owns for the batch path;
  * clear_velocity != 0 additionally drops the carried velocity LSTM state (what setting
  * `model.velocity.rnn_state = None` does in the reference). */

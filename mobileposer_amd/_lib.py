@@ -32,6 +32,8 @@ SIGNATURES = {
     "mp_reduced_global_to_full": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "mp_translate_offline": (_i, [_vp, _vp, _vp, _vp, _ip, _i, _i, _vp, _vp]),
     "mp_fk": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "mp_set_mesh": (_i, [_vp, _fp, _fp, _i]),
+    "mp_fk_mesh": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "mp_reset_state": (_i, [_vp, _i]),
     "mp_get_velocity_state": (_i, [_vp, _vp, C.POINTER(_i)]),
     "mp_set_velocity_state": (_i, [_vp, _vp, _i]),

@@ -44,12 +44,12 @@ class ParametricModel:
         self._net = net
 
     def forward_kinematics(self, pose, shape=None, tran=None, calc_mesh=False):
-        """articulate/model.py:208-232 on the GPU (mp_fk).  pose [N,24,3,3] (or reshapeable) cuda tensor."""
-        if shape is not None or calc_mesh:
-            raise NotImplementedError("shape blend / mesh LBS are outside the hot path (SURVEY.md 8(f) rank 1)")
+        """articulate/model.py:208-240 on the GPU (mp_fk / mp_fk_mesh).  pose [N,24,3,3] (or reshapeable) cuda tensor."""
+        if shape is not None:
+            raise NotImplementedError("shape blend shapes are outside the hot path (mean shape only)")
         if self._net is None:
             raise RuntimeError("ParametricModel is not bound to a MobilePoserNet (no GPU handle)")
-        return self._net.forward_kinematics(pose, tran)
+        return self._net.forward_kinematics(pose, tran, calc_mesh=calc_mesh)
 
 
 assert SMPL_PARENT[0] == -1

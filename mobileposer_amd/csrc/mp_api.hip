@@ -126,6 +126,11 @@ struct mp_handle {
     int* parent_dev = nullptr;
     int* depth_dev = nullptr;
     float* bone_dev = nullptr;
+    float* jrest_dev = nullptr;      // root-aligned rest joints [24,3]
+    float* vrest_dev = nullptr;      // root-aligned template vertices [V,3] (mp_set_mesh)
+    float* skinw_dev = nullptr;      // skinning weights [V,24]
+    int n_vertex = 0;
+    float J0[3] = {0, 0, 0};
     float floor_y = 0.f;
     float feet_pos[6] = {0, 0, 0, 0, 0, 0};
     hipStream_t s_main = nullptr, s_vel = nullptr, s_foot = nullptr, s_gp = nullptr;
@@ -259,6 +264,9 @@ int setup_smpl(mp_handle* h, const int32_t parent[24], const float J[72]) {
     if (int rc = dev_alloc(h, (void**)&h->parent_dev, sizeof(par))) return rc;
     if (int rc = dev_alloc(h, (void**)&h->depth_dev, sizeof(depth))) return rc;
     if (int rc = dev_alloc(h, (void**)&h->bone_dev, sizeof(bone))) return rc;
+    if (int rc = dev_alloc(h, (void**)&h->jrest_dev, sizeof(j))) return rc;
+    HIPCHK(h, hipMemcpy(h->jrest_dev, j, sizeof(j), hipMemcpyHostToDevice));
+    for (int c = 0; c < 3; ++c) h->J0[c] = J[c];
     HIPCHK(h, hipMemcpy(h->parent_dev, par, sizeof(par), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->depth_dev, depth, sizeof(depth), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->bone_dev, bone, sizeof(bone), hipMemcpyHostToDevice));
@@ -772,7 +780,7 @@ void mp_destroy(mp_handle* h) {
     }
     void* misc[] = {h->parent_dev, h->depth_dev, h->bone_dev, h->vstate.h, h->vstate.c, h->sc.window, h->sc.fresh,
                     h->sc.mask_dev, h->sc.st.last_foot, h->sc.st.root_y, h->sc.st.root_pos, h->sc.joints, h->sc.vel,
-                    h->sc.contact, h->err_dev};
+                    h->sc.contact, h->err_dev, h->jrest_dev, h->vrest_dev, h->skinw_dev};
     for (void* p : misc) if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     hipEvent_t evs[5] = {h->ev_in, h->ev_out, h->ev_j, h->ev_v, h->ev_f};
@@ -911,6 +919,39 @@ int mp_fk(mp_handle* h, const float* pose_dev, const float* tran_dev, int64_t N,
     if (!h || !pose_dev || !rglobal_dev || !joint_dev || N < 0) return h ? fail(h, MP_ERR_INVALID, "mp_fk: bad argument") : MP_ERR_INVALID;
     if (int rc = enter(h, stream)) return rc;
     mp_launch_fk(pose_dev, tran_dev, (long)N, h->bone_dev, h->parent_dev, h->depth_dev, rglobal_dev, joint_dev, h->s_main);
+    HIPCHK(h, hipGetLastError());
+    return leave(h, stream);
+}
+
+int mp_set_mesh(mp_handle* h, const float* v_template_host, const float* weights_host, int n_vertex) {
+    if (!h || !v_template_host || !weights_host || n_vertex < 1) return h ? fail(h, MP_ERR_INVALID, "mp_set_mesh: bad argument") : MP_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    if (h->vrest_dev) (void)hipFree(h->vrest_dev);
+    if (h->skinw_dev) (void)hipFree(h->skinw_dev);
+    h->vrest_dev = h->skinw_dev = nullptr; h->n_vertex = 0;
+    std::vector<float> v((size_t)n_vertex * 3);
+    for (int i = 0; i < n_vertex; ++i)
+        for (int c = 0; c < 3; ++c) v[(size_t)i * 3 + c] = v_template_host[(size_t)i * 3 + c] - h->J0[c];   // model.py:87
+    if (int rc = dev_alloc(h, (void**)&h->vrest_dev, v.size() * sizeof(float))) return rc;
+    if (int rc = dev_alloc(h, (void**)&h->skinw_dev, (size_t)n_vertex * 24 * sizeof(float))) return rc;
+    HIPCHK(h, hipMemcpy(h->vrest_dev, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->skinw_dev, weights_host, (size_t)n_vertex * 24 * sizeof(float), hipMemcpyHostToDevice));
+    h->n_vertex = n_vertex;
+    return MP_OK;
+}
+
+int mp_fk_mesh(mp_handle* h, const float* pose_dev, const float* tran_dev, int64_t N, float* rglobal_dev, float* joint_dev,
+               float* vert_dev, void* stream) {
+    if (!h || !pose_dev || !rglobal_dev || !joint_dev || !vert_dev || N < 0) return h ? fail(h, MP_ERR_INVALID, "mp_fk_mesh: bad argument") : MP_ERR_INVALID;
+    if (!h->n_vertex) return fail(h, MP_ERR_INVALID, "mp_fk_mesh before mp_set_mesh");
+    if (int rc = enter(h, stream)) return rc;
+    mp_launch_fk(pose_dev, tran_dev, (long)N, h->bone_dev, h->parent_dev, h->depth_dev, rglobal_dev, joint_dev, h->s_main);
+    for (int64_t n0 = 0; n0 < N; n0 += 32768) {                   // grid.y limit
+        const long cnt = (long)(N - n0 < 32768 ? N - n0 : 32768);
+        mp_launch_lbs(rglobal_dev + n0 * 216, joint_dev + n0 * 72, tran_dev ? tran_dev + n0 * 3 : nullptr, cnt, h->jrest_dev,
+                      h->vrest_dev, h->skinw_dev, h->n_vertex, vert_dev + n0 * h->n_vertex * 3, h->s_main);
+    }
     HIPCHK(h, hipGetLastError());
     return leave(h, stream);
 }

@@ -86,6 +86,10 @@ void mp_launch_r6d_ik_strided(const float* r6d, long N, long rowStride, long row
 void mp_launch_fk(const float* pose, const float* tran, long N, const float* bone_dev, const int* parent_dev,
                   const int* depth_dev, float* rglobal, float* joint, hipStream_t s);
 
+// linear blend skinning on mp_fk's outputs (joint already translated by tran); grid.y = N frames (<= 65535 per launch)
+void mp_launch_lbs(const float* rglobal, const float* joint, const float* tran, long N, const float* jrest_dev,
+                   const float* vrest_dev, const float* weights_dev, int V, float* vert, hipStream_t s);
+
 // ---------------------------------------------------------------- K6: translation solver
 void mp_launch_translate_offline(const float* joints, const float* vel, const float* contact, const int* lengths,
                                  int B, int T, float floor_y, float* tran, hipStream_t s);

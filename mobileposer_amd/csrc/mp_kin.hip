@@ -138,7 +138,58 @@ __global__ __launch_bounds__(256) void mp_fk(const float* __restrict__ pose, con
     }
 }
 
+// Linear blend skinning of the SMPL mesh on top of mp_fk's outputs (articulate/model.py:234-240, no pose
+// blendshape):  T_j = [R_j | p_j - R_j j_j],  vert_v = sum_j w_vj T_j [v_rest; 1]  (+ tran).
+// One workgroup per (frame, 256-vertex chunk); the frame's 24 transforms sit in LDS.  HBM-bound on the output:
+// 12 B per vertex written, weights / template stay in L2.
+__global__ __launch_bounds__(256) void mp_lbs(const float* __restrict__ rglobal, const float* __restrict__ joint,
+                                               const float* __restrict__ tran, const float* __restrict__ jrest,
+                                               const float* __restrict__ vrest, const float* __restrict__ weights,
+                                               int V, float* __restrict__ vert) {
+    __shared__ float T[24 * 12];
+    const long n = blockIdx.y;
+    float tx = 0.f, ty = 0.f, tz = 0.f;
+    if (tran) { tx = tran[n * 3 + 0]; ty = tran[n * 3 + 1]; tz = tran[n * 3 + 2]; }
+    if (threadIdx.x < 24) {
+        const int j = threadIdx.x;
+        const float* R = rglobal + (n * 24 + j) * 9;
+        const float* p = joint + (n * 24 + j) * 3;          // already translated by `tran`
+        const float jx = jrest[j * 3 + 0], jy = jrest[j * 3 + 1], jz = jrest[j * 3 + 2];
+        float* t = T + j * 12;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            t[r * 4 + 0] = R[r * 3 + 0]; t[r * 4 + 1] = R[r * 3 + 1]; t[r * 4 + 2] = R[r * 3 + 2];
+            t[r * 4 + 3] = (p[r] - (r == 0 ? tx : (r == 1 ? ty : tz))) - (R[r * 3 + 0] * jx + R[r * 3 + 1] * jy + R[r * 3 + 2] * jz);
+        }
+    }
+    __syncthreads();
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const float vx = vrest[v * 3 + 0], vy = vrest[v * 3 + 1], vz = vrest[v * 3 + 2];
+    const float* w = weights + (size_t)v * 24;
+    float m[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) m[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 24; ++j) {
+        const float wj = w[j];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) m[k] += wj * T[j * 12 + k];
+    }
+    float* o = vert + ((size_t)n * V + v) * 3;
+    o[0] = m[0] * vx + m[1] * vy + m[2] * vz + m[3] + tx;
+    o[1] = m[4] * vx + m[5] * vy + m[6] * vz + m[7] + ty;
+    o[2] = m[8] * vx + m[9] * vy + m[10] * vz + m[11] + tz;
+}
+
 }  // namespace
+
+void mp_launch_lbs(const float* rglobal, const float* joint, const float* tran, long N, const float* jrest_dev,
+                   const float* vrest_dev, const float* weights_dev, int V, float* vert, hipStream_t s) {
+    if (N <= 0 || V <= 0) return;
+    hipLaunchKernelGGL(mp_lbs, dim3((V + 255) / 256, (unsigned)N), dim3(256), 0, s, rglobal, joint, tran, jrest_dev,
+                       vrest_dev, weights_dev, V, vert);
+}
 
 void mp_launch_r6d_ik_strided(const float* r6d, long N, long rowStride, long rowOffset, float* pose,
                               const int* parent_dev, hipStream_t s) {

@@ -1,11 +1,10 @@
 """Evaluation harness: mirror of mobileposer/evaluate.py (PoseEvaluator :16-36, evaluate_pose :39-107, CLI :110-126).
 
 Per sequence: ``model.reset()`` -> ``forward_offline`` -> (env ONLINE=1: ``forward_online`` for every frame plus
-5 repeated tail frames, first 5 outputs dropped, evaluate.py:62-64) -> errors.  The metrics follow
-``FullMotionEvaluator.__call__`` (articulate/evaluator.py:292-343) computed on the GPU with the library's
-forward kinematics; two documented differences: the mesh (vertex) error needs LBS over the SMPL mesh, which is
-outside the hot path and is reported as NaN, and rotation angles use
-2*asin(|R_p^T R_t - I|_F / (2*sqrt 2)) instead of a per-matrix cv2.Rodrigues call (same value).
+5 repeated tail frames, first 5 outputs dropped, evaluate.py:62-64) -> errors.  ``FullMotionEvaluator`` follows
+articulate/evaluator.py:292-343 with forward kinematics and mesh skinning on the GPU (mp_fk_mesh); rotation angles
+are 2*asin(|R_p^T R_t - I|_F / (2*sqrt 2)) instead of a per-matrix cv2.Rodrigues call (same value); the
+mean / std reductions of the error table are plain torch reductions on the device.
 """
 import argparse
 import math
@@ -40,27 +39,54 @@ def angle_between(Ra, Rb):
     return 2.0 * torch.asin((n / (2.0 * math.sqrt(2.0))).clamp(0.0, 1.0))
 
 
+class FullMotionEvaluator:
+    """articulate/evaluator.py:269-343: 10 x [mean, std] error table (mean shape, rotation-matrix inputs)."""
+
+    def __init__(self, model, joint_mask=None, fps=60, align_joint=0):
+        self.model, self.joint_mask, self.fps, self.align_joint = model, joint_mask, fps, align_joint
+
+    def __call__(self, pose_p, pose_t, tran_p=None, tran_t=None):
+        f, m = self.fps, self.model
+        mesh = m.n_vertex > 0
+        if mesh:
+            Rg_p, j_p, v_p = m.forward_kinematics(pose_p, tran_p, calc_mesh=True)
+            Rg_t, j_t, v_t = m.forward_kinematics(pose_t, tran_t, calc_mesh=True)
+        else:
+            Rg_p, j_p = m.forward_kinematics(pose_p, tran_p)
+            Rg_t, j_t = m.forward_kinematics(pose_t, tran_t)
+        dev = j_p.device
+        pl_p = pose_p.to(dev).reshape(-1, 24, 3, 3)
+        pl_t = pose_t.to(dev).reshape(-1, 24, 3, 3)
+        off = (j_t[:, self.align_joint] - j_p[:, self.align_joint]).unsqueeze(1)
+        je = (j_p + off - j_t).norm(dim=2)
+        ve = (v_p + off - v_t).norm(dim=2) if mesh else torch.full((1, 1), float("nan"), device=dev)
+        lae = torch.rad2deg(angle_between(pl_p, pl_t))
+        gae = torch.rad2deg(angle_between(Rg_p, Rg_t))
+        jkp = ((j_p[3:] - 3 * j_p[2:-1] + 3 * j_p[1:-2] - j_p[:-3]) * (f ** 3)).norm(dim=2)
+        jkt = ((j_t[3:] - 3 * j_t[2:-1] + 3 * j_t[1:-2] - j_t[:-3]) * (f ** 3)).norm(dim=2)
+        te = ((j_p[f:, :1] - j_p[:-f, :1]) - (j_t[f:, :1] - j_t[:-f, :1])).norm(dim=2) * 100
+        jm = self.joint_mask
+        zero = torch.zeros(1, 1, device=dev)
+        rows = [je, ve, lae, gae, jkp, jkt, te,
+                je[:, jm] if jm is not None else zero, lae[:, jm] if jm is not None else zero,
+                gae[:, jm] if jm is not None else zero]
+
+        def ms(x):
+            if x.numel() == 0:
+                return torch.full((2,), float("nan"), device=dev)
+            return torch.stack((x.mean(), x.std(dim=0).mean() if x.shape[0] > 1 else x.new_tensor(float("nan"))))
+
+        return torch.stack([ms(x) for x in rows])
+
+
 class PoseEvaluator:
+    """evaluate.py:16-36."""
     names = ['SIP Error (deg)', 'Angular Error (deg)', 'Masked Angular Error (deg)', 'Positional Error (cm)',
              'Masked Positional Error (cm)', 'Mesh Error (cm)', 'Jitter Error (100m/s^3)', 'Distance Error (cm)']
 
     def __init__(self, model, joint_mask=(2, 5, 16, 20), fps=datasets.fps):
-        self.model, self.mask, self.fps = model, list(joint_mask), fps
-
-    def _errs(self, pose_p, pose_t, tran_p, tran_t):
-        f = self.fps
-        Rg_p, j_p = self.model.forward_kinematics(pose_p, tran_p)
-        Rg_t, j_t = self.model.forward_kinematics(pose_t, tran_t)
-        off = (j_t[:, 0] - j_p[:, 0]).unsqueeze(1)
-        je = (j_p + off - j_t).norm(dim=2)
-        gae = torch.rad2deg(angle_between(Rg_p, Rg_t))
-        jkp = ((j_p[3:] - 3 * j_p[2:-1] + 3 * j_p[1:-2] - j_p[:-3]) * (f ** 3)).norm(dim=2)
-        te = ((j_p[f:, :1] - j_p[:-f, :1]) - (j_t[f:, :1] - j_t[:-f, :1])).norm(dim=2) * 100
-        ms = lambda x: torch.stack((x.mean(), x.std(dim=0).mean())) if x.numel() else torch.full((2,), float("nan"), device=x.device)
-        nan = torch.full((2,), float("nan"), device=je.device)
-        mgae, mje = gae[:, self.mask], je[:, self.mask]
-        # evaluate.py:29: [errs[9], errs[3], errs[9], errs[0]*100, errs[7]*100, errs[1]*100, errs[4]/100, errs[6]]
-        return torch.stack([ms(mgae), ms(gae), ms(mgae), ms(je) * 100, ms(mje) * 100, nan, ms(jkp) / 100, ms(te)])
+        self.model = model
+        self._eval_fn = FullMotionEvaluator(model, joint_mask=list(joint_mask), fps=fps)
 
     def eval(self, pose_p, pose_t, joint_p=None, tran_p=None, tran_t=None):
         dev = self.model.device
@@ -71,7 +97,9 @@ class PoseEvaluator:
         eye = torch.eye(3, device=dev)
         pose_p[:, joint_set.ignored] = eye                                               # evaluate.py:25-26
         pose_t[:, joint_set.ignored] = eye
-        return self._errs(pose_p, pose_t, tran_p, tran_t)
+        errs = self._eval_fn(pose_p, pose_t, tran_p=tran_p, tran_t=tran_t)
+        # evaluate.py:29
+        return torch.stack([errs[9], errs[3], errs[9], errs[0] * 100, errs[7] * 100, errs[1] * 100, errs[4] / 100, errs[6]])
 
     @classmethod
     def print(cls, errors):

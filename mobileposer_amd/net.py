@@ -141,6 +141,14 @@ class MobilePoserNet:
         assert abs(fy.value - self.floor_y) < 1e-6
         self._io = {}
         self._stream_S = 0
+        self.n_vertex = 0
+        bm = self.bodymodel
+        if getattr(bm, "_v_template", None) is not None and getattr(bm, "_skinning_weights", None) is not None:
+            vt = np.ascontiguousarray(bm._v_template, dtype=np.float32)
+            sw = np.ascontiguousarray(bm._skinning_weights, dtype=np.float32)
+            _lib.check(self._lib.mp_set_mesh(self._h, vt.ctypes.data_as(C.POINTER(C.c_float)),
+                                             sw.ctypes.data_as(C.POINTER(C.c_float)), vt.shape[0]), self._h)
+            self.n_vertex = int(vt.shape[0])
 
     def __del__(self):
         try:
@@ -330,16 +338,23 @@ class MobilePoserNet:
         _lib.check(self._lib.mp_reduced_global_to_full(self._h, _ptr(r), r.shape[0], _ptr(out), self._stream()), self._h)
         return out
 
-    def forward_kinematics(self, pose, tran=None):
-        """articulate/model.py:208-232 (no mesh): local pose [N,24,3,3] -> (R_global [N,24,3,3], joint [N,24,3])."""
+    def forward_kinematics(self, pose, tran=None, calc_mesh=False):
+        """articulate/model.py:208-240: local pose [N,24,3,3] -> (R_global [N,24,3,3], joint [N,24,3])
+        and, with ``calc_mesh``, the skinned vertices [N,V,3] (mean shape, no pose blendshape)."""
         self._require_weights()
         p = pose.to(device=self.device, dtype=torch.float32).reshape(-1, 24, 3, 3).contiguous()
         N = p.shape[0]
         t = None if tran is None else tran.to(device=self.device, dtype=torch.float32).reshape(N, 3).contiguous()
         Rg = torch.empty(N, 24, 3, 3, device=self.device, dtype=torch.float32)
         jg = torch.empty(N, 24, 3, device=self.device, dtype=torch.float32)
-        _lib.check(self._lib.mp_fk(self._h, _ptr(p), _ptr(t), N, _ptr(Rg), _ptr(jg), self._stream()), self._h)
-        return Rg, jg
+        if not calc_mesh:
+            _lib.check(self._lib.mp_fk(self._h, _ptr(p), _ptr(t), N, _ptr(Rg), _ptr(jg), self._stream()), self._h)
+            return Rg, jg
+        if not self.n_vertex:
+            raise RuntimeError("the body model has no mesh (v_template / weights) loaded")
+        vg = torch.empty(N, self.n_vertex, 3, device=self.device, dtype=torch.float32)
+        _lib.check(self._lib.mp_fk_mesh(self._h, _ptr(p), _ptr(t), N, _ptr(Rg), _ptr(jg), _ptr(vg), self._stream()), self._h)
+        return Rg, jg, vg
 
     def rnn_forward(self, module, x, input_lengths, state=None):
         """RNN.forward of one sub-module (models/rnn.py:20-33): -> (y [B,T,n_out], (h_n, c_n))."""

@@ -315,3 +315,35 @@ def translate_offline(joints, vel, contact, floor_y):
     tran = np.stack([velocity[:i + 1].sum(axis=0, dtype=F32) for i in range(T)]).astype(F32) if T <= 512 \
         else np.cumsum(velocity.astype(np.float64), axis=0).astype(F32)
     return tran
+
+
+# --------------------------------------------------------------------------------------------
+# a15: FullMotionEvaluator.__call__ (articulate/evaluator.py:292-343)
+# --------------------------------------------------------------------------------------------
+def angle_between(Ra, Rb):
+    """articulate/math/angular.py:86-99: |rotvec(Ra^T Rb)| in radians (the reference goes through cv2.Rodrigues)."""
+    D = np.matmul(np.swapaxes(np.asarray(Ra, dtype=np.float64), -1, -2), np.asarray(Rb, dtype=np.float64))
+    n = np.linalg.norm(D - np.eye(3), axis=(-1, -2))
+    return 2.0 * np.arcsin(np.clip(n / (2.0 * np.sqrt(2.0)), 0.0, 1.0))
+
+
+def full_motion_evaluator(pose_p, pose_t, smpl, tran_p=None, tran_t=None, fps=30, joint_mask=(2, 5, 16, 20),
+                          align_joint=0, parent=PARENT):
+    """The 10 x [mean, std] error table of FullMotionEvaluator.__call__ (evaluator.py:292-343), mean shape.
+    std follows torch: ``x.std(dim=0).mean()`` with Bessel's correction."""
+    f = fps
+    pose_p = np.asarray(pose_p, dtype=F32).reshape(-1, 24, 3, 3)
+    pose_t = np.asarray(pose_t, dtype=F32).reshape(-1, 24, 3, 3)
+    Rg_p, j_p, v_p = forward_kinematics_mesh(pose_p, smpl, parent, tran_p)
+    Rg_t, j_t, v_t = forward_kinematics_mesh(pose_t, smpl, parent, tran_t)
+    off = (j_t[:, align_joint] - j_p[:, align_joint])[:, None]
+    ve = np.linalg.norm(v_p + off - v_t, axis=2)
+    je = np.linalg.norm(j_p + off - j_t, axis=2)
+    lae = np.degrees(angle_between(pose_p, pose_t))
+    gae = np.degrees(angle_between(Rg_p, Rg_t))
+    jkp = np.linalg.norm((j_p[3:] - 3 * j_p[2:-1] + 3 * j_p[1:-2] - j_p[:-3]) * (f ** 3), axis=2)
+    jkt = np.linalg.norm((j_t[3:] - 3 * j_t[2:-1] + 3 * j_t[1:-2] - j_t[:-3]) * (f ** 3), axis=2)
+    te = np.linalg.norm((j_p[f:, :1] - j_p[:-f, :1]) - (j_t[f:, :1] - j_t[:-f, :1]), axis=2) * 100
+    m = list(joint_mask)
+    rows = [je, ve, lae, gae, jkp, jkt, te, je[:, m], lae[:, m], gae[:, m]]
+    return np.array([[x.mean(), x.std(axis=0, ddof=1).mean()] for x in rows], dtype=np.float64)

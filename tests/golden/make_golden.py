@@ -199,6 +199,34 @@ def main():
         g8[f"item{idx}_joint"], g8[f"item{idx}_tran"] = joint.numpy(), tran.numpy()
     np.savez_compressed(os.path.join(HERE, "g8_dataset.npz"), **g8)
 
+    # ---- G9 the evaluator (evaluate.py:16-29 PoseEvaluator.eval -> articulate/evaluator.py:292-343) ------------
+    # cv2 is not installed here: rotation_matrix_to_axis_angle (angular.py:161-164) gets an oracle-side stand-in
+    # with the same contract (Rodrigues vector of a rotation matrix, here via scipy); only its norm is used.
+    cv2 = types.ModuleType("cv2")
+
+    def _rodrigues(R):
+        from scipy.spatial.transform import Rotation
+        return Rotation.from_matrix(np.asarray(R, dtype=np.float64)).as_rotvec().reshape(3, 1).astype(np.float32), None
+
+    cv2.Rodrigues = _rodrigues
+    sys.modules["cv2"] = cv2
+    rng = np.random.Generator(np.random.PCG64(9))
+    n = 45
+    pose_t = synthetic._random_rotations(rng, n * 24).reshape(n, 24, 3, 3)
+    noise = rng.standard_normal((n, 24, 3)) * 0.15
+    from scipy.spatial.transform import Rotation
+    pose_p = np.einsum("njab,njbc->njac", pose_t, Rotation.from_rotvec(noise.reshape(-1, 3)).as_matrix().reshape(n, 24, 3, 3))
+    tran_t = np.cumsum(rng.standard_normal((n, 3)) * 0.02, axis=0)
+    tran_p = tran_t + np.cumsum(rng.standard_normal((n, 3)) * 0.01, axis=0)
+    ev = art.FullMotionEvaluator(str(paths.smpl_file), joint_mask=torch.tensor([2, 5, 16, 20]), fps=30)
+    pp, pt = torch.from_numpy(pose_p).float(), torch.from_numpy(pose_t).float()
+    ign = [0, 7, 8, 10, 11, 20, 21, 22, 23]
+    pp[:, ign] = torch.eye(3)
+    pt[:, ign] = torch.eye(3)
+    errs = ev(pp, pt, tran_p=torch.from_numpy(tran_p).float(), tran_t=torch.from_numpy(tran_t).float())
+    np.savez_compressed(os.path.join(HERE, "g9_evaluator.npz"), pose_p=pose_p.astype(np.float32), pose_t=pose_t.astype(np.float32),
+                        tran_p=tran_p.astype(np.float32), tran_t=tran_t.astype(np.float32), errs=errs.numpy())
+
     print("golden vectors written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         print("  %-24s %8d B" % (fn, os.path.getsize(os.path.join(HERE, fn))))

@@ -347,3 +347,20 @@ def test_many_shapes_evict_plans(torch_mod, net):
     again = net.forward(cu(torch_mod, imu[:, :12]), [12])[1]
     assert torch_mod.equal(first, again)
     assert net.device_error() == 0
+
+
+def test_g6_fk_mesh_and_g9_evaluator_golden(torch_mod, net):
+    """mp_fk_mesh (LBS) against the reference's vertices, and the evaluator error table against the reference's."""
+    from mobileposer_amd.evaluate import FullMotionEvaluator
+    g = load_golden("g6_fk.npz")
+    Rg, jg, vg = net.forward_kinematics(cu(torch_mod, g["pose"]), cu(torch_mod, g["tran"]), calc_mesh=True)
+    assert np.abs(npy(jg) - g["joint_tran"]).max() < 1e-5
+    assert np.abs(npy(vg) - g["vert_tran"]).max() < 1e-5
+    g9 = load_golden("g9_evaluator.npz")
+    pp, pt = cu(torch_mod, g9["pose_p"]).clone(), cu(torch_mod, g9["pose_t"]).clone()
+    ign = [0, 7, 8, 10, 11, 20, 21, 22, 23]
+    pp[:, ign] = torch_mod.eye(3, device="cuda")
+    pt[:, ign] = torch_mod.eye(3, device="cuda")
+    ev = FullMotionEvaluator(net, joint_mask=[2, 5, 16, 20], fps=30)
+    errs = npy(ev(pp, pt, tran_p=cu(torch_mod, g9["tran_p"]), tran_t=cu(torch_mod, g9["tran_t"])))
+    np.testing.assert_allclose(errs, g9["errs"], rtol=2e-4, atol=1e-5)

@@ -148,3 +148,15 @@ def test_torch_baseline_restatement_matches_golden(weights, smpl, tag):
     assert np.abs(vel - g[f"{tag}_vel"]).max() < TIGHT
     assert np.abs(contact - g[f"{tag}_contact"]).max() < TIGHT
     assert geodesic(pose, g[f"{tag}_pose"]).max() < TOL
+
+
+def test_g9_full_motion_evaluator(smpl):
+    """The evaluator restatement against the reference's own FullMotionEvaluator table (cv2 stand-in in the
+    golden script: only |rotvec| is used)."""
+    g = load_golden("g9_evaluator.npz")
+    pp, pt = g["pose_p"].copy(), g["pose_t"].copy()
+    pp[:, O.IGNORED] = np.eye(3)
+    pt[:, O.IGNORED] = np.eye(3)
+    e = O.full_motion_evaluator(pp, pt, smpl, g["tran_p"], g["tran_t"])
+    assert np.abs(e - g["errs"]).max() / np.abs(g["errs"]).max() < 1e-6
+    np.testing.assert_allclose(e, g["errs"], rtol=2e-5)
