@@ -138,6 +138,7 @@ struct mp_handle {
     hipEvent_t ev_x[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int* err_dev = nullptr;          // device error word of the persistent kernels
     long long* prof_dev = nullptr;   // debug: per-workgroup phase cycle sums of the last persistent launch
+    int n_cu = 256;                  // compute units of this device: bounds the co-resident persistent grids
     bool persist = true;
     bool uni2 = false;               // velocity block as ONE two-layer wavefront launch (mp_set_lstm_mode(h, 2) / env
                                      // MP_LSTM_UNI2=1).  Off by default: it is 20 % faster than two launches but fills every
@@ -283,6 +284,12 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     auto bail = [&](int rc) { g_create_error = h->err; mp_destroy(h); return rc; };
     if (hipSetDevice(device) != hipSuccess) { h->err = "hipSetDevice failed"; return bail(MP_ERR_HIP); }
     if (const char* e = getenv("MP_NO_GRAPH")) h->use_graph = !(e[0] && e[0] != '0');
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
+        // a persistent layer needs at least one cluster (dirs x 16 workgroups) resident at one workgroup per CU
+        if (h->n_cu < 32) h->persist = false;
+    }
     if (const char* e = getenv("MP_LSTM_MODE")) h->persist = strcmp(e, "step") != 0;
     if (const char* e = getenv("MP_LSTM_UNI2")) h->uni2 = e[0] == '1';
     if (const char* e = getenv("MP_LSTM_SLICES")) h->nslice_env = atoi(e) == 8 ? 8 : (atoi(e) == 16 ? 16 : 0);
@@ -504,7 +511,8 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         // two-layer wavefront launch: layer 0 and layer 1 together when asked for layer 0, nothing for layer 1
         if (l == 1) return MP_OK;
         HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
-        const int nslab = (B + 15) / 16, chunk = 16;            // 16 slabs x 16 slices = 256 workgroups, one per CU
+        const int nslab = (B + 15) / 16;
+        const int chunk = (h->n_cu < 256 ? h->n_cu : 256) / 16 > 0 ? (h->n_cu < 256 ? h->n_cu : 256) / 16 : 1;   // one workgroup per CU
         SegScope seg(h, s, 5, (nslab + chunk - 1) / chunk, 2.0 * (double)B * T * 4.0 * H * (4.0 * H));
         const bool inplace = j.out_h == j.in_h && j.out_h;
         for (int s0 = 0; s0 < nslab; s0 += chunk) {
@@ -528,7 +536,8 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));     // every polled word is re-zeroed before every launch
         const int nslab = (B + 15) / 16;
         const int nsl = m.nslice;
-        const int chunk = 256 / (dirs * nsl);                         // slabs per launch: grid <= 256 workgroups, one per CU
+        const int cus = h->n_cu < 256 ? h->n_cu : 256;
+        const int chunk = cus / (dirs * nsl) > 0 ? cus / (dirs * nsl) : 1;   // slabs per launch: grid <= #CUs, one workgroup per CU
         const int kin = l == 0 ? H : dirs * H;
         // timing classes: 1 = H256 bidirectional K_in=256, 4 = H256 bidirectional K_in=512, 5 = H256 unidirectional
         const int cls = H != 256 ? 6 : (dirs == 1 ? 5 : (kin == 256 ? 1 : 4));
