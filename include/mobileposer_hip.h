@@ -161,6 +161,9 @@ int mp_set_graph_mode(mp_handle* h, int on);
  * workgroups as tagged granules (default); 2 = same, and the unidirectional velocity block as ONE two-layer
  * wavefront launch; 0 = input-projection GEMM + one launch per time step (env MP_LSTM_MODE=step). */
 int mp_set_lstm_mode(mp_handle* h, int mode);
+/* Test hook for the hidden-state exchange of the persistent kernels: 0 = pick the transport per producer from
+ * its real XCC id (default), 1 = always use the any-placement write-through (sc1) transport. */
+int mp_set_transport(mp_handle* h, int force_remote);
 /* Synchronises the library's stream and returns the device error word of the persistent kernels:
  * 0 = ok, 1+step = a bounded wait for another workgroup's hidden state timed out (results invalid). */
 int mp_device_error(mp_handle* h, int* code);

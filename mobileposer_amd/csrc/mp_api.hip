@@ -138,6 +138,7 @@ struct mp_handle {
     hipEvent_t ev_x[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int* err_dev = nullptr;          // device error word of the persistent kernels
     long long* prof_dev = nullptr;   // debug: per-workgroup phase cycle sums of the last persistent launch
+    bool force_remote = false;       // test hook (mp_set_transport)
     int n_cu = 256;                  // compute units of this device: bounds the co-resident persistent grids
     bool persist = true;
     bool uni2 = false;               // velocity block as ONE two-layer wavefront launch (mp_set_lstm_mode(h, 2) / env
@@ -521,7 +522,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             a.slab0 = s0; a.nslab = nslab - s0 < chunk ? nslab - s0 : chunk;
             a.hx = w.hx + (size_t)2 * s0 * ((size_t)4 * 16 * H + 16);
             a.err = h->err_dev; a.max_spin = 1u << 18; a.prof = nullptr;
-            a.zero_state = j.mode == STATE_ZERO ? 1 : 0;
+            a.zero_state = j.mode == STATE_ZERO ? 1 : 0; a.force_remote = h->force_remote ? 1 : 0;
             for (int ll = 0; ll < 2; ++ll) {
                 LstmDir& dd = a.d[ll];
                 dd.wpack = m.whhP[ll][0]; dd.xproj = nullptr; dd.out = w.out1;
@@ -551,7 +552,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             a.slab0 = s0; a.nslab = nslab - s0 < chunk ? nslab - s0 : chunk;
             a.hx = w.hx + (size_t)dirs * s0 * ((size_t)4 * 16 * H + 16);
             a.err = h->err_dev; a.max_spin = 1u << 18; a.prof = h->prof_dev;
-            a.zero_state = j.mode == STATE_ZERO ? 1 : 0;
+            a.zero_state = j.mode == STATE_ZERO ? 1 : 0; a.force_remote = h->force_remote ? 1 : 0;
             for (int d = 0; d < dirs; ++d) {
                 LstmDir& dd = a.d[d];
                 dd.wpack = m.whhP[l][d]; dd.xproj = nullptr; dd.out = outp + (size_t)d * H;
@@ -1132,6 +1133,15 @@ int mp_set_lstm_mode(mp_handle* h, int mode) {
     HIPCHK(h, hipDeviceSynchronize());
     h->persist = mode != 0;
     h->uni2 = mode == 2;
+    return MP_OK;
+}
+
+int mp_set_transport(mp_handle* h, int force_remote) {
+    if (!h) return MP_ERR_INVALID;
+    HIPCHK(h, hipDeviceSynchronize());
+    h->force_remote = force_remote != 0;
+    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);     // captured launches carry the old setting
+    h->graphs.clear();
     return MP_OK;
 }
 

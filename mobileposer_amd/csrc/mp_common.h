@@ -67,6 +67,7 @@ struct LstmPersistArgs {
     int* err;                     // device error word (0 = ok, 1+step = a gather timed out)
     int ndir, B, T, slab0, nslab;
     int zero_state;               // 1: start from h = c = 0 without reading hbuf / cbuf
+    int force_remote;             // test hook: use the any-placement (sc1) transport even inside one XCD
     unsigned max_spin;
     long long* prof;              // optional [grid][6] cycle sums per phase (debug), else nullptr
 };

@@ -105,19 +105,14 @@ __global__ __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) voi
     f32x4* red = reinterpret_cast<f32x4*>(smem);                       // [finishing wave][source kq][o][lane]
     f32x4* wxl = reinterpret_cast<f32x4*>(smem) + C::RED_F4;           // [wave][x-step < XL][tile group][lane]
 
-    // 1-D grid over (direction, slab, slice).  When the number of (direction, slab) clusters is a multiple of 8
-    // the NSLICE workgroups of a cluster are given block ids that are congruent mod 8, i.e. (observed dispatch,
-    // block b -> XCD b % 8) they share an XCD and its L2: speed only, never correctness.
+    // 1-D grid of 8 * ceil(ncl/8) * NSLICE blocks over (cluster = (direction, slab), slice).  The NSLICE workgroups
+    // of a cluster get block ids that are congruent mod 8, i.e. (observed dispatch: block b -> XCD b % 8) they
+    // share an XCD and its L2 -- speed only, never correctness (the transport is chosen from the real XCC ids).
+    // Blocks whose cluster index falls beyond ncl (ncl not a multiple of 8) exit at once.
     const int ncl = a.ndir * a.nslab;
-    int cl, slice;
-    if ((ncl & 7) == 0) {
-        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-        cl = (i / NSLICE) * 8 + xcd;
-        slice = i % NSLICE;
-    } else {
-        cl = blockIdx.x / NSLICE;
-        slice = blockIdx.x % NSLICE;
-    }
+    const int cl = ((int)(blockIdx.x >> 3) / NSLICE) * 8 + (int)(blockIdx.x & 7);
+    const int slice = (int)(blockIdx.x >> 3) % NSLICE;
+    if (cl >= ncl) return;
     const int dir = cl / a.nslab, slab = cl % a.nslab;
     const LstmDir d = a.d[dir];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -210,6 +205,11 @@ __global__ __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) voi
 #pragma unroll
         for (int i = 0; i < NPW; ++i) src_local[i] = (same >> (NPW * kq + i)) & 1;   // k-steps of part i come from slice NPW*kq+i
         if (__ballot(peer == ~0u)) spin_budget = 0;
+        if (a.force_remote) {                               // test hook: exercise the any-placement transport
+            all_local = false;
+#pragma unroll
+            for (int i = 0; i < NPW; ++i) src_local[i] = false;
+        }
     }
 
     // ---- x_0: this lane's A values of the input projection, k = kq*KQ + j*16 + q*4 + i  (x-step s = 4j+i)
@@ -445,15 +445,9 @@ __global__ __launch_bounds__(512, 1) void mp_lstm_fused_uni2(LstmPersistArgs a) 
     f32x4* wximg = reinterpret_cast<f32x4*>(smem) + 2 * 4 * 4 * 64;     // [layer][wave kq][k-step][lane]
 
     const int ncl = a.nslab;
-    int slab, slice;
-    if ((ncl & 7) == 0) {
-        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-        slab = (i / NSLICE) * 8 + xcd;
-        slice = i % NSLICE;
-    } else {
-        slab = blockIdx.x / NSLICE;
-        slice = blockIdx.x % NSLICE;
-    }
+    const int slab = ((int)(blockIdx.x >> 3) / NSLICE) * 8 + (int)(blockIdx.x & 7);     // same block -> XCD trick as above
+    const int slice = (int)(blockIdx.x >> 3) % NSLICE;
+    if (slab >= ncl) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kq = wave & 3, layer = wave >> 2;
     const LstmDir d = a.d[layer];
@@ -526,6 +520,11 @@ __global__ __launch_bounds__(512, 1) void mp_lstm_fused_uni2(LstmPersistArgs a) 
 #pragma unroll
         for (int i = 0; i < NPW; ++i) src_local[i] = (same >> (NPW * kq + i)) & 1;
         if (__ballot(peer == ~0u)) spin_budget = 0;
+        if (a.force_remote) {
+            all_local = false;
+#pragma unroll
+            for (int i = 0; i < NPW; ++i) src_local[i] = false;
+        }
     }
 
     f32x4 xa[NXJ];
@@ -701,7 +700,7 @@ template <int H, int NSLICE, int KIN, int TW>
 void launch_fused(const LstmPersistArgs& a, hipStream_t s) {
     using C = Cfg<H, NSLICE, KIN, TW>;
     const size_t lds = (size_t)C::RED_F4 * 16 + (size_t)C::NWV * C::XL * C::NTG * 64 * 16;
-    const dim3 grid(a.nslab * NSLICE * a.ndir);
+    const dim3 grid(((a.nslab * a.ndir + 7) / 8) * 8 * NSLICE);
     if (a.prof) {
         static bool once = (hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, TW, true>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
@@ -742,7 +741,7 @@ void mp_launch_lstm_uni2(const LstmPersistArgs& a, hipStream_t s) {
     static bool once = (hipFuncSetAttribute((const void*)mp_lstm_fused_uni2<256>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
-    hipLaunchKernelGGL((mp_lstm_fused_uni2<256>), dim3(a.nslab * 16), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((mp_lstm_fused_uni2<256>), dim3(((a.nslab + 7) / 8) * 8 * 16), dim3(512), lds, s, a);
 }
 
 void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice, hipStream_t s) {

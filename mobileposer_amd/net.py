@@ -387,6 +387,10 @@ class MobilePoserNet:
         """0/False: per-step kernels; 1/True: fused persistent layers (default); 2: + two-layer wavefront velocity kernel."""
         _lib.check(self._lib.mp_set_lstm_mode(self._h, int(mode)), self._h)
 
+    def set_transport(self, force_remote):
+        """Test hook: force the any-placement (sc1) hidden-state transport of the persistent kernels."""
+        _lib.check(self._lib.mp_set_transport(self._h, int(bool(force_remote))), self._h)
+
     def device_error(self):
         """0 = ok; otherwise 1+step at which a persistent-kernel wait timed out (synchronises)."""
         code = C.c_int(0)

@@ -364,3 +364,21 @@ def test_g6_fk_mesh_and_g9_evaluator_golden(torch_mod, net):
     ev = FullMotionEvaluator(net, joint_mask=[2, 5, 16, 20], fps=30)
     errs = npy(ev(pp, pt, tran_p=cu(torch_mod, g9["tran_p"]), tran_t=cu(torch_mod, g9["tran_t"])))
     np.testing.assert_allclose(errs, g9["errs"], rtol=2e-4, atol=1e-5)
+
+
+def test_hidden_state_transports_agree(torch_mod, net):
+    """The same-XCD (L2) transport and the any-placement (write-through) transport of the persistent kernels carry
+    the same values: bitwise-identical outputs, for a full-chip batch and for a single small cluster."""
+    from mobileposer_amd import synthetic
+    for B, T in ((256, 30), (3, 40)):
+        x = cu(torch_mod, synthetic.make_imu(B, T, seed=29))
+        lengths = [T] * B
+        outs = []
+        for remote in (False, True):
+            net.set_transport(remote)
+            net.reset_all()
+            outs.append([t.clone() for t in net.forward(x, lengths)])
+            assert net.device_error() == 0
+        net.set_transport(False)
+        for a, b in zip(*outs):
+            assert torch_mod.equal(a, b)
