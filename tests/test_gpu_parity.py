@@ -382,3 +382,29 @@ def test_hidden_state_transports_agree(torch_mod, net):
         net.set_transport(False)
         for a, b in zip(*outs):
             assert torch_mod.equal(a, b)
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 2), (17, 3), (2, 45)])
+def test_tiny_shapes_vs_oracle(torch_mod, net, weights, smpl, B, T):
+    """Edge shapes: single frame, single sequence, a slab with one valid row, the online window length."""
+    from mobileposer_amd import synthetic
+    from oracle import mp_oracle as O
+    imu = synthetic.make_imu(B, T, seed=100 + B + T)
+    lengths = [T] * B
+    if B > 2:
+        lengths[B // 2] = 1
+    net.reset_all()
+    pose, joints, tran, contact = net.forward_offline(cu(torch_mod, imu), lengths)
+    assert net.device_error() == 0
+    for b in range(B):
+        L = lengths[b]
+        ref = O.OracleNet(weights, smpl["J"])
+        rp, rj, rt, rc = ref.forward_offline(imu[b:b + 1, :L], [L])
+        jb = npy(joints[b, :L]) if B > 1 else npy(joints[0, :L])
+        tb = npy(tran[b, :L]) if B > 1 else npy(tran[:L])
+        cb = npy(contact[b, :L]) if B > 1 else npy(contact[:L])
+        pb = npy(pose).reshape(B, T, 24, 3, 3)[b, :L]
+        assert np.abs(jb - rj[0]).max() < TOL
+        assert np.abs(cb - rc).max() < TOL
+        assert np.abs(tb - rt).max() < TOL_TRAN
+        assert geodesic(pb, rp).max() < TOL
