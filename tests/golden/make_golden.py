@@ -227,6 +227,34 @@ def main():
     np.savez_compressed(os.path.join(HERE, "g9_evaluator.npz"), pose_p=pose_p.astype(np.float32), pose_t=pose_t.astype(np.float32),
                         tran_p=tran_p.astype(np.float32), tran_t=tran_t.astype(np.float32), errs=errs.numpy())
 
+    # ---- G10 live front-end math (live_demo.py:161-174 calibration, :213-236 frame formation) -------------------
+    # the demo script is not importable (everything sits under __main__); the same expressions are evaluated here
+    # with the reference's own articulate.math functions on seeded sensor readings
+    q2r = art.math.quaternion_to_rotation_matrix
+    rng = np.random.Generator(np.random.PCG64(10))
+    ref_q = torch.from_numpy(rng.standard_normal(4)).float()
+    tq = torch.from_numpy(rng.standard_normal((5, 4))).float()
+    ta = torch.from_numpy(rng.standard_normal((5, 3)) * 9.8).float()
+    smpl2imu = q2r(ref_q).view(3, 3).t()
+    device2bone = smpl2imu.matmul(q2r(tq)).transpose(1, 2).matmul(torch.eye(3))
+    acc_offsets = smpl2imu.matmul(ta.unsqueeze(-1))
+    fq = torch.from_numpy(rng.standard_normal((7, 5, 4))).float()
+    fa = torch.from_numpy(rng.standard_normal((7, 5, 3)) * 9.8).float()
+    ori_raw = q2r(fq).view(-1, 5, 3, 3)
+    glb_acc = (smpl2imu.matmul(fa.view(-1, 5, 3, 1)) - acc_offsets).view(-1, 5, 3)
+    glb_ori = smpl2imu.matmul(ori_raw).matmul(device2bone)
+    _acc = glb_acc.view(-1, 5, 3)[:, [1, 4, 3, 0, 2]] / 30
+    _ori = glb_ori.view(-1, 5, 3, 3)[:, [1, 4, 3, 0, 2]]
+    acc, ori = torch.zeros_like(_acc), torch.zeros_like(_ori)
+    cc = [0, 3]                                           # 'lw_rp'
+    acc[:, cc], ori[:, cc] = _acc[:, cc], _ori[:, cc]
+    imu_input = torch.cat([acc.flatten(1), ori.flatten(1)], dim=1)
+    rot = synthetic._random_rotations(rng, 24).astype(np.float32)
+    aa = art.math.rotation_matrix_to_axis_angle(torch.from_numpy(rot))       # cv2 stand-in from G9
+    np.savez_compressed(os.path.join(HERE, "g10_live.npz"), ref_q=ref_q.numpy(), tq=tq.numpy(), ta=ta.numpy(),
+                        fq=fq.numpy(), fa=fa.numpy(), smpl2imu=smpl2imu.numpy(), device2bone=device2bone.numpy(),
+                        acc_offsets=acc_offsets.numpy(), imu_input=imu_input.numpy(), rot=rot, axis_angle=aa.numpy())
+
     print("golden vectors written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         print("  %-24s %8d B" % (fn, os.path.getsize(os.path.join(HERE, fn))))

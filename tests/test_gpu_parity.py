@@ -408,3 +408,25 @@ def test_tiny_shapes_vs_oracle(torch_mod, net, weights, smpl, B, T):
         assert np.abs(cb - rc).max() < TOL
         assert np.abs(tb - rt).max() < TOL_TRAN
         assert geodesic(pb, rp).max() < TOL
+
+
+def test_live_session_feeds_stream_step(torch_mod, weights, smpl):
+    """Live front-end (calibration + frame formation) -> GPU streaming tick == forward_online on the same frames."""
+    from mobileposer_amd import live
+    from mobileposer_amd.net import MobilePoserNet
+    rng = np.random.default_rng(4)
+    S, n = 2, 4
+    cals = [live.Calibration.from_measurements(torch_mod.from_numpy(rng.standard_normal(4)).float(),
+                                               torch_mod.from_numpy(rng.standard_normal((5, 4))).float(),
+                                               torch_mod.from_numpy(rng.standard_normal((5, 3))).float()) for _ in range(S)]
+    quats = rng.standard_normal((n, S, 5, 4)).astype(np.float32)
+    accs = (rng.standard_normal((n, S, 5, 3)) * 3).astype(np.float32)
+    sess = live.LiveSession(MobilePoserNet.from_numpy(weights, smpl), cals)
+    singles = [MobilePoserNet.from_numpy(weights, smpl) for _ in range(S)]
+    for k in range(n):
+        pose, root, packets = sess.tick(quats[k], accs[k])
+        assert len(packets) == S and packets[0].endswith(b"$")
+        for s in range(S):
+            frame = live.form_frame(cals[s], torch_mod.from_numpy(quats[k, s])[None], torch_mod.from_numpy(accs[k, s])[None])[0]
+            p1, _, r1, _ = singles[s].forward_online(frame.cuda())
+            assert np.abs(npy(pose[s]) - npy(p1)).max() < 1e-5 and np.abs(npy(root[s]) - npy(r1)).max() < 1e-5
