@@ -78,6 +78,8 @@ struct ModuleW {
     float* whh[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};    // per-step kernel layout
     float* whhP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // persistent kernel layout
     float* wihP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // W_ih, persistent kernel layout
+    float* whhX[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // split-bf16 kernel layout (H = 256 modules)
+    float* wihX[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     float* wihG1 = nullptr;          // unidirectional H=256 block: layer-1 W_ih in granule k-order (wavefront kernel)
 };
 struct ModuleWS {
@@ -145,6 +147,7 @@ struct mp_handle {
                                      // MP_LSTM_UNI2=1).  Off by default: it is 20 % faster than two launches but fills every
                                      // CU's registers and LDS, so the foot-contact layers and pose's linear2 / IK / FK can no
                                      // longer run beside the velocity block and the forward as a whole gets slower.
+    bool x3 = false;                 // H = 256 layers on split-bf16 MFMA operands (mp_lstm_x3.hip): mp_set_lstm_mode(h, 3)
     int nslice_env = 0;              // 0: pick per module (8 slices / 8 waves for bidirectional layers that fill the
                                      // chip, 16 slices / 4 waves for unidirectional ones); env MP_LSTM_SLICES=8|16 forces one             // LSTM recurrence: persistent kernel (default) or per-step launches
     std::map<std::pair<int, int>, Plan*> plans;
@@ -214,6 +217,10 @@ int pack_weights(mp_handle* h, const float* blob) {
                 if (int rc = dev_alloc(h, (void**)&m.whhP[l][d], mp_whh_pack_floats(m.H) * sizeof(float))) return rc;
                 const int kin = l == 0 ? m.H : m.dirs * m.H;
                 if (int rc = dev_alloc(h, (void**)&m.wihP[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
+                if (m.H == 256) {
+                    if (int rc = dev_alloc(h, (void**)&m.whhX[l][d], (size_t)4 * m.H * m.H * sizeof(float))) return rc;
+                    if (int rc = dev_alloc(h, (void**)&m.wihX[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
+                }
             }
     }
     const std::vector<Entry>& man = manifest();
@@ -235,6 +242,10 @@ int pack_weights(mp_handle* h, const float* blob) {
                 mp_launch_pack_whh(find(s.id, K_WHH, l, d), m.whh[l][d], m.H, h->s_main);
                 mp_launch_pack_whh_persist(find(s.id, K_WHH, l, d), m.whhP[l][d], m.H, m.nslice, h->s_main);
                 mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP[l][d], m.H, m.ih[l].K, m.nslice, 0, h->s_main);
+                if (m.H == 256) {
+                    mp_launch_pack_w_x3(find(s.id, K_WHH, l, d), m.whhX[l][d], m.H, m.nslice, h->s_main);
+                    mp_launch_pack_w_x3(find(s.id, K_WIH, l, d), m.wihX[l][d], m.ih[l].K, m.nslice, h->s_main);
+                }
                 if (l == 1 && m.dirs == 1 && m.H == 256 && m.nslice == 16) {
                     if (int rc = dev_alloc(h, (void**)&m.wihG1, (size_t)4 * m.H * m.ih[1].K * sizeof(float))) return rc;
                     mp_launch_pack_wih_persist(find(s.id, K_WIH, 1, 0), m.wihG1, m.H, m.ih[1].K, 16, 1, h->s_main);
@@ -291,7 +302,10 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
         // a persistent layer needs at least one cluster (dirs x 16 workgroups) resident at one workgroup per CU
         if (h->n_cu < 32) h->persist = false;
     }
-    if (const char* e = getenv("MP_LSTM_MODE")) h->persist = strcmp(e, "step") != 0;
+    if (const char* e = getenv("MP_LSTM_MODE")) {
+        h->persist = strcmp(e, "step") != 0;
+        h->x3 = strcmp(e, "x3") == 0;
+    }
     if (const char* e = getenv("MP_LSTM_UNI2")) h->uni2 = e[0] == '1';
     if (const char* e = getenv("MP_LSTM_SLICES")) h->nslice_env = atoi(e) == 8 ? 8 : (atoi(e) == 16 ? 16 : 0);
     if (getenv("MP_PERSIST_PROF")) {
@@ -440,11 +454,11 @@ RowMap internal_map(const float* base, int B, int width) { return RowMap{base, (
 RowMap user_map(const float* base, int T, int width) { return RowMap{base, (long)T * width, (long)width, width}; }
 
 int run_gemm(mp_handle* h, hipStream_t s, RowMap a0, RowMap a1, const Packed& w, float* C, long cStrideB,
-             long cStrideT, int M, int B, int relu) {
+             long cStrideT, int M, int B, int relu, bool pair_out = false) {
     SegScope seg(h, s, 0, 1, 2.0 * M * (double)w.N * w.K);
     GemmArgs g;
     g.a0 = a0; g.a1 = a1; g.W = w.W; g.bias = w.bias; g.C = C; g.cStrideB = cStrideB; g.cStrideT = cStrideT;
-    g.M = M; g.N = w.N; g.K = w.K; g.Kpad = w.Kpad; g.B = B; g.relu = relu;
+    g.M = M; g.N = w.N; g.K = w.K; g.Kpad = w.Kpad; g.B = B; g.relu = relu; g.pairOut = pair_out ? 1 : 0;
     mp_launch_gemm(g, w.bn, s);
     return MP_OK;
 }
@@ -467,6 +481,9 @@ struct RnnJob {
 
 // linear1's output X1 normally lives in out1's memory (dead until layer 1 writes it); the two-layer wavefront
 // kernel writes out1 while layer 0 is still reading X1, so there X1 goes to the (otherwise unused) out0
+// split-bf16 operands for this module's LSTM layers?  (X1 and the layer-0 output are then stored as pairs)
+bool use_x3(const mp_handle* h, const ModuleW& m) { return h->persist && h->x3 && !h->uni2 && m.H == 256; }
+
 float* x1_buffer(const mp_handle* h, const ModuleW& m, ModuleWS& w) {
     return (h->persist && h->uni2 && m.wihG1) ? w.out0 : w.out1;
 }
@@ -478,7 +495,7 @@ int rnn_g0(const RnnJob& j, hipStream_t s) {
     const int B = j.p->B, T = j.p->T, M = B * T, H = m.H, dirs = m.dirs;
     const RowMap none{nullptr, 0, 0, 0};
     float* X1 = x1_buffer(h, m, w);
-    run_gemm(h, s, j.a0, j.a1, m.lin1, X1, H, (long)B * H, M, B, 1);                       // rnn.py:22
+    run_gemm(h, s, j.a0, j.a1, m.lin1, X1, H, (long)B * H, M, B, 1, use_x3(h, m));          // rnn.py:22
     // the per-step kernels take the input projection from a GEMM; the persistent kernel computes it itself
     if (!h->persist && !w.xproj) return fail(h, MP_ERR_INVALID, "internal: per-step workspace missing");
     if (!h->persist)
@@ -553,17 +570,20 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             a.hx = w.hx + (size_t)dirs * s0 * ((size_t)4 * 16 * H + 16);
             a.err = h->err_dev; a.max_spin = 1u << 18; a.prof = h->prof_dev;
             a.zero_state = j.mode == STATE_ZERO ? 1 : 0; a.force_remote = h->force_remote ? 1 : 0;
+            const bool x3 = use_x3(h, m);
+            a.out_pairs = x3 && l == 0 ? 1 : 0;
             for (int d = 0; d < dirs; ++d) {
                 LstmDir& dd = a.d[d];
-                dd.wpack = m.whhP[l][d]; dd.xproj = nullptr; dd.out = outp + (size_t)d * H;
+                dd.wpack = x3 ? m.whhX[l][d] : m.whhP[l][d]; dd.xproj = nullptr; dd.out = outp + (size_t)d * H;
                 const bool inplace = j.out_h == j.in_h && j.out_h;
                 dd.hbuf = inplace ? j.out_h + (size_t)(l * dirs + d) * B * H : w.hbuf[l][d];
                 dd.cbuf = inplace ? j.out_c + (size_t)(l * dirs + d) * B * H : w.cbuf[l][d];
                 dd.xprojStride = 0; dd.outStride = dirs * H; dd.reverse = d;
-                dd.wihpack = m.wihP[l][d]; dd.bias = m.ih[l].bias + (size_t)d * 4 * H; dd.xin = xin;
+                dd.wihpack = x3 ? m.wihX[l][d] : m.wihP[l][d]; dd.bias = m.ih[l].bias + (size_t)d * 4 * H; dd.xin = xin;
             }
             if (dirs == 1) a.d[1] = a.d[0];
-            mp_launch_lstm_persist(a, H, kin, nsl, s);
+            if (x3) mp_launch_lstm_x3(a, kin, nsl, s);
+            else mp_launch_lstm_persist(a, H, kin, nsl, s);
         }
     } else {
         SegScope seg(h, s, 7, T, 2.0 * dirs * (double)B * T * 4.0 * H * H);
@@ -785,6 +805,8 @@ void mp_destroy(mp_handle* h) {
             if (m.whh[l][d]) (void)hipFree(m.whh[l][d]);
             if (m.whhP[l][d]) (void)hipFree(m.whhP[l][d]);
             if (m.wihP[l][d]) (void)hipFree(m.wihP[l][d]);
+            if (m.whhX[l][d]) (void)hipFree(m.whhX[l][d]);
+            if (m.wihX[l][d]) (void)hipFree(m.wihX[l][d]);
         }
         if (m.wihG1) (void)hipFree(m.wihG1);
     }
@@ -828,7 +850,7 @@ int mp_forward(mp_handle* h, const float* imu_dev, const int32_t* lengths_host, 
     h->segs.clear(); h->ev_used = 0;
     GraphKey key;
     memset(&key, 0, sizeof(key));
-    key.kind = 0; key.B = B; key.T = T; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0) | (h->uni2 ? 4 : 0);
+    key.kind = 0; key.B = B; key.T = T; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0) | (h->uni2 ? 4 : 0) | (h->x3 ? 8 : 0);
     key.p[0] = imu_dev; key.p[1] = pose_dev; key.p[2] = joints_dev; key.p[3] = vel_dev; key.p[4] = contact_dev;
     key.p[5] = r6d; key.p[6] = h->vstate.h;
     int rc;
@@ -862,7 +884,7 @@ int mp_forward_offline(mp_handle* h, const float* imu_dev, const int32_t* length
     h->segs.clear(); h->ev_used = 0;
     GraphKey key;
     memset(&key, 0, sizeof(key));
-    key.kind = 2; key.B = B; key.T = T; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0) | (h->uni2 ? 4 : 0);
+    key.kind = 2; key.B = B; key.T = T; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0) | (h->uni2 ? 4 : 0) | (h->x3 ? 8 : 0);
     key.p[0] = imu_dev; key.p[1] = pose_dev; key.p[2] = joints_dev; key.p[3] = vel_dev; key.p[4] = contact_dev;
     key.p[5] = tran_dev; key.p[6] = h->vstate.h; key.p[7] = rglobal_dev;
     int rc;
@@ -1050,7 +1072,7 @@ int mp_stream_step(mp_handle* h, const float* frames_dev, float* pose_dev, float
     h->segs.clear(); h->ev_used = 0;
     GraphKey key;
     memset(&key, 0, sizeof(key));
-    key.kind = 1; key.B = S; key.T = W; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0) | (h->uni2 ? 4 : 0);
+    key.kind = 1; key.B = S; key.T = W; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0) | (h->uni2 ? 4 : 0) | (h->x3 ? 8 : 0);
     key.p[0] = frames_dev; key.p[1] = pose_dev; key.p[2] = joints; key.p[3] = root_pos_dev; key.p[4] = contact_dev;
     key.p[6] = h->vstate.h;
     int rc;
@@ -1129,10 +1151,11 @@ int mp_debug_read_prof(mp_handle* h, long long* out, int n_words) {
 }
 
 int mp_set_lstm_mode(mp_handle* h, int mode) {
-    if (!h || mode < 0 || mode > 2) return MP_ERR_INVALID;
+    if (!h || mode < 0 || mode > 3) return MP_ERR_INVALID;
     HIPCHK(h, hipDeviceSynchronize());
     h->persist = mode != 0;
     h->uni2 = mode == 2;
+    h->x3 = mode == 3;
     return MP_OK;
 }
 

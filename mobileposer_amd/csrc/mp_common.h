@@ -3,6 +3,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// gfx950 co-execution erratum observed on MI355X (DESIGN.md "packed-fp32 beside bf16 MFMA"): a wave's
+// packed-fp32 VALU results (v_pk_mul/add/fma_f32) come out wrong in lanes 48..63, at random, while another wave
+// on the same CU issues v_mfma_f32_16x16x32_bf16.  Every kernel of this library can run beside the split-bf16
+// LSTM layers, so none of them may contain packed-fp32 instructions: the build passes
+// `-Xclang -target-feature -Xclang -packed-fp32-ops` for all device code (__graft_entry__.build) and
+// tests/test_cabi_cpu.py disassembles the library to check that none slipped in.
+#define MP_KERNEL __global__
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -26,6 +34,7 @@ struct GemmArgs {
     float* C;
     long cStrideB, cStrideT;
     int M, N, K, Kpad, B, relu;
+    int pairOut = 0;     // 1: store C as split-bf16 pairs (mp_lstm_dev.h pair_of) -- input format of mp_lstm_x3.hip
 };
 // bn: 128, 96 or 32 (chosen by the caller from N)
 void mp_launch_gemm(const GemmArgs& g, int bn, hipStream_t s);
@@ -70,6 +79,7 @@ struct LstmPersistArgs {
     int force_remote;             // test hook: use the any-placement (sc1) transport even inside one XCD
     unsigned max_spin;
     long long* prof;              // optional [grid][6] cycle sums per phase (debug), else nullptr
+    int out_pairs = 0;            // split-bf16 kernel only: write the layer output as pairs (it feeds another layer)
 };
 // nslice: workgroups sharing one slab of an H = 256 layer: 16 (4-wave workgroups, two per CU) or 8 (8-wave, one per CU)
 void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice, hipStream_t s);
@@ -78,6 +88,11 @@ void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, in
 int mp_persist_max_wg(int H, int nslice);    // largest grid that is co-resident
 // both layers of a unidirectional 2-layer H = 256 LSTM as one wavefront launch (d[0] = layer 0, d[1] = layer 1)
 void mp_launch_lstm_uni2(const LstmPersistArgs& a, hipStream_t s);
+
+// split-bf16 variant of the persistent layer (mp_lstm_x3.hip), H = 256 only: xin and (out_pairs) out hold pairs,
+// wpack / wihpack come from mp_launch_pack_w_x3 (W_hh: K = 256; W_ih: K = K_in)
+void mp_launch_lstm_x3(const LstmPersistArgs& a, int KIN, int nslice, hipStream_t s);
+void mp_launch_pack_w_x3(const float* w, float* dst, int K, int nslice, hipStream_t s);
 
 // ---------------------------------------------------------------- K4/K5: kinematics
 void mp_launch_r6d_ik(const float* r6d, long N, float* pose, const int* parent_dev, hipStream_t s);

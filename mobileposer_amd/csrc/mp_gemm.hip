@@ -11,7 +11,7 @@
 // A and W use the same one.  Register prefetch of the next k-tile overlaps HBM/L2 latency with the MFMAs.
 // blockIdx -> tile mapping keeps all n-tiles of one m-tile on one XCD (same L2) so the A panel is fetched
 // from HBM once.
-#include "mp_common.h"
+#include "mp_lstm_dev.h"
 
 namespace {
 
@@ -19,7 +19,7 @@ constexpr int BK = 32;
 constexpr int LDK = 36;   // LDS row pitch in floats (144 B: 16-B aligned, conflict-free b128 reads)
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
-__global__ __launch_bounds__(256) void mp_gemm_f32(GemmArgs g, int nTilesM, int nTilesN) {
+MP_KERNEL __launch_bounds__(256) void mp_gemm_f32(GemmArgs g, int nTilesM, int nTilesN) {
     constexpr int BM = WAVES_M * TM * 32;
     constexpr int BN = WAVES_N * TN * 32;
     static_assert(BM == 128, "BM is 128");
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void mp_gemm_f32(GemmArgs g, int nTilesM, int 
                 if (m0 + ml < g.M) {
                     float v = acc[a][b][r] + bias;
                     if (g.relu) v = fmaxf(v, 0.f);
-                    g.C[rowOffC[ml] + n] = v;
+                    g.C[rowOffC[ml] + n] = g.pairOut ? __uint_as_float(pair_of(v)) : v;
                 }
             }
         }

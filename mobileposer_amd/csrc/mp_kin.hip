@@ -56,7 +56,7 @@ __device__ __forceinline__ void global_rot(const float* __restrict__ row96, int 
 
 // frame n reads its 96 numbers at r6d + n*rowStride + rowOffset (lets the streaming step convert only
 // window index 40 of every stream); writes pose[n][24][9]
-__global__ __launch_bounds__(256) void mp_r6d_ik(const float* __restrict__ r6d, long N, long rowStride,
+MP_KERNEL __launch_bounds__(256) void mp_r6d_ik(const float* __restrict__ r6d, long N, long rowStride,
                                                   long rowOffset, float* __restrict__ pose,
                                                   const int* __restrict__ parent) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void mp_r6d_ik(const float* __restrict__ r6d, 
 }
 
 // lanes = joints, 2 frames per wave; bone[24][3] = j_i - j_parent(i) (bone[0] = j_0 = 0), depth[24]
-__global__ __launch_bounds__(256) void mp_fk(const float* __restrict__ pose, const float* __restrict__ tran, long N,
+MP_KERNEL __launch_bounds__(256) void mp_fk(const float* __restrict__ pose, const float* __restrict__ tran, long N,
                                               const float* __restrict__ bone, const int* __restrict__ parent,
                                               const int* __restrict__ depth, float* __restrict__ rglobal,
                                               float* __restrict__ joint) {
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void mp_fk(const float* __restrict__ pose, con
 // blendshape):  T_j = [R_j | p_j - R_j j_j],  vert_v = sum_j w_vj T_j [v_rest; 1]  (+ tran).
 // One workgroup per (frame, 256-vertex chunk); the frame's 24 transforms sit in LDS.  HBM-bound on the output:
 // 12 B per vertex written, weights / template stay in L2.
-__global__ __launch_bounds__(256) void mp_lbs(const float* __restrict__ rglobal, const float* __restrict__ joint,
+MP_KERNEL __launch_bounds__(256) void mp_lbs(const float* __restrict__ rglobal, const float* __restrict__ joint,
                                                const float* __restrict__ tran, const float* __restrict__ jrest,
                                                const float* __restrict__ vrest, const float* __restrict__ weights,
                                                int V, float* __restrict__ vert) {

@@ -32,7 +32,7 @@ __device__ __forceinline__ float tanhf_(float x) {
 
 // H: hidden size; KSPLIT: wave groups splitting K (2 for H=256, 1 for H=64); UBW = 4/KSPLIT unit blocks
 template <int H, int KSPLIT>
-__global__ __launch_bounds__(256) void mp_lstm_step(LstmStepArgs a) {
+MP_KERNEL __launch_bounds__(256) void mp_lstm_step(LstmStepArgs a) {
     constexpr int UBW = 4 / KSPLIT;            // waves along units
     constexpr int UNITS = 16 * UBW;            // hidden units per workgroup
     constexpr int NSLICE = H / UNITS;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void mp_lstm_step(LstmStepArgs a) {
 // dst[((((slice*UBW + ub)*KSPLIT + kh)*NKS + ks)*64 + lane)*4 + g]
 //   = W_hh[g*H + slice*UNITS + ub*16 + (lane&15)][kh*KW + (lane>>4)*NKS + ks]
 template <int H, int KSPLIT>
-__global__ void mp_pack_whh(const float* __restrict__ whh, float* __restrict__ dst) {
+MP_KERNEL void mp_pack_whh(const float* __restrict__ whh, float* __restrict__ dst) {
     constexpr int UBW = 4 / KSPLIT, UNITS = 16 * UBW, KW = H / KSPLIT, NKS = KW / 4;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)4 * H * H) return;
@@ -174,7 +174,7 @@ __global__ void mp_pack_whh(const float* __restrict__ whh, float* __restrict__ d
 }
 
 // W_ih [4H][K] (rows g*H + j) -> rows dirOff + 4*j + g of dstW [.][Kpad]; bias = b_ih + b_hh
-__global__ void mp_pack_wih(const float* __restrict__ wih, const float* __restrict__ bih,
+MP_KERNEL void mp_pack_wih(const float* __restrict__ wih, const float* __restrict__ bih,
                             const float* __restrict__ bhh, float* __restrict__ dstW, float* __restrict__ dstBias,
                             int H, int K, int Kpad, int dirOff) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -187,7 +187,7 @@ __global__ void mp_pack_wih(const float* __restrict__ wih, const float* __restri
     if (k == 0) dstBias[drow] = bih[srow] + bhh[srow];
 }
 
-__global__ void mp_pack_linear(const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ dstW,
+MP_KERNEL void mp_pack_linear(const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ dstW,
                                float* __restrict__ dstBias, int N, int K, int Kpad) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)N * K) return;

@@ -1,0 +1,53 @@
+// Device helpers shared by the persistent LSTM kernels (mp_lstm_persist.hip: exact-fp32 MFMA operands,
+// mp_lstm_x3.hip: split-bf16 operands): activation functions, the {epoch, value} granule hand-off of
+// cdna_hip_programming.md Guideline 16 (form R2), the XCC id, and the bf16 hi/lo pair encoding.
+#pragma once
+#include "mp_common.h"
+
+typedef unsigned long long u64;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// v_exp_f32 / v_rcp_f32 are 1-ulp instructions: sigma and tanh come out within ~2e-7 absolute of libm
+static __device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+static __device__ __forceinline__ float tanhf_(float x) {
+    const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * x);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+static __device__ __forceinline__ u64 granule_load(const u64* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ void granule_store_bits(u64* p, unsigned epoch, unsigned v) {
+    __hip_atomic_store(p, ((u64)epoch << 32) | (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// same granule as an ordinary store: through the write-through L1 into THIS XCD's L2, where it stays
+static __device__ __forceinline__ void granule_store_l2_bits(u64* p, unsigned epoch, unsigned v) {
+    __hip_atomic_store(p, ((u64)epoch << 32) | (u64)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+static __device__ __forceinline__ void granule_store(u64* p, unsigned epoch, float v) {
+    granule_store_bits(p, epoch, __float_as_uint(v));
+}
+static __device__ __forceinline__ void granule_store_l2(u64* p, unsigned epoch, float v) {
+    granule_store_l2_bits(p, epoch, __float_as_uint(v));
+}
+static __device__ __forceinline__ unsigned xcc_id() {
+    return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF;   // s_getreg_b32 hwreg(HW_REG_XCC_ID)
+}
+constexpr unsigned XCC_TAG = 0x7fffffffu;
+
+// ---- split-bf16 pair: one fp32 value v as two bf16 numbers in one 32-bit word, hi = bf16_rne(v) in the upper
+// half and lo = bf16_rne(v - hi) in the lower half.  hi + lo carries 16 significand bits of v (relative error
+// <= 2^-17); the products hi*hi + hi*lo + lo*hi of two such pairs, accumulated in fp32 by the MFMA, reproduce the
+// fp32 product to ~2^-16 relative -- measured end to end: 4e-7 on the network outputs, the same as the
+// exact-fp32 path's own distance from the reference (DESIGN.md "split-bf16").
+static __device__ __forceinline__ unsigned bf16_rne_bits(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;             // finite inputs only (activations and weights)
+}
+static __device__ __forceinline__ unsigned pair_of(float x) {
+    const unsigned hi = bf16_rne_bits(x);
+    const float rest = x - __uint_as_float(hi << 16);           // exact in fp32
+    return (hi << 16) | bf16_rne_bits(rest);
+}

@@ -29,37 +29,12 @@
 // meet in LDS and every wave finishes a quarter of the (sequence, unit) pairs.
 // All workgroups of a launch must be co-resident (grid <= 256, one per CU); every spin is bounded and a
 // timeout raises a device-side error word instead of hanging the GPU.
-#include "mp_common.h"
+#include "mp_lstm_dev.h"
 
 namespace {
 
-typedef unsigned long long u64;
-
-// v_exp_f32 / v_rcp_f32 are 1-ulp instructions: sigma and tanh come out within ~2e-7 absolute of libm
-__device__ __forceinline__ float sigmoidf_(float x) {
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
-}
-__device__ __forceinline__ float tanhf_(float x) {
-    const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * x);
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-}
 // granule index of (row, hidden unit j) inside one [16][H] slab-parity block
 __device__ __forceinline__ int granule_index(int row, int j) { return (((j >> 2) * 16 + row) << 2) + (j & 3); }
-
-__device__ __forceinline__ u64 granule_load(const u64* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void granule_store(u64* p, unsigned epoch, float v) {
-    __hip_atomic_store(p, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// same granule as an ordinary store: through the write-through L1 into THIS XCD's L2, where it stays
-__device__ __forceinline__ void granule_store_l2(u64* p, unsigned epoch, float v) {
-    __hip_atomic_store(p, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ unsigned xcc_id() {
-    return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF;   // s_getreg_b32 hwreg(HW_REG_XCC_ID)
-}
-constexpr unsigned XCC_TAG = 0x7fffffffu;
 
 // Wave layout: 4*TW waves.  Wave w takes K quarter kq = w & 3 of both GEMM parts and tile group tw = w >> 2:
 //   TW = 1  : every wave computes all 4*NUB gate tiles                          (H = 64:  4 waves)
@@ -95,7 +70,7 @@ struct Cfg {
 };
 
 template <int H, int NSLICE, int KIN, int TW, bool PROF>
-__global__ __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void mp_lstm_fused(LstmPersistArgs a) {
+MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void mp_lstm_fused(LstmPersistArgs a) {
     using C = Cfg<H, NSLICE, KIN, TW>;
     constexpr int U = C::U, NUB = C::NUB, NWV = C::NWV, NTW = C::NTW, NTG = C::NTG, KW = C::KW, NKS = C::NKS, KQ = C::KQ;
     constexpr int NXS = C::NXS, NXJ = C::NXJ, NOWN = C::NOWN, XL = C::XL, XR = C::XR, NPW = C::NPW;
@@ -436,7 +411,7 @@ __global__ __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) voi
 // VGPRs each).  W_hh0 / W_hh1 in VGPRs, W_ih0 / W_ih1 as two 64 KB LDS images, 32 KB reduction scratch = 160 KB.
 // d[0] / d[1] describe layer 0 / layer 1.
 template <int H>
-__global__ __launch_bounds__(512, 1) void mp_lstm_fused_uni2(LstmPersistArgs a) {
+MP_KERNEL __launch_bounds__(512, 1) void mp_lstm_fused_uni2(LstmPersistArgs a) {
     constexpr int NSLICE = 16, U = 16, KW = H / 4, NKS = KW / 4, KQ = H / 4, NXS = KQ / 4, NXJ = KQ / 16, NPW = 4;
     constexpr int KSP = NKS / NPW;
     constexpr int IMG_F4 = 4 * NXS * 64;                                // one W_ih LDS image, in float4
@@ -654,7 +629,7 @@ __global__ __launch_bounds__(512, 1) void mp_lstm_fused_uni2(LstmPersistArgs a) 
 // W_hh: dst[(((slice*NWV + w)*NKS + ks)*NTW + lt)*64 + lane]
 //         = W_hh[g*H + slice*U + ub*16 + (lane&15)][kq*KW + 4*ks + (lane>>4)]
 template <int H, int NSLICE, int TW>
-__global__ void mp_pack_whh_persist(const float* __restrict__ whh, float* __restrict__ dst) {
+MP_KERNEL void mp_pack_whh_persist(const float* __restrict__ whh, float* __restrict__ dst) {
     constexpr int U = H / NSLICE, NUB = U / 16, NWV = 4 * TW, NTW = 4 * NUB / TW, KW = H / 4, NKS = KW / 4;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)4 * H * H) return;
@@ -676,7 +651,7 @@ __global__ void mp_pack_whh_persist(const float* __restrict__ whh, float* __rest
 // korder != 0: k-steps in granule order, k = kq*KQ + 4*s + (lane>>4) (layer 1 of the two-layer wavefront kernel,
 // whose input arrives as granules rather than as 16-byte row pieces)
 template <int H, int NSLICE, int TW>
-__global__ void mp_pack_wih_persist(const float* __restrict__ wih, float* __restrict__ dst, int KIN, int korder) {
+MP_KERNEL void mp_pack_wih_persist(const float* __restrict__ wih, float* __restrict__ dst, int KIN, int korder) {
     constexpr int U = H / NSLICE, NUB = U / 16, NWV = 4 * TW, NTW = 4 * NUB / TW, NTG = NTW / 4;
     const int KQ = KIN / 4, NXS = KQ / 4;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -21,7 +21,7 @@ __device__ __forceinline__ float prob_to_weight(float p) {   // net.py:90-91
     return (fminf(fmaxf(p, 0.5f), 0.9f) - 0.5f) / 0.4f;
 }
 
-__global__ __launch_bounds__(64) void mp_translate_offline(const float* __restrict__ joints,
+MP_KERNEL __launch_bounds__(64) void mp_translate_offline(const float* __restrict__ joints,
                                                             const float* __restrict__ vel,
                                                             const float* __restrict__ contact,
                                                             const int* __restrict__ lengths, int B, int T,
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64) void mp_translate_offline(const float* __restri
 }
 
 // one thread per stream: forward_online's solver on window index `idx` (= num_past_frames = 40)
-__global__ void mp_translate_online(const float* __restrict__ joints, const float* __restrict__ vel,
+MP_KERNEL void mp_translate_online(const float* __restrict__ joints, const float* __restrict__ vel,
                                     const float* __restrict__ contact, int S, int T, int idx, float floor_y_f,
                                     OnlineState st, float* __restrict__ root_pos_out,
                                     float* __restrict__ contact_out) {
@@ -140,7 +140,7 @@ void mp_launch_translate_online(const float* joints, const float* vel, const flo
 namespace {
 
 // one block per stream; the 45 x 60 window is shifted in place through registers
-__global__ __launch_bounds__(256) void mp_window_push(float* __restrict__ window, const float* __restrict__ frames,
+MP_KERNEL __launch_bounds__(256) void mp_window_push(float* __restrict__ window, const float* __restrict__ frames,
                                                        uint8_t* __restrict__ fresh, int S, int W) {
     const int s = blockIdx.x;
     float* win = window + (size_t)s * W * 60;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void mp_window_push(float* __restrict__ window
     if (threadIdx.x == 0) fresh[s] = 0;
 }
 
-__global__ void mp_stream_reset(const uint8_t* __restrict__ mask, uint8_t* __restrict__ fresh,
+MP_KERNEL void mp_stream_reset(const uint8_t* __restrict__ mask, uint8_t* __restrict__ fresh,
                                 double* __restrict__ root_y, float* __restrict__ root_pos, float* __restrict__ velH,
                                 float* __restrict__ velC, int S) {
     const int s = blockIdx.x;

@@ -22,10 +22,15 @@ def torch_mod():
     return torch
 
 
-@pytest.fixture()
-def net(torch_mod, weights, smpl):
+@pytest.fixture(params=["fp32", "x3"])
+def net(request, torch_mod, weights, smpl):
+    """Every parity test runs twice: exact-fp32 MFMA operands (LSTM mode 1) and split-bf16 operands (mode 3,
+    mp_lstm_x3.hip) -- same goldens, same oracle, same tolerances."""
     from mobileposer_amd.net import MobilePoserNet
-    return MobilePoserNet.from_numpy(weights, smpl, device="cuda:0")
+    n = MobilePoserNet.from_numpy(weights, smpl, device="cuda:0")
+    n.lstm_mode = 3 if request.param == "x3" else 1
+    n.set_lstm_mode(n.lstm_mode)
+    return n
 
 
 def cu(torch, a):
@@ -270,15 +275,15 @@ def test_persistent_and_step_recurrence_agree(torch_mod, net):
     lengths = [T] * B
     lengths[3], lengths[17], lengths[39] = 5, 49, 1
     outs = {}
-    for mode in (1, 0, 2):          # fused persistent layers | per-step kernels | + two-layer wavefront velocity kernel
+    for mode in (1, 0, 2, 3):       # fused persistent | per-step kernels | + two-layer wavefront velocity | split-bf16
         net.set_lstm_mode(mode)
         net.reset_all()
         outs[mode] = [t.clone() for t in net.forward(imu, lengths)]
         # carried velocity state must survive the mode as well (second call starts from the first call's state)
         outs[mode] += [t.clone() for t in net.forward(imu, lengths)]
         assert net.device_error() == 0
-    net.set_lstm_mode(1)
-    for other in (0, 2):
+    net.set_lstm_mode(net.lstm_mode)
+    for other in (0, 2, 3):
         for a, b in zip(outs[1], outs[other]):
             assert float((a - b).abs().max()) < 2e-5, other
 
