@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmobileposer_hip.so")
+LIB_PATH = os.environ.get("MP_LIB_PATH") or os.path.join(_HERE, "libmobileposer_hip.so")   # override: kernel-variant A/B runs
 
 MP_OK = 0
 MP_ERR_INVALID, MP_ERR_HIP, MP_ERR_STATE_SHAPE, MP_ERR_NO_STREAMS, MP_ERR_LENGTHS = -1, -2, -3, -4, -5
