@@ -108,6 +108,7 @@ struct Plan {
     std::vector<void*> allocs;
 };
 
+constexpr size_t kProfWords = 512 * 8 + 2048 * 32 * 8;   // per-workgroup phase sums + (debug builds) a 32-step trace
 struct Seg { int cls; hipEvent_t a, b; int launches; double flop; };
 
 struct StreamCtx {
@@ -309,8 +310,8 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     if (const char* e = getenv("MP_LSTM_UNI2")) h->uni2 = e[0] == '1';
     if (const char* e = getenv("MP_LSTM_SLICES")) h->nslice_env = atoi(e) == 8 ? 8 : (atoi(e) == 16 ? 16 : 0);
     if (getenv("MP_PERSIST_PROF")) {
-        if (hipMalloc((void**)&h->prof_dev, 512 * 8 * sizeof(long long)) != hipSuccess) h->prof_dev = nullptr;
-        else (void)hipMemset(h->prof_dev, 0, 512 * 8 * sizeof(long long));
+        if (hipMalloc((void**)&h->prof_dev, kProfWords * sizeof(long long)) != hipSuccess) h->prof_dev = nullptr;
+        else (void)hipMemset(h->prof_dev, 0, kProfWords * sizeof(long long));
     }
     hipError_t e = hipSuccess;
     e = e ? e : hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking);
@@ -568,7 +569,8 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             a.lengths = j.p->lengths_dev; a.ndir = dirs; a.B = B; a.T = T;
             a.slab0 = s0; a.nslab = nslab - s0 < chunk ? nslab - s0 : chunk;
             a.hx = w.hx + (size_t)dirs * s0 * ((size_t)4 * 16 * H + 16);
-            a.err = h->err_dev; a.max_spin = 1u << 18; a.prof = h->prof_dev;
+            static const int prof_layer = getenv("MP_PERSIST_PROF_LAYER") ? atoi(getenv("MP_PERSIST_PROF_LAYER")) : -1;
+            a.err = h->err_dev; a.max_spin = 1u << 18; a.prof = (prof_layer < 0 || prof_layer == l) ? h->prof_dev : nullptr;
             a.zero_state = j.mode == STATE_ZERO ? 1 : 0; a.force_remote = h->force_remote ? 1 : 0;
             const bool x3 = use_x3(h, m);
             a.out_pairs = x3 && l == 0 ? 1 : 0;
@@ -1144,7 +1146,7 @@ int mp_device_error(mp_handle* h, int* code) {
 }
 
 int mp_debug_read_prof(mp_handle* h, long long* out, int n_words) {
-    if (!h || !out || !h->prof_dev || n_words > 512 * 8) return MP_ERR_INVALID;
+    if (!h || !out || !h->prof_dev || n_words > (int)kProfWords) return MP_ERR_INVALID;
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipMemcpy(out, h->prof_dev, (size_t)n_words * sizeof(long long), hipMemcpyDeviceToHost));
     return MP_OK;

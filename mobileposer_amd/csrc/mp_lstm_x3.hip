@@ -54,15 +54,20 @@ struct CfgX {
     static constexpr int NXC = KQ / 32;               // x: chunks per wave (2 | 4)
     static constexpr int NHC = 2;                     // h: chunks per wave (K quarter 64)
     static constexpr int CH_U4 = 8 * 64;              // uint4 per wave per chunk: [tile*2 + part][lane]
-    static constexpr int RED_F4 = NWV * 4 * 64;       // [finishing wave][source kq][lane]
-    static constexpr int LDS_BUDGET = NSLICE == 16 ? 80 * 1024 : 160 * 1024;
-    static constexpr int XLC_MAX = (LDS_BUDGET - RED_F4 * 16) / (NWV * CH_U4 * 16);
-    static constexpr int XLC = NXC <= XLC_MAX ? NXC : XLC_MAX;   // x chunks served from LDS
-    static constexpr int XRC = NXC - XLC;                        // x chunks served from registers
+    static constexpr int RED_F4 = NWV * 4 * 64;       // one reduction buffer: [finishing wave][source kq][lane]
+    // x chunks [0, XRC) of a wave's W_ih live in registers and are multiplied first (nothing to wait for at the top
+    // of a step); chunks [XRC, NXC) stream from LDS and are fetched while the register chunks run.
+    // K_in = 256: 1 + 1 (212 + 32 VGPRs), K_in = 512: 2 + 2.
+    static constexpr int XLC = KIN > H ? 2 : 1;       // x chunks served from LDS
+    static constexpr int XRC = NXC - XLC;             // x chunks served from registers
+    // the LDS that K_in = 256 no longer needs for weights holds a second reduction buffer: steps alternate
+    // buffers, which removes the write-after-read barrier of the K reduction
+    static constexpr int RED_BUFS = KIN > H ? 1 : 2;
     static constexpr bool BIG = KIN > H;
     static constexpr int WG_PER_CU = NSLICE == 16 ? 2 : 1;
     static constexpr int NPW = NSLICE / 4;            // producer slices inside one wave's K quarter (2 | 4)
-    static_assert(XLC >= 1 && (XRC == 0 || XRC == NXC / 2), "register-resident chunks are the second half");
+    static constexpr int LDS_BYTES = RED_BUFS * RED_F4 * 16 + NWV * XLC * CH_U4 * 16;
+    static_assert(LDS_BYTES <= (NSLICE == 16 ? 80 : 160) * 1024, "LDS budget (two workgroups per CU for the 4-wave packing)");
 };
 
 constexpr int x3_threads(int nslice) { return 64 * 4 * (256 / nslice / 16); }
@@ -76,7 +81,7 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
     constexpr int NTHREADS = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* red = reinterpret_cast<f32x4*>(smem);                        // [finishing wave][source kq][lane]
-    u32x4* wxl = reinterpret_cast<u32x4*>(smem) + C::RED_F4;            // [wave][chunk < XLC][tile*2+part][lane]
+    u32x4* wxl = reinterpret_cast<u32x4*>(smem) + C::RED_BUFS * C::RED_F4;   // [wave][LDS chunk][tile*2+part][lane]
 
     // block -> (cluster = (direction, slab), slice): see mp_lstm_persist.hip (slices of a cluster share an XCD)
     const int ncl = a.ndir * a.nslab;
@@ -91,16 +96,16 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
     const int B = a.B, T = a.T;
     const int brow0 = (a.slab0 + slab) * 16;
 
-    // ---- W_ih slice: chunks [0, XLC) -> LDS, [XLC, NXC) -> registers; W_hh slice -> registers
+    // ---- W_ih slice: chunks [0, XRC) -> registers, [XRC, NXC) -> LDS; W_hh slice -> registers
     {
         const u32x4* src = reinterpret_cast<const u32x4*>(d.wihpack) + (size_t)slice * NWV * NXC * CH_U4;
         for (int w = 0; w < NWV; ++w)
             for (int i = threadIdx.x; i < XLC * CH_U4; i += NTHREADS)
-                wxl[(size_t)w * XLC * CH_U4 + i] = src[(size_t)w * NXC * CH_U4 + i];
+                wxl[(size_t)w * XLC * CH_U4 + i] = src[((size_t)w * NXC + XRC) * CH_U4 + i];
     }
-    u32x4 wxr[XRC > 0 ? XRC : 1][8];
-    if (XRC > 0) {
-        const u32x4* src = reinterpret_cast<const u32x4*>(d.wihpack) + ((size_t)(slice * NWV + wave) * NXC + XLC) * CH_U4 + lane;
+    u32x4 wxr[XRC][8];
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(d.wihpack) + (size_t)(slice * NWV + wave) * NXC * CH_U4 + lane;
 #pragma unroll
         for (int c = 0; c < XRC; ++c)
 #pragma unroll
@@ -186,7 +191,7 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
     // ---- x_0: pair words of this lane's row, chunk c: k = kq*KQ + c*32 + q*8 + e
     u32x4 xw[NXC][2];
     constexpr bool SPLIT_X = C::BIG;                      // second half of x_t fetched at the top of step t
-    constexpr int XC_PRE = SPLIT_X ? NXC / 2 : NXC;
+    constexpr int XC_PRE = SPLIT_X ? XRC : NXC;
     auto load_x = [&](int step, int c0, int c1) {
         const bool on = step < alen;
         const int t = on ? (d.reverse ? alen - 1 - step : step) : 0;
@@ -221,27 +226,37 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(alo, w[2 * t], acc[t]);
     };
-    auto proj_chunk = [&](int c) {
-        if (c < XLC) {
-            u32x4 wl[8];
+    u32x4 wl[8];                                               // the LDS-resident chunk being multiplied next
+    auto lds_chunk = [&](int c) {                              // c: LDS chunk index in [0, XLC)
 #pragma unroll
-            for (int tp = 0; tp < 8; ++tp) wl[tp] = wxw[(size_t)(c * 8 + tp) * 64];
-            chunk_mma(xw[c][0], xw[c][1], wl);
-        } else {
-            chunk_mma(xw[c][0], xw[c][1], wxr[c >= XLC ? c - XLC : 0]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int tp = 0; tp < 8; ++tp) wl[tp] = wxw[(size_t)(c * 8 + tp) * 64];
     };
 
     for (int step = 0; step < T; ++step) {
         PROF_T(0);
+#ifdef X3_TRACE
+        long long* tr = (PROF && a.prof && lane == 0 && step >= 64 && step < 96) ? a.prof + 4096 + ((size_t)(blockIdx.x * 8 + wave) * 32 + (step - 64)) * 8 : nullptr;
+#define TR(i) do { if (tr) tr[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TR(i) do { } while (0)
+#endif
+        TR(0);
         if (SPLIT_X) load_x(step, XC_PRE, NXC);
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // ---- first half of x_t W_ih^T (independent of h: fills the wait for the peers)
+        // ---- x_t W_ih^T, register-resident chunks (independent of h: this is what fills the wait for the peers);
+        // the first LDS-resident chunk is fetched underneath
+        lds_chunk(0);
+        TR(6);
+#ifndef X3_SKIP_PROJ
 #pragma unroll
-        for (int c = 0; c < NXC / 2; ++c) proj_chunk(c);
+        for (int c = 0; c < XRC; ++c) {
+            chunk_mma(xw[c][0], xw[c][1], wxr[c]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
 
+        TR(7);
         // ---- request h_{step-1}: 16 granules per lane, 512 contiguous bytes per instruction
         u64 gr[NHC][8];
         const unsigned epoch = (unsigned)step;                 // written by the producers at the end of step-1
@@ -253,9 +268,16 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
 #pragma unroll
                 for (int e = 0; e < 8; ++e) gr[c][e] = granule_load(srcb[c] + poff + (size_t)e * 64);
         }
-        // ---- second half of the input projection
+        TR(1);
+        // ---- LDS-resident chunks
+#ifndef X3_SKIP_PROJ
 #pragma unroll
-        for (int c = NXC / 2; c < NXC; ++c) proj_chunk(c);
+        for (int c = 0; c < XLC; ++c) {
+            chunk_mma(xw[XRC + c][0], xw[XRC + c][1], wl);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < XLC) lds_chunk(c + 1);
+        }
+#endif
         PROF_E(0); PROF_T(1);
 
         // ---- validate the granules; the slow path (cheap gate, then sweep) only runs when some were stale
@@ -301,24 +323,36 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
 #pragma unroll
                 for (int e = 0; e < 8; ++e) hw[c][e >> 2][e & 3] = (unsigned)gr[c][e];
         }
-        load_x(step + 1, 0, XC_PRE);     // next step's x, issued after the granule wait (see mp_lstm_persist.hip)
+        TR(2);
+#ifndef X3_SKIP_XLOAD
+        load_x(step + 1, 0, XC_PRE);     // next step's x
+#endif
+        //, issued after the granule wait (see mp_lstm_persist.hip)
         PROF_E(1); PROF_T(2);
 
         // ---- recurrent part: h_{t-1} W_hh^T on top of the input projection
+#ifndef X3_SKIP_HMMA
 #pragma unroll
         for (int c = 0; c < NHC; ++c) chunk_mma(hw[c][0], hw[c][1], whh[c]);
+#else
+        acc[0][0] += __uint_as_float(hw[0][0][0] ^ hw[1][1][3]) * 1e-30f;
+#endif
+        TR(3);
         PROF_E(2); PROF_T(3);
 
-        // ---- K reduction through LDS: finishing wave (dk, tw) takes accumulator reg dk of unit block tw
-        __syncthreads();                                       // previous step's reads of `red` are done
+        // ---- K reduction through LDS: finishing wave (dk, tw) takes accumulator reg dk of unit block tw.  With two
+        // buffers a step never overwrites what a slower wave may still be reading (it is two barriers behind).
+        f32x4* redb = red + (C::RED_BUFS == 2 ? (step & 1) * C::RED_F4 : 0);
+        if (C::RED_BUFS == 1) __syncthreads();                 // previous step's reads of `red` are done
 #pragma unroll
         for (int dk = 0; dk < 4; ++dk)
-            red[((tw * 4 + dk) * 4 + kq) * 64 + lane] = f32x4{acc[0][dk], acc[1][dk], acc[2][dk], acc[3][dk]};
+            redb[((tw * 4 + dk) * 4 + kq) * 64 + lane] = f32x4{acc[0][dk], acc[1][dk], acc[2][dk], acc[3][dk]};
         __syncthreads();
-        f32x4 gate = red[(wave * 4 + 0) * 64 + lane];
+        f32x4 gate = redb[(wave * 4 + 0) * 64 + lane];
 #pragma unroll
-        for (int sw = 1; sw < 4; ++sw) gate += red[(wave * 4 + sw) * 64 + lane];
+        for (int sw = 1; sw < 4; ++sw) gate += redb[(wave * 4 + sw) * 64 + lane];
         gate += bias4;
+        TR(4);
         PROF_E(3); PROF_T(4);
 
         // ---- cell update (fp32, register-local), publish h_step as a pair, write the layer output
@@ -339,11 +373,16 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         const int gi = granule_index_x3(q * 4 + kq, jown);
         granule_store_l2_bits(hxL + doff + gi, (unsigned)(step + 1), hp);
         if (!all_local) granule_store_bits(hxR + doff + gi, (unsigned)(step + 1), hp);
+#ifdef X3_SKIP_OUT
+        if (inb && step == T - 1) {
+#else
         if (inb) {
+#endif
             float* op = d.out + ((size_t)tt * B + bown) * d.outStride + jown;
             if (a.out_pairs) *reinterpret_cast<unsigned*>(op) = act ? hp : 0u;
             else *op = oval;
         }
+        TR(5);
         PROF_E(4);
     }
     if (PROF && prof) {
@@ -391,7 +430,7 @@ MP_KERNEL void mp_pack_w_x3(const float* __restrict__ w, unsigned* __restrict__ 
 template <int NSLICE, int KIN>
 void launch_x3(const LstmPersistArgs& a, hipStream_t s) {
     using C = CfgX<NSLICE, KIN>;
-    const size_t lds = (size_t)C::RED_F4 * 16 + (size_t)C::NWV * C::XLC * C::CH_U4 * 16;
+    const size_t lds = (size_t)C::LDS_BYTES;
     const dim3 grid(((a.nslab * a.ndir + 7) / 8) * 8 * NSLICE);
     if (a.prof) {
         static bool once = (hipFuncSetAttribute((const void*)mp_lstm_x3<NSLICE, KIN, true>,

@@ -1,0 +1,61 @@
+"""Accuracy table for DESIGN.md: how far each implementation of the network forward is from the SAME arithmetic
+carried out in float64 (the oracle with its dtype switched), on one seeded batch.
+
+  python tools_accuracy.py [B] [T]      (GPU box; writes profiles/r01_accuracy.json)
+
+Rows: numpy fp32 oracle, torch CPU fp32 (nn.LSTM, what the reference runs), HIP path with exact-fp32 MFMA operands,
+HIP path with split-bf16 operands.  The point: the split-bf16 mode is as close to exact arithmetic as fp32 itself.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+from mobileposer_amd import synthetic                      # noqa: E402
+from mobileposer_amd.net import MobilePoserNet             # noqa: E402
+from oracle import mp_oracle as O                          # noqa: E402
+from oracle.torch_ref import TorchNet                      # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 125
+sd, smpl = synthetic.make_weights(0), synthetic.synthetic_smpl()
+imu = synthetic.make_imu(B, T, seed=1)
+lengths = [T] * B
+
+
+def oracle_run(dtype):
+    O.F32 = dtype
+    try:
+        net = O.OracleNet(sd, smpl["J"])
+        pose, joints, vel, contact = net.forward(imu, lengths)
+        return {"r6d": np.asarray(net._last_r6d, np.float64), "joints": np.asarray(joints, np.float64),
+                "vel": np.asarray(vel, np.float64), "contact": np.asarray(contact, np.float64)}
+    finally:
+        O.F32 = np.float32
+
+
+truth = oracle_run(np.float64)
+rows = {"numpy fp32 oracle": oracle_run(np.float32)}
+tn = TorchNet(sd, smpl["J"])
+tp, tj, tv, tc, tr6 = tn.forward(imu, lengths)
+rows["torch CPU fp32 (nn.LSTM)"] = {"r6d": tr6, "joints": tj, "vel": tv, "contact": tc}
+net = MobilePoserNet.from_numpy(sd, smpl, device="cuda:0")
+x = torch.from_numpy(imu).cuda()
+for name, mode in (("HIP, exact fp32 MFMA operands (mode 1)", 1), ("HIP, split-bf16 MFMA operands (mode 3)", 3)):
+    net.set_lstm_mode(mode)
+    net.reset_all()
+    pose, joints, vel, contact = net.forward(x, lengths)
+    rows[name] = {"r6d": net._io[(B, T)]["r6d"].cpu().numpy(), "joints": joints.cpu().numpy(),
+                  "vel": vel.cpu().numpy(), "contact": contact.cpu().numpy()}
+out = {"batch": B, "frames": T, "reference": "oracle arithmetic in float64", "max_abs_error": {}}
+print("%-42s %10s %10s %10s %10s" % ("max |x - float64|", "r6d", "joints", "velocity", "contact"))
+for name, r in rows.items():
+    e = {k: float(np.abs(np.asarray(r[k], np.float64).reshape(truth[k].shape) - truth[k]).max()) for k in truth}
+    out["max_abs_error"][name] = e
+    print("%-42s %10.2e %10.2e %10.2e %10.2e" % (name, e["r6d"], e["joints"], e["vel"], e["contact"]))
+os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(REPO, "gpurun_out", "r01_accuracy.json"), "w"), indent=1)
