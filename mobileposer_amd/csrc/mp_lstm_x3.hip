@@ -16,8 +16,21 @@
 //   * a lane's A fragment (8 consecutive k of one sequence row) is built from 8 pair words with 8 v_perm_b32.
 // k mapping: wave kq owns K quarter kq; chunk c = 32 k of it; lane (row r16, k-block q) holds
 //   k = kq*KQ + c*32 + q*8 + e,  e = 0..7.
-// Granules are laid out [k/32][k%8][row][(k/8)%4]: the 64 lanes of a consumer wave still read 512 contiguous
-// bytes per instruction and a producer workgroup's granules still form one contiguous block.
+// Hidden-state exchange.  With the matrix pipe out of the way a step is bound by how fast h_t crosses the 8 (16)
+// workgroups of a cluster, and the tagged 8-byte granules of the fp32 kernel become the bottleneck: every CU
+// issued 128 wave-wide loads per step (64 KB through a 64 B/clk L1 path; every value fetched twice, half of the
+// bytes tags) -- measured 1500-2500 cycles of load issue on the critical path of a 6400-cycle step.  Here:
+//   * a producer wave stores its (row, unit) pair words untagged into its slice's [16 rows][U units] block
+//     (parity-double-buffered), waits for the stores to be acknowledged (s_waitcnt vmcnt(0)) and raises its own
+//     flag word to epoch step+1 -- no workgroup barrier on the publishing side;
+//   * a consumer wave watches the flags of the producer slice(s) it is responsible for (one 64-byte line per
+//     producer, lanes = that producer's waves), then fetches the 2 KB (1 KB) block with two (four) 16-byte loads
+//     per lane that bypass the L1, writes it into an LDS tile [16 rows][256 units], and after one barrier every
+//     wave reads its MFMA A fragments from LDS: each value crosses the L1 path once per CU (16 KB per step).
+//   * flags only grow, a producer can be at most one epoch ahead (it needs this workgroup's flags to go further),
+//     and the block it is then writing is the other parity: ">= epoch" is the complete test.
+//   Same two transports as the fp32 kernel, chosen per producer from the real XCC ids: L (plain stores that stay
+//   in this XCD's L2) / R (write-through stores), both read with L1-bypassing loads.  Waits are bounded.
 // H = 256 only (a K quarter must hold a 32-wide chunk); the H = 64 foot-contact block keeps the fp32 kernel.
 #include "mp_lstm_dev.h"
 
@@ -39,11 +52,6 @@ __device__ __forceinline__ void split_pairs(u32x4 w0, u32x4 w1, u32x4& hi, u32x4
     lo[2] = __builtin_amdgcn_perm(w1[1], w1[0], 0x05040100u);
     lo[3] = __builtin_amdgcn_perm(w1[3], w1[2], 0x05040100u);
 }
-// granule index of (row, hidden unit j) inside one [16][256] slab-parity block: [j/32][j%8][row][(j/8)%4]
-__device__ __forceinline__ int granule_index_x3(int row, int j) {
-    return ((((j >> 5) * 8 + (j & 7)) * 16 + row) << 2) + ((j >> 3) & 3);
-}
-
 template <int NSLICE, int KIN>
 struct CfgX {
     static constexpr int H = 256;
@@ -62,11 +70,20 @@ struct CfgX {
     static constexpr int XRC = NXC - XLC;             // x chunks served from registers
     // the LDS that K_in = 256 no longer needs for weights holds a second reduction buffer: steps alternate
     // buffers, which removes the write-after-read barrier of the K reduction
-    static constexpr int RED_BUFS = KIN > H ? 1 : 2;
+    static constexpr int RED_BUFS = (KIN > H || NSLICE == 16) ? 1 : 2;     // (4-wave packing: 80 KB per workgroup)
     static constexpr bool BIG = KIN > H;
     static constexpr int WG_PER_CU = NSLICE == 16 ? 2 : 1;
-    static constexpr int NPW = NSLICE / 4;            // producer slices inside one wave's K quarter (2 | 4)
-    static constexpr int LDS_BYTES = RED_BUFS * RED_F4 * 16 + NWV * XLC * CH_U4 * 16;
+    // hidden-state exchange (see the kernel header): a wave fetches the blocks of PPW producer slices
+    static constexpr int PPW = NSLICE / NWV;          // producers per consumer wave (1 | 4)
+    static constexpr int LPB = 64 / PPW;              // lanes that share one producer block (64 | 16)
+    static constexpr int WPL = 16 * U / LPB;          // 32-bit words per lane (8 | 16)
+    static constexpr int PARTS = U / WPL;             // lanes per row of a block (4 | 1)
+    static constexpr int HPITCH = H + 4;              // LDS row pitch of the staged h tile (conflict-free b128 reads)
+    static constexpr int HT_BYTES = 16 * HPITCH * 4;
+    // K_in = 512 has no LDS left: the h tile shares the (single) reduction buffer -- the barriers of the step
+    // separate the two uses (h tile: written .. barrier .. read | barrier | partial sums: written .. barrier .. read)
+    static constexpr bool HT_ALIAS = KIN > H;
+    static constexpr int LDS_BYTES = RED_BUFS * RED_F4 * 16 + NWV * XLC * CH_U4 * 16 + (HT_ALIAS ? 0 : HT_BYTES);
     static_assert(LDS_BYTES <= (NSLICE == 16 ? 80 : 160) * 1024, "LDS budget (two workgroups per CU for the 4-wave packing)");
 };
 
@@ -77,11 +94,13 @@ template <int NSLICE, int KIN, bool PROF>
 MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_lstm_x3(LstmPersistArgs a) {
     using C = CfgX<NSLICE, KIN>;
     constexpr int H = 256, U = C::U, NWV = C::NWV, KQ = C::KQ, NXC = C::NXC, NHC = C::NHC, XLC = C::XLC, XRC = C::XRC;
-    constexpr int NPW = C::NPW, CH_U4 = C::CH_U4;
+    constexpr int CH_U4 = C::CH_U4, PPW = C::PPW, LPB = C::LPB, WPL = C::WPL, PARTS = C::PARTS, HPITCH = C::HPITCH;
     constexpr int NTHREADS = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* red = reinterpret_cast<f32x4*>(smem);                        // [finishing wave][source kq][lane]
     u32x4* wxl = reinterpret_cast<u32x4*>(smem) + C::RED_BUFS * C::RED_F4;   // [wave][LDS chunk][tile*2+part][lane]
+    unsigned* hT = C::HT_ALIAS ? reinterpret_cast<unsigned*>(smem)          // staged h_{t-1} tile [16 rows][HPITCH] pair words
+                               : reinterpret_cast<unsigned*>(wxl + (size_t)NWV * XLC * CH_U4);
 
     // block -> (cluster = (direction, slab), slice): see mp_lstm_persist.hip (slices of a cluster share an XCD)
     const int ncl = a.ndir * a.nslab;
@@ -147,11 +166,15 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
                 hw[c][e >> 2][e & 3] = (arow_in && !a.zero_state) ? pair_of(p[c * 32 + e]) : 0u;
     }
 
-    // granules of this slab: hx[cluster] = { L[2 parities][16*H], R[2 parities][16*H], xcc[16] }
-    constexpr size_t SLABW = (size_t)4 * 16 * H + 16;
-    u64* hxL = a.hx + (size_t)cl * SLABW;
-    u64* hxR = hxL + (size_t)2 * 16 * H;
-    u64* xtab = hxL + (size_t)4 * 16 * H;
+    // exchange area of this cluster (32-bit words): hx[cluster] = { dataL[2 parities][16*H], dataR[2][16*H],
+    //   flagsL[NSLICE][16], flagsR[NSLICE][16], ..., xcc table (64-bit granules at word 2*4*16*H) }
+    constexpr size_t SLABW = (size_t)4 * 16 * H + 16;                       // in 64-bit words (host allocation unit)
+    unsigned* hxw = reinterpret_cast<unsigned*>(a.hx + (size_t)cl * SLABW);
+    unsigned* dataL = hxw;
+    unsigned* dataR = hxw + 2 * 16 * H;
+    unsigned* flagsL = hxw + 4 * 16 * H;
+    unsigned* flagsR = flagsL + NSLICE * 16;
+    u64* xtab = a.hx + (size_t)cl * SLABW + (size_t)4 * 16 * H;
     unsigned spin_budget = a.max_spin;
     const unsigned my_xcc = xcc_id();
     unsigned long long same = ~0ull;
@@ -173,20 +196,23 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         if (__ballot(peer == ~0u)) spin_budget = 0;
         if (a.force_remote) { all_local = false; same = 0; }      // test hook: exercise the any-placement transport
     }
-    // producer slice of unit k = kq*64 + c*32 + q*8 + e:  NSLICE = 8: 2*kq + c;  NSLICE = 16: 4*kq + 2*c + (q >> 1)
-    const u64* srcb[NHC];                       // this lane's source block per chunk (parity / chunk offsets added later)
-#pragma unroll
-    for (int c = 0; c < NHC; ++c) {
-        const int prod = NSLICE == 8 ? 2 * kq + c : 4 * kq + 2 * c + (q >> 1);
-        srcb[c] = (((same >> prod) & 1) ? hxL : hxR) + (size_t)((kq * 2 + c) * 8) * 64 + r16 * 4 + q;
-    }
-    // gate lanes: lane i < NPW watches one granule of producer slice NPW*kq + i
-    const u64* gatep = hxL;
-    if (lane < NPW) {
-        const int prod = NPW * kq + lane;
-        const int gc = NSLICE == 8 ? lane : lane >> 1, gq = NSLICE == 8 ? 0 : 2 * (lane & 1);
-        gatep = (((same >> prod) & 1) ? hxL : hxR) + (size_t)((kq * 2 + gc) * 8) * 64 + gq;
-    }
+    // consumer role of this lane: producer slice PPW*wave + lane/LPB; inside its [16 rows][U units] block this lane
+    // fetches WPL consecutive words of row li/PARTS and puts them at the same (row, unit) of the LDS tile
+    const int cprod = PPW * wave + lane / LPB;
+    const int cli = lane % LPB;
+    const int crow = cli / PARTS, cpart = cli % PARTS;
+    const bool cloc = (same >> cprod) & 1;
+    const unsigned* csrc = (cloc ? dataL : dataR) + (size_t)cprod * 16 * U + crow * U + cpart * WPL;
+    unsigned* cdst = hT + crow * HPITCH + cprod * U + cpart * WPL;
+    // lanes 0 .. PPW*NWV-1 of a wave watch the flags of its producers' waves: flag[producer][wave of the producer]
+    const bool cwatch = lane < PPW * NWV;
+    const int wprod = PPW * wave + lane / NWV;
+    const unsigned* cflag = ((((same >> (cwatch ? wprod : 0)) & 1) ? flagsL : flagsR)) + (cwatch ? wprod * 16 + lane % NWV : 0);
+    // producer role: this lane's (row q*4+kq, unit jown) word of the slice's block, and this wave's flag
+    unsigned* pdstL = dataL + (size_t)slice * 16 * U + (q * 4 + kq) * U + (jown - slice * U);
+    unsigned* pdstR = dataR + (size_t)slice * 16 * U + (q * 4 + kq) * U + (jown - slice * U);
+    // reader role: A fragments of the recurrent product from the LDS tile
+    const unsigned* hrd = hT + r16 * HPITCH + kq * 64 + q * 8;
 
     // ---- x_0: pair words of this lane's row, chunk c: k = kq*KQ + c*32 + q*8 + e
     u32x4 xw[NXC][2];
@@ -226,11 +252,45 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(alo, w[2 * t], acc[t]);
     };
-    u32x4 wl[8];                                               // the LDS-resident chunk being multiplied next
-    auto lds_chunk = [&](int c) {                              // c: LDS chunk index in [0, XLC)
+    // LDS-resident chunks: 8 fragments per chunk = (hi, lo) of the 4 gate tiles.  K_in = 256 fetches a whole chunk
+    // at the top of a step (32 registers, under the register chunks).  K_in = 512 cannot hold that through the
+    // register chunks: only the hi fragments are fetched there, the lo fragments follow when the x words of the
+    // register chunks are dead, and each half is refilled right after the MFMAs that read it were issued.
+    u32x4 wl[8];
+    auto lds_fetch = [&](int c, int part) {                    // part: 0 = hi fragments, 1 = lo fragments, 2 = both
 #pragma unroll
-        for (int tp = 0; tp < 8; ++tp) wl[tp] = wxw[(size_t)(c * 8 + tp) * 64];
+        for (int tp = 0; tp < 8; ++tp)
+            if (part == 2 || (tp & 1) == part) wl[tp] = wxw[(size_t)(c * 8 + tp) * 64];
     };
+    auto lds_chunk_mma = [&](int c, u32x4 x0, u32x4 x1) {      // multiplies chunk c (already fetched), fetches the next
+        if constexpr (C::BIG) {
+            u32x4 ahi, alo;
+            split_pairs(x0, x1, ahi, alo);
+            if (c == 0) lds_fetch(0, 1);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(ahi, wl[2 * t], acc[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(alo, wl[2 * t], acc[t]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < XLC) lds_fetch(c + 1, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(ahi, wl[2 * t + 1], acc[t]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < XLC) lds_fetch(c + 1, 1);
+        } else {
+            chunk_mma(x0, x1, wl);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < XLC) lds_fetch(c + 1, 2);
+        }
+    };
+    // The first register chunk of step t+1 is multiplied at the END of step t, between issuing the stores of h_t
+    // and waiting for their acknowledgement (the loop is rotated): the matrix pipe works through the store latency
+    // instead of after it.  Step 0's is done here.
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifndef X3_SKIP_PROJ
+    chunk_mma(xw[0][0], xw[0][1], wxr[0]);
+#endif
 
     for (int step = 0; step < T; ++step) {
         PROF_T(0);
@@ -242,86 +302,72 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
 #endif
         TR(0);
         if (SPLIT_X) load_x(step, XC_PRE, NXC);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // ---- x_t W_ih^T, register-resident chunks (independent of h: this is what fills the wait for the peers);
-        // the first LDS-resident chunk is fetched underneath
-        lds_chunk(0);
+        // ---- first look at the producers' flags (epoch = step), in flight under the MFMAs below; the peers are in
+        // the same phase, so it usually succeeds and the wave never polls.  The blocks are requested as soon as the
+        // flags are up: measured, delaying that request by one more chunk of MFMAs costs more than the chunk hides.
+        unsigned flagA = ~0u;
+        if (step > 0 && cwatch) flagA = __hip_atomic_load(cflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- x_t W_ih^T (independent of h: this is what fills the exchange latencies); chunk 0 was multiplied at
+        // the end of the previous step, the first LDS-resident chunk is fetched here
+        lds_fetch(0, C::BIG ? 0 : 2);
         TR(6);
+        constexpr int XL_EARLY = 0;                            // LDS chunks multiplied before the blocks are requested (measured: 0 is best)
 #ifndef X3_SKIP_PROJ
 #pragma unroll
-        for (int c = 0; c < XRC; ++c) {
+        for (int c = 1; c < XRC; ++c) {
             chunk_mma(xw[c][0], xw[c][1], wxr[c]);
             __builtin_amdgcn_sched_barrier(0);
         }
 #endif
-
-        TR(7);
-        // ---- request h_{step-1}: 16 granules per lane, 512 contiguous bytes per instruction
-        u64 gr[NHC][8];
-        const unsigned epoch = (unsigned)step;                 // written by the producers at the end of step-1
-        const size_t poff = (size_t)((step + 1) & 1) * 16 * H;
-        constexpr bool EARLY_GATHER = !C::BIG;
-        if (EARLY_GATHER && step > 0) {
-#pragma unroll
-            for (int c = 0; c < NHC; ++c)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) gr[c][e] = granule_load(srcb[c] + poff + (size_t)e * 64);
-        }
-        TR(1);
-        // ---- LDS-resident chunks
 #ifndef X3_SKIP_PROJ
 #pragma unroll
-        for (int c = 0; c < XLC; ++c) {
-            chunk_mma(xw[XRC + c][0], xw[XRC + c][1], wl);
-            __builtin_amdgcn_sched_barrier(0);
-            if (c + 1 < XLC) lds_chunk(c + 1);
-        }
+        for (int c = 0; c < XL_EARLY; ++c) lds_chunk_mma(c, xw[XRC + c][0], xw[XRC + c][1]);
 #endif
+        TR(7);
         PROF_E(0); PROF_T(1);
 
-        // ---- validate the granules; the slow path (cheap gate, then sweep) only runs when some were stale
+        // ---- h_{step-1}: once the flags are up, fetch the producers' blocks (16-byte loads that bypass the L1) ...
+        u32x4 blk[WPL / 4];
         if (step > 0) {
-            if (!EARLY_GATHER) {
-#pragma unroll
-                for (int c = 0; c < NHC; ++c)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) gr[c][e] = granule_load(srcb[c] + poff + (size_t)e * 64);
-            }
-            bool ok = true;
-#pragma unroll
-            for (int c = 0; c < NHC; ++c)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ok = ok && ((unsigned)(gr[c][e] >> 32) == epoch);
+            const size_t poff = (size_t)((step + 1) & 1) * 16 * H;
             unsigned spins = 0;
             bool timed_out = false;
-            if (PROF && prof && !__all(ok)) pt[5] += 1;      // slow-path entries
-            while (!__all(ok) && !timed_out) {
-                while (true) {
-                    bool ready = true;
-                    if (lane < NPW) ready = (unsigned)(granule_load(gatep + poff) >> 32) == epoch;
-                    if (__all(ready)) break;
-                    if (++spins > spin_budget) { timed_out = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                ok = true;
-#pragma unroll
-                for (int c = 0; c < NHC; ++c)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        gr[c][e] = granule_load(srcb[c] + poff + (size_t)e * 64);
-                        ok = ok && ((unsigned)(gr[c][e] >> 32) == epoch);
-                    }
-                if (++spins > spin_budget) timed_out = true;
+            bool ready = flagA >= (unsigned)step;
+            if (PROF && prof && !__all(ready)) pt[5] += 1;      // steps whose first look came too early
+            while (!__all(ready)) {
+                if (++spins > spin_budget) { timed_out = true; break; }
+                if (cwatch) ready = __hip_atomic_load(cflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)step;
             }
             if (timed_out) {                                   // bounded: flag the error and never wait again
                 if (lane == 0) atomicExch(a.err, 1 + step);
                 spin_budget = 0;
             }
+            TR(1);
 #pragma unroll
-            for (int c = 0; c < NHC; ++c)
+            for (int i = 0; i < WPL / 4; ++i)
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(blk[i]) : "v"(csrc + poff), "n"(16 * i) : "memory");
+        }
+        PROF_E(1); PROF_T(0);
+        // ---- ... and multiply what is left of x_t W_ih^T while they are in flight
+#ifndef X3_SKIP_PROJ
 #pragma unroll
-                for (int e = 0; e < 8; ++e) hw[c][e >> 2][e & 3] = (unsigned)gr[c][e];
+        for (int c = XL_EARLY; c < XLC; ++c) lds_chunk_mma(c, xw[XRC + c][0], xw[XRC + c][1]);
+#endif
+        PROF_E(0); PROF_T(1);
+        // ---- stage the blocks in LDS and read this lane's A fragments of the recurrent product from there
+        if (step > 0) {
+            if constexpr (WPL == 8) asm volatile("s_waitcnt vmcnt(0)" : "+v"(blk[0]), "+v"(blk[1]) :: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(blk[0]), "+v"(blk[1]), "+v"(blk[2]), "+v"(blk[3]) :: "memory");
+            // (shared with the reduction buffer: every wave must be done with the previous step's partial sums)
+            if (C::HT_ALIAS) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < WPL / 4; ++i) *reinterpret_cast<u32x4*>(cdst + 4 * i) = blk[i];
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < NHC; ++c) {
+                hw[c][0] = *reinterpret_cast<const u32x4*>(hrd + c * 32);
+                hw[c][1] = *reinterpret_cast<const u32x4*>(hrd + c * 32 + 4);
+            }
         }
         TR(2);
 #ifndef X3_SKIP_XLOAD
@@ -356,7 +402,6 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         PROF_E(3); PROF_T(4);
 
         // ---- cell update (fp32, register-local), publish h_step as a pair, write the layer output
-        const size_t doff = (size_t)(step & 1) * 16 * H;
         const bool act = step < blen;
         const int tt = act ? (d.reverse ? blen - 1 - step : step) : step;
         float oval = 0.f;
@@ -370,9 +415,23 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
             oval = hst;
         }
         const unsigned hp = pair_of(hst);
-        const int gi = granule_index_x3(q * 4 + kq, jown);
-        granule_store_l2_bits(hxL + doff + gi, (unsigned)(step + 1), hp);
-        if (!all_local) granule_store_bits(hxR + doff + gi, (unsigned)(step + 1), hp);
+        const size_t doff = (size_t)(step & 1) * 16 * H;
+        __hip_atomic_store(pdstL + doff, hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // -> this XCD's L2
+        if (!all_local) __hip_atomic_store(pdstR + doff, hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
+        // next step's first register chunk while the stores travel (x_{t+1} was prefetched after the staging above)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifndef X3_SKIP_PROJ
+        chunk_mma(xw[0][0], xw[0][1], wxr[0]);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's flag: raised once all of its stores of the step have been acknowledged
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            __hip_atomic_store(flagsL + slice * 16 + wave, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!all_local) __hip_atomic_store(flagsR + slice * 16 + wave, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #ifdef X3_SKIP_OUT
         if (inb && step == T - 1) {
 #else
