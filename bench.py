@@ -32,7 +32,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA p
 X3_NAMES = {         # the same timing classes when the H = 256 layers run on split-bf16 operands (--lstm-mode x3)
     1: "mp_lstm_x3<8,256> bidirectional layer 0 (joints, pose)",
     4: "mp_lstm_x3<8,512> bidirectional layer 1 (joints, pose)",
-    5: "mp_lstm_x3<16,256> unidirectional layers (velocity)",
+    5: "mp_lstm_x3<8,256> unidirectional layers (velocity; 128 workgroups)",
 }
 
 KERNEL_CLASSES = {   # timing classes of the C ABI (include/mobileposer_hip.h, mp_timing_read)
@@ -164,10 +164,10 @@ def main():
     ap.add_argument("--workload", choices=["offline", "stream"], default="offline",
                     help="offline (default, the BASELINE metric) or stream: config 5, S concurrent 45-frame windows per GPU")
     ap.add_argument("--streams", type=int, default=512)
-    ap.add_argument("--lstm-mode", choices=["fp32", "x3"], default="fp32",
-                    help="MFMA operands of the H=256 LSTM layers for the headline value: fp32 (exact v_mfma_f32_16x16x4_f32, "
-                         "default) or x3 (3-term split-bf16 on v_mfma_f32_16x16x32_bf16); the other mode is timed as well "
-                         "and reported beside it")
+    ap.add_argument("--lstm-mode", choices=["fp32", "x3"], default="x3",
+                    help="MFMA operands of the H=256 LSTM layers for the headline value: x3 (the library default: every fp32 "
+                         "product as 3 bf16 products on v_mfma_f32_16x16x32_bf16, fp32 accumulate) or fp32 (exact "
+                         "v_mfma_f32_16x16x4_f32); the other mode is timed as well and reported beside it")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -322,7 +322,7 @@ def main():
         key = {1: "mp_lstm_fused<256, 8, 256, 2, false>", 4: "mp_lstm_fused<256, 8, 512, 2, false>",
                5: "mp_lstm_fused<256, 16, 256, 1, false>", 0: "mp_gemm_f32<2, 2, 2, 2>"}.get(dominant)
         if args.lstm_mode == "x3":
-            key = {1: "mp_lstm_x3<8, 256, false>", 4: "mp_lstm_x3<8, 512, false>", 5: "mp_lstm_x3<16, 256, false>",
+            key = {1: "mp_lstm_x3<8, 256, false>", 4: "mp_lstm_x3<8, 512, false>", 5: "mp_lstm_x3<8, 256, false>",
                    0: "mp_gemm_f32<2, 2, 2, 2>"}.get(dominant)
         traffic = pmc[key]["hbm_bytes_per_launch_corrected"] if key in pmc else None
     except Exception:

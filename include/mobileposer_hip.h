@@ -157,12 +157,14 @@ int mp_timing_enable(mp_handle* h, int on);
 int mp_timing_read(mp_handle* h, int cls, int* launches, float* ms, double* gflop);
 /* 0: eager launches, 1: replay captured hipGraphs (default; env MP_NO_GRAPH=1 flips the default). */
 int mp_set_graph_mode(mp_handle* h, int on);
-/* LSTM implementation: 1 = fused persistent layer kernels, one launch per layer, hidden state exchanged between
- * workgroups as tagged granules (default); 2 = same, and the unidirectional velocity block as ONE two-layer
- * wavefront launch; 0 = input-projection GEMM + one launch per time step (env MP_LSTM_MODE=step);
- * 3 = mode 1 with the H = 256 layers' two matrix products per step on split-bf16 MFMA operands (each fp32 product
- * as hi*hi + hi*lo + lo*hi of bf16 parts, fp32 accumulate and fp32 state; env MP_LSTM_MODE=x3) -- same 1e-4 parity
- * bound, measured 4e-7 from the fp32 reference. */
+/* LSTM implementation of the H = 256 layers (the H = 64 foot-contact block always uses the fp32 kernels):
+ *   3 (default; env MP_LSTM_MODE=x3): fused persistent layer kernels, one launch per layer, whose two matrix products
+ *       per step run on split-bf16 MFMA operands -- every fp32 product as hi*hi + hi*lo + lo*hi of bf16 parts on
+ *       v_mfma_f32_16x16x32_bf16, fp32 accumulate, fp32 state (mp_lstm_x3.hip).  Measured 2e-7 from the same
+ *       arithmetic in float64 (exact-fp32 operands: 1e-7; PyTorch CPU fp32: 2e-7), same 1e-4 parity bound;
+ *   1 (env MP_LSTM_MODE=fp32): the same layers on exact-fp32 MFMA operands (v_mfma_f32_16x16x4_f32, mp_lstm_persist.hip);
+ *   2: mode 1 plus the unidirectional velocity block as ONE two-layer wavefront launch;
+ *   0 (env MP_LSTM_MODE=step): input-projection GEMM + one launch per time step. */
 int mp_set_lstm_mode(mp_handle* h, int mode);
 /* Test hook for the hidden-state exchange of the persistent kernels: 0 = pick the transport per producer from
  * its real XCC id (default), 1 = always use the any-placement write-through (sc1) transport. */

@@ -73,7 +73,7 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 struct Packed { float* W = nullptr; float* bias = nullptr; int N = 0, K = 0, Kpad = 0, Npad = 0, bn = 0; };
 struct ModuleW {
-    int n_in = 0, n_out = 0, H = 0, dirs = 0, nslice = 0;
+    int n_in = 0, n_out = 0, H = 0, dirs = 0, nslice = 0, nsliceX = 0;   // slices per slab: fp32 kernels | split-bf16 kernels
     Packed lin1, ih[2], lin2;
     float* whh[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};    // per-step kernel layout
     float* whhP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // persistent kernel layout
@@ -148,7 +148,8 @@ struct mp_handle {
                                      // MP_LSTM_UNI2=1).  Off by default: it is 20 % faster than two launches but fills every
                                      // CU's registers and LDS, so the foot-contact layers and pose's linear2 / IK / FK can no
                                      // longer run beside the velocity block and the forward as a whole gets slower.
-    bool x3 = false;                 // H = 256 layers on split-bf16 MFMA operands (mp_lstm_x3.hip): mp_set_lstm_mode(h, 3)
+    bool x3 = true;                  // H = 256 layers on split-bf16 MFMA operands (mp_lstm_x3.hip, the default): mode 3;
+                                     // mp_set_lstm_mode(h, 1) / MP_LSTM_MODE=fp32 selects exact-fp32 MFMA operands instead
     int nslice_env = 0;              // 0: pick per module (8 slices / 8 waves for bidirectional layers that fill the
                                      // chip, 16 slices / 4 waves for unidirectional ones); env MP_LSTM_SLICES=8|16 forces one             // LSTM recurrence: persistent kernel (default) or per-step launches
     std::map<std::pair<int, int>, Plan*> plans;
@@ -207,6 +208,10 @@ int pack_weights(mp_handle* h, const float* blob) {
         // reaches the same 256 with 16 slices.  (Two 4-wave workgroups per CU were measured slower: the
         // lock-step of a cluster turns any contention between co-resident workgroups into waiting for everyone.)
         m.nslice = m.H != 256 ? 4 : (h->nslice_env ? h->nslice_env : (m.dirs == 2 ? 8 : 16));
+        // split-bf16 kernels: 8 slices (8-wave workgroups) for every H = 256 layer -- the unidirectional velocity
+        // layers then occupy 128 CUs and leave the other half of the chip to the foot-contact block (measured:
+        // 312 vs 326 us per velocity layer, foot-contact layers 200 vs 265 us)
+        m.nsliceX = h->nslice_env ? h->nslice_env : 8;
         if (int rc = alloc_packed(h, m.lin1, m.H, m.n_in)) return rc;
         if (int rc = alloc_packed(h, m.ih[0], m.dirs * 4 * m.H, m.H)) return rc;
         if (int rc = alloc_packed(h, m.ih[1], m.dirs * 4 * m.H, m.dirs * m.H)) return rc;
@@ -244,8 +249,8 @@ int pack_weights(mp_handle* h, const float* blob) {
                 mp_launch_pack_whh_persist(find(s.id, K_WHH, l, d), m.whhP[l][d], m.H, m.nslice, h->s_main);
                 mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP[l][d], m.H, m.ih[l].K, m.nslice, 0, h->s_main);
                 if (m.H == 256) {
-                    mp_launch_pack_w_x3(find(s.id, K_WHH, l, d), m.whhX[l][d], m.H, m.nslice, h->s_main);
-                    mp_launch_pack_w_x3(find(s.id, K_WIH, l, d), m.wihX[l][d], m.ih[l].K, m.nslice, h->s_main);
+                    mp_launch_pack_w_x3(find(s.id, K_WHH, l, d), m.whhX[l][d], m.H, m.nsliceX, h->s_main);
+                    mp_launch_pack_w_x3(find(s.id, K_WIH, l, d), m.wihX[l][d], m.ih[l].K, m.nsliceX, h->s_main);
                 }
                 if (l == 1 && m.dirs == 1 && m.H == 256 && m.nslice == 16) {
                     if (int rc = dev_alloc(h, (void**)&m.wihG1, (size_t)4 * m.H * m.ih[1].K * sizeof(float))) return rc;
@@ -305,7 +310,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     }
     if (const char* e = getenv("MP_LSTM_MODE")) {
         h->persist = strcmp(e, "step") != 0;
-        h->x3 = strcmp(e, "x3") == 0;
+        h->x3 = h->persist && strcmp(e, "fp32") != 0;          // "x3" (default) | "fp32" | "step"
     }
     if (const char* e = getenv("MP_LSTM_UNI2")) h->uni2 = e[0] == '1';
     if (const char* e = getenv("MP_LSTM_SLICES")) h->nslice_env = atoi(e) == 8 ? 8 : (atoi(e) == 16 ? 16 : 0);
@@ -554,7 +559,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
     } else if (h->persist) {
         HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));     // every polled word is re-zeroed before every launch
         const int nslab = (B + 15) / 16;
-        const int nsl = m.nslice;
+        const int nsl = use_x3(h, m) ? m.nsliceX : m.nslice;
         const int cus = h->n_cu < 256 ? h->n_cu : 256;
         const int chunk = cus / (dirs * nsl) > 0 ? cus / (dirs * nsl) : 1;   // slabs per launch: grid <= #CUs, one workgroup per CU
         const int kin = l == 0 ? H : dirs * H;

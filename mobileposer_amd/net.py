@@ -384,7 +384,8 @@ class MobilePoserNet:
         return n.value, ms.value, gf.value
 
     def set_lstm_mode(self, mode):
-        """0/False: per-step kernels; 1/True: fused persistent layers (default); 2: + two-layer wavefront velocity kernel."""
+        """3: fused persistent layers on split-bf16 MFMA operands (default); 1: the same on exact-fp32 operands;
+        2: mode 1 + two-layer wavefront velocity kernel; 0: per-step kernels.  (include/mobileposer_hip.h)"""
         _lib.check(self._lib.mp_set_lstm_mode(self._h, int(mode)), self._h)
 
     def set_transport(self, force_remote):

@@ -1,0 +1,102 @@
+"""rocprofv3 evidence for bench.py, run ON THE GPU BOX:  python tools_profile.py <tag> [bench args...]
+
+  1. rocprofv3 --kernel-trace --stats  of  python bench.py --steps 20 --warmup 5 --no-cpu-baseline <bench args>
+  2. four rocprofv3 --pmc passes (one counter group per pass, with --kernel-trace only -- never combined with
+     sys/hip/hsa traces) of the same command with --steps 3 --warmup 1
+  3. gpurun_out/<tag>_kernel_stats.{csv,md} and gpurun_out/<tag>_pmc_summary.json, which get copied into profiles/.
+
+Counter arithmetic follows /opt/skills/guides/MI355X_MICROARCH.md: GRBM_GUI_ACTIVE is summed over the 8 XCDs;
+HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (FETCH_SIZE reads half of wide coalesced streaming reads on gfx950).
+"""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(REPO, "gpurun_out")
+PMC_GROUPS = [["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], ["FETCH_SIZE"], ["WRITE_SIZE"],
+              ["SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_VALU_MFMA_MOPS_F32"]]
+
+
+def short(name):
+    name = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    for tail in ("(LstmPersistArgs)", "(LstmStepArgs)", "(GemmArgs, int, int)"):
+        name = name.replace(tail, "")
+    return name.split("(")[0] if name.startswith("mp_") or name.startswith("__amd") else name[:70]
+
+
+def run(cmd):
+    env = dict(os.environ, TMPDIR="/tmp")
+    print("+", " ".join(cmd), flush=True)
+    r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    return r.returncode, r.stdout
+
+
+def main():
+    tag = sys.argv[1]
+    extra = sys.argv[2:]
+    bench = [sys.executable, os.path.join(REPO, "bench.py"), "--no-cpu-baseline"] + extra
+    os.makedirs(OUT, exist_ok=True)
+    # ---- 1. kernel trace + stats
+    d = os.path.join(OUT, "prof_" + tag)
+    rc, log = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "bench", "--"]
+                  + bench + ["--steps", "20", "--warmup", "5"])
+    line = [l for l in log.splitlines() if l.startswith("{")]
+    bench_line = json.loads(line[-1]) if line else None
+    stats = glob.glob(os.path.join(d, "**", "bench_kernel_stats.csv"), recursive=True)
+    rows = list(csv.DictReader(open(stats[0]))) if stats else []
+    with open(os.path.join(OUT, tag + "_kernel_stats.csv"), "w") as f:
+        f.write(open(stats[0]).read() if stats else "")
+    with open(os.path.join(OUT, tag + "_kernel_stats.md"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats (%s)\n\n" % tag)
+        f.write("Command (MI355X, via gpurun): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
+                "--no-cpu-baseline %s --steps 20 --warmup 5`\n" % " ".join(extra))
+        f.write("(bench.py times BOTH LSTM operand modes in one process: 25 graph-replayed forwards per mode + 3 eager "
+                "event-timed forwards of the headline mode, B=256 x T=125; raw CSV next to this file)\n\n")
+        if bench_line:
+            f.write("bench line of this (profiled) run: %.4f ms/step = %.0f frames/s headline (%s); modes: %s\n\n"
+                    % (bench_line["ms_per_step"], bench_line["value"], bench_line["config"].get("lstm_mode"),
+                       json.dumps({k: v for k, v in bench_line["modes"].items() if isinstance(v, dict)})))
+            f.write("roofline kernel (HIP events, live): %s: avg %.4f ms/launch\n\n"
+                    % (bench_line["roofline"]["kernel"], bench_line["roofline"]["avg_launch_ms"]))
+        f.write("| kernel | calls | total ms | % | avg us | min us | max us |\n|---|---|---|---|---|---|---|\n")
+        for r in rows[:24]:
+            f.write("| %s | %s | %.3f | %s | %.1f | %.1f | %.1f |\n" % (
+                short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, r["Percentage"],
+                float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
+    # ---- 2. PMC passes
+    acc = {}
+    for gi, group in enumerate(PMC_GROUPS):
+        d = os.path.join(OUT, "pmc_%s_%d" % (tag, gi))
+        rc, log = run(["rocprofv3", "--kernel-trace", "--pmc"] + group + ["--output-format", "csv", "-d", d, "-o", "pmc", "--"]
+                      + bench + ["--steps", "3", "--warmup", "1"])
+        files = glob.glob(os.path.join(d, "**", "pmc_counter_collection.csv"), recursive=True)
+        if not files:
+            print("no counter file for", group, "\n", log[-2000:])
+            continue
+        for r in csv.DictReader(open(files[0])):
+            k = short(r["Kernel_Name"])
+            if not k.startswith("mp_"):
+                continue
+            e = acc.setdefault(k, {}).setdefault(r["Counter_Name"], [0.0, 0])
+            e[0] += float(r["Counter_Value"])
+            e[1] += 1
+    summary = {"note": __doc__.split("Counter arithmetic")[1].strip(), "kernels": {}}
+    for k, c in acc.items():
+        e = {n: v[0] / v[1] for n, v in c.items()}
+        e["launches_sampled"] = max(v[1] for v in c.values())
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in e and e.get("GRBM_GUI_ACTIVE"):
+            e["mfma_util_pct"] = round(100.0 * e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 1)
+        if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+            e["hbm_bytes_per_launch_corrected"] = int((2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0)
+        summary["kernels"][k] = e
+    json.dump(summary, open(os.path.join(OUT, tag + "_pmc_summary.json"), "w"), indent=1)
+    print(json.dumps({k: {n: v for n, v in e.items() if n in ("mfma_util_pct", "hbm_bytes_per_launch_corrected")}
+                      for k, e in summary["kernels"].items()}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
