@@ -435,3 +435,22 @@ def test_live_session_feeds_stream_step(torch_mod, weights, smpl):
             frame = live.form_frame(cals[s], torch_mod.from_numpy(quats[k, s])[None], torch_mod.from_numpy(accs[k, s])[None])[0]
             p1, _, r1, _ = singles[s].forward_online(frame.cuda())
             assert np.abs(npy(pose[s]) - npy(p1)).max() < 1e-5 and np.abs(npy(root[s]) - npy(r1)).max() < 1e-5
+
+
+def test_soak_bitwise_stable_under_concurrency(torch_mod, net):
+    """Glitch detector: the whole captured forward + FK + solver -- LSTM layers, GEMMs, IK, FK and the
+    solver running beside each other on four streams -- must give bit-identical outputs every time."""
+    from mobileposer_amd import synthetic
+    B, T = 256, 125
+    x = cu(torch_mod, synthetic.make_imu(B, T, seed=41))
+    lengths = [T] * B
+    ref = None
+    for it in range(12):
+        net.reset_all()
+        outs = [t.clone() for t in net.forward_offline(x, lengths)]
+        if ref is None:
+            ref = outs
+        else:
+            for a, b in zip(ref, outs):
+                assert torch_mod.equal(a, b), it
+    assert net.device_error() == 0
