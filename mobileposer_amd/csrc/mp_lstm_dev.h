@@ -51,3 +51,10 @@ static __device__ __forceinline__ unsigned pair_of(float x) {
     const float rest = x - __uint_as_float(hi << 16);           // exact in fp32
     return (hi << 16) | bf16_rne_bits(rest);
 }
+
+// Workgroup barrier that only waits for this wave's LDS traffic (lgkmcnt), not for its outstanding global loads
+// and stores: __syncthreads() also drains vmcnt, which would put the latency of a prefetch that is in flight on
+// every wave of the workgroup.  Use it where the barrier orders LDS accesses only.
+static __device__ __forceinline__ void barrier_lds_only() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}

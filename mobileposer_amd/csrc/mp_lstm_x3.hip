@@ -389,11 +389,12 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         // ---- K reduction through LDS: finishing wave (dk, tw) takes accumulator reg dk of unit block tw.  With two
         // buffers a step never overwrites what a slower wave may still be reading (it is two barriers behind).
         f32x4* redb = red + (C::RED_BUFS == 2 ? (step & 1) * C::RED_F4 : 0);
-        if (C::RED_BUFS == 1) __syncthreads();                 // previous step's reads of `red` are done
+        // (LDS-only barriers: __syncthreads() would also drain vmcnt, i.e. wait here for the x_{t+1} prefetch)
+        if (C::RED_BUFS == 1) barrier_lds_only();              // previous step's reads of `red` are done
 #pragma unroll
         for (int dk = 0; dk < 4; ++dk)
             redb[((tw * 4 + dk) * 4 + kq) * 64 + lane] = f32x4{acc[0][dk], acc[1][dk], acc[2][dk], acc[3][dk]};
-        __syncthreads();
+        barrier_lds_only();
         f32x4 gate = redb[(wave * 4 + 0) * 64 + lane];
 #pragma unroll
         for (int sw = 1; sw < 4; ++sw) gate += redb[(wave * 4 + sw) * 64 + lane];
