@@ -71,7 +71,8 @@ size_t manifest_floats() {
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-struct Packed { float* W = nullptr; float* bias = nullptr; int N = 0, K = 0, Kpad = 0, Npad = 0, bn = 0; };
+struct Packed { float* W = nullptr; float* bias = nullptr; int N = 0, K = 0, Kpad = 0, Npad = 0, bn = 0;
+                float* Wp = nullptr; };   // Wp: the same padded matrix as split-bf16 pair words (linear layers only)
 struct ModuleW {
     int n_in = 0, n_out = 0, H = 0, dirs = 0, nslice = 0, nsliceX = 0;   // slices per slab: fp32 kernels | split-bf16 kernels
     Packed lin1, ih[2], lin2;
@@ -241,6 +242,11 @@ int pack_weights(mp_handle* h, const float* blob) {
                               m.lin1.K, m.lin1.Kpad, h->s_main);
         mp_launch_pack_linear(find(s.id, K_L2W, 0, 0), find(s.id, K_L2B, 0, 0), m.lin2.W, m.lin2.bias, m.lin2.N,
                               m.lin2.K, m.lin2.Kpad, h->s_main);
+        for (Packed* pk : {&m.lin1, &m.lin2}) {
+            const size_t n = (size_t)pk->Npad * pk->Kpad;
+            if (int rc = dev_alloc(h, (void**)&pk->Wp, n * sizeof(float))) return rc;
+            mp_launch_pairs(pk->W, pk->Wp, n, h->s_main);
+        }
         for (int l = 0; l < 2; ++l)
             for (int d = 0; d < m.dirs; ++d) {
                 mp_launch_pack_wih(find(s.id, K_WIH, l, d), find(s.id, K_BIH, l, d), find(s.id, K_BHH, l, d),
@@ -460,12 +466,17 @@ RowMap internal_map(const float* base, int B, int width) { return RowMap{base, (
 RowMap user_map(const float* base, int T, int width) { return RowMap{base, (long)T * width, (long)width, width}; }
 
 int run_gemm(mp_handle* h, hipStream_t s, RowMap a0, RowMap a1, const Packed& w, float* C, long cStrideB,
-             long cStrideT, int M, int B, int relu, bool pair_out = false) {
+             long cStrideT, int M, int B, int relu, bool pair_out = false, bool a_pairs = false, bool x3_gemm = false) {
     SegScope seg(h, s, 0, 1, 2.0 * M * (double)w.N * w.K);
     GemmArgs g;
     g.a0 = a0; g.a1 = a1; g.W = w.W; g.bias = w.bias; g.C = C; g.cStrideB = cStrideB; g.cStrideT = cStrideT;
     g.M = M; g.N = w.N; g.K = w.K; g.Kpad = w.Kpad; g.B = B; g.relu = relu; g.pairOut = pair_out ? 1 : 0;
-    mp_launch_gemm(g, w.bn, s);
+    if (x3_gemm && w.Wp) {                                    // split-bf16 mode: the H = 256 blocks' linear layers run on bf16 MFMAs as well
+        g.W = w.Wp; g.aPairs = a_pairs ? 1 : 0;
+        mp_launch_gemm_x3(g, w.bn, s);
+    } else {
+        mp_launch_gemm(g, w.bn, s);
+    }
     return MP_OK;
 }
 
@@ -501,7 +512,7 @@ int rnn_g0(const RnnJob& j, hipStream_t s) {
     const int B = j.p->B, T = j.p->T, M = B * T, H = m.H, dirs = m.dirs;
     const RowMap none{nullptr, 0, 0, 0};
     float* X1 = x1_buffer(h, m, w);
-    run_gemm(h, s, j.a0, j.a1, m.lin1, X1, H, (long)B * H, M, B, 1, use_x3(h, m));          // rnn.py:22
+    run_gemm(h, s, j.a0, j.a1, m.lin1, X1, H, (long)B * H, M, B, 1, use_x3(h, m), false, use_x3(h, m));   // rnn.py:22
     // the per-step kernels take the input projection from a GEMM; the persistent kernel computes it itself
     if (!h->persist && !w.xproj) return fail(h, MP_ERR_INVALID, "internal: per-step workspace missing");
     if (!h->persist)
@@ -578,7 +589,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             a.err = h->err_dev; a.max_spin = 1u << 18; a.prof = (prof_layer < 0 || prof_layer == l) ? h->prof_dev : nullptr;
             a.zero_state = j.mode == STATE_ZERO ? 1 : 0; a.force_remote = h->force_remote ? 1 : 0;
             const bool x3 = use_x3(h, m);
-            a.out_pairs = x3 && l == 0 ? 1 : 0;
+            a.out_pairs = x3 ? 1 : 0;                          // both layers feed split-bf16 consumers (layer 1 / linear2)
             for (int d = 0; d < dirs; ++d) {
                 LstmDir& dd = a.d[d];
                 dd.wpack = x3 ? m.whhX[l][d] : m.whhP[l][d]; dd.xproj = nullptr; dd.out = outp + (size_t)d * H;
@@ -637,7 +648,8 @@ int rnn_g2(const RnnJob& j, hipStream_t s) {
                 HIPCHK(h, hipMemcpyAsync(j.out_c + (size_t)k * B * H, w.cbuf[l][d], n, hipMemcpyDeviceToDevice, s));
             }
     }
-    run_gemm(h, s, internal_map(w.out1, B, dirs * H), none, m.lin2, j.y, j.yStrideB, j.yStrideT, M, B, 0);   // rnn.py:32
+    run_gemm(h, s, internal_map(w.out1, B, dirs * H), none, m.lin2, j.y, j.yStrideB, j.yStrideT, M, B, 0, false,
+             use_x3(h, m), use_x3(h, m));                                                          // rnn.py:32
     HIPCHK(h, hipGetLastError());
     return MP_OK;
 }
@@ -807,7 +819,7 @@ void mp_destroy(mp_handle* h) {
     h->plans.clear();
     for (ModuleW& m : h->mod) {
         Packed* ps[4] = {&m.lin1, &m.ih[0], &m.ih[1], &m.lin2};
-        for (Packed* p : ps) { if (p->W) (void)hipFree(p->W); if (p->bias) (void)hipFree(p->bias); }
+        for (Packed* p : ps) { if (p->W) (void)hipFree(p->W); if (p->bias) (void)hipFree(p->bias); if (p->Wp) (void)hipFree(p->Wp); }
         for (int l = 0; l < 2; ++l) for (int d = 0; d < 2; ++d) {
             if (m.whh[l][d]) (void)hipFree(m.whh[l][d]);
             if (m.whhP[l][d]) (void)hipFree(m.whhP[l][d]);

@@ -35,10 +35,14 @@ struct GemmArgs {
     long cStrideB, cStrideT;
     int M, N, K, Kpad, B, relu;
     int pairOut = 0;     // 1: store C as split-bf16 pairs (mp_lstm_dev.h pair_of) -- input format of mp_lstm_x3.hip
+    int aPairs = 0;      // mp_gemm_x3 only: the A segments already hold pair words
 };
 // bn: 128, 96 or 32 (chosen by the caller from N)
 void mp_launch_gemm(const GemmArgs& g, int bn, hipStream_t s);
 int mp_gemm_pick_bn(int N);
+// the same GEMM on split-bf16 MFMA operands (mp_gemm_x3.hip); g.W = pair words made by mp_launch_pairs
+void mp_launch_gemm_x3(const GemmArgs& g, int bn, hipStream_t s);
+void mp_launch_pairs(const float* src, float* dst, size_t n, hipStream_t s);
 
 // ---------------------------------------------------------------- K2: LSTM recurrence step
 struct LstmDir {

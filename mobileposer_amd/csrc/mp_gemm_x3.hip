@@ -1,0 +1,185 @@
+// K1x/K3x -- the linear layers (models/rnn.py:22,32; the fused torch.cat of net.py:106,113) with SPLIT-bf16 MFMA
+// operands, for the default LSTM mode: same arithmetic contract as mp_lstm_x3.hip (every fp32 product a*w as
+// a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on v_mfma_f32_16x16x32_bf16, fp32 accumulate, fp32 bias / ReLU / output).
+// Why: mp_gemm_f32 leaves the fp32 matrix pipe 26-33 % busy on these shapes (M = B*T = 32000, N = 72..256,
+// K = 60..512: one 128-row tile per CU, 64-cycle MFMAs between two barriers per k-tile) and the four linear layers
+// on the critical path of a forward cost 170 us of 2.2 ms; with 3 x 19-cycle MFMAs per 32 k the same tile loop is
+// bound by its loads.
+// A operand: two K segments (RowMap) of fp32 values, converted to pair words while they are staged to LDS, or of pair
+// words already (the layer-1 output of mp_lstm_x3, aPairs).  W: pair words [Npad][Kpad] (mp_launch_pairs).
+// 128 x BN block tile, 32-wide k-chunks, 4 waves (32 rows x BN each), LDS pitch 36 words, register prefetch of the
+// next chunk, XCD-aware tile order as mp_gemm_f32.
+#include "mp_lstm_dev.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BK = 32, LDK = 36;
+
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void split_pairs(u32x4 w0, u32x4 w1, u32x4& hi, u32x4& lo) {
+    hi[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x07060302u);
+    hi[1] = __builtin_amdgcn_perm(w0[3], w0[2], 0x07060302u);
+    hi[2] = __builtin_amdgcn_perm(w1[1], w1[0], 0x07060302u);
+    hi[3] = __builtin_amdgcn_perm(w1[3], w1[2], 0x07060302u);
+    lo[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x05040100u);
+    lo[1] = __builtin_amdgcn_perm(w0[3], w0[2], 0x05040100u);
+    lo[2] = __builtin_amdgcn_perm(w1[1], w1[0], 0x05040100u);
+    lo[3] = __builtin_amdgcn_perm(w1[3], w1[2], 0x05040100u);
+}
+
+template <int BN>
+MP_KERNEL __launch_bounds__(256) void mp_gemm_x3(GemmArgs g, int nTilesM, int nTilesN) {
+    constexpr int BM = 128, NCT = BN / 16;
+    constexpr int A_ROWS_PER_THREAD = BM / 32, W_ROWS_PER_THREAD = BN / 32;
+    __shared__ __attribute__((aligned(16))) unsigned smem[(BM + BN) * LDK + 2 * BM];
+    unsigned* As = smem;
+    unsigned* Ws = smem + BM * LDK;
+    long* rowOffC = reinterpret_cast<long*>(smem + (BM + BN) * LDK);
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int mt = (idx / nTilesN) * 8 + xcd;
+    const int nt = idx % nTilesN;
+    if (mt >= nTilesM) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int lr = tid >> 3;            // row within a 32-row group
+    const int kc = (tid & 7) * 4;       // k column of this thread's 4 words
+
+    long offA0[A_ROWS_PER_THREAD], offA1[A_ROWS_PER_THREAD];
+    bool rowOk[A_ROWS_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < A_ROWS_PER_THREAD; ++j) {
+        const int m = m0 + lr + 32 * j;
+        rowOk[j] = m < g.M;
+        const int mm = rowOk[j] ? m : 0;
+        const int b = mm % g.B, t = mm / g.B;
+        offA0[j] = (long)b * g.a0.strideB + (long)t * g.a0.strideT;
+        offA1[j] = (long)b * g.a1.strideB + (long)t * g.a1.strideT;
+    }
+    if (tid < BM) {
+        const int m = m0 + tid;
+        const int mm = m < g.M ? m : 0;
+        rowOffC[tid] = (long)(mm % g.B) * g.cStrideB + (long)(mm / g.B) * g.cStrideT;
+    }
+
+    u32x4 ra[A_ROWS_PER_THREAD], rw[W_ROWS_PER_THREAD];
+    const unsigned* Wp = reinterpret_cast<const unsigned*>(g.W);
+    auto load_tile = [&](int k0) {
+        const int k = k0 + kc;
+#pragma unroll
+        for (int j = 0; j < A_ROWS_PER_THREAD; ++j) {
+            u32x4 v = {0u, 0u, 0u, 0u};                        // fp32 zero and the zero pair are the same bits
+            if (rowOk[j]) {
+                if (k < g.a0.width) v = *reinterpret_cast<const u32x4*>(g.a0.base + offA0[j] + k);
+                else if (k < g.K)   v = *reinterpret_cast<const u32x4*>(g.a1.base + offA1[j] + (k - g.a0.width));
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < W_ROWS_PER_THREAD; ++j)
+            rw[j] = *reinterpret_cast<const u32x4*>(Wp + (long)(n0 + lr + 32 * j) * g.Kpad + k);
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_ROWS_PER_THREAD; ++j) {
+            u32x4 v = ra[j];
+            if (!g.aPairs) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = pair_of(__uint_as_float(v[e]));
+            }
+            *reinterpret_cast<u32x4*>(As + (lr + 32 * j) * LDK + kc) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < W_ROWS_PER_THREAD; ++j)
+            *reinterpret_cast<u32x4*>(Ws + (lr + 32 * j) * LDK + kc) = rw[j];
+    };
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int r16 = lane & 15, q = lane >> 4;
+    f32x4 acc[2][NCT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NCT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.Kpad / BK;
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+        u32x4 ahi[2], alo[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const unsigned* p = As + (wave * 32 + a * 16 + r16) * LDK + q * 8;
+            split_pairs(*reinterpret_cast<const u32x4*>(p), *reinterpret_cast<const u32x4*>(p + 4), ahi[a], alo[a]);
+        }
+#pragma unroll
+        for (int b = 0; b < NCT; ++b) {
+            const unsigned* p = Ws + (b * 16 + r16) * LDK + q * 8;
+            u32x4 whi, wlo;
+            split_pairs(*reinterpret_cast<const u32x4*>(p), *reinterpret_cast<const u32x4*>(p + 4), whi, wlo);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) acc[a][b] = mfma_bf16(ahi[a], whi, acc[a][b]);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) acc[a][b] = mfma_bf16(ahi[a], wlo, acc[a][b]);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) acc[a][b] = mfma_bf16(alo[a], whi, acc[a][b]);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: D[row = 4*q + reg][col = r16] of tile (a, b); bias (+ReLU), fp32 or pair-word output, row-mapped store
+#pragma unroll
+    for (int b = 0; b < NCT; ++b) {
+        const int n = n0 + b * 16 + r16;
+        if (n >= g.N) continue;
+        const float bias = g.bias[n];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ml = wave * 32 + a * 16 + 4 * q + r;
+                if (m0 + ml < g.M) {
+                    float v = acc[a][b][r] + bias;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    g.C[rowOffC[ml] + n] = g.pairOut ? __uint_as_float(pair_of(v)) : v;
+                }
+            }
+    }
+}
+
+MP_KERNEL void mp_pairs(const float* __restrict__ src, unsigned* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = pair_of(src[i]);
+}
+
+template <int BN>
+void launch(const GemmArgs& g, hipStream_t s) {
+    const int nTilesM = (g.M + 127) / 128;
+    const int nTilesN = (g.N + BN - 1) / BN;
+    const int grid = ((nTilesM + 7) / 8) * 8 * nTilesN;
+    hipLaunchKernelGGL((mp_gemm_x3<BN>), dim3(grid), dim3(256), 0, s, g, nTilesM, nTilesN);
+}
+
+}  // namespace
+
+// g.W: pair words of the padded weight matrix (mp_launch_pairs); bn as mp_gemm_pick_bn
+void mp_launch_gemm_x3(const GemmArgs& g, int bn, hipStream_t s) {
+    if (bn == 128) launch<128>(g, s);
+    else if (bn == 96) launch<96>(g, s);
+    else launch<32>(g, s);
+}
+
+void mp_launch_pairs(const float* src, float* dst, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(mp_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, reinterpret_cast<unsigned*>(dst), n);
+}
