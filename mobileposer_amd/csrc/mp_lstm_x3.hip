@@ -1,17 +1,17 @@
 // K2x -- the persistent fused nn.LSTM layer of mp_lstm_persist.hip (models/rnn.py:27) with SPLIT-bf16 MFMA
-// operands: same mapping, same hand-off protocol, same fp32 state / gates / accumulation, but every fp32
+// operands: same decomposition, same fp32 state / gates / accumulation, but every fp32
 // product a*w inside the two matrix products of a step is evaluated as
 //        a_hi*w_hi + a_hi*w_lo + a_lo*w_hi         (a = a_hi + a_lo, w = w_hi + w_lo, each part a bf16 number)
 // on v_mfma_f32_16x16x32_bf16 (fp32 accumulate).  One such MFMA covers 8x the K of v_mfma_f32_16x16x4_f32 in
 // about the same issue time, so 3 of them replace 8 fp32 MFMAs: the matrix pipe is no longer what bounds a
 // step.  The dropped a_lo*w_lo term is <= 2^-18 relative per product, hi+lo itself carries 16 significand
-// bits; measured end to end (oracle experiment and tests/test_gpu_parity.py) the outputs stay 4e-7 from the
-// fp32 reference -- 250x inside the 1e-4 parity bound, the same distance as the exact-fp32 kernel's.
+// bits; measured end to end (tools_accuracy.py, tests/test_gpu_parity.py) the outputs stay <= 5e-7 from the same
+// arithmetic in float64 -- 200x inside the 1e-4 parity bound, the level of fp32's own rounding noise.
 // A single bf16 term (1e-4 .. 5e-4) does NOT pass; that is why the split exists.
 //
 // Data formats (all 4 bytes per value, so buffers, LDS images and register counts keep their sizes):
-//   * activations that feed an LSTM layer (linear1's output X1, layer 0's output) and the h granules are
-//     "pairs": (bf16 hi << 16) | bf16 lo  (mp_lstm_dev.h pair_of);
+//   * activations that feed an LSTM layer or a linear layer (linear1's output X1, both layers' outputs) and the
+//     exchanged hidden state are "pairs": (bf16 hi << 16) | bf16 lo  (mp_lstm_dev.h pair_of);
 //   * W_hh / W_ih are packed as separate hi and lo bf16x8 B-fragments (mp_pack_*_x3 below);
 //   * a lane's A fragment (8 consecutive k of one sequence row) is built from 8 pair words with 8 v_perm_b32.
 // k mapping: wave kq owns K quarter kq; chunk c = 32 k of it; lane (row r16, k-block q) holds
@@ -373,7 +373,7 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
 #ifndef X3_SKIP_XLOAD
         load_x(step + 1, 0, XC_PRE);     // next step's x
 #endif
-        //, issued after the granule wait (see mp_lstm_persist.hip)
+        // (issued after the staging wait above, so that this wait does not drain these loads as well)
         PROF_E(1); PROF_T(2);
 
         // ---- recurrent part: h_{t-1} W_hh^T on top of the input projection
