@@ -568,8 +568,10 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             mp_launch_lstm_uni2(a, s);
         }
     } else if (h->persist) {
-        HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));     // every polled word is re-zeroed before every launch
         const int nslab = (B + 15) / 16;
+        // every polled word is re-zeroed before every launch: all granules (fp32 kernels) or the flags (split-bf16 kernels)
+        if (use_x3(h, m)) mp_launch_zero_exchange_x3(w.hx, dirs * nslab, s);
+        else HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
         const int nsl = use_x3(h, m) ? m.nsliceX : m.nslice;
         const int cus = h->n_cu < 256 ? h->n_cu : 256;
         const int chunk = cus / (dirs * nsl) > 0 ? cus / (dirs * nsl) : 1;   // slabs per launch: grid <= #CUs, one workgroup per CU

@@ -97,6 +97,8 @@ void mp_launch_lstm_uni2(const LstmPersistArgs& a, hipStream_t s);
 // wpack / wihpack come from mp_launch_pack_w_x3 (W_hh: K = 256; W_ih: K = K_in)
 void mp_launch_lstm_x3(const LstmPersistArgs& a, int KIN, int nslice, hipStream_t s);
 void mp_launch_pack_w_x3(const float* w, float* dst, int K, int nslice, hipStream_t s);
+// zero the polled words (flags, XCC table) of `ncl` clusters of an exchange area before a split-bf16 launch
+void mp_launch_zero_exchange_x3(unsigned long long* hx, int ncl, hipStream_t s);
 
 // ---------------------------------------------------------------- K4/K5: kinematics
 void mp_launch_r6d_ik(const float* r6d, long N, float* pose, const int* parent_dev, hipStream_t s);

@@ -505,7 +505,23 @@ void launch_x3(const LstmPersistArgs& a, hipStream_t s) {
     }
 }
 
+// Re-arm the exchange area before a launch: only the words that are POLLED need zeroing -- the epoch flags of both
+// transports and the XCC table of every cluster (2.2 KB of each 131 KB cluster); the untagged data blocks are only
+// read after their flag went up.  (A 7 us memset node of the whole area per layer becomes a 2 us kernel.)
+MP_KERNEL void mp_zero_exchange_x3(unsigned long long* hx, int ncl) {
+    constexpr size_t SLABW = (size_t)4 * 16 * 256 + 16;                  // 64-bit words per cluster
+    const int cl = blockIdx.x;
+    if (cl >= ncl) return;
+    unsigned* w = reinterpret_cast<unsigned*>(hx + (size_t)cl * SLABW);
+    for (int i = threadIdx.x; i < 2 * 16 * 16; i += blockDim.x) w[4 * 16 * 256 + i] = 0u;        // flagsL, flagsR (<= 16 slices)
+    for (int i = threadIdx.x; i < 32; i += blockDim.x) w[2 * 4 * 16 * 256 + i] = 0u;             // XCC table
+}
+
 }  // namespace
+
+void mp_launch_zero_exchange_x3(unsigned long long* hx, int ncl, hipStream_t s) {
+    hipLaunchKernelGGL(mp_zero_exchange_x3, dim3(ncl), dim3(256), 0, s, hx, ncl);
+}
 
 // H = 256 only; nslice 8 (8-wave workgroups) or 16 (4-wave workgroups, two per CU); K = 256 | 512
 void mp_launch_pack_w_x3(const float* w, float* dst, int K, int nslice, hipStream_t s) {
