@@ -47,9 +47,18 @@ static __device__ __forceinline__ unsigned bf16_rne_bits(float x) {
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;             // finite inputs only (activations and weights)
 }
 static __device__ __forceinline__ unsigned pair_of(float x) {
-    const unsigned hi = bf16_rne_bits(x);
+#ifdef MP_PAIR_SWCVT
+    const unsigned hi = bf16_rne_bits(x);                        // integer form, kept as the cross-check
     const float rest = x - __uint_as_float(hi << 16);           // exact in fp32
     return (hi << 16) | bf16_rne_bits(rest);
+#else
+    // gfx950 converts in hardware (v_cvt_pk_bf16_f32, round to nearest even): 5 instructions instead of 14.  The whole
+    // forward is bit-identical to the integer form above (checked on the 256 x 125 batch, 30 repetitions).
+    const __bf16 h = (__bf16)x;
+    const unsigned hi = __builtin_bit_cast(unsigned short, h);
+    const __bf16 l = (__bf16)(x - __uint_as_float(hi << 16));  // the difference is exact in fp32
+    return (hi << 16) | (unsigned)__builtin_bit_cast(unsigned short, l);
+#endif
 }
 
 // Workgroup barrier that only waits for this wave's LDS traffic (lgkmcnt), not for its outstanding global loads

@@ -7,7 +7,10 @@ batch-size change raises Q2, padded-sequence semantics Q4, raw-logit online weig
 All arithmetic happens in hand-written HIP kernels behind the C ABI; torch only owns device memory.
 There is no CPU path: constructing the model without the built library raises.
 """
+import atexit
 import ctypes as C
+import sys
+import weakref
 
 import numpy as np
 import torch
@@ -21,6 +24,18 @@ from .model_utils import blob_to_state_dict, state_dict_to_blob
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+_LIVE = weakref.WeakSet()       # nets that own a native handle
+
+
+@atexit.register
+def _close_all():               # runs before interpreter finalisation, while the HIP runtime is still loaded
+    for net in list(_LIVE):
+        try:
+            net.close()
+        except Exception:
+            pass
 
 
 class _VelocityView:
@@ -135,6 +150,7 @@ class MobilePoserNet:
             self._blob = blob_host
         _lib.check(rc, None)
         self._h = h
+        _LIVE.add(self)
         fy = C.c_float()
         fp = (C.c_float * 6)()
         _lib.check(self._lib.mp_get_constants(self._h, C.byref(fy), fp), self._h)
@@ -150,11 +166,18 @@ class MobilePoserNet:
                                              sw.ctypes.data_as(C.POINTER(C.c_float)), vt.shape[0]), self._h)
             self.n_vertex = int(vt.shape[0])
 
+    def close(self):
+        """Release the native handle (weights, workspaces, streams, graphs).  Idempotent."""
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None:
+            self._lib.mp_destroy(h)
+
     def __del__(self):
+        # at interpreter shutdown the HIP runtime may already be gone: native handles are then released by the atexit
+        # hook below (which runs first), never from a finalizer
         try:
-            if getattr(self, "_h", None) is not None:
-                self._lib.mp_destroy(self._h)
-                self._h = None
+            if not sys.is_finalizing():
+                self.close()
         except Exception:
             pass
 
