@@ -29,7 +29,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x
 PEAK_BF16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
 
-X3_NAMES = {         # the same timing classes when the H = 256 layers run on split-bf16 operands (--lstm-mode x3)
+X3_NAMES = {         # the same timing classes when the H = 256 blocks run on split-bf16 operands (--lstm-mode x3)
+    0: "mp_gemm_x3 (linear1 / linear2 of the H=256 blocks) + mp_gemm_f32 (foot-contact block)",
     1: "mp_lstm_x3<8,256> bidirectional layer 0 (joints, pose)",
     4: "mp_lstm_x3<8,512> bidirectional layer 1 (joints, pose)",
     5: "mp_lstm_x3<8,256> unidirectional layers (velocity; 128 workgroups)",
@@ -323,7 +324,7 @@ def main():
                5: "mp_lstm_fused<256, 16, 256, 1, false>", 0: "mp_gemm_f32<2, 2, 2, 2>"}.get(dominant)
         if args.lstm_mode == "x3":
             key = {1: "mp_lstm_x3<8, 256, false>", 4: "mp_lstm_x3<8, 512, false>", 5: "mp_lstm_x3<8, 256, false>",
-                   0: "mp_gemm_f32<2, 2, 2, 2>"}.get(dominant)
+                   0: "mp_gemm_x3<128, 64>"}.get(dominant)
         traffic = pmc[key]["hbm_bytes_per_launch_corrected"] if key in pmc else None
     except Exception:
         traffic = None
@@ -333,7 +334,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.lstm_mode == "fp32" else "f32 (LSTM matrix products as 3-term split-bf16 MFMA, fp32 accumulate)",
+        "dtype": "f32" if args.lstm_mode == "fp32" else "f32 (LSTM and linear-layer matrix products as 3-term split-bf16 MFMA, fp32 accumulate)",
         "data": "synthetic",
         "config": {"workload": "configs[2]+solver: full MobilePoserNet (4 LSTM modules) + r6d/IK + SMPL FK + offline "
                                "translation solver, B=256 x T=125 per GPU, seeded synthetic IMU (lw_rp combo), "
