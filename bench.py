@@ -350,8 +350,10 @@ def main():
             "note": "fp32 = exact v_mfma_f32_16x16x4_f32 operands; x3 = each fp32 product as hi*hi+hi*lo+lo*hi of bf16 "
                     "parts on v_mfma_f32_16x16x32_bf16 with fp32 accumulate and fp32 state (mp_set_lstm_mode(h, 3)); both "
                     "pass the same parity tests at 1e-4 / 1 mm (tests/test_gpu_parity.py runs every test in both modes)"},
-        "end_to_end": {"tflops": round(value * FLOP_PER_FRAME / 1e12, 3),
+        "end_to_end": {"tflops": round(value * FLOP_PER_FRAME / 1e12, 3),      # algorithmic fp32 FLOPs of the 4 modules
                        "frac_of_fp32_mfma_peak": round(value / world * FLOP_PER_FRAME / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                       "frac_of_bf16_mfma_peak_executed": (round(3.0 * value / world * FLOP_PER_FRAME / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
+                                                           if args.lstm_mode != "fp32" else None),
                        "hbm_gbps_compulsory": round(value / world * BYTES_PER_FRAME / 1e9, 2)},
         "roofline": {"kernel": names[dominant], "bound": "mfma",
                      "achieved": round(roof_achieved, 2), "peak": roof_peak, "unit": "TFLOP/s",
