@@ -362,7 +362,7 @@ def main():
                      "avg_launch_ms": round(dms / dn, 4), "note": roof_note},
         "kernels": kern,
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed on rank 0 of the single-GPU run only
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))
     if dist is not None:
