@@ -203,6 +203,11 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
     const int crow = cli / PARTS, cpart = cli % PARTS;
     const bool cloc = (same >> cprod) & 1;
     const unsigned* csrc = (cloc ? dataL : dataR) + (size_t)cprod * 16 * U + crow * U + cpart * WPL;
+    // the blocks are fetched with buffer loads (16 bytes per lane, sc1 = past the L1) that the compiler can see: with
+    // inline-asm loads its s_waitcnt arithmetic does not know about them and every wait for an OLDER load (the x words of
+    // the chunk multiplied under the fetch) silently waits for the fetch as well -- no overlap at all
+    const __amdgpu_buffer_rsrc_t hxrsrc = __builtin_amdgcn_make_buffer_rsrc(hxw, 0, (int)(SLABW * 8), 0x27000);
+    const int csrc_byte = (int)((csrc - hxw) * 4);
     unsigned* cdst = hT + crow * HPITCH + cprod * U + cpart * WPL;
     // lanes 0 .. PPW*NWV-1 of a wave watch the flags of its producers' waves: flag[producer][wave of the producer]
     const bool cwatch = lane < PPW * NWV;
@@ -343,9 +348,10 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
                 spin_budget = 0;
             }
             TR(1);
+            asm volatile("" ::: "memory");                   // (compiler fence: the fetch stays behind the flag test)
 #pragma unroll
             for (int i = 0; i < WPL / 4; ++i)
-                asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(blk[i]) : "v"(csrc + poff), "n"(16 * i) : "memory");
+                blk[i] = __builtin_amdgcn_raw_buffer_load_b128(hxrsrc, csrc_byte + (int)poff * 4 + 16 * i, 0, 16 /* sc1 */);
         }
         PROF_E(1); PROF_T(0);
         // ---- ... and multiply what is left of x_t W_ih^T while they are in flight
@@ -356,8 +362,6 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         PROF_E(0); PROF_T(1);
         // ---- stage the blocks in LDS and read this lane's A fragments of the recurrent product from there
         if (step > 0) {
-            if constexpr (WPL == 8) asm volatile("s_waitcnt vmcnt(0)" : "+v"(blk[0]), "+v"(blk[1]) :: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(blk[0]), "+v"(blk[1]), "+v"(blk[2]), "+v"(blk[3]) :: "memory");
             // (shared with the reduction buffer: every wave must be done with the previous step's partial sums)
             if (C::HT_ALIAS) __syncthreads();
 #pragma unroll
