@@ -334,7 +334,6 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         // ---- h_{step-1}: once the flags are up, fetch the producers' blocks (16-byte loads that bypass the L1) ...
         u32x4 blk[WPL / 4];
         if (step > 0) {
-            const size_t poff = (size_t)((step + 1) & 1) * 16 * H;
             unsigned spins = 0;
             bool timed_out = false;
             bool ready = flagA >= (unsigned)step;
@@ -348,10 +347,16 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
                 spin_budget = 0;
             }
             TR(1);
-            asm volatile("" ::: "memory");                   // (compiler fence: the fetch stays behind the flag test)
+        }
+        // The fetch is issued on EVERY step, also on step 0 where its result is not used: inside `if (step > 0)` the
+        // compiler has to merge the two paths' wait counts and then waits for these loads as soon as an older load (the x
+        // words of the chunks below) is needed -- which serialises the fetch and the MFMAs that are meant to hide it.
+        asm volatile("" ::: "memory");                       // (compiler fence: the fetch stays behind the flag test)
+        {
+            const int poff_b = (int)(((step + 1) & 1) * 16 * H) * 4;
 #pragma unroll
             for (int i = 0; i < WPL / 4; ++i)
-                blk[i] = __builtin_amdgcn_raw_buffer_load_b128(hxrsrc, csrc_byte + (int)poff * 4 + 16 * i, 0, 16 /* sc1 */);
+                blk[i] = __builtin_amdgcn_raw_buffer_load_b128(hxrsrc, csrc_byte + poff_b + 16 * i, 0, 16 /* sc1 */);
         }
         PROF_E(1); PROF_T(0);
         // ---- ... and multiply what is left of x_t W_ih^T while they are in flight
