@@ -221,7 +221,7 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
 
     // ---- x_0: pair words of this lane's row, chunk c: k = kq*KQ + c*32 + q*8 + e
     u32x4 xw[NXC][2];
-    constexpr bool SPLIT_X = C::BIG;                      // second half of x_t fetched at the top of step t
+    constexpr bool SPLIT_X = C::BIG;                      // x words of the LDS-resident chunks prefetched at a different point
     constexpr int XC_PRE = SPLIT_X ? XRC : NXC;
     auto load_x = [&](int step, int c0, int c1) {
         const bool on = step < alen;
@@ -230,11 +230,15 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
 #pragma unroll
         for (int c = 0; c < NXC; ++c)
             if (c >= c0 && c < c1) {
-                xw[c][0] = on ? *reinterpret_cast<const u32x4*>(p + c * 32) : u32x4{0u, 0u, 0u, 0u};
-                xw[c][1] = on ? *reinterpret_cast<const u32x4*>(p + c * 32 + 4) : u32x4{0u, 0u, 0u, 0u};
+                // (unconditional loads + select: a branch around the loads makes the compiler merge wait counts at the join
+                //  and wait for these prefetches whenever an older load is needed; t is clamped to a valid row)
+                const u32x4 v0 = *reinterpret_cast<const u32x4*>(p + c * 32);
+                const u32x4 v1 = *reinterpret_cast<const u32x4*>(p + c * 32 + 4);
+                xw[c][0] = on ? v0 : u32x4{0u, 0u, 0u, 0u};
+                xw[c][1] = on ? v1 : u32x4{0u, 0u, 0u, 0u};
             }
     };
-    load_x(0, 0, XC_PRE);
+    load_x(0, 0, NXC);
     __syncthreads();                                          // W_ih LDS image complete
 
     long long pt[6] = {0, 0, 0, 0, 0, 0};
@@ -306,12 +310,16 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
 #define TR(i) do { } while (0)
 #endif
         TR(0);
-        if (SPLIT_X) load_x(step, XC_PRE, NXC);
+        // (Wait counts across the loop back-edge are merged conservatively: the first use of a prefetched x word in a step
+        //  costs an `s_waitcnt vmcnt(0)`.  Consume that wait HERE, while only old loads are outstanding, so that it does not
+        //  land behind the flag look and the next prefetches and serialise them with the MFMAs.)
+        if constexpr (XRC > 1) asm volatile("" :: "v"(xw[1][0]), "v"(xw[1][1]));
         // ---- first look at the producers' flags (epoch = step), in flight under the MFMAs below; the peers are in
         // the same phase, so it usually succeeds and the wave never polls.  The blocks are requested as soon as the
         // flags are up: measured, delaying that request by one more chunk of MFMAs costs more than the chunk hides.
-        unsigned flagA = ~0u;
-        if (step > 0 && cwatch) flagA = __hip_atomic_load(cflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (every lane loads -- the non-watching lanes an arbitrary flag word -- and on every step: under a condition the
+        //  compiler folds the test into the branch and waits for the load on the spot)
+        const unsigned flagA = __hip_atomic_load(cflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- x_t W_ih^T (independent of h: this is what fills the exchange latencies); chunk 0 was multiplied at
         // the end of the previous step, the first LDS-resident chunk is fetched here
         lds_fetch(0, C::BIG ? 0 : 2);
@@ -336,7 +344,7 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         if (step > 0) {
             unsigned spins = 0;
             bool timed_out = false;
-            bool ready = flagA >= (unsigned)step;
+            bool ready = !cwatch || flagA >= (unsigned)step;
             if (PROF && prof && !__all(ready)) pt[5] += 1;      // steps whose first look came too early
             while (!__all(ready)) {
                 if (++spins > spin_budget) { timed_out = true; break; }
@@ -364,6 +372,9 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
 #pragma unroll
         for (int c = XL_EARLY; c < XLC; ++c) lds_chunk_mma(c, xw[XRC + c][0], xw[XRC + c][1]);
 #endif
+        // K_in = 512: the x words of the LDS-resident chunks are dead now -- fetch the next step's right away (issued
+        // after the block fetch, so the staging wait below does not include them; a full step of latency to hide in)
+        if (SPLIT_X) load_x(step + 1, XC_PRE, NXC);
         PROF_E(0); PROF_T(1);
         // ---- stage the blocks in LDS and read this lane's A fragments of the recurrent product from there
         if (step > 0) {
@@ -380,7 +391,8 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         }
         TR(2);
 #ifndef X3_SKIP_XLOAD
-        load_x(step + 1, 0, XC_PRE);     // next step's x
+        load_x(step + 1, 0, XC_PRE);     // next step's x (the scheduler sinks these loads among the MFMAs below: measured better
+                                         // than pinning them here, on the critical chain in front of the recurrent product)
 #endif
         // (issued after the staging wait above, so that this wait does not drain these loads as well)
         PROF_E(1); PROF_T(2);
@@ -436,20 +448,24 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         chunk_mma(xw[0][0], xw[0][1], wxr[0]);
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        // this wave's flag: raised once all of its stores of the step have been acknowledged
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) {
-            __hip_atomic_store(flagsL + slice * 16 + wave, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (!all_local) __hip_atomic_store(flagsR + slice * 16 + wave, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
 #ifdef X3_SKIP_OUT
         if (inb && step == T - 1) {
 #else
-        if (inb) {
+        if (inb) {                                            // (before the wait: no store may be pending after it)
 #endif
             float* op = d.out + ((size_t)tt * B + bown) * d.outStride + jown;
             if (a.out_pairs) *reinterpret_cast<unsigned*>(op) = act ? hp : 0u;
             else *op = oval;
+        }
+        // this wave's flag: raised once all of its stores of the step have been acknowledged
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (the same wait once more as a builtin: it costs nothing and tells the compiler's wait-count bookkeeping that no
+        //  store is outstanding any more -- with loads and stores both pending it falls back to vmcnt(0) for every later wait,
+        //  e.g. it would wait for the x prefetch when only the hidden-state blocks are needed)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (lane == 0) {
+            __hip_atomic_store(flagsL + slice * 16 + wave, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!all_local) __hip_atomic_store(flagsR + slice * 16 + wave, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         TR(5);
         PROF_E(4);
