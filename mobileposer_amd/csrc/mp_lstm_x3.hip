@@ -366,6 +366,7 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
             for (int i = 0; i < WPL / 4; ++i)
                 blk[i] = __builtin_amdgcn_raw_buffer_load_b128(hxrsrc, csrc_byte + poff_b + 16 * i, 0, 16 /* sc1 */);
         }
+        __builtin_amdgcn_sched_barrier(0);                     // (the MFMAs below stay below the fetch)
         PROF_E(1); PROF_T(0);
         // ---- ... and multiply what is left of x_t W_ih^T while they are in flight
 #ifndef X3_SKIP_PROJ
