@@ -239,6 +239,18 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
             }
     };
     load_x(0, 0, NXC);
+    // K_in = 256: the x words of chunk 0 (multiplied at the END of the previous step, on the critical path in front of the
+    // flag) are prefetched TWO steps ahead through a second register pair, so that those MFMAs never wait for a load
+    u32x4 xq[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+    auto load_xq = [&](int step) {
+        const bool on = step < alen;
+        const int t = on ? (d.reverse ? alen - 1 - step : step) : 0;
+        const unsigned* p = xbase + (size_t)t * xtstride;
+        const u32x4 v0 = *reinterpret_cast<const u32x4*>(p);
+        const u32x4 v1 = *reinterpret_cast<const u32x4*>(p + 4);
+        xq[0] = on ? v0 : u32x4{0u, 0u, 0u, 0u};
+        xq[1] = on ? v1 : u32x4{0u, 0u, 0u, 0u};
+    };
     __syncthreads();                                          // W_ih LDS image complete
 
     long long pt[6] = {0, 0, 0, 0, 0, 0};
@@ -300,6 +312,7 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
 #ifndef X3_SKIP_PROJ
     chunk_mma(xw[0][0], xw[0][1], wxr[0]);
 #endif
+    if constexpr (!C::BIG) load_xq(1);
 
     for (int step = 0; step < T; ++step) {
         PROF_T(0);
@@ -392,8 +405,14 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         }
         TR(2);
 #ifndef X3_SKIP_XLOAD
-        load_x(step + 1, 0, XC_PRE);     // next step's x (the scheduler sinks these loads among the MFMAs below: measured better
+        if constexpr (C::BIG) {
+            load_x(step + 1, 0, XC_PRE); // next step's x (the scheduler sinks these loads among the MFMAs below: measured better
                                          // than pinning them here, on the critical chain in front of the recurrent product)
+        } else {
+            xw[0][0] = xq[0]; xw[0][1] = xq[1];               // x_{t+1} chunk 0, requested a whole step ago
+            load_xq(step + 2);
+            load_x(step + 1, 1, XC_PRE);
+        }
 #endif
         // (issued after the staging wait above, so that this wait does not drain these loads as well)
         PROF_E(1); PROF_T(2);
