@@ -68,18 +68,20 @@ MP_KERNEL __launch_bounds__(256) void mp_gemm_x3(GemmArgs g, int nTilesM, int nT
     }
 
     u32x4 ra[A_ROWS_PER_THREAD], rw[W_ROWS_PER_THREAD];
+    bool ra_live = false;                                     // k range of the prefetched A words inside [0, K)
     const unsigned* Wp = reinterpret_cast<const unsigned*>(g.W);
     auto load_tile = [&](int k0) {
         const int k = k0 + kc;
+        // unconditional loads from a clamped (always valid) address, then a select: loads under branches are serialised by
+        // the compiler's wait-count merging at every join (load, vmcnt(0), load, vmcnt(0) ... in the ISA), which is fatal
+        // for a loop that is bound by load latency.  fp32 zero and the zero pair are the same bits.
+        const bool in0 = k < g.a0.width, in1 = !in0 && k < g.K;
 #pragma unroll
         for (int j = 0; j < A_ROWS_PER_THREAD; ++j) {
-            u32x4 v = {0u, 0u, 0u, 0u};                        // fp32 zero and the zero pair are the same bits
-            if (rowOk[j]) {
-                if (k < g.a0.width) v = *reinterpret_cast<const u32x4*>(g.a0.base + offA0[j] + k);
-                else if (k < g.K)   v = *reinterpret_cast<const u32x4*>(g.a1.base + offA1[j] + (k - g.a0.width));
-            }
-            ra[j] = v;
+            const float* src = in1 ? g.a1.base + offA1[j] + (k - g.a0.width) : g.a0.base + offA0[j] + (in0 ? k : 0);
+            ra[j] = *reinterpret_cast<const u32x4*>(src);     // (masked when it is stored to LDS: a select here would be a use)
         }
+        ra_live = in0 || in1;
 #pragma unroll
         for (int j = 0; j < W_ROWS_PER_THREAD; ++j)
             rw[j] = *reinterpret_cast<const u32x4*>(Wp + (long)(n0 + lr + 32 * j) * g.Kpad + k);
@@ -87,7 +89,7 @@ MP_KERNEL __launch_bounds__(256) void mp_gemm_x3(GemmArgs g, int nTilesM, int nT
     auto store_tile = [&]() {
 #pragma unroll
         for (int j = 0; j < A_ROWS_PER_THREAD; ++j) {
-            u32x4 v = ra[j];
+            u32x4 v = (rowOk[j] && ra_live) ? ra[j] : u32x4{0u, 0u, 0u, 0u};
             if (!g.aPairs) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = pair_of(__uint_as_float(v[e]));
