@@ -87,7 +87,8 @@ struct ModuleWS {
     float *xproj = nullptr, *out0 = nullptr, *out1 = nullptr;   // X1 (linear1 output) aliases out1
     float* hbuf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     float* cbuf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    unsigned long long* hx = nullptr;   // granule exchange buffer of the persistent kernel
+    unsigned long long* hx = nullptr;   // hidden-state exchange buffer of the persistent kernels (split-bf16 mode: of layer 0)
+    unsigned long long* hx2 = nullptr;  // split-bf16 mode: exchange buffer of layer 1 (re-armed by the layer-0 launch)
     size_t hx_bytes = 0;
 };
 struct VelState { float* h = nullptr; float* c = nullptr; int B = 0; int cap = 0; };   // [2][B][256] each
@@ -398,6 +399,8 @@ int get_plan(mp_handle* h, int B, int T, Plan** out) {
             }
         w.hx_bytes = (size_t)2 * ((B + 15) / 16) * ((size_t)4 * 16 * m.H + 16) * sizeof(unsigned long long);
         if (int rc = dev_alloc(h, (void**)&w.hx, w.hx_bytes, &p->allocs)) return rc;
+        if (m.H == 256)
+            if (int rc = dev_alloc(h, (void**)&w.hx2, w.hx_bytes, &p->allocs)) return rc;
     }
     if (int rc = dev_alloc(h, (void**)&p->r6d, M * 96 * sizeof(float), &p->allocs)) return rc;
     if (int rc = dev_alloc(h, (void**)&p->lengths_dev, (size_t)B * sizeof(int), &p->allocs)) return rc;
@@ -466,13 +469,14 @@ RowMap internal_map(const float* base, int B, int width) { return RowMap{base, (
 RowMap user_map(const float* base, int T, int width) { return RowMap{base, (long)T * width, (long)width, width}; }
 
 int run_gemm(mp_handle* h, hipStream_t s, RowMap a0, RowMap a1, const Packed& w, float* C, long cStrideB,
-             long cStrideT, int M, int B, int relu, bool pair_out = false, bool a_pairs = false, bool x3_gemm = false) {
+             long cStrideT, int M, int B, int relu, bool pair_out = false, bool a_pairs = false, bool x3_gemm = false,
+             unsigned long long* zero_hx = nullptr, int zero_ncl = 0) {
     SegScope seg(h, s, 0, 1, 2.0 * M * (double)w.N * w.K);
     GemmArgs g;
     g.a0 = a0; g.a1 = a1; g.W = w.W; g.bias = w.bias; g.C = C; g.cStrideB = cStrideB; g.cStrideT = cStrideT;
     g.M = M; g.N = w.N; g.K = w.K; g.Kpad = w.Kpad; g.B = B; g.relu = relu; g.pairOut = pair_out ? 1 : 0;
     if (x3_gemm && w.Wp) {                                    // split-bf16 mode: the H = 256 blocks' linear layers run on bf16 MFMAs as well
-        g.W = w.Wp; g.aPairs = a_pairs ? 1 : 0;
+        g.W = w.Wp; g.aPairs = a_pairs ? 1 : 0; g.zero_hx = zero_hx; g.zero_ncl = zero_hx ? zero_ncl : 0;
         mp_launch_gemm_x3(g, w.bn, s);
     } else {
         mp_launch_gemm(g, w.bn, s);
@@ -512,7 +516,9 @@ int rnn_g0(const RnnJob& j, hipStream_t s) {
     const int B = j.p->B, T = j.p->T, M = B * T, H = m.H, dirs = m.dirs;
     const RowMap none{nullptr, 0, 0, 0};
     float* X1 = x1_buffer(h, m, w);
-    run_gemm(h, s, j.a0, j.a1, m.lin1, X1, H, (long)B * H, M, B, 1, use_x3(h, m), false, use_x3(h, m));   // rnn.py:22
+    // (split-bf16 mode: this GEMM also re-arms the exchange area of the layer-0 launch that follows it)
+    run_gemm(h, s, j.a0, j.a1, m.lin1, X1, H, (long)B * H, M, B, 1, use_x3(h, m), false, use_x3(h, m),
+             use_x3(h, m) ? w.hx : nullptr, dirs * ((B + 15) / 16));                               // rnn.py:22
     // the per-step kernels take the input projection from a GEMM; the persistent kernel computes it itself
     if (!h->persist && !w.xproj) return fail(h, MP_ERR_INVALID, "internal: per-step workspace missing");
     if (!h->persist)
@@ -570,8 +576,9 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
     } else if (h->persist) {
         const int nslab = (B + 15) / 16;
         // every polled word is re-zeroed before every launch: all granules (fp32 kernels) or the flags (split-bf16 kernels)
-        if (use_x3(h, m)) mp_launch_zero_exchange_x3(w.hx, dirs * nslab, s);
-        else HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
+        // (split-bf16 kernels: the flags of layer 0's area were zeroed by the linear1 GEMM, those of layer 1's area by the layer-0 launch)
+        if (!use_x3(h, m)) HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
+        unsigned long long* hx_l = (use_x3(h, m) && l == 1) ? w.hx2 : w.hx;
         const int nsl = use_x3(h, m) ? m.nsliceX : m.nslice;
         const int cus = h->n_cu < 256 ? h->n_cu : 256;
         const int chunk = cus / (dirs * nsl) > 0 ? cus / (dirs * nsl) : 1;   // slabs per launch: grid <= #CUs, one workgroup per CU
@@ -586,7 +593,8 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             LstmPersistArgs a;
             a.lengths = j.p->lengths_dev; a.ndir = dirs; a.B = B; a.T = T;
             a.slab0 = s0; a.nslab = nslab - s0 < chunk ? nslab - s0 : chunk;
-            a.hx = w.hx + (size_t)dirs * s0 * ((size_t)4 * 16 * H + 16);
+            a.hx = hx_l + (size_t)dirs * s0 * ((size_t)4 * 16 * H + 16);
+            a.hx_next = (use_x3(h, m) && l == 0) ? w.hx2 + (size_t)dirs * s0 * ((size_t)4 * 16 * H + 16) : nullptr;
             static const int prof_layer = getenv("MP_PERSIST_PROF_LAYER") ? atoi(getenv("MP_PERSIST_PROF_LAYER")) : -1;
             a.err = h->err_dev; a.max_spin = 1u << 18; a.prof = (prof_layer < 0 || prof_layer == l) ? h->prof_dev : nullptr;
             a.zero_state = j.mode == STATE_ZERO ? 1 : 0; a.force_remote = h->force_remote ? 1 : 0;

@@ -36,6 +36,10 @@ struct GemmArgs {
     int M, N, K, Kpad, B, relu;
     int pairOut = 0;     // 1: store C as split-bf16 pairs (mp_lstm_dev.h pair_of) -- input format of mp_lstm_x3.hip
     int aPairs = 0;      // mp_gemm_x3 only: the A segments already hold pair words
+    // mp_gemm_x3 only: re-arm (zero the polled words of) `zero_ncl` clusters of a split-bf16 exchange area on the way -- the
+    // linear1 GEMM of a block does it for the layer-0 launch that follows, which saves a kernel boundary on the critical path
+    unsigned long long* zero_hx = nullptr;
+    int zero_ncl = 0;
 };
 // bn: 128, 96 or 32 (chosen by the caller from N)
 void mp_launch_gemm(const GemmArgs& g, int bn, hipStream_t s);
@@ -84,6 +88,8 @@ struct LstmPersistArgs {
     unsigned max_spin;
     long long* prof;              // optional [grid][6] cycle sums per phase (debug), else nullptr
     int out_pairs = 0;            // split-bf16 kernel only: write the layer output as pairs (it feeds another layer)
+    unsigned long long* hx_next = nullptr;   // split-bf16 kernel only: exchange area of the NEXT layer's launch (same cluster
+                                              // indexing), re-armed by this launch at its start
 };
 // nslice: workgroups sharing one slab of an H = 256 layer: 16 (4-wave workgroups, two per CU) or 8 (8-wave, one per CU)
 void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice, hipStream_t s);

@@ -67,3 +67,13 @@ static __device__ __forceinline__ unsigned pair_of(float x) {
 static __device__ __forceinline__ void barrier_lds_only() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+
+// Re-arm one cluster of a split-bf16 exchange area (mp_lstm_x3.hip layout, H = 256): zero the words that are POLLED --
+// the epoch flags of both transports and the XCC table (2.2 KB of the 131 KB); the untagged data blocks are only read
+// after their flag went up.  Called by all threads of a workgroup.
+static __device__ __forceinline__ void rearm_exchange_cluster(unsigned long long* hx, int cl, int tid, int nthreads) {
+    constexpr size_t SLABW = (size_t)4 * 16 * 256 + 16;                  // 64-bit words per cluster
+    unsigned* w = reinterpret_cast<unsigned*>(hx + (size_t)cl * SLABW);
+    for (int i = tid; i < 2 * 16 * 16; i += nthreads) w[4 * 16 * 256 + i] = 0u;        // flagsL, flagsR (<= 16 slices)
+    for (int i = tid; i < 32; i += nthreads) w[2 * 4 * 16 * 256 + i] = 0u;             // XCC table
+}

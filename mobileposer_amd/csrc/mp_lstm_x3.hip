@@ -109,6 +109,9 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
     if (cl >= ncl) return;
     const int dir = cl / a.nslab, slab = cl % a.nslab;
     const LstmDir d = a.d[dir];
+    // the next layer's launch uses another exchange area: its cluster `cl` is re-armed here (by the slice-0 workgroup), which
+    // saves a separate kernel -- and a kernel boundary on the critical path -- between the two layers
+    if (a.hx_next != nullptr && slice == 0) rearm_exchange_cluster(a.hx_next, cl, threadIdx.x, NTHREADS);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kq = wave & 3, tw = wave >> 2;
     const int q = lane >> 4, r16 = lane & 15;
@@ -554,12 +557,7 @@ void launch_x3(const LstmPersistArgs& a, hipStream_t s) {
 // transports and the XCC table of every cluster (2.2 KB of each 131 KB cluster); the untagged data blocks are only
 // read after their flag went up.  (A 7 us memset node of the whole area per layer becomes a 2 us kernel.)
 MP_KERNEL void mp_zero_exchange_x3(unsigned long long* hx, int ncl) {
-    constexpr size_t SLABW = (size_t)4 * 16 * 256 + 16;                  // 64-bit words per cluster
-    const int cl = blockIdx.x;
-    if (cl >= ncl) return;
-    unsigned* w = reinterpret_cast<unsigned*>(hx + (size_t)cl * SLABW);
-    for (int i = threadIdx.x; i < 2 * 16 * 16; i += blockDim.x) w[4 * 16 * 256 + i] = 0u;        // flagsL, flagsR (<= 16 slices)
-    for (int i = threadIdx.x; i < 32; i += blockDim.x) w[2 * 4 * 16 * 256 + i] = 0u;             // XCC table
+    if ((int)blockIdx.x < ncl) rearm_exchange_cluster(hx, blockIdx.x, threadIdx.x, blockDim.x);
 }
 
 }  // namespace
