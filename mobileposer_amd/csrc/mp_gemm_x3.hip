@@ -40,7 +40,7 @@ MP_KERNEL __launch_bounds__(256) void mp_gemm_x3(GemmArgs g, int nTilesM, int nT
     long* rowOffC = reinterpret_cast<long*>(smem + (BM + BN) * LDK);
 
     const int bid = blockIdx.x;
-    for (int cl = bid; cl < g.zero_ncl; cl += gridDim.x) rearm_exchange_cluster(g.zero_hx, cl, threadIdx.x, 256);
+    if (g.zero_ncl > 0) rearm_exchange(g.zero_hx, g.zero_ncl, bid, gridDim.x, threadIdx.x, 256);
     const int xcd = bid & 7, idx = bid >> 3;
     const int mt = (idx / nTilesN) * 8 + xcd;
     const int nt = idx % nTilesN;

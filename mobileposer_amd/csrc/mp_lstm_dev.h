@@ -68,12 +68,14 @@ static __device__ __forceinline__ void barrier_lds_only() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Re-arm one cluster of a split-bf16 exchange area (mp_lstm_x3.hip layout, H = 256): zero the words that are POLLED --
-// the epoch flags of both transports and the XCC table (2.2 KB of the 131 KB); the untagged data blocks are only read
-// after their flag went up.  Called by all threads of a workgroup.
-static __device__ __forceinline__ void rearm_exchange_cluster(unsigned long long* hx, int cl, int tid, int nthreads) {
-    constexpr size_t SLABW = (size_t)4 * 16 * 256 + 16;                  // 64-bit words per cluster
-    unsigned* w = reinterpret_cast<unsigned*>(hx + (size_t)cl * SLABW);
-    for (int i = tid; i < 2 * 16 * 16; i += nthreads) w[4 * 16 * 256 + i] = 0u;        // flagsL, flagsR (<= 16 slices)
-    for (int i = tid; i < 32; i += nthreads) w[2 * 4 * 16 * 256 + i] = 0u;             // XCC table
+// Re-arm the split-bf16 exchange area of `ncl` clusters (mp_lstm_x3.hip layout, H = 256): everything that is polled
+// must read as "nothing published yet" -- the tag bit of every data word, the XCC table.  The area is simply zeroed
+// (131 KB per cluster); the caller is share `part` of `nparts` equal shares, all threads of a workgroup take part.
+static __device__ __forceinline__ void rearm_exchange(unsigned long long* hx, int ncl, int part, int nparts, int tid, int nthreads) {
+    constexpr size_t SLABQ = ((size_t)4 * 16 * 256 + 16) / 2;            // 16-byte words per cluster
+    const size_t total = (size_t)ncl * SLABQ;
+    const size_t per = (total + nparts - 1) / nparts;
+    const size_t lo = (size_t)part * per, hi = lo + per < total ? lo + per : total;
+    u32x4* w = reinterpret_cast<u32x4*>(hx);
+    for (size_t i = lo + tid; i < hi; i += nthreads) w[i] = u32x4{0u, 0u, 0u, 0u};
 }

@@ -10,8 +10,9 @@
 // A single bf16 term (1e-4 .. 5e-4) does NOT pass; that is why the split exists.
 //
 // Data formats (all 4 bytes per value, so buffers, LDS images and register counts keep their sizes):
-//   * activations that feed an LSTM layer or a linear layer (linear1's output X1, both layers' outputs) and the
-//     exchanged hidden state are "pairs": (bf16 hi << 16) | bf16 lo  (mp_lstm_dev.h pair_of);
+//   * activations that feed an LSTM layer or a linear layer (linear1's output X1, both layers' outputs) are "pairs":
+//     (bf16 hi << 16) | bf16 lo  (mp_lstm_dev.h pair_of); the exchanged hidden state is a pair with a 7-bit lo
+//     mantissa and an epoch tag in bit 0 (below);
 //   * W_hh / W_ih are packed as separate hi and lo bf16x8 B-fragments (mp_pack_*_x3 below);
 //   * a lane's A fragment (8 consecutive k of one sequence row) is built from 8 pair words with 8 v_perm_b32.
 // k mapping: wave kq owns K quarter kq; chunk c = 32 k of it; lane (row r16, k-block q) holds
@@ -19,18 +20,27 @@
 // Hidden-state exchange.  With the matrix pipe out of the way a step is bound by how fast h_t crosses the 8 (16)
 // workgroups of a cluster, and the tagged 8-byte granules of the fp32 kernel become the bottleneck: every CU
 // issued 128 wave-wide loads per step (64 KB through a 64 B/clk L1 path; every value fetched twice, half of the
-// bytes tags) -- measured 1500-2500 cycles of load issue on the critical path of a 6400-cycle step.  Here:
-//   * a producer wave stores its (row, unit) pair words untagged into its slice's [16 rows][U units] block
-//     (parity-double-buffered), waits for the stores to be acknowledged (s_waitcnt vmcnt(0)) and raises its own
-//     flag word to epoch step+1 -- no workgroup barrier on the publishing side;
-//   * a consumer wave watches the flags of the producer slice(s) it is responsible for (one 64-byte line per
-//     producer, lanes = that producer's waves), then fetches the 2 KB (1 KB) block with two (four) 16-byte loads
-//     per lane that bypass the L1, writes it into an LDS tile [16 rows][256 units], and after one barrier every
-//     wave reads its MFMA A fragments from LDS: each value crosses the L1 path once per CU (16 KB per step).
-//   * flags only grow, a producer can be at most one epoch ahead (it needs this workgroup's flags to go further),
-//     and the block it is then writing is the other parity: ">= epoch" is the complete test.
-//   Same two transports as the fp32 kernel, chosen per producer from the real XCC ids: L (plain stores that stay
-//   in this XCD's L2) / R (write-through stores), both read with L1-bypassing loads.  Waits are bounded.
+// bytes tags) -- measured 1500-2500 cycles of load issue on the critical path of a 6400-cycle step.  Here the
+// exchanged word is its own flag at no extra bytes:
+//   * the lo part of an exchanged pair is rounded to 7 mantissa bits (hpair_of: hi + lo then carries 15 significand
+//     bits, measured <= 1e-6 end to end) and bit 0 holds an epoch tag: ((step / 2) + 1) & 1.  Blocks are parity-
+//     double-buffered, so a word of one buffer is rewritten every second step and its tag alternates; a producer can
+//     be at most one step ahead of a consumer (it needs this workgroup's h to go further), writing the OTHER buffer:
+//     "tag == tag_of_step(step - 1)" is the complete test.  The area is zeroed by the kernel that runs before the
+//     layer (rearm_exchange), the first write of every word carries tag 1.
+//   * a producer wave stores its (row, unit) words into its slice's [16 rows][U units] block and goes on -- no
+//     acknowledgement wait, no flag, no barrier on the publishing side;
+//   * a consumer wave fetches the 2 KB (1 KB) block of the producer slice(s) it is responsible for with two (four)
+//     16-byte loads per lane that bypass the L1, optimistically (peers run in the same phase: issued at the top of a
+//     step, one chunk of MFMAs after its own stores, the block is complete 99 % of the time; requested 200 cycles
+//     earlier it is stale 95 % of the time), checks the tags after the MFMAs that hide the flight, refetches while any
+//     word is stale (bounded), writes the block -- tags cleared -- into an LDS tile [16 rows][256 units], and after one
+//     barrier every wave reads its MFMA A fragments from LDS: each value crosses the L1 path once per CU (16 KB/step).
+//   One round trip per step (store -> L2 -> load) instead of the two of a data + flag protocol (store, acknowledge,
+//   flag store, flag poll, block fetch), and nothing in the loop waits for a store: the previous version's
+//   `s_waitcnt vmcnt(0)` before the flag also waited for the x_{t+1} prefetch (HBM/MALL misses) on every step.
+//   Same two transports as the fp32 kernel, chosen per producer from the real XCC ids: L (stores that stay in this
+//   XCD's L2) / R (write-through stores), both read with L1-bypassing loads.  Waits are bounded.
 // H = 256 only (a K quarter must hold a 32-wide chunk); the H = 64 foot-contact block keeps the fp32 kernel.
 #include "mp_lstm_dev.h"
 
@@ -52,6 +62,25 @@ __device__ __forceinline__ void split_pairs(u32x4 w0, u32x4 w1, u32x4& hi, u32x4
     lo[2] = __builtin_amdgcn_perm(w1[1], w1[0], 0x05040100u);
     lo[3] = __builtin_amdgcn_perm(w1[3], w1[2], 0x05040100u);
 }
+// ---- the exchanged hidden-state word: a pair whose lo part is rounded (to nearest even) to 7 mantissa bits, so that bit 0
+// is free for the epoch tag of the exchange; tag of the h written at `step` = ((step / 2) + 1) & 1 (see the kernel header)
+__device__ __forceinline__ unsigned hpair_of(float x) {
+    const unsigned w = pair_of(x);
+    return (w + ((w >> 1) & 1u)) & ~1u;
+}
+__device__ __forceinline__ unsigned tag_of_step(int step) { return (((unsigned)step >> 1) + 1u) & 1u; }
+// stores of the exchange as inline asm: the compiler's s_waitcnt bookkeeping must not see a store in the loop (with loads
+// AND stores pending it waits with vmcnt(0) everywhere); nothing ever waits for these stores -- the data is its own flag
+__device__ __forceinline__ void store_word_xcd(unsigned* p, unsigned v) {          // stays in this XCD's L2
+    asm volatile("global_store_dword %0, %1, off sc0" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_word_dev(unsigned* p, unsigned v) {          // write-through: visible device-wide
+    asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_word_plain(unsigned* p, unsigned v) {
+    asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory");
+}
+
 template <int NSLICE, int KIN>
 struct CfgX {
     static constexpr int H = 256;
@@ -109,9 +138,9 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
     if (cl >= ncl) return;
     const int dir = cl / a.nslab, slab = cl % a.nslab;
     const LstmDir d = a.d[dir];
-    // the next layer's launch uses another exchange area: its cluster `cl` is re-armed here (by the slice-0 workgroup), which
+    // the next layer's launch uses another exchange area: its cluster `cl` is re-armed here (each slice its share), which
     // saves a separate kernel -- and a kernel boundary on the critical path -- between the two layers
-    if (a.hx_next != nullptr && slice == 0) rearm_exchange_cluster(a.hx_next, cl, threadIdx.x, NTHREADS);
+    if (a.hx_next != nullptr) rearm_exchange(a.hx_next + (size_t)cl * ((size_t)4 * 16 * H + 16), 1, slice, NSLICE, threadIdx.x, NTHREADS);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kq = wave & 3, tw = wave >> 2;
     const int q = lane >> 4, r16 = lane & 15;
@@ -166,17 +195,15 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         for (int c = 0; c < NHC; ++c)
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                hw[c][e >> 2][e & 3] = (arow_in && !a.zero_state) ? pair_of(p[c * 32 + e]) : 0u;
+                hw[c][e >> 2][e & 3] = (arow_in && !a.zero_state) ? hpair_of(p[c * 32 + e]) : 0u;
     }
 
     // exchange area of this cluster (32-bit words): hx[cluster] = { dataL[2 parities][16*H], dataR[2][16*H],
-    //   flagsL[NSLICE][16], flagsR[NSLICE][16], ..., xcc table (64-bit granules at word 2*4*16*H) }
+    //   xcc table (64-bit granules at word 2*4*16*H) }
     constexpr size_t SLABW = (size_t)4 * 16 * H + 16;                       // in 64-bit words (host allocation unit)
     unsigned* hxw = reinterpret_cast<unsigned*>(a.hx + (size_t)cl * SLABW);
     unsigned* dataL = hxw;
     unsigned* dataR = hxw + 2 * 16 * H;
-    unsigned* flagsL = hxw + 4 * 16 * H;
-    unsigned* flagsR = flagsL + NSLICE * 16;
     u64* xtab = a.hx + (size_t)cl * SLABW + (size_t)4 * 16 * H;
     unsigned spin_budget = a.max_spin;
     const unsigned my_xcc = xcc_id();
@@ -212,11 +239,7 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
     const __amdgpu_buffer_rsrc_t hxrsrc = __builtin_amdgcn_make_buffer_rsrc(hxw, 0, (int)(SLABW * 8), 0x27000);
     const int csrc_byte = (int)((csrc - hxw) * 4);
     unsigned* cdst = hT + crow * HPITCH + cprod * U + cpart * WPL;
-    // lanes 0 .. PPW*NWV-1 of a wave watch the flags of its producers' waves: flag[producer][wave of the producer]
-    const bool cwatch = lane < PPW * NWV;
-    const int wprod = PPW * wave + lane / NWV;
-    const unsigned* cflag = ((((same >> (cwatch ? wprod : 0)) & 1) ? flagsL : flagsR)) + (cwatch ? wprod * 16 + lane % NWV : 0);
-    // producer role: this lane's (row q*4+kq, unit jown) word of the slice's block, and this wave's flag
+    // producer role: this lane's (row q*4+kq, unit jown) word of the slice's block
     unsigned* pdstL = dataL + (size_t)slice * 16 * U + (q * 4 + kq) * U + (jown - slice * U);
     unsigned* pdstR = dataR + (size_t)slice * 16 * U + (q * 4 + kq) * U + (jown - slice * U);
     // reader role: A fragments of the recurrent product from the LDS tile
@@ -233,26 +256,25 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
 #pragma unroll
         for (int c = 0; c < NXC; ++c)
             if (c >= c0 && c < c1) {
-                // (unconditional loads + select: a branch around the loads makes the compiler merge wait counts at the join
-                //  and wait for these prefetches whenever an older load is needed; t is clamped to a valid row)
-                const u32x4 v0 = *reinterpret_cast<const u32x4*>(p + c * 32);
-                const u32x4 v1 = *reinterpret_cast<const u32x4*>(p + c * 32 + 4);
-                xw[c][0] = on ? v0 : u32x4{0u, 0u, 0u, 0u};
-                xw[c][1] = on ? v1 : u32x4{0u, 0u, 0u, 0u};
+                // (unconditional loads from a clamped, always valid row; rows past their length are zeroed where the words are
+                //  USED (xsel): a branch around the loads makes the compiler merge wait counts at the join, and a select here
+                //  is a use that the scheduler sinks to the next scheduling barrier -- behind the stores of the exchange,
+                //  where waiting for these loads means waiting for the stores' acknowledgements too)
+                xw[c][0] = *reinterpret_cast<const u32x4*>(p + c * 32);
+                xw[c][1] = *reinterpret_cast<const u32x4*>(p + c * 32 + 4);
             }
     };
+    auto xsel = [&](u32x4 v, int step) { return step < alen ? v : u32x4{0u, 0u, 0u, 0u}; };
     load_x(0, 0, NXC);
-    // K_in = 256: the x words of chunk 0 (multiplied at the END of the previous step, on the critical path in front of the
-    // flag) are prefetched TWO steps ahead through a second register pair, so that those MFMAs never wait for a load
+    // K_in = 256: the x words of chunk 0 (multiplied at the END of the previous step, right behind the stores of the
+    // exchange) are prefetched TWO steps ahead through a second register pair, so that those MFMAs never wait for a load
     u32x4 xq[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
     auto load_xq = [&](int step) {
         const bool on = step < alen;
         const int t = on ? (d.reverse ? alen - 1 - step : step) : 0;
         const unsigned* p = xbase + (size_t)t * xtstride;
-        const u32x4 v0 = *reinterpret_cast<const u32x4*>(p);
-        const u32x4 v1 = *reinterpret_cast<const u32x4*>(p + 4);
-        xq[0] = on ? v0 : u32x4{0u, 0u, 0u, 0u};
-        xq[1] = on ? v1 : u32x4{0u, 0u, 0u, 0u};
+        xq[0] = *reinterpret_cast<const u32x4*>(p);
+        xq[1] = *reinterpret_cast<const u32x4*>(p + 4);
     };
     __syncthreads();                                          // W_ih LDS image complete
 
@@ -313,9 +335,18 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifndef X3_SKIP_PROJ
-    chunk_mma(xw[0][0], xw[0][1], wxr[0]);
+    chunk_mma(xsel(xw[0][0], 0), xsel(xw[0][1], 0), wxr[0]);
 #endif
     if constexpr (!C::BIG) load_xq(1);
+
+    // the blocks of the h written at step `pstep` (parity pstep & 1)
+    u32x4 blk[WPL / 4];
+    auto fetch_blocks = [&](int pstep) {
+        const int poff_b = (pstep & 1) * 16 * H * 4;
+#pragma unroll
+        for (int i = 0; i < WPL / 4; ++i)
+            blk[i] = __builtin_amdgcn_raw_buffer_load_b128(hxrsrc, csrc_byte + poff_b + 16 * i, 0, 16 /* sc1 */);
+    };
 
     for (int step = 0; step < T; ++step) {
         PROF_T(0);
@@ -328,14 +359,8 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         TR(0);
         // (Wait counts across the loop back-edge are merged conservatively: the first use of a prefetched x word in a step
         //  costs an `s_waitcnt vmcnt(0)`.  Consume that wait HERE, while only old loads are outstanding, so that it does not
-        //  land behind the flag look and the next prefetches and serialise them with the MFMAs.)
+        //  land behind the block fetch and the next prefetches and serialise them with the MFMAs.)
         if constexpr (XRC > 1) asm volatile("" :: "v"(xw[1][0]), "v"(xw[1][1]));
-        // ---- first look at the producers' flags (epoch = step), in flight under the MFMAs below; the peers are in
-        // the same phase, so it usually succeeds and the wave never polls.  The blocks are requested as soon as the
-        // flags are up: measured, delaying that request by one more chunk of MFMAs costs more than the chunk hides.
-        // (every lane loads -- the non-watching lanes an arbitrary flag word -- and on every step: under a condition the
-        //  compiler folds the test into the branch and waits for the load on the spot)
-        const unsigned flagA = __hip_atomic_load(cflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- x_t W_ih^T (independent of h: this is what fills the exchange latencies); chunk 0 was multiplied at
         // the end of the previous step, the first LDS-resident chunk is fetched here
         lds_fetch(0, C::BIG ? 0 : 2);
@@ -344,61 +369,67 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
 #ifndef X3_SKIP_PROJ
 #pragma unroll
         for (int c = 1; c < XRC; ++c) {
-            chunk_mma(xw[c][0], xw[c][1], wxr[c]);
+            chunk_mma(xsel(xw[c][0], step), xsel(xw[c][1], step), wxr[c]);
             __builtin_amdgcn_sched_barrier(0);
         }
 #endif
 #ifndef X3_SKIP_PROJ
 #pragma unroll
-        for (int c = 0; c < XL_EARLY; ++c) lds_chunk_mma(c, xw[XRC + c][0], xw[XRC + c][1]);
+        for (int c = 0; c < XL_EARLY; ++c) lds_chunk_mma(c, xsel(xw[XRC + c][0], step), xsel(xw[XRC + c][1], step));
 #endif
         TR(7);
         PROF_E(0); PROF_T(1);
 
-        // ---- h_{step-1}: once the flags are up, fetch the producers' blocks (16-byte loads that bypass the L1) ...
-        u32x4 blk[WPL / 4];
-        if (step > 0) {
-            unsigned spins = 0;
-            bool timed_out = false;
-            bool ready = !cwatch || flagA >= (unsigned)step;
-            if (PROF && prof && !__all(ready)) pt[5] += 1;      // steps whose first look came too early
-            while (!__all(ready)) {
-                if (++spins > spin_budget) { timed_out = true; break; }
-                if (cwatch) ready = __hip_atomic_load(cflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)step;
-            }
-            if (timed_out) {                                   // bounded: flag the error and never wait again
-                if (lane == 0) atomicExch(a.err, 1 + step);
-                spin_budget = 0;
-            }
-            TR(1);
-        }
+        // ---- h_{step-1}: request the producers' blocks (16-byte loads that bypass the L1) -- optimistically: every word
+        // carries its own epoch tag, the peers are in the same phase and published a chunk of MFMAs ago, so the words are
+        // normally there; they are checked below, after the MFMAs that hide the flight.
         // The fetch is issued on EVERY step, also on step 0 where its result is not used: inside `if (step > 0)` the
         // compiler has to merge the two paths' wait counts and then waits for these loads as soon as an older load (the x
         // words of the chunks below) is needed -- which serialises the fetch and the MFMAs that are meant to hide it.
-        asm volatile("" ::: "memory");                       // (compiler fence: the fetch stays behind the flag test)
-        {
-            const int poff_b = (int)(((step + 1) & 1) * 16 * H) * 4;
-#pragma unroll
-            for (int i = 0; i < WPL / 4; ++i)
-                blk[i] = __builtin_amdgcn_raw_buffer_load_b128(hxrsrc, csrc_byte + poff_b + 16 * i, 0, 16 /* sc1 */);
-        }
+        fetch_blocks(step - 1);
+        TR(1);
         __builtin_amdgcn_sched_barrier(0);                     // (the MFMAs below stay below the fetch)
         PROF_E(1); PROF_T(0);
         // ---- ... and multiply what is left of x_t W_ih^T while they are in flight
 #ifndef X3_SKIP_PROJ
 #pragma unroll
-        for (int c = XL_EARLY; c < XLC; ++c) lds_chunk_mma(c, xw[XRC + c][0], xw[XRC + c][1]);
+        for (int c = XL_EARLY; c < XLC; ++c) lds_chunk_mma(c, xsel(xw[XRC + c][0], step), xsel(xw[XRC + c][1], step));
 #endif
         // K_in = 512: the x words of the LDS-resident chunks are dead now -- fetch the next step's right away (issued
         // after the block fetch, so the staging wait below does not include them; a full step of latency to hide in)
         if (SPLIT_X) load_x(step + 1, XC_PRE, NXC);
         PROF_E(0); PROF_T(1);
-        // ---- stage the blocks in LDS and read this lane's A fragments of the recurrent product from there
+        // ---- check the tags (refetch until every word of the block is of epoch step-1: bounded), stage the blocks in LDS
+        // and read this lane's A fragments of the recurrent product from there
         if (step > 0) {
+            const unsigned want = tag_of_step(step - 1);
+            auto stale = [&]() {
+                unsigned m = 0;
+#pragma unroll
+                for (int i = 0; i < WPL / 4; ++i) m |= (blk[i][0] ^ want) | (blk[i][1] ^ want) | (blk[i][2] ^ want) | (blk[i][3] ^ want);
+                return (m & 1u) != 0;
+            };
+            bool late = stale();
+            if (!__all(!late)) {
+                if (PROF && prof) pt[5] += 1;                   // steps whose optimistic fetch came too early
+                unsigned spins = 0;
+                do {
+                    if (++spins > spin_budget) {                // bounded: flag the error and never wait again
+                        if (lane == 0) atomicExch(a.err, 1 + step);
+                        spin_budget = 0;
+                        break;
+                    }
+                    if (late) {
+                        fetch_blocks(step - 1);
+                        late = stale();
+                    }
+                } while (!__all(!late));
+            }
             // (shared with the reduction buffer: every wave must be done with the previous step's partial sums)
             if (C::HT_ALIAS) __syncthreads();
 #pragma unroll
-            for (int i = 0; i < WPL / 4; ++i) *reinterpret_cast<u32x4*>(cdst + 4 * i) = blk[i];
+            for (int i = 0; i < WPL / 4; ++i)
+                *reinterpret_cast<u32x4*>(cdst + 4 * i) = blk[i] & u32x4{~1u, ~1u, ~1u, ~1u};
             __syncthreads();
 #pragma unroll
             for (int c = 0; c < NHC; ++c) {
@@ -459,37 +490,32 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
             hst = og * tanhf_(cst);
             oval = hst;
         }
-        const unsigned hp = pair_of(hst);
+        // the x words of the chunks that are multiplied before the next fetch must have arrived BEFORE the stores below are
+        // issued: a wait for them afterwards (one in-order counter) would wait for the stores' acknowledgements as well
+#pragma unroll
+        for (int c = 0; c < XRC; ++c) asm volatile("" :: "v"(xw[c][0]), "v"(xw[c][1]));
+        const unsigned hp = hpair_of(hst);
+        const unsigned hpt = hp | tag_of_step(step);
         const size_t doff = (size_t)(step & 1) * 16 * H;
-        __hip_atomic_store(pdstL + doff, hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // -> this XCD's L2
-        if (!all_local) __hip_atomic_store(pdstR + doff, hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
-        // next step's first register chunk while the stores travel (x_{t+1} was prefetched after the staging above)
+        store_word_xcd(pdstL + doff, hpt);
+        if (!all_local) store_word_dev(pdstR + doff, hpt);
+#ifdef X3_SKIP_OUT
+        if (inb && step == T - 1) {
+#else
+        if (inb) {
+#endif
+            unsigned* op = reinterpret_cast<unsigned*>(d.out + ((size_t)tt * B + bown) * d.outStride + jown);
+            store_word_plain(op, a.out_pairs ? (act ? pair_of(hst) : 0u) : __float_as_uint(oval));
+        }
+        // next step's first register chunk while the stores travel (x_{t+1} was prefetched after the staging above); nobody
+        // waits for an acknowledgement: the tagged words are the publication
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifndef X3_SKIP_PROJ
-        chunk_mma(xw[0][0], xw[0][1], wxr[0]);
+        chunk_mma(xsel(xw[0][0], step + 1), xsel(xw[0][1], step + 1), wxr[0]);
 #endif
         __builtin_amdgcn_sched_barrier(0);
-#ifdef X3_SKIP_OUT
-        if (inb && step == T - 1) {
-#else
-        if (inb) {                                            // (before the wait: no store may be pending after it)
-#endif
-            float* op = d.out + ((size_t)tt * B + bown) * d.outStride + jown;
-            if (a.out_pairs) *reinterpret_cast<unsigned*>(op) = act ? hp : 0u;
-            else *op = oval;
-        }
-        // this wave's flag: raised once all of its stores of the step have been acknowledged
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // (the same wait once more as a builtin: it costs nothing and tells the compiler's wait-count bookkeeping that no
-        //  store is outstanding any more -- with loads and stores both pending it falls back to vmcnt(0) for every later wait,
-        //  e.g. it would wait for the x prefetch when only the hidden-state blocks are needed)
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        if (lane == 0) {
-            __hip_atomic_store(flagsL + slice * 16 + wave, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (!all_local) __hip_atomic_store(flagsR + slice * 16 + wave, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         TR(5);
         PROF_E(4);
     }
@@ -553,11 +579,10 @@ void launch_x3(const LstmPersistArgs& a, hipStream_t s) {
     }
 }
 
-// Re-arm the exchange area before a launch: only the words that are POLLED need zeroing -- the epoch flags of both
-// transports and the XCC table of every cluster (2.2 KB of each 131 KB cluster); the untagged data blocks are only
-// read after their flag went up.  (A 7 us memset node of the whole area per layer becomes a 2 us kernel.)
+// Re-arm (zero) the exchange areas of `ncl` clusters as a kernel of its own -- normally the kernel that runs before the
+// layer does it on the way (mp_gemm_x3 for layer 0, the layer-0 launch for layer 1)
 MP_KERNEL void mp_zero_exchange_x3(unsigned long long* hx, int ncl) {
-    if ((int)blockIdx.x < ncl) rearm_exchange_cluster(hx, blockIdx.x, threadIdx.x, blockDim.x);
+    rearm_exchange(hx, ncl, blockIdx.x, gridDim.x, threadIdx.x, blockDim.x);
 }
 
 }  // namespace
