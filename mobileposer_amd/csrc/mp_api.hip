@@ -724,19 +724,22 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         // the r6d/IK kernel go to side streams.
         auto rec = [&](int i, hipStream_t on) -> int { HIPCHK(h, hipEventRecord(h->ev_x[i], on)); return MP_OK; };
         auto wait = [&](int i, hipStream_t on) -> int { HIPCHK(h, hipStreamWaitEvent(on, h->ev_x[i], 0)); return MP_OK; };
-        HIPCHK(h, hipStreamWaitEvent(sp, h->ev_j, 0));
-        RC(rnn_g0(P, sp)); RC(rec(0, sp));                       // linear1 of the three blocks, concurrently
-        RC(rnn_g0(V, sv)); RC(rec(1, sv));
+        // (every cross-stream edge into a node of the critical chain costs 8-20 us of graph dependency resolution, so the
+        //  chain joints -> pose linear1 -> pose layers -> velocity layers -> velocity linear2 stays on s_main and the one
+        //  edge it needs from a side stream -- velocity's linear1 -- is taken early, in front of the pose layers)
+        RC(rnn_g0(V, sv)); RC(rec(1, sv));                       // linear1 of the three blocks, concurrently
         RC(rnn_g0(F, sf));
-        RC(wait(0, sm)); RC(rnn_rec(P, 0, sm)); RC(rnn_rec(P, 1, sm)); RC(rec(2, sm));      // net.py:106-107
+        RC(rnn_g0(P, sm));
+        RC(rnn_rec(P, 0, sm)); RC(rnn_rec(P, 1, sm)); RC(rec(2, sm));                       // net.py:106-107
+        // (captured BEFORE the side-stream work that hangs off the same event: the graph launches the successors of a
+        //  node in creation order, and the velocity layers are the critical chain)
+        RC(wait(1, sm)); RC(rnn_rec(V, 0, sm)); RC(rnn_rec(V, 1, sm)); RC(rnn_g2(V, sm));   // net.py:117
+        HIPCHK(h, hipEventRecord(h->ev_v, sm));
         RC(wait(2, sp)); RC(rnn_g2(P, sp));
         { SegScope seg(h, sp, 2, 1);
           mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sp); }   // net.py:110
         if (fk_rglobal) mp_launch_fk(pose, nullptr, poseRows, h->bone_dev, h->parent_dev, h->depth_dev, fk_rglobal, fk_joint, sp);
         RC(rec(3, sp));
-        RC(wait(1, sm)); RC(rnn_rec(V, 0, sm)); RC(rnn_rec(V, 1, sm)); RC(rec(4, sm));      // net.py:117
-        RC(wait(4, sv)); RC(rnn_g2(V, sv));
-        HIPCHK(h, hipEventRecord(h->ev_v, sv));
         RC(wait(2, sf)); RC(rnn_rec(F, 0, sf)); RC(rnn_rec(F, 1, sf)); RC(rnn_g2(F, sf));   // net.py:113-114
         HIPCHK(h, hipEventRecord(h->ev_f, sf));
         RC(wait(3, sm));
