@@ -32,7 +32,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA p
 X3_NAMES = {         # the same timing classes when the H = 256 blocks run on split-bf16 operands (--lstm-mode x3)
     0: "mp_gemm_x3 (linear1 / linear2 of the H=256 blocks) + mp_gemm_f32 (foot-contact block)",
     1: "mp_lstm_x3<8,256> bidirectional layer 0 (joints, pose)",
-    4: "mp_lstm_x3<8,512> bidirectional layer 1 (joints, pose)",
+    4: "mp_lstm_x3w<512> bidirectional layer 1 (joints, pose)",
     5: "mp_lstm_x3<8,256> unidirectional layers (velocity; 128 workgroups)",
 }
 
@@ -323,7 +323,7 @@ def main():
         key = {1: "mp_lstm_fused<256, 8, 256, 2, false>", 4: "mp_lstm_fused<256, 8, 512, 2, false>",
                5: "mp_lstm_fused<256, 16, 256, 1, false>", 0: "mp_gemm_f32<2, 2, 2, 2>"}.get(dominant)
         if args.lstm_mode == "x3":
-            key = {1: "mp_lstm_x3<8, 256, false>", 4: "mp_lstm_x3<8, 512, false>", 5: "mp_lstm_x3<8, 256, false>",
+            key = {1: "mp_lstm_x3<8, 256, false>", 4: "mp_lstm_x3w<512, false>", 5: "mp_lstm_x3<8, 256, false>",
                    0: "mp_gemm_x3<128, 64>"}.get(dominant)
         traffic = pmc[key]["hbm_bytes_per_launch_corrected"] if key in pmc else None
     except Exception:

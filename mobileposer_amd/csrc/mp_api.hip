@@ -152,6 +152,8 @@ struct mp_handle {
                                      // longer run beside the velocity block and the forward as a whole gets slower.
     bool x3 = true;                  // H = 256 layers on split-bf16 MFMA operands (mp_lstm_x3.hip, the default): mode 3;
                                      // mp_set_lstm_mode(h, 1) / MP_LSTM_MODE=fp32 selects exact-fp32 MFMA operands instead
+    int x3w_mask = 2;                // split-bf16 layers run by the 4-wave kernel mp_lstm_x3w: bit 0 K_in = 256, bit 1 K_in = 512
+                                     // (default: the K_in = 512 layers, measured 373 vs 391 us; K_in = 256: 300 vs 285 us; env MP_X3W)
     int nslice_env = 0;              // 0: pick per module (8 slices / 8 waves for bidirectional layers that fill the
                                      // chip, 16 slices / 4 waves for unidirectional ones); env MP_LSTM_SLICES=8|16 forces one             // LSTM recurrence: persistent kernel (default) or per-step launches
     std::map<std::pair<int, int>, Plan*> plans;
@@ -320,6 +322,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
         h->x3 = h->persist && strcmp(e, "fp32") != 0;          // "x3" (default) | "fp32" | "step"
     }
     if (const char* e = getenv("MP_LSTM_UNI2")) h->uni2 = e[0] == '1';
+    if (const char* e = getenv("MP_X3W")) h->x3w_mask = atoi(e) & 3;
     if (const char* e = getenv("MP_LSTM_SLICES")) h->nslice_env = atoi(e) == 8 ? 8 : (atoi(e) == 16 ? 16 : 0);
     if (getenv("MP_PERSIST_PROF")) {
         if (hipMalloc((void**)&h->prof_dev, kProfWords * sizeof(long long)) != hipSuccess) h->prof_dev = nullptr;
@@ -610,7 +613,8 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
                 dd.wihpack = x3 ? m.wihX[l][d] : m.wihP[l][d]; dd.bias = m.ih[l].bias + (size_t)d * 4 * H; dd.xin = xin;
             }
             if (dirs == 1) a.d[1] = a.d[0];
-            if (x3) mp_launch_lstm_x3(a, kin, nsl, s);
+            if (x3 && nsl == 8 && (h->x3w_mask & (kin == 256 ? 1 : 2))) mp_launch_lstm_x3w(a, kin, s);
+            else if (x3) mp_launch_lstm_x3(a, kin, nsl, s);
             else mp_launch_lstm_persist(a, H, kin, nsl, s);
         }
     } else {

@@ -13,22 +13,7 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BK = 32, LDK = 36;
-
-__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ void split_pairs(u32x4 w0, u32x4 w1, u32x4& hi, u32x4& lo) {
-    hi[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x07060302u);
-    hi[1] = __builtin_amdgcn_perm(w0[3], w0[2], 0x07060302u);
-    hi[2] = __builtin_amdgcn_perm(w1[1], w1[0], 0x07060302u);
-    hi[3] = __builtin_amdgcn_perm(w1[3], w1[2], 0x07060302u);
-    lo[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x05040100u);
-    lo[1] = __builtin_amdgcn_perm(w0[3], w0[2], 0x05040100u);
-    lo[2] = __builtin_amdgcn_perm(w1[1], w1[0], 0x05040100u);
-    lo[3] = __builtin_amdgcn_perm(w1[3], w1[2], 0x05040100u);
-}
 
 template <int BN, int BM>
 MP_KERNEL __launch_bounds__(256) void mp_gemm_x3(GemmArgs g, int nTilesM, int nTilesN) {

@@ -79,3 +79,40 @@ static __device__ __forceinline__ void rearm_exchange(unsigned long long* hx, in
     u32x4* w = reinterpret_cast<u32x4*>(hx);
     for (size_t i = lo + tid; i < hi; i += nthreads) w[i] = u32x4{0u, 0u, 0u, 0u};
 }
+
+// ---- shared by the split-bf16 LSTM kernels (mp_lstm_x3.hip, mp_lstm_x3w.hip)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+static __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// 8 pair words (k = e) -> hi fragment (8 bf16, element e in the low/high half of dword e/2) and lo fragment
+static __device__ __forceinline__ void split_pairs(u32x4 w0, u32x4 w1, u32x4& hi, u32x4& lo) {
+    hi[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x07060302u);
+    hi[1] = __builtin_amdgcn_perm(w0[3], w0[2], 0x07060302u);
+    hi[2] = __builtin_amdgcn_perm(w1[1], w1[0], 0x07060302u);
+    hi[3] = __builtin_amdgcn_perm(w1[3], w1[2], 0x07060302u);
+    lo[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x05040100u);
+    lo[1] = __builtin_amdgcn_perm(w0[3], w0[2], 0x05040100u);
+    lo[2] = __builtin_amdgcn_perm(w1[1], w1[0], 0x05040100u);
+    lo[3] = __builtin_amdgcn_perm(w1[3], w1[2], 0x05040100u);
+}
+// ---- the exchanged hidden-state word: a pair whose lo part is rounded (to nearest even) to 7 mantissa bits, so that bit 0
+// is free for the epoch tag of the exchange; tag of the h written at `step` = ((step / 2) + 1) & 1 (see the kernel header)
+static __device__ __forceinline__ unsigned hpair_of(float x) {
+    const unsigned w = pair_of(x);
+    return (w + ((w >> 1) & 1u)) & ~1u;
+}
+static __device__ __forceinline__ unsigned tag_of_step(int step) { return (((unsigned)step >> 1) + 1u) & 1u; }
+// stores of the exchange as inline asm: the compiler's s_waitcnt bookkeeping must not see a store in the loop (with loads
+// AND stores pending it waits with vmcnt(0) everywhere); nothing ever waits for these stores -- the data is its own flag
+static __device__ __forceinline__ void store_word_xcd(unsigned* p, unsigned v) {          // stays in this XCD's L2
+    asm volatile("global_store_dword %0, %1, off sc0" :: "v"(p), "v"(v) : "memory");
+}
+static __device__ __forceinline__ void store_word_dev(unsigned* p, unsigned v) {          // write-through: visible device-wide
+    asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+static __device__ __forceinline__ void store_word_plain(unsigned* p, unsigned v) {
+    asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory");
+}
+

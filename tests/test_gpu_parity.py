@@ -389,6 +389,33 @@ def test_hidden_state_transports_agree(torch_mod, net):
             assert torch_mod.equal(a, b)
 
 
+def test_split_bf16_kernel_variants_agree(torch_mod, weights, smpl, monkeypatch):
+    """The two split-bf16 layer kernels (mp_lstm_x3: eight 256-register waves per workgroup; mp_lstm_x3w: four
+    512-register waves, inline-asm MFMAs with AccVGPR operands) do the same arithmetic in the same order: whichever of them runs the K_in = 256 /
+    K_in = 512 layers (MP_X3W bit mask, default 2), the outputs are bitwise identical -- full-chip batch, ragged
+    lengths, and a continued velocity state.  (This is also the check on the hand-placed MFMA wait states of mp_lstm_x3w.)"""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    B, T = 256, 40
+    x = cu(torch_mod, synthetic.make_imu(B, T, seed=31))
+    rng = np.random.default_rng(5)
+    lengths = [int(v) for v in rng.integers(1, T + 1, size=B)]
+    lengths[0] = T
+    outs = {}
+    for mask in (0, 1, 2, 3):
+        monkeypatch.setenv("MP_X3W", str(mask))
+        n = MobilePoserNet.from_numpy(weights, smpl, device="cuda:0")
+        n.set_lstm_mode(3)
+        o1 = [t.clone() for t in n.forward(x, lengths)]
+        o2 = [t.clone() for t in n.forward(x, lengths)]          # second call: velocity continues from its state (Q1)
+        assert n.device_error() == 0
+        outs[mask] = o1 + o2
+        n.close()
+    for mask in (1, 2, 3):
+        for a, b in zip(outs[0], outs[mask]):
+            assert torch_mod.equal(a, b), "MP_X3W=%d differs from MP_X3W=0 by %g" % (mask, float((a - b).abs().max()))
+
+
 @pytest.mark.parametrize("B,T", [(1, 1), (1, 2), (17, 3), (2, 45)])
 def test_tiny_shapes_vs_oracle(torch_mod, net, weights, smpl, B, T):
     """Edge shapes: single frame, single sequence, a slab with one valid row, the online window length."""

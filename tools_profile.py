@@ -23,7 +23,7 @@ PMC_GROUPS = [["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], ["FETCH_SIZE"], [
 
 def short(name):
     name = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
-    for tail in ("(LstmPersistArgs)", "(LstmStepArgs)", "(GemmArgs, int, int)"):
+    for tail in ("(LstmPersistArgs)", "(LstmStepArgs)", "(GemmArgs, int, int)"):  # noqa
         name = name.replace(tail, "")
     return name.split("(")[0] if name.startswith("mp_") or name.startswith("__amd") else name[:70]
 
