@@ -104,8 +104,6 @@ void mp_launch_lstm_uni2(const LstmPersistArgs& a, hipStream_t s);
 void mp_launch_lstm_x3(const LstmPersistArgs& a, int KIN, int nslice, hipStream_t s);
 void mp_launch_lstm_x3w(const LstmPersistArgs& a, int KIN, hipStream_t s);   // four 512-register waves per workgroup (8 slices)
 void mp_launch_pack_w_x3(const float* w, float* dst, int K, int nslice, hipStream_t s);
-// zero the polled words (flags, XCC table) of `ncl` clusters of an exchange area before a split-bf16 launch
-void mp_launch_zero_exchange_x3(unsigned long long* hx, int ncl, hipStream_t s);
 
 // ---------------------------------------------------------------- K4/K5: kinematics
 void mp_launch_r6d_ik(const float* r6d, long N, float* pose, const int* parent_dev, hipStream_t s);

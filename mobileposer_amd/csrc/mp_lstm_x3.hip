@@ -544,17 +544,7 @@ void launch_x3(const LstmPersistArgs& a, hipStream_t s) {
     }
 }
 
-// Re-arm (zero) the exchange areas of `ncl` clusters as a kernel of its own -- normally the kernel that runs before the
-// layer does it on the way (mp_gemm_x3 for layer 0, the layer-0 launch for layer 1)
-MP_KERNEL void mp_zero_exchange_x3(unsigned long long* hx, int ncl) {
-    rearm_exchange(hx, ncl, blockIdx.x, gridDim.x, threadIdx.x, blockDim.x);
-}
-
 }  // namespace
-
-void mp_launch_zero_exchange_x3(unsigned long long* hx, int ncl, hipStream_t s) {
-    hipLaunchKernelGGL(mp_zero_exchange_x3, dim3(ncl), dim3(256), 0, s, hx, ncl);
-}
 
 // H = 256 only; nslice 8 (8-wave workgroups) or 16 (4-wave workgroups, two per CU); K = 256 | 512
 void mp_launch_pack_w_x3(const float* w, float* dst, int K, int nslice, hipStream_t s) {
