@@ -47,6 +47,7 @@ static __device__ __forceinline__ unsigned bf16_rne_bits(float x) {
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;             // finite inputs only (activations and weights)
 }
 static __device__ __forceinline__ unsigned pair_of(float x) {
+#pragma clang fp contract(off)
 #ifdef MP_PAIR_SWCVT
     const unsigned hi = bf16_rne_bits(x);                        // integer form, kept as the cross-check
     const float rest = x - __uint_as_float(hi << 16);           // exact in fp32
@@ -56,7 +57,10 @@ static __device__ __forceinline__ unsigned pair_of(float x) {
     // forward is bit-identical to the integer form above (checked on the 256 x 125 batch, 30 repetitions).
     const __bf16 h = (__bf16)x;
     const unsigned hi = __builtin_bit_cast(unsigned short, h);
-    const __bf16 l = (__bf16)(x - __uint_as_float(hi << 16));  // the difference is exact in fp32
+    // (the difference is exact in fp32.  `fp contract(off)` above: with x = a * b the compiler would otherwise fuse the
+    //  subtraction into fma(a, b, -hi), i.e. take the residual of the UNROUNDED product -- a lo part that differs in its
+    //  last bit from the pair of the fp32 value, and only in those instantiations where the scheduler happens to see it)
+    const __bf16 l = (__bf16)(x - __uint_as_float(hi << 16));
     return (hi << 16) | (unsigned)__builtin_bit_cast(unsigned short, l);
 #endif
 }

@@ -72,12 +72,23 @@ struct CfgX {
     static constexpr int LPB = 64 / PPW;              // lanes that share one producer block (64 | 16)
     static constexpr int WPL = 16 * U / LPB;          // 32-bit words per lane (8 | 16)
     static constexpr int PARTS = U / WPL;             // lanes per row of a block (4 | 1)
-    static constexpr int HPITCH = H + 4;              // LDS row pitch of the staged h tile (conflict-free b128 reads)
+    // x sharing (8-wave packing, K_in = 256): the two waves (kq, tw = 0 | 1) that own the two unit blocks of a K quarter
+    // need the same x words.  Each of them loads ONE of the quarter's two chunks (two steps ahead), passes it to its
+    // partner through a 16 KB LDS tile and reads the other chunk from there: a CU pulls 16 KB of x per step through its
+    // L1 instead of 32 KB (the loads cost 8 % of such a layer; K_in = 512 has no LDS left for this -- mp_lstm_x3w.hip).
+    // The 16 KB come from an unpadded, XOR-swizzled h tile (the budget closes with 0 bytes to spare).
+#ifndef X3_XSHARE
+#define X3_XSHARE 1
+#endif
+    static constexpr bool XSHARE = X3_XSHARE && TW == 2 && KIN == H;
+    static constexpr bool SWZ = XSHARE;
+    static constexpr int HPITCH = SWZ ? H : H + 4; // LDS row pitch of the staged h tile (conflict-free b128 reads: padding | swizzle)
     static constexpr int HT_BYTES = 16 * HPITCH * 4;
+    static constexpr int XT_BYTES = XSHARE ? 4 * NXC * 64 * 32 : 0;   // [kq][chunk][lane][8 words]
     // K_in = 512 has no LDS left: the h tile shares the (single) reduction buffer -- the barriers of the step
     // separate the two uses (h tile: written .. barrier .. read | barrier | partial sums: written .. barrier .. read)
     static constexpr bool HT_ALIAS = KIN > H;
-    static constexpr int LDS_BYTES = RED_BUFS * RED_F4 * 16 + NWV * XLC * CH_U4 * 16 + (HT_ALIAS ? 0 : HT_BYTES);
+    static constexpr int LDS_BYTES = RED_BUFS * RED_F4 * 16 + NWV * XLC * CH_U4 * 16 + (HT_ALIAS ? 0 : HT_BYTES) + XT_BYTES;
     static_assert(LDS_BYTES <= (NSLICE == 16 ? 80 : 160) * 1024, "LDS budget (two workgroups per CU for the 4-wave packing)");
 };
 
@@ -203,12 +214,20 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
     // the chunk multiplied under the fetch) silently waits for the fetch as well -- no overlap at all
     const __amdgpu_buffer_rsrc_t hxrsrc = __builtin_amdgcn_make_buffer_rsrc(hxw, 0, (int)(SLABW * 8), 0x27000);
     const int csrc_byte = (int)((csrc - hxw) * 4);
-    unsigned* cdst = hT + crow * HPITCH + cprod * U + cpart * WPL;
+    // (16-byte unit u of row r lives at unit u ^ (r & 7) when the tile is unpadded: XSHARE)
+    auto hT_off = [&](int row, int unit) { return row * HPITCH + ((C::SWZ ? unit ^ (row & 7) : unit) << 2); };
+    int cdst_off[WPL / 4];
+#pragma unroll
+    for (int i = 0; i < WPL / 4; ++i) cdst_off[i] = hT_off(crow, (cprod * U + cpart * WPL) / 4 + i);
     // producer role: this lane's (row q*4+kq, unit jown) word of the slice's block
     unsigned* pdstL = dataL + (size_t)slice * 16 * U + (q * 4 + kq) * U + (jown - slice * U);
     unsigned* pdstR = dataR + (size_t)slice * 16 * U + (q * 4 + kq) * U + (jown - slice * U);
     // reader role: A fragments of the recurrent product from the LDS tile
-    const unsigned* hrd = hT + r16 * HPITCH + kq * 64 + q * 8;
+    int hrd_off[NHC][2];
+#pragma unroll
+    for (int c = 0; c < NHC; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) hrd_off[c][j] = hT_off(r16, kq * 16 + c * 8 + q * 2 + j);
 
     // ---- x_0: pair words of this lane's row, chunk c: k = kq*KQ + c*32 + q*8 + e
     u32x4 xw[NXC][2];
@@ -241,6 +260,28 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         xq[0] = *reinterpret_cast<const u32x4*>(p);
         xq[1] = *reinterpret_cast<const u32x4*>(p + 4);
     };
+    // x sharing: xw[0] / xw[1] hold this wave's OWN chunk (tw) and the partner's chunk of the current x; xqa / xqb are the
+    // own chunk two steps ahead (two sets that alternate: the step loop is unrolled by two, no copies on the back edge)
+    unsigned* xT = hT + 16 * HPITCH;                          // [kq][chunk][lane][8 words]
+    const unsigned* xown = xbase + tw * 32;
+    const bool tw0 = tw == 0;
+    u32x4 xqa[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}}, xqb[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+    auto load_own = [&](u32x4 (&dst)[2], int step) {
+        const bool on = step < alen;
+        const int t = on ? (d.reverse ? alen - 1 - step : step) : 0;
+        const unsigned* p = xown + (size_t)t * xtstride;
+        dst[0] = *reinterpret_cast<const u32x4*>(p);
+        dst[1] = *reinterpret_cast<const u32x4*>(p + 4);
+    };
+    // chunk c of the current x from (own, partner's): a wave-uniform select
+    auto xpick = [&](int c, int k) { return (c == 0) == tw0 ? xw[0][k] : xw[1][k]; };
+    if constexpr (C::XSHARE) {
+        // (x_0 was loaded in full by every wave: xw[c] = chunk c; re-label as (own, partner's))
+        const u32x4 o0 = tw0 ? xw[0][0] : xw[1][0], o1 = tw0 ? xw[0][1] : xw[1][1];
+        const u32x4 p0 = tw0 ? xw[1][0] : xw[0][0], p1 = tw0 ? xw[1][1] : xw[0][1];
+        xw[0][0] = o0; xw[0][1] = o1; xw[1][0] = p0; xw[1][1] = p1;
+        load_own(xqa, 1);
+    }
     __syncthreads();                                          // W_ih LDS image complete
 
     long long pt[6] = {0, 0, 0, 0, 0, 0};
@@ -300,9 +341,10 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifndef X3_SKIP_PROJ
-    chunk_mma(xsel(xw[0][0], 0), xsel(xw[0][1], 0), wxr[0]);
+    if constexpr (C::XSHARE) chunk_mma(xsel(xpick(0, 0), 0), xsel(xpick(0, 1), 0), wxr[0]);
+    else chunk_mma(xsel(xw[0][0], 0), xsel(xw[0][1], 0), wxr[0]);
 #endif
-    if constexpr (!C::BIG) load_xq(1);
+    if constexpr (!C::BIG && !C::XSHARE) load_xq(1);
 
     // the blocks of the h written at step `pstep` (parity pstep & 1)
     u32x4 blk[WPL / 4];
@@ -313,7 +355,9 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
             blk[i] = __builtin_amdgcn_raw_buffer_load_b128(hxrsrc, csrc_byte + poff_b + 16 * i, 0, 16 /* sc1 */);
     };
 
-    for (int step = 0; step < T; ++step) {
+    // one time step.  (xqc, xqn): x sharing only -- xqc holds the own chunk of x_{step+1} (requested during step-1), xqn
+    // receives the own chunk of x_{step+2}
+    auto body = [&](int step, u32x4 (&xqc)[2], u32x4 (&xqn)[2]) {
         PROF_T(0);
 #ifdef X3_TRACE
         long long* tr = (PROF && a.prof && lane == 0 && step >= 64 && step < 96) ? a.prof + 4096 + ((size_t)(blockIdx.x * 8 + wave) * 32 + (step - 64)) * 8 : nullptr;
@@ -358,7 +402,10 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         // ---- ... and multiply what is left of x_t W_ih^T while they are in flight
 #ifndef X3_SKIP_PROJ
 #pragma unroll
-        for (int c = XL_EARLY; c < XLC; ++c) lds_chunk_mma(c, xsel(xw[XRC + c][0], step), xsel(xw[XRC + c][1], step));
+        for (int c = XL_EARLY; c < XLC; ++c) {
+            if constexpr (C::XSHARE) lds_chunk_mma(c, xsel(xpick(1, 0), step), xsel(xpick(1, 1), step));
+            else lds_chunk_mma(c, xsel(xw[XRC + c][0], step), xsel(xw[XRC + c][1], step));
+        }
 #endif
         // K_in = 512: the x words of the LDS-resident chunks are dead now -- fetch the next step's right away (issued
         // after the block fetch, so the staging wait below does not include them; a full step of latency to hide in)
@@ -394,12 +441,12 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
             if (C::HT_ALIAS) __syncthreads();
 #pragma unroll
             for (int i = 0; i < WPL / 4; ++i)
-                *reinterpret_cast<u32x4*>(cdst + 4 * i) = blk[i] & u32x4{~1u, ~1u, ~1u, ~1u};
+                *reinterpret_cast<u32x4*>(hT + cdst_off[i]) = blk[i] & u32x4{~1u, ~1u, ~1u, ~1u};
             __syncthreads();
 #pragma unroll
             for (int c = 0; c < NHC; ++c) {
-                hw[c][0] = *reinterpret_cast<const u32x4*>(hrd + c * 32);
-                hw[c][1] = *reinterpret_cast<const u32x4*>(hrd + c * 32 + 4);
+                hw[c][0] = *reinterpret_cast<const u32x4*>(hT + hrd_off[c][0]);
+                hw[c][1] = *reinterpret_cast<const u32x4*>(hT + hrd_off[c][1]);
             }
         }
         TR(2);
@@ -407,6 +454,13 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         if constexpr (C::BIG) {
             load_x(step + 1, 0, XC_PRE); // next step's x (the scheduler sinks these loads among the MFMAs below: measured better
                                          // than pinning them here, on the critical chain in front of the recurrent product)
+        } else if constexpr (C::XSHARE) {
+            // own chunk of x_{t+1} (requested a whole step ago): keep it, pass it to the partner wave; request x_{t+2}'s
+            xw[0][0] = xqc[0]; xw[0][1] = xqc[1];
+            unsigned* xo = xT + ((kq * 2 + tw) * 64 + lane) * 8;
+            *reinterpret_cast<u32x4*>(xo) = xqc[0];
+            *reinterpret_cast<u32x4*>(xo + 4) = xqc[1];
+            load_own(xqn, step + 2);
         } else {
             xw[0][0] = xq[0]; xw[0][1] = xq[1];               // x_{t+1} chunk 0, requested a whole step ago
             load_xq(step + 2);
@@ -435,6 +489,11 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         for (int dk = 0; dk < 4; ++dk)
             redb[((tw * 4 + dk) * 4 + kq) * 64 + lane] = f32x4{acc[0][dk], acc[1][dk], acc[2][dk], acc[3][dk]};
         barrier_lds_only();
+        if constexpr (C::XSHARE) {                            // the partner's chunk of x_{t+1} (written before this barrier)
+            const unsigned* xp = xT + ((kq * 2 + (1 - tw)) * 64 + lane) * 8;
+            xw[1][0] = *reinterpret_cast<const u32x4*>(xp);
+            xw[1][1] = *reinterpret_cast<const u32x4*>(xp + 4);
+        }
         f32x4 gate = redb[(wave * 4 + 0) * 64 + lane];
 #pragma unroll
         for (int sw = 1; sw < 4; ++sw) gate += redb[(wave * 4 + sw) * 64 + lane];
@@ -451,7 +510,8 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
             const float fg = sigmoidf_(gate[1]);
             const float gg = tanhf_(gate[2]);
             const float og = sigmoidf_(gate[3]);
-            cst = fg * cst + ig * gg;
+            cst = __builtin_fmaf(fg, cst, ig * gg);    // (explicit: which product gets fused must not depend on the compiler's mood --
+                                                       //  mp_lstm_x3w does the same and the two kernels are tested to agree bitwise)
             hst = og * tanhf_(cst);
             oval = hst;
         }
@@ -459,6 +519,7 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         // issued: a wait for them afterwards (one in-order counter) would wait for the stores' acknowledgements as well
 #pragma unroll
         for (int c = 0; c < XRC; ++c) asm volatile("" :: "v"(xw[c][0]), "v"(xw[c][1]));
+        if constexpr (C::XSHARE) asm volatile("" :: "v"(xw[1][0]), "v"(xw[1][1]));
         const unsigned hp = hpair_of(hst);
         const unsigned hpt = hp | tag_of_step(step);
         const size_t doff = (size_t)(step & 1) * 16 * H;
@@ -478,11 +539,20 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifndef X3_SKIP_PROJ
-        chunk_mma(xsel(xw[0][0], step + 1), xsel(xw[0][1], step + 1), wxr[0]);
+        if constexpr (C::XSHARE) chunk_mma(xsel(xpick(0, 0), step + 1), xsel(xpick(0, 1), step + 1), wxr[0]);
+        else chunk_mma(xsel(xw[0][0], step + 1), xsel(xw[0][1], step + 1), wxr[0]);
 #endif
         __builtin_amdgcn_sched_barrier(0);
         TR(5);
         PROF_E(4);
+    };
+    if constexpr (C::XSHARE) {
+        for (int step = 0; step < T; step += 2) {
+            body(step, xqa, xqb);
+            if (step + 1 < T) body(step + 1, xqb, xqa);
+        }
+    } else {
+        for (int step = 0; step < T; ++step) body(step, xqa, xqa);
     }
     if (PROF && prof) {
         long long* o = a.prof + (size_t)blockIdx.x * 8;

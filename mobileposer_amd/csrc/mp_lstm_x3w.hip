@@ -387,7 +387,7 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
                 og[ub] = sigmoidf_(gate[ub][3]);
             }
 #pragma unroll
-            for (int ub = 0; ub < UB; ++ub) cn[ub] = fg[ub] * cst[ub] + ig[ub] * gg[ub];
+            for (int ub = 0; ub < UB; ++ub) cn[ub] = __builtin_fmaf(fg[ub], cst[ub], ig[ub] * gg[ub]);
 #pragma unroll
             for (int ub = 0; ub < UB; ++ub) hn[ub] = og[ub] * tanhf_(cn[ub]);
 #pragma unroll
