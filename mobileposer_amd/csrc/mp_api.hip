@@ -215,7 +215,7 @@ int pack_weights(mp_handle* h, const float* blob) {
         // split-bf16 kernels: 8 slices (8-wave workgroups) for every H = 256 layer -- the unidirectional velocity
         // layers then occupy 128 CUs and leave the other half of the chip to the foot-contact block (measured:
         // 312 vs 326 us per velocity layer, foot-contact layers 200 vs 265 us)
-        m.nsliceX = h->nslice_env ? h->nslice_env : 8;
+        m.nsliceX = 8;                                   // (MP_LSTM_SLICES only concerns the fp32 kernels)
         if (int rc = alloc_packed(h, m.lin1, m.H, m.n_in)) return rc;
         if (int rc = alloc_packed(h, m.ih[0], m.dirs * 4 * m.H, m.H)) return rc;
         if (int rc = alloc_packed(h, m.ih[1], m.dirs * 4 * m.H, m.dirs * m.H)) return rc;

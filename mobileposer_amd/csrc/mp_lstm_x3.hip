@@ -616,20 +616,18 @@ void launch_x3(const LstmPersistArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// H = 256 only; nslice 8 (8-wave workgroups) or 16 (4-wave workgroups, two per CU); K = 256 | 512
+// H = 256 only, 8 slices; K = 256 | 512
 void mp_launch_pack_w_x3(const float* w, float* dst, int K, int nslice, hipStream_t s) {
     const size_t n = (size_t)4 * 256 * K;
     const int grid = (int)((n + 255) / 256);
-    if (nslice == 16) hipLaunchKernelGGL((mp_pack_w_x3<16>), dim3(grid), dim3(256), 0, s, w, reinterpret_cast<unsigned*>(dst), K);
-    else hipLaunchKernelGGL((mp_pack_w_x3<8>), dim3(grid), dim3(256), 0, s, w, reinterpret_cast<unsigned*>(dst), K);
+    (void)nslice;
+    hipLaunchKernelGGL((mp_pack_w_x3<8>), dim3(grid), dim3(256), 0, s, w, reinterpret_cast<unsigned*>(dst), K);
 }
 
 void mp_launch_lstm_x3(const LstmPersistArgs& a, int KIN, int nslice, hipStream_t s) {
-    if (nslice == 16) {
-        if (KIN == 256) launch_x3<16, 256>(a, s);
-        else launch_x3<16, 512>(a, s);
-    } else {
-        if (KIN == 256) launch_x3<8, 256>(a, s);
-        else launch_x3<8, 512>(a, s);
-    }
+    // (8 slices only: the 16-slice / two-workgroups-per-CU packing was measured slower on every layer -- DESIGN.md -- and is
+    //  no longer instantiated; `nslice` stays in the signature for the packing helper's sake)
+    (void)nslice;
+    if (KIN == 256) launch_x3<8, 256>(a, s);
+    else launch_x3<8, 512>(a, s);
 }
