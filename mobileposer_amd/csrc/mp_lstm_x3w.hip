@@ -12,6 +12,11 @@
 // K quarter), a wave may use all 512 registers of its SIMD lane, and K_in = 256 keeps all of W_ih in registers (no
 // LDS streaming at all); K_in = 512 keeps two of its four x chunks in LDS exactly as mp_lstm_x3 does.
 // The matrix pipe sees the same 96 (144) MFMAs per SIMD and step, now from one wave.
+// Recurrent A operand: chunk c of K quarter kq IS row r16 of producer slice 2*kq + c (32 units = one chunk), so a wave
+// fetches its A fragments straight from the producers' blocks -- 32 contiguous bytes per lane and chunk, the same 16 KB
+// per CU and step as whole blocks -- with no LDS tile and no workgroup barrier between the fetch and the recurrent MFMAs
+// (372 -> 354 us on the K_in = 512 layer).  In mp_lstm_x3 the two unit-block waves of a K quarter would both have to
+// fetch them (32 KB per CU and step): measured 391 -> 453 us there, which is why that kernel stages blocks in LDS.
 // Exchange protocol, data formats, k mapping: see mp_lstm_x3.hip.
 #include "mp_lstm_dev.h"
 #include <type_traits>
@@ -59,14 +64,7 @@ struct CfgW {
     static constexpr int XRC = NXC - XLC;             // x chunks whose W_ih fragments live in registers (2 | 2)
     static constexpr int RED_F4 = NWV * 4 * UB * 64;  // one reduction buffer: [finishing wave][source kq][unit block][lane]
     static constexpr int RED_BUFS = BIG ? 1 : 2;
-    static constexpr int PPW = NSLICE / NWV;          // producer slices per consumer wave (2)
-    static constexpr int LPB = 64 / PPW;              // lanes per producer block (32)
-    static constexpr int WPL = 16 * U / LPB;          // words per lane (16)
-    static constexpr int PARTS = U / WPL;             // lanes per row of a block (2)
-    static constexpr int HPITCH = H + 4;
-    static constexpr int HT_BYTES = 16 * HPITCH * 4;
-    static constexpr bool HT_ALIAS = BIG;             // K_in = 512: the h tile shares the (single) reduction buffer
-    static constexpr int LDS_BYTES = RED_BUFS * RED_F4 * 16 + NWV * XLC * UB * CH_U4 * 16 + (HT_ALIAS ? 0 : HT_BYTES);
+    static constexpr int LDS_BYTES = RED_BUFS * RED_F4 * 16 + NWV * XLC * UB * CH_U4 * 16;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -74,13 +72,11 @@ template <int KIN, bool PROF>
 MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
     using C = CfgW<KIN>;
     constexpr int H = 256, NSLICE = 8, U = 32, UB = 2, NWV = 4, KQ = C::KQ, NXC = C::NXC, NHC = C::NHC, XLC = C::XLC, XRC = C::XRC;
-    constexpr int FR = C::FR, CH_U4 = C::CH_U4, PPW = C::PPW, LPB = C::LPB, WPL = C::WPL, PARTS = C::PARTS, HPITCH = C::HPITCH;
+    constexpr int FR = C::FR, CH_U4 = C::CH_U4;
     constexpr int NTHREADS = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* red = reinterpret_cast<f32x4*>(smem);
     u32x4* wxl = reinterpret_cast<u32x4*>(smem) + C::RED_BUFS * C::RED_F4;   // [wave][LDS chunk][unit block][fragment][lane]
-    unsigned* hT = C::HT_ALIAS ? reinterpret_cast<unsigned*>(smem)
-                               : reinterpret_cast<unsigned*>(wxl + (size_t)NWV * XLC * UB * CH_U4);
 
     // block -> (cluster = (direction, slab), slice): as mp_lstm_x3 (slices of a cluster share an XCD)
     const int ncl = a.ndir * a.nslab;
@@ -183,19 +179,18 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
         if (__ballot(peer == ~0u)) spin_budget = 0;
         if (a.force_remote) { all_local = false; same = 0; }
     }
-    // consumer role: producer slice PPW*wave + lane/LPB; WPL consecutive words of row cli/PARTS of its [16][U] block
-    const int cprod = PPW * wave + lane / LPB;
-    const int cli = lane % LPB;
-    const int crow = cli / PARTS, cpart = cli % PARTS;
-    const bool cloc = (same >> cprod) & 1;
-    const unsigned* csrc = (cloc ? dataL : dataR) + (size_t)cprod * 16 * U + crow * U + cpart * WPL;
+    // consumer role: chunk c of this wave's K quarter = row r16 of producer slice 2*kq + c, units q*8 .. q*8+7
     const __amdgpu_buffer_rsrc_t hxrsrc = __builtin_amdgcn_make_buffer_rsrc(hxw, 0, (int)(SLABW * 8), 0x27000);
-    const int csrc_byte = (int)((csrc - hxw) * 4);
-    unsigned* cdst = hT + crow * HPITCH + cprod * U + cpart * WPL;
+    int dsrc_byte[NHC];
+#pragma unroll
+    for (int c = 0; c < NHC; ++c) {
+        const int p = 2 * kq + c;
+        const unsigned* src = (((same >> p) & 1) ? dataL : dataR) + (size_t)p * 16 * U + r16 * U + q * 8;
+        dsrc_byte[c] = (int)((src - hxw) * 4);
+    }
     // producer role: this lane's two words (row q*4 + wave, units ub*16 + r16) of the slice's block
     unsigned* pdstL = dataL + (size_t)slice * 16 * U + (q * 4 + wave) * U + r16;
     unsigned* pdstR = dataR + (size_t)slice * 16 * U + (q * 4 + wave) * U + r16;
-    const unsigned* hrd = hT + r16 * HPITCH + kq * 64 + q * 8;
 
     // ---- x: pair words of this lane's row, chunk c: k = kq*KQ + c*32 + q*8 + e.  Loads are unconditional (clamped row),
     // rows past their length are zeroed where the words are used (see mp_lstm_x3.hip, wait-count hygiene).
@@ -274,12 +269,12 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
     chunk_mma(IN_V, xsel(xa[0][0], 0), xsel(xa[0][1], 0), wxr[0], true);
 
     // the blocks of the h written at step `pstep` (parity pstep & 1)
-    u32x4 blk[WPL / 4];
+    u32x4 blk[2 * NHC];
     auto fetch_blocks = [&](int pstep) {
         const int poff_b = (pstep & 1) * 16 * H * 4;
 #pragma unroll
-        for (int i = 0; i < WPL / 4; ++i)
-            blk[i] = __builtin_amdgcn_raw_buffer_load_b128(hxrsrc, csrc_byte + poff_b + 16 * i, 0, 16 /* sc1 */);
+        for (int i = 0; i < 2 * NHC; ++i)
+            blk[i] = __builtin_amdgcn_raw_buffer_load_b128(hxrsrc, dsrc_byte[i >> 1] + 16 * (i & 1) + poff_b, 0, 16 /* sc1 */);
     };
 
     // one time step; xc = x_step (chunk 0 already multiplied), xn = x_{step+1}  (K_in = 512: the same set)
@@ -305,13 +300,13 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
             chunk_mma(IN_A, xsel(xc[1][0], step), xsel(xc[1][1], step), wxr[1]);
         }
         PROF_E(0); PROF_T(1);
-        // ---- check the tags (refetch while any word is stale: bounded), stage the blocks in LDS, read the A fragments
+        // ---- check the tags (refetch while any word is stale: bounded); no staging: the words are the A fragments
         if (step > 0) {
             const unsigned want = tag_of_step(step - 1);
             auto stale = [&]() {
                 unsigned m = 0;
 #pragma unroll
-                for (int i = 0; i < WPL / 4; ++i) m |= (blk[i][0] ^ want) | (blk[i][1] ^ want) | (blk[i][2] ^ want) | (blk[i][3] ^ want);
+                for (int i = 0; i < 2 * NHC; ++i) m |= (blk[i][0] ^ want) | (blk[i][1] ^ want) | (blk[i][2] ^ want) | (blk[i][3] ^ want);
                 return (m & 1u) != 0;
             };
             bool late = stale();
@@ -330,18 +325,14 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
                     }
                 } while (!__all(!late));
             }
-            if (C::HT_ALIAS) __syncthreads();
-#pragma unroll
-            for (int i = 0; i < WPL / 4; ++i)
-                *reinterpret_cast<u32x4*>(cdst + 4 * i) = blk[i] & u32x4{~1u, ~1u, ~1u, ~1u};
-            __syncthreads();
+            // the fetched words ARE the A fragments (tags cleared)
 #pragma unroll
             for (int c = 0; c < NHC; ++c) {
-                hw[c][0] = *reinterpret_cast<const u32x4*>(hrd + c * 32);
-                hw[c][1] = *reinterpret_cast<const u32x4*>(hrd + c * 32 + 4);
+                hw[c][0] = blk[2 * c] & u32x4{~1u, ~1u, ~1u, ~1u};
+                hw[c][1] = blk[2 * c + 1] & u32x4{~1u, ~1u, ~1u, ~1u};
             }
         }
-        // ---- next x (after the staging wait, so that this wait does not drain these loads as well)
+        // ---- next x (after the wait for the blocks, so that this wait does not drain these loads as well)
         if constexpr (C::BIG) load_x(xn, step + 1, 0, XRC);
         else load_x(xc, step + 2, 0, NXC);                  // (x_step is dead: its registers take x_{step+2})
         PROF_E(1); PROF_T(2);
