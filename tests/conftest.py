@@ -14,6 +14,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """Leave the GPU in a quiet state before the interpreter (and torch's / HIP's static objects) are torn down: destroy
+    every library handle that is still alive -- streams, graphs, events -- and drain the device."""
+    net = sys.modules.get("mobileposer_amd.net")
+    if net is not None and hasattr(net, "_close_all"):
+        net._close_all()
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available():
+        torch.cuda.synchronize()
+    import gc
+    gc.collect()
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name)))
 
