@@ -19,7 +19,7 @@ assert net._lib.mp_debug_read_prof(net._h, buf, NW) == 0
 tr = np.array(buf[4096:]).reshape(-1, 8, 32, 8)     # [block][wave][step][stamp]
 nb = 256
 tr = tr[:nb]
-names = ["start", "flags seen", "x-next issued(A ready)", "h mma done", "gates ready", "published", "lds issued", "reg chunks done"]
+names = ["start", "fetch issued", "A ready", "h mma done", "gates ready", "published", "lds issued", "reg chunks done"]
 for blk in (0, 135):
     t = tr[blk]                                         # [wave][step][stamp]
     base = t[:, :, 0].min(axis=0)
