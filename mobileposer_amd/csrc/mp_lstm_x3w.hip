@@ -194,9 +194,10 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
 
     // ---- x: pair words of this lane's row, chunk c: k = kq*KQ + c*32 + q*8 + e.  Loads are unconditional (clamped row),
     // rows past their length are zeroed where the words are used (see mp_lstm_x3.hip, wait-count hygiene).
-    // K_in = 256: x is requested TWO steps ahead into two register sets that alternate (the step loop is unrolled by two,
-    // so no register copies -- and no wait for a fresh load -- sit on the loop's back edge);
-    // K_in = 512: one set, as mp_lstm_x3 (register chunks after the staging of a step, LDS chunks right after their use)
+    // All of x is requested TWO steps ahead into two register sets that alternate (the step loop is unrolled by two, so
+    // no register copies -- and no wait for a fresh load -- sit on the loop's back edge): x_{t+2} is requested right after
+    // the tag check of step t, into the registers of x_t, which is dead by then; nothing in the loop ever waits for an x
+    // load (K_in = 512: 1.806 -> 1.77 ms for the whole forward against loading x_{t+1} during step t)
     typedef u32x4 XBuf[NXC][2];
     XBuf xa, xb;
     auto load_x = [&](XBuf& xw, int step, int c0, int c1) {
@@ -212,7 +213,7 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
     };
     auto xsel = [&](u32x4 v, int step) { return step < alen ? v : u32x4{0u, 0u, 0u, 0u}; };
     load_x(xa, 0, 0, NXC);
-    if constexpr (!C::BIG) load_x(xb, 1, 0, NXC);
+    load_x(xb, 1, 0, NXC);
     __syncthreads();                                          // W_ih LDS image complete
 
     long long pt[6] = {0, 0, 0, 0, 0, 0};
@@ -283,7 +284,6 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
         // ---- h_{step-1}: request the producers' blocks optimistically (every word carries its epoch tag); K_in = 512
         // multiplies its second register chunk first, which puts the request where mp_lstm_x3 has it
         if constexpr (C::BIG) {
-            asm volatile("" :: "v"(xc[1][0]), "v"(xc[1][1]));
             chunk_mma(IN_A, xsel(xc[1][0], step), xsel(xc[1][1], step), wxr[1]);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -295,7 +295,6 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
         if constexpr (C::BIG) {
 #pragma unroll
             for (int c = 0; c < XLC; ++c) lds_chunk_mma(c, xsel(xc[XRC + c][0], step), xsel(xc[XRC + c][1], step));
-            load_x(xn, step + 1, XRC, NXC);                 // those x words are dead now: next step's right away
         } else {
             chunk_mma(IN_A, xsel(xc[1][0], step), xsel(xc[1][1], step), wxr[1]);
         }
@@ -333,8 +332,7 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
             }
         }
         // ---- next x (after the wait for the blocks, so that this wait does not drain these loads as well)
-        if constexpr (C::BIG) load_x(xn, step + 1, 0, XRC);
-        else load_x(xc, step + 2, 0, NXC);                  // (x_step is dead: its registers take x_{step+2})
+        load_x(xc, step + 2, 0, NXC);                       // (x_step is dead: its registers take x_{step+2})
         PROF_E(1); PROF_T(2);
 
         // ---- recurrent part: h_{t-1} W_hh^T on top of the input projection
@@ -389,11 +387,6 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
                 ow[ub] = a.out_pairs ? (act ? pair_of(hst[ub]) : 0u) : (act ? __float_as_uint(hst[ub]) : 0u);
             }
         }
-        // the x words of the chunks multiplied before the next fetch must have arrived BEFORE the stores are issued
-        if constexpr (C::BIG) {
-#pragma unroll
-            for (int c = 0; c < XRC; ++c) asm volatile("" :: "v"(xn[c][0]), "v"(xn[c][1]));
-        }
         const size_t doff = (size_t)(step & 1) * 16 * H;
 #pragma unroll
         for (int ub = 0; ub < UB; ++ub) store_word_xcd(pdstL + doff + ub * 16, hpt[ub]);
@@ -412,13 +405,9 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         PROF_E(4);
     };
-    if constexpr (C::BIG) {
-        for (int step = 0; step < T; ++step) body(step, xa, xa);
-    } else {
-        for (int step = 0; step < T; step += 2) {
-            body(step, xa, xb);
-            if (step + 1 < T) body(step + 1, xb, xa);
-        }
+    for (int step = 0; step < T; step += 2) {
+        body(step, xa, xb);
+        if (step + 1 < T) body(step + 1, xb, xa);
     }
     if (PROF && prof) {
         long long* o = a.prof + (size_t)blockIdx.x * 8;
