@@ -38,3 +38,9 @@ x1 = torch.from_numpy(synthetic.make_imu(1, 3000, seed=3)).cuda()
 report("configs[0]-like single sequence T=3000 forward_offline", 3000,
        timeit(lambda: (net.reset_all(), net.forward_offline(x1, [3000])), reps=3, warm=1))
 print("device error:", net.device_error())
+
+# throughput against the batch size (forward_offline = net + FK + solver, T = 125)
+for Bs in (16, 64, 128, 256, 512, 1024, 2048):
+    xs = torch.from_numpy(synthetic.make_imu(Bs, T, seed=5)).cuda()
+    ls = [T] * Bs
+    report("forward_offline, %4d x 125" % Bs, Bs * T, timeit(lambda: (net.reset_all(), net.forward_offline(xs, ls)), reps=5, warm=2))
