@@ -152,6 +152,8 @@ struct mp_handle {
                                      // longer run beside the velocity block and the forward as a whole gets slower.
     bool x3 = true;                  // H = 256 layers on split-bf16 MFMA operands (mp_lstm_x3.hip, the default): mode 3;
                                      // mp_set_lstm_mode(h, 1) / MP_LSTM_MODE=fp32 selects exact-fp32 MFMA operands instead
+    bool fuse_pv = true;             // MP_FUSE_PV=0: separate linear1 launches for pose and velocity
+    Packed lin1_pv;                  // pose.linear1 and velocity.linear1 stacked (split-bf16 mode: one GEMM over the shared rows)
     int x3w_mask = 2;                // split-bf16 layers run by the 4-wave kernel mp_lstm_x3w: bit 0 K_in = 256, bit 1 K_in = 512
                                      // (default: the K_in = 512 layers, measured 373 vs 391 us; K_in = 256: 300 vs 285 us; env MP_X3W)
     int nslice_env = 0;              // 0: pick per module (8 slices / 8 waves for bidirectional layers that fill the
@@ -267,6 +269,22 @@ int pack_weights(mp_handle* h, const float* blob) {
                 }
             }
     }
+    {   // pose.linear1 on top of velocity.linear1 (same inputs: cat(joints, imu), net.py:106,113): pair words and bias
+        const Packed& a = h->mod[MP_MOD_POSE].lin1;
+        const Packed& b = h->mod[MP_MOD_VELOCITY].lin1;
+        Packed& pv = h->lin1_pv;
+        if (a.K == b.K && a.Kpad == b.Kpad && a.N == a.Npad && a.bn == b.bn && a.N % a.bn == 0) {
+            pv.N = a.N + b.N; pv.K = a.K; pv.Kpad = a.Kpad; pv.bn = a.bn; pv.Npad = a.Npad + b.Npad;
+            if (int rc = dev_alloc(h, (void**)&pv.Wp, (size_t)pv.Npad * pv.Kpad * sizeof(float))) return rc;
+            if (int rc = dev_alloc(h, (void**)&pv.bias, (size_t)pv.Npad * sizeof(float))) return rc;
+            pv.W = pv.Wp;                                      // (split-bf16 GEMM only: there is no fp32 image of the stack)
+            const size_t na = (size_t)a.Npad * a.Kpad, nb = (size_t)b.Npad * b.Kpad;
+            HIPCHK(h, hipMemcpyAsync(pv.Wp, a.Wp, na * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+            HIPCHK(h, hipMemcpyAsync(pv.Wp + na, b.Wp, nb * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+            HIPCHK(h, hipMemcpyAsync(pv.bias, a.bias, (size_t)a.Npad * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+            HIPCHK(h, hipMemcpyAsync(pv.bias + a.Npad, b.bias, (size_t)b.Npad * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+        }
+    }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->s_main));
     return MP_OK;
@@ -323,6 +341,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     }
     if (const char* e = getenv("MP_LSTM_UNI2")) h->uni2 = e[0] == '1';
     if (const char* e = getenv("MP_X3W")) h->x3w_mask = atoi(e) & 3;
+    if (const char* e = getenv("MP_FUSE_PV")) h->fuse_pv = atoi(e) != 0;
     if (const char* e = getenv("MP_LSTM_SLICES")) h->nslice_env = atoi(e) == 8 ? 8 : (atoi(e) == 16 ? 16 : 0);
     if (getenv("MP_PERSIST_PROF")) {
         if (hipMalloc((void**)&h->prof_dev, kProfWords * sizeof(long long)) != hipSuccess) h->prof_dev = nullptr;
@@ -545,6 +564,33 @@ int rnn_g0(const RnnJob& j, hipStream_t s) {
     return MP_OK;
 }
 
+// linear1 of the pose and the velocity block in ONE split-bf16 GEMM (same rows cat(joints, imu); stacked weights): one launch
+// instead of two on two streams, and no cross-stream edge into the velocity layers later.  Only what rnn_g0 does for
+// the persistent split-bf16 path with zero / in-place state; returns false when that does not apply.
+bool rnn_g0_pose_velocity(const RnnJob& jp, const RnnJob& jv, hipStream_t s, int* rc) {
+    mp_handle* h = jp.h;
+    const ModuleW& mp = h->mod[jp.id];
+    const ModuleW& mv = h->mod[jv.id];
+    *rc = MP_OK;
+    if (!h->fuse_pv || !h->lin1_pv.Wp || !h->persist || !use_x3(h, mp) || !use_x3(h, mv)) return false;
+    if (jp.mode != STATE_ZERO || !(jv.mode == STATE_ZERO || (jv.out_h == jv.in_h && jv.out_h))) return false;
+    if (jp.a0.base != jv.a0.base || jp.a1.base != jv.a1.base) return false;
+    ModuleWS& wp = jp.p->ws[jp.id];
+    ModuleWS& wv = jv.p->ws[jv.id];
+    const int B = jp.p->B, T = jp.p->T, M = B * T, H = mp.H;
+    SegScope seg(h, s, 0, 1, 2.0 * M * (double)h->lin1_pv.N * h->lin1_pv.K);
+    GemmArgs g;
+    const Packed& w = h->lin1_pv;
+    g.a0 = jp.a0; g.a1 = jp.a1; g.W = w.Wp; g.bias = w.bias; g.C = x1_buffer(h, mp, wp); g.C2 = x1_buffer(h, mv, wv);
+    g.nsplit = mp.lin1.Npad; g.cStrideB = H; g.cStrideT = (long)B * H;
+    g.M = M; g.N = w.N; g.K = w.K; g.Kpad = w.Kpad; g.B = B; g.relu = 1; g.pairOut = 1; g.aPairs = 0;
+    const int nslab = (B + 15) / 16;
+    g.zero_hx = wp.hx; g.zero_ncl = mp.dirs * nslab; g.zero_hx2 = wv.hx; g.zero_ncl2 = mv.dirs * nslab;
+    mp_launch_gemm_x3(g, w.bn, s);
+    if (hipGetLastError() != hipSuccess) *rc = fail(h, MP_ERR_HIP, "fused linear1 launch failed");
+    return true;
+}
+
 int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
     mp_handle* h = j.h;
     const ModuleW& m = h->mod[j.id];
@@ -731,13 +777,19 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         // (every cross-stream edge into a node of the critical chain costs 8-20 us of graph dependency resolution, so the
         //  chain joints -> pose linear1 -> pose layers -> velocity layers -> velocity linear2 stays on s_main and the one
         //  edge it needs from a side stream -- velocity's linear1 -- is taken early, in front of the pose layers)
-        RC(rnn_g0(V, sv)); RC(rec(1, sv));                       // linear1 of the three blocks, concurrently
-        RC(rnn_g0(F, sf));
-        RC(rnn_g0(P, sm));
+        RC(rnn_g0(F, sf));                                       // linear1 of the three blocks, concurrently
+        int rc_pv = MP_OK;
+        const bool fused_pv = rnn_g0_pose_velocity(P, V, sm, &rc_pv);   // pose + velocity: one GEMM on the main stream
+        RC(rc_pv);
+        if (!fused_pv) {
+            RC(rnn_g0(V, sv)); RC(rec(1, sv));
+            RC(rnn_g0(P, sm));
+        }
         RC(rnn_rec(P, 0, sm)); RC(rnn_rec(P, 1, sm)); RC(rec(2, sm));                       // net.py:106-107
         // (captured BEFORE the side-stream work that hangs off the same event: the graph launches the successors of a
         //  node in creation order, and the velocity layers are the critical chain)
-        RC(wait(1, sm)); RC(rnn_rec(V, 0, sm)); RC(rnn_rec(V, 1, sm)); RC(rnn_g2(V, sm));   // net.py:117
+        if (!fused_pv) RC(wait(1, sm));
+        RC(rnn_rec(V, 0, sm)); RC(rnn_rec(V, 1, sm)); RC(rnn_g2(V, sm));                    // net.py:117
         HIPCHK(h, hipEventRecord(h->ev_v, sm));
         RC(wait(2, sp)); RC(rnn_g2(P, sp));
         { SegScope seg(h, sp, 2, 1);

@@ -40,6 +40,12 @@ struct GemmArgs {
     // linear1 GEMM of a block does it for the layer-0 launch that follows, which saves a kernel boundary on the critical path
     unsigned long long* zero_hx = nullptr;
     int zero_ncl = 0;
+    // mp_gemm_x3 only: two linear layers over the same rows in one launch -- output columns [nsplit, N) go to C2 (as its
+    // columns [0, N - nsplit), same row strides); a second exchange area to re-arm
+    float* C2 = nullptr;
+    int nsplit = 0;
+    unsigned long long* zero_hx2 = nullptr;
+    int zero_ncl2 = 0;
 };
 // bn: 128, 96 or 32 (chosen by the caller from N)
 void mp_launch_gemm(const GemmArgs& g, int bn, hipStream_t s);

@@ -26,6 +26,7 @@ MP_KERNEL __launch_bounds__(256) void mp_gemm_x3(GemmArgs g, int nTilesM, int nT
 
     const int bid = blockIdx.x;
     if (g.zero_ncl > 0) rearm_exchange(g.zero_hx, g.zero_ncl, bid, gridDim.x, threadIdx.x, 256);
+    if (g.zero_ncl2 > 0) rearm_exchange(g.zero_hx2, g.zero_ncl2, bid, gridDim.x, threadIdx.x, 256);
     const int xcd = bid & 7, idx = bid >> 3;
     const int mt = (idx / nTilesN) * 8 + xcd;
     const int nt = idx % nTilesN;
@@ -140,7 +141,9 @@ MP_KERNEL __launch_bounds__(256) void mp_gemm_x3(GemmArgs g, int nTilesM, int nT
                 if (m0 + ml < g.M) {
                     float v = acc[a][b][r] + bias;
                     if (g.relu) v = fmaxf(v, 0.f);
-                    g.C[rowOffC[ml] + n] = g.pairOut ? __uint_as_float(pair_of(v)) : v;
+                    const float o = g.pairOut ? __uint_as_float(pair_of(v)) : v;
+                    if (g.nsplit > 0 && n >= g.nsplit) g.C2[rowOffC[ml] + (n - g.nsplit)] = o;   // (uniform per block: BN divides nsplit)
+                    else g.C[rowOffC[ml] + n] = o;
                 }
             }
     }
