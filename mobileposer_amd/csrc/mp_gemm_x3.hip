@@ -19,10 +19,13 @@ template <int BN, int BM>
 MP_KERNEL __launch_bounds__(256) void mp_gemm_x3(GemmArgs g, int nTilesM, int nTilesN) {
     constexpr int NCT = BN / 16, NRT = BM / 64;                 // 16-wide column tiles, 16-row tiles per wave
     constexpr int A_ROWS_PER_THREAD = BM / 32, W_ROWS_PER_THREAD = BN / 32;
-    __shared__ __attribute__((aligned(16))) unsigned smem[(BM + BN) * LDK + 2 * BM];
+    // (the output tile is staged in the same LDS after the k loop: BM x (BN + 4) words)
+    constexpr int OPITCH = BN + 4;
+    constexpr int SMEM_MAIN = (BM + BN) * LDK, SMEM_OUT = BM * OPITCH;
+    __shared__ __attribute__((aligned(16))) unsigned smem[(SMEM_MAIN > SMEM_OUT ? SMEM_MAIN : SMEM_OUT) + 2 * BM];
     unsigned* As = smem;
     unsigned* Ws = smem + BM * LDK;
-    long* rowOffC = reinterpret_cast<long*>(smem + (BM + BN) * LDK);
+    long* rowOffC = reinterpret_cast<long*>(smem + (SMEM_MAIN > SMEM_OUT ? SMEM_MAIN : SMEM_OUT));
 
     const int bid = blockIdx.x;
     if (g.zero_ncl > 0) rearm_exchange(g.zero_hx, g.zero_ncl, bid, gridDim.x, threadIdx.x, 256);
@@ -127,25 +130,44 @@ MP_KERNEL __launch_bounds__(256) void mp_gemm_x3(GemmArgs g, int nTilesM, int nT
         }
     }
 
-    // epilogue: D[row = 4*q + reg][col = r16] of tile (a, b); bias (+ReLU), fp32 or pair-word output, row-mapped store
+    // epilogue: D[row = 4*q + reg][col = r16] of tile (a, b); bias (+ReLU), fp32 or pair-word output.  The tile goes through
+    // LDS so that a wave writes whole row segments (16 bytes per lane, 512 contiguous bytes per row of a 128-wide tile)
+    // instead of 64-byte pieces of four rows per store instruction: these GEMMs are bound by their output traffic.
+    unsigned* Os = smem;                                  // (the k loop ended with a barrier: A / W tiles are dead)
 #pragma unroll
     for (int b = 0; b < NCT; ++b) {
         const int n = n0 + b * 16 + r16;
-        if (n >= g.N) continue;
-        const float bias = g.bias[n];
+        const float bias = n < g.N ? g.bias[n] : 0.f;
 #pragma unroll
         for (int a = 0; a < NRT; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ml = wave * (BM / 4) + a * 16 + 4 * q + r;
-                if (m0 + ml < g.M) {
-                    float v = acc[a][b][r] + bias;
-                    if (g.relu) v = fmaxf(v, 0.f);
-                    const float o = g.pairOut ? __uint_as_float(pair_of(v)) : v;
-                    if (g.nsplit > 0 && n >= g.nsplit) g.C2[rowOffC[ml] + (n - g.nsplit)] = o;   // (uniform per block: BN divides nsplit)
-                    else g.C[rowOffC[ml] + n] = o;
-                }
+                float v = acc[a][b][r] + bias;
+                if (g.relu) v = fmaxf(v, 0.f);
+                Os[ml * OPITCH + b * 16 + r16] = g.pairOut ? pair_of(v) : __float_as_uint(v);
             }
+    }
+    __syncthreads();
+    {
+        const bool second = g.nsplit > 0 && n0 >= g.nsplit;          // (uniform per block: BN divides nsplit)
+        float* Cb = second ? g.C2 : g.C;
+        const int nb = second ? n0 - g.nsplit : n0;                  // first output column of the tile in its matrix
+        const int nvalid = g.N - n0 < BN ? g.N - n0 : BN;            // columns of the tile that exist
+        constexpr int V4 = BN / 4;
+        for (int idx = tid; idx < BM * V4; idx += 256) {
+            const int ml = idx / V4, c4 = (idx % V4) * 4;
+            if (m0 + ml >= g.M || c4 >= nvalid) continue;
+            float* dst = Cb + rowOffC[ml] + nb + c4;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(Os + ml * OPITCH + c4);
+            if (c4 + 4 <= nvalid && (reinterpret_cast<size_t>(dst) & 15) == 0) {
+                *reinterpret_cast<u32x4*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c4 + e < nvalid) dst[e] = __uint_as_float(v[e]);
+            }
+        }
     }
 }
 
