@@ -121,7 +121,9 @@ def bench_stream(args, net, dev, dist, rank, world):
     S = args.streams
     frames = torch.from_numpy(synthetic.make_imu(S, args.steps + args.warmup + 1, seed=7 + rank)).to(dev)
     net.stream_create(S)
-    io = net._sio
+    f32 = torch.float32
+    io = {"pose": torch.empty(S, 24, 9, device=dev, dtype=f32), "joints": torch.empty(S, 45, 72, device=dev, dtype=f32),
+          "root": torch.empty(S, 3, device=dev, dtype=f32), "contact": torch.empty(S, 2, device=dev, dtype=f32)}
 
     def sync():
         if dist is not None:

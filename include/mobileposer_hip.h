@@ -13,7 +13,7 @@
  *   - every function returns MP_OK (0) or a negative mp_status; mp_last_error() gives the text.
  *     No C++ exception crosses the ABI.
  *   - a handle is bound to one device, is NOT thread-safe, and owns its weights, workspaces,
- *     streams, captured hipGraphs and the carried state (velocity LSTM state, streaming windows).
+ *     streams and the carried state (velocity LSTM state, streaming windows).
  *   - `stream` is the caller's HIP stream (void* = hipStream_t; NULL = the legacy default
  *     stream).  Work is ordered after everything already enqueued on it and the caller's later
  *     work on that stream is ordered after the call's results (event fork/join onto the
@@ -38,8 +38,11 @@ typedef enum mp_status {
     MP_ERR_STATE_SHAPE = -3, /* carried velocity state has another batch size (reference quirk Q2:   */
                              /* nn.LSTM raises when h0's batch differs, models/velocity.py:45-48)    */
     MP_ERR_NO_STREAMS = -4,  /* mp_stream_* called before mp_stream_create                           */
-    MP_ERR_LENGTHS = -5      /* lengths[] not in 1..T or max(lengths) != T (the reference's           */
+    MP_ERR_LENGTHS = -5,     /* lengths[] not in 1..T or max(lengths) != T (the reference's           */
                              /* torch.cat at models/net.py:106 fails in that case)                    */
+    MP_ERR_DEVICE = -6       /* a persistent LSTM kernel of an EARLIER call gave up a bounded wait    */
+                             /* (its grid was starved of CUs): that call's outputs are invalid.       */
+                             /* Reported once by the next API entry, or by mp_device_error().         */
 } mp_status;
 
 /* module ids for mp_rnn_forward: the four RNN blocks built at models/net.py:40-43 */
@@ -84,8 +87,8 @@ int mp_forward(mp_handle* h, const float* imu_dev, const int32_t* lengths_host, 
                float* pose_dev, float* joints_dev, float* vel_dev, float* contact_dev,
                float* r6d_dev, void* stream);
 
-/* MobilePoserNet.forward_offline (models/net.py:121-171, PHYSICS off) batched over sequences, as ONE captured
- * graph: mp_forward + the translation solver (tran_dev [B,T,3]) and, when rglobal_dev / joint_dev are given
+/* MobilePoserNet.forward_offline (models/net.py:121-171, PHYSICS off) batched over sequences, as ONE call:
+ * mp_forward + the translation solver (tran_dev [B,T,3]) and, when rglobal_dev / joint_dev are given
  * (both or neither), the SMPL forward kinematics of the predicted pose that the evaluator applies next
  * (articulate/evaluator.py:319; R_global [B*T,24,3,3], joint [B*T,24,3], no translation added). */
 int mp_forward_offline(mp_handle* h, const float* imu_dev, const int32_t* lengths_host, int B, int T,
@@ -137,7 +140,8 @@ int mp_set_velocity_state(mp_handle* h, const float* state_dev, int batch);
 /* ---- streaming: MobilePoserNet.forward_online (models/net.py:173-219) for S concurrent streams --
  * Each stream owns a 45-frame window (40 past + 5 future, config.py:52-54), last foot positions,
  * current_root_y, last_root_pos and its rows of the velocity LSTM state.  One step consumes one
- * new frame per stream and is replayed from a captured hipGraph. */
+ * new frame per stream (eager launches on the library's streams; a captured hipGraph with
+ * mp_set_graph_mode(h, 1)). */
 int mp_stream_create(mp_handle* h, int S);
 /* frames [S,60] -> pose [S,24,9], joints [S,45,72] (optional NULL), root_pos [S,3], contact [S,2] */
 int mp_stream_step(mp_handle* h, const float* frames_dev, float* pose_dev, float* joints_dev,
@@ -145,9 +149,15 @@ int mp_stream_step(mp_handle* h, const float* frames_dev, float* pose_dev, float
 /* reset(): all streams (mask_host == NULL) or those with mask_host[s] != 0.  Like the reference's
  * reset() it leaves the velocity LSTM state alone unless clear_velocity != 0. */
 int mp_stream_reset(mp_handle* h, const uint8_t* mask_host, int clear_velocity);
+/* The per-stream variables of the reference object (models/net.py:59-64, updated at :205-208), read back for stream s
+ * (synchronises the library stream; every pointer optional): window [45,60] = `self.imu` (device buffer), last_foot
+ * [2*3] = last_lfoot_pos, last_rfoot_pos, root_y = current_root_y, root_pos [3] = last_root_pos, fresh != 0 while the
+ * stream has not seen a frame since reset() (`self.imu is None`). */
+int mp_stream_get_state(mp_handle* h, int s, float* window_dev, float last_foot_host[6], double* root_y_host,
+                        float root_pos_host[3], int* fresh_host);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------------
- * With timing on, every call runs eagerly (no hipGraph) and brackets each kernel launch of the classes below
+ * With timing on, every call runs eagerly and brackets each kernel launch of the classes below
  * with HIP events on the library stream that launches it.  mp_timing_read returns, for the last call, the
  * number of launches, the summed event-measured milliseconds and the algorithmic GFLOP of a class:
  *   0 = MFMA GEMM (linear1 / linear2),   1 = fused LSTM layer H=256 bidirectional K_in=256,
@@ -155,23 +165,30 @@ int mp_stream_reset(mp_handle* h, const uint8_t* mask_host, int clear_velocity);
  *   6 = fused LSTM layer H=64,   7 = per-step LSTM kernels (fallback mode),   2 = r6d/IK,   3 = whole call. */
 int mp_timing_enable(mp_handle* h, int on);
 int mp_timing_read(mp_handle* h, int cls, int* launches, float* ms, double* gflop);
-/* 0: eager launches, 1: replay captured hipGraphs (default; env MP_NO_GRAPH=1 flips the default). */
+/* 0 (default): eager launches on the library's four streams; 1 (env MP_GRAPH=1): capture every (entry point, shape,
+ * buffer set) once into a hipGraph and replay it.  Opt-in because the multi-branch graph executor of the HIP runtime
+ * in this image can crash in hipGraphLaunch depending on the hardware-queue placement of the streams a process has
+ * created (profiles/r02_hipgraph_segv.md; GPU_MAX_HW_QUEUES=8 avoids it); outputs are bitwise identical either way. */
 int mp_set_graph_mode(mp_handle* h, int on);
 /* LSTM implementation of the H = 256 layers (the H = 64 foot-contact block always uses the fp32 kernels):
- *   3 (default; env MP_LSTM_MODE=x3): fused persistent layer kernels, one launch per layer, whose two matrix products
- *       per step run on split-bf16 MFMA operands -- every fp32 product as hi*hi + hi*lo + lo*hi of bf16 parts on
- *       v_mfma_f32_16x16x32_bf16, fp32 accumulate, fp32 state (mp_lstm_x3.hip).  Measured 2e-7 from the same
- *       arithmetic in float64 (exact-fp32 operands: 1e-7; PyTorch CPU fp32: 2e-7), same 1e-4 parity bound;
- *   1 (env MP_LSTM_MODE=fp32): the same layers on exact-fp32 MFMA operands (v_mfma_f32_16x16x4_f32, mp_lstm_persist.hip);
+ *   1 (default; env MP_LSTM_MODE=fp32): fused persistent layer kernels, one launch per layer, exact-fp32 MFMA operands
+ *       (v_mfma_f32_16x16x4_f32, mp_lstm_persist.hip) -- the reference's arithmetic;
+ *   3 (opt-in; env MP_LSTM_MODE=x3): the same layers with the two matrix products per step on split-bf16 MFMA operands
+ *       -- every fp32 product as hi*hi + hi*lo + lo*hi of bf16 parts on v_mfma_f32_16x16x32_bf16, fp32 accumulate,
+ *       fp32 state (mp_lstm_x3.hip).  16 significand bits per operand: 5e-7 from float64 on the network outputs (mode 1:
+ *       1.2e-7), inside the same 1e-4 parity bound, 2.6x faster;
  *   2: mode 1 plus the unidirectional velocity block as ONE two-layer wavefront launch;
  *   0 (env MP_LSTM_MODE=step): input-projection GEMM + one launch per time step. */
 int mp_set_lstm_mode(mp_handle* h, int mode);
 /* Test hook for the hidden-state exchange of the persistent kernels: 0 = pick the transport per producer from
  * its real XCC id (default), 1 = always use the any-placement write-through (sc1) transport. */
 int mp_set_transport(mp_handle* h, int force_remote);
-/* Synchronises the library's stream and returns the device error word of the persistent kernels:
- * 0 = ok, 1+step = a bounded wait for another workgroup's hidden state timed out (results invalid). */
+/* Synchronises the library's stream and returns (and clears) the error word of the persistent kernels:
+ * 0 = ok, 1+step = a bounded wait for another workgroup's hidden state timed out (results invalid).
+ * Without this call the same condition is reported as MP_ERR_DEVICE by the next API entry. */
 int mp_device_error(mp_handle* h, int* code);
+/* Test hook: make a kernel store `code` into the error word exactly as a timed-out persistent kernel would. */
+int mp_debug_poke_error(mp_handle* h, int code);
 /* Debug (env MP_PERSIST_PROF=1 at mp_create): per-workgroup cycle sums [grid][6] of the phases of the last
  * persistent-kernel launch: wait, sweep, mfma, reduce, cell+publish, steps. */
 int mp_debug_read_prof(mp_handle* h, long long* out, int n_words);

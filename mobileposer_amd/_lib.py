@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MP_LIB_PATH") or os.path.join(_HERE, "libmobileposer_hip.so")   # override: kernel-variant A/B runs
 
 MP_OK = 0
-MP_ERR_INVALID, MP_ERR_HIP, MP_ERR_STATE_SHAPE, MP_ERR_NO_STREAMS, MP_ERR_LENGTHS = -1, -2, -3, -4, -5
+MP_ERR_INVALID, MP_ERR_HIP, MP_ERR_STATE_SHAPE, MP_ERR_NO_STREAMS, MP_ERR_LENGTHS, MP_ERR_DEVICE = -1, -2, -3, -4, -5, -6
 MOD_JOINTS, MOD_POSE, MOD_FOOT_CONTACT, MOD_VELOCITY = 0, 1, 2, 3
 
 _vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
@@ -40,12 +40,14 @@ SIGNATURES = {
     "mp_stream_create": (_i, [_vp, _i]),
     "mp_stream_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_stream_reset": (_i, [_vp, C.POINTER(C.c_uint8), _i]),
+    "mp_stream_get_state": (_i, [_vp, _i, _vp, _fp, C.POINTER(C.c_double), _fp, C.POINTER(_i)]),
     "mp_timing_enable": (_i, [_vp, _i]),
     "mp_timing_read": (_i, [_vp, _i, C.POINTER(_i), _fp, C.POINTER(C.c_double)]),
     "mp_set_graph_mode": (_i, [_vp, _i]),
     "mp_set_lstm_mode": (_i, [_vp, _i]),
     "mp_set_transport": (_i, [_vp, _i]),
     "mp_device_error": (_i, [_vp, C.POINTER(_i)]),
+    "mp_debug_poke_error": (_i, [_vp, _i]),
     "mp_debug_read_prof": (_i, [_vp, C.POINTER(C.c_longlong), _i]),
 }
 

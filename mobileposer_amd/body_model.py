@@ -4,6 +4,7 @@ Mirror of the subset of ``ParametricModel`` (articulate/model.py:20-39,77-92,208
 MobilePoserNet and the evaluator: ``parent``, zero-pose joints, ``forward_kinematics`` (no mesh).
 """
 import pickle
+import weakref
 
 import numpy as np
 
@@ -22,7 +23,7 @@ class ParametricModel:
         self._v_template = np.asarray(data["v_template"], dtype=np.float32) if "v_template" in data else None
         self._skinning_weights = np.asarray(data["weights"], dtype=np.float32) if "weights" in data else None
         self.face = data.get("f")
-        self._net = None
+        self._net_ref = None
 
     @classmethod
     def synthetic(cls):
@@ -40,8 +41,13 @@ class ParametricModel:
         return j, v
 
     def bind(self, net):
-        """Attach the MobilePoserNet whose library handle (holding these constants on the GPU) runs FK."""
-        self._net = net
+        """Attach the MobilePoserNet whose library handle (holding these constants on the GPU) runs FK.
+        Held weakly: the net owns the body model, not the other way round."""
+        self._net_ref = weakref.ref(net)
+
+    @property
+    def _net(self):
+        return self._net_ref() if self._net_ref is not None else None
 
     def forward_kinematics(self, pose, shape=None, tran=None, calc_mesh=False):
         """articulate/model.py:208-240 on the GPU (mp_fk / mp_fk_mesh).  pose [N,24,3,3] (or reshapeable) cuda tensor."""

@@ -6,6 +6,18 @@ self-contained on the GPU box.  Reference: mobileposer/config.py:40-54 (model_co
 """
 
 
+class paths:
+    """config.py:26-38: locations relative to the working directory, exactly as the reference resolves them
+    (``Path().absolute()`` at import time).  Only the entries the inference / evaluation path reads."""
+    from pathlib import Path as _P
+    root_dir = _P().absolute()
+    checkpoint = root_dir / "checkpoints"
+    smpl_file = root_dir / "smpl/basicmodel_m.pkl"
+    weights_file = root_dir / "checkpoints/weights.pth"
+    eval_dir = root_dir / "data/processed_datasets/eval"
+    processed_datasets = root_dir / "data/processed_datasets"
+
+
 class model_config:
     n_joints = 5                 # IMU locations (lw, rw, lp, rp, head)      config.py:46
     n_imu = 12 * n_joints        # 5 x (3 acc + 9 ori) = 60                  config.py:47

@@ -4,10 +4,21 @@
 //   joints RNN -> [pose RNN + r6d/IK] || velocity RNN || foot-contact RNN
 // on three library-owned HIP streams (fork/join by events), each RNN being
 //   GEMM(linear1+ReLU) -> GEMM(W_ih l0) -> T x lstm_step -> GEMM(W_ih l1) -> T x lstm_step -> GEMM(linear2),
-// captured once per (shape, buffer set) into a hipGraph and replayed.  Weights are re-laid-out once at load
-// time into MFMA fragment order; workspaces are sized per (B, T) plan and kept (288 GB of HBM: no reuse games).
+// launched eagerly (default) or, opt-in, captured once per (shape, buffer set) into a hipGraph and replayed.
+// Weights are re-laid-out once at load time into MFMA fragment order; workspaces are sized per (B, T) plan and
+// kept (288 GB of HBM: no reuse games).
+//
+// Why eager is the default: the multi-branch graph executor of the HIP runtime this image ships (libamdhip64 of
+// ROCm 7.0, hip::Graph::UpdateStreams) picks max_streams-1 of the max_streams internal streams a hipGraphExec_t owns,
+// skipping those that share a hardware queue with the launch stream, WITHOUT a bounds check: when two of them map to
+// the launch stream's queue (GPU_MAX_HW_QUEUES = 4 by default, so this depends on every stream the process has ever
+// created) it reads past the end of the vector and the process dies with SIGSEGV inside hipGraphLaunch
+// (profiles/r02_hipgraph_segv.md: backtrace, disassembly, and the GPU_MAX_HW_QUEUES experiment).  Eager launches on
+// the library's four streams measure 1.755 vs 1.716 ms (split-bf16 mode) and 4.46 vs 4.57 ms (fp32 mode) per
+// 256 x 125 batch, i.e. nothing is lost.
 #include "../../include/mobileposer_hip.h"
 #include "mp_common.h"
+#include "mp_lstm_dev.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -141,7 +152,9 @@ struct mp_handle {
     hipStream_t s_main = nullptr, s_vel = nullptr, s_foot = nullptr, s_gp = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_j = nullptr, ev_v = nullptr, ev_f = nullptr;
     hipEvent_t ev_x[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int* err_dev = nullptr;          // device error word of the persistent kernels
+    int* err_host = nullptr;         // error word of the persistent kernels: pinned, coherent host memory that the kernels
+    int* err_dev = nullptr;          // store to directly (err_dev = its device address), so that every API entry can
+                                     // look at it without synchronising anything
     long long* prof_dev = nullptr;   // debug: per-workgroup phase cycle sums of the last persistent launch
     bool force_remote = false;       // test hook (mp_set_transport)
     int n_cu = 256;                  // compute units of this device: bounds the co-resident persistent grids
@@ -150,8 +163,9 @@ struct mp_handle {
                                      // MP_LSTM_UNI2=1).  Off by default: it is 20 % faster than two launches but fills every
                                      // CU's registers and LDS, so the foot-contact layers and pose's linear2 / IK / FK can no
                                      // longer run beside the velocity block and the forward as a whole gets slower.
-    bool x3 = true;                  // H = 256 layers on split-bf16 MFMA operands (mp_lstm_x3.hip, the default): mode 3;
-                                     // mp_set_lstm_mode(h, 1) / MP_LSTM_MODE=fp32 selects exact-fp32 MFMA operands instead
+    bool x3 = false;                 // false (default, mode 1): H = 256 layers on exact-fp32 MFMA operands -- the reference's
+                                     // arithmetic; true (mode 3, mp_set_lstm_mode(h, 3) / MP_LSTM_MODE=x3): the opt-in fast
+                                     // mode, split-bf16 MFMA operands (mp_lstm_x3.hip)
     bool fuse_pv = true;             // MP_FUSE_PV=0: separate linear1 launches for pose and velocity
     Packed lin1_pv;                  // pose.linear1 and velocity.linear1 stacked (split-bf16 mode: one GEMM over the shared rows)
     int x3w_mask = 2;                // split-bf16 layers run by the 4-wave kernel mp_lstm_x3w: bit 0 K_in = 256, bit 1 K_in = 512
@@ -163,7 +177,7 @@ struct mp_handle {
     unsigned long long use_clock = 0;
     VelState vstate;
     StreamCtx sc;
-    bool use_graph = true;
+    bool use_graph = false;          // opt-in (mp_set_graph_mode / MP_GRAPH=1): see the note at the top of this file
     bool timing = false;
     std::vector<Seg> segs;
     std::vector<hipEvent_t> ev_pool;
@@ -328,7 +342,14 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     h->device = device;
     auto bail = [&](int rc) { g_create_error = h->err; mp_destroy(h); return rc; };
     if (hipSetDevice(device) != hipSuccess) { h->err = "hipSetDevice failed"; return bail(MP_ERR_HIP); }
-    if (const char* e = getenv("MP_NO_GRAPH")) h->use_graph = !(e[0] && e[0] != '0');
+    if (const char* e = getenv("MP_GRAPH")) h->use_graph = e[0] && e[0] != '0';
+    if (const char* e = getenv("MP_NO_GRAPH")) if (e[0] && e[0] != '0') h->use_graph = false;
+    {   // dynamic-LDS limits of the persistent kernels are per-device attributes (and must not be set under capture)
+        hipError_t ea = mp_lstm_persist_device_attrs();
+        if (ea == hipSuccess) ea = mp_lstm_x3_device_attrs();
+        if (ea == hipSuccess) ea = mp_lstm_x3w_device_attrs();
+        if (ea != hipSuccess) { h->err = std::string("hipFuncSetAttribute failed: ") + hipGetErrorString(ea); return bail(MP_ERR_HIP); }
+    }
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
@@ -337,7 +358,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     }
     if (const char* e = getenv("MP_LSTM_MODE")) {
         h->persist = strcmp(e, "step") != 0;
-        h->x3 = h->persist && strcmp(e, "fp32") != 0;          // "x3" (default) | "fp32" | "step"
+        h->x3 = h->persist && strcmp(e, "x3") == 0;            // "fp32" (default) | "x3" | "step"
     }
     if (const char* e = getenv("MP_LSTM_UNI2")) h->uni2 = e[0] == '1';
     if (const char* e = getenv("MP_X3W")) h->x3w_mask = atoi(e) & 3;
@@ -353,8 +374,8 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     e = e ? e : hipStreamCreateWithFlags(&h->s_foot, hipStreamNonBlocking);
     e = e ? e : hipStreamCreateWithFlags(&h->s_gp, hipStreamNonBlocking);
     for (hipEvent_t& ev : h->ev_x) e = e ? e : hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    if (!e) e = hipMalloc((void**)&h->err_dev, sizeof(int));
-    if (!e) e = hipMemset(h->err_dev, 0, sizeof(int));
+    if (!e) e = hipHostMalloc((void**)&h->err_host, 64, hipHostMallocMapped | hipHostMallocCoherent);
+    if (!e) { *h->err_host = 0; e = hipHostGetDevicePointer((void**)&h->err_dev, h->err_host, 0); }
     hipEvent_t* evs[5] = {&h->ev_in, &h->ev_out, &h->ev_j, &h->ev_v, &h->ev_f};
     for (hipEvent_t* ev : evs) e = e ? e : hipEventCreateWithFlags(ev, hipEventDisableTiming);
     if (e != hipSuccess) { h->err = std::string("stream/event creation failed: ") + hipGetErrorString(e); return bail(MP_ERR_HIP); }
@@ -754,9 +775,9 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
     // joints(batch)                                                                       net.py:103
     RC(run_rnn(J, sm));
     HIPCHK(h, hipEventRecord(h->ev_j, sm));
-    HIPCHK(h, hipStreamWaitEvent(sv, h->ev_j, 0));
     HIPCHK(h, hipStreamWaitEvent(sf, h->ev_j, 0));
     if (!h->persist) {
+        HIPCHK(h, hipStreamWaitEvent(sv, h->ev_j, 0));
         // per-step kernels have no cross-workgroup waits: the three remaining blocks simply run side by side
         RC(run_rnn(F, sf));                                                               // net.py:113-114
         HIPCHK(h, hipEventRecord(h->ev_f, sf));
@@ -781,7 +802,8 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         int rc_pv = MP_OK;
         const bool fused_pv = rnn_g0_pose_velocity(P, V, sm, &rc_pv);   // pose + velocity: one GEMM on the main stream
         RC(rc_pv);
-        if (!fused_pv) {
+        if (!fused_pv) {                                         // (s_vel is only forked into the call when it gets work)
+            HIPCHK(h, hipStreamWaitEvent(sv, h->ev_j, 0));
             RC(rnn_g0(V, sv)); RC(rec(1, sv));
             RC(rnn_g0(P, sm));
         }
@@ -835,7 +857,19 @@ int run_maybe_graph(mp_handle* h, const GraphKey& key, Body body) {
     return MP_OK;
 }
 
+// A bounded wait inside a persistent kernel of an EARLIER call timed out (the grid was starved of CUs -- e.g. the GPU is
+// shared with another process): the results of that call are invalid.  Reported once, by the next API entry.
+int pending_device_error(mp_handle* h, const char* where) {
+    const int code = h->err_host ? *(volatile int*)h->err_host : 0;
+    if (!code) return MP_OK;
+    *(volatile int*)h->err_host = 0;
+    return fail(h, MP_ERR_DEVICE, "%s: a previous call's persistent LSTM kernel timed out waiting for another workgroup's "
+                "hidden state (code %d: 1+step, or 1000000 = start-up handshake); the outputs of that call are invalid",
+                where, code);
+}
+
 int enter(mp_handle* h, void* stream) {
+    if (int rc = pending_device_error(h, "mobileposer")) return rc;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipEventRecord(h->ev_in, (hipStream_t)stream));
     HIPCHK(h, hipStreamWaitEvent(h->s_main, h->ev_in, 0));
@@ -900,8 +934,9 @@ void mp_destroy(mp_handle* h) {
     }
     void* misc[] = {h->parent_dev, h->depth_dev, h->bone_dev, h->vstate.h, h->vstate.c, h->sc.window, h->sc.fresh,
                     h->sc.mask_dev, h->sc.st.last_foot, h->sc.st.root_y, h->sc.st.root_pos, h->sc.joints, h->sc.vel,
-                    h->sc.contact, h->err_dev, h->jrest_dev, h->vrest_dev, h->skinw_dev};
+                    h->sc.contact, h->jrest_dev, h->vrest_dev, h->skinw_dev, h->lin1_pv.Wp, h->lin1_pv.bias, h->prof_dev};
     for (void* p : misc) if (p) (void)hipFree(p);
+    if (h->err_host) (void)hipHostFree(h->err_host);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     hipEvent_t evs[5] = {h->ev_in, h->ev_out, h->ev_j, h->ev_v, h->ev_f};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
@@ -1197,6 +1232,27 @@ int mp_stream_reset(mp_handle* h, const uint8_t* mask_host, int clear_velocity) 
     return MP_OK;
 }
 
+int mp_stream_get_state(mp_handle* h, int s, float* window_dev, float last_foot_host[6], double* root_y_host,
+                        float root_pos_host[3], int* fresh_host) {
+    if (!h) return MP_ERR_INVALID;
+    StreamCtx& c = h->sc;
+    if (!c.S) return fail(h, MP_ERR_NO_STREAMS, "mp_stream_get_state before mp_stream_create");
+    if (s < 0 || s >= c.S) return fail(h, MP_ERR_INVALID, "mp_stream_get_state: stream %d outside 0..%d", s, c.S - 1);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->s_main));
+    if (window_dev)
+        HIPCHK(h, hipMemcpy(window_dev, c.window + (size_t)s * 45 * 60, (size_t)45 * 60 * sizeof(float), hipMemcpyDeviceToDevice));
+    if (last_foot_host) HIPCHK(h, hipMemcpy(last_foot_host, c.st.last_foot + (size_t)s * 6, 6 * sizeof(float), hipMemcpyDeviceToHost));
+    if (root_y_host) HIPCHK(h, hipMemcpy(root_y_host, c.st.root_y + s, sizeof(double), hipMemcpyDeviceToHost));
+    if (root_pos_host) HIPCHK(h, hipMemcpy(root_pos_host, c.st.root_pos + (size_t)s * 3, 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (fresh_host) {
+        uint8_t f = 0;
+        HIPCHK(h, hipMemcpy(&f, c.fresh + s, 1, hipMemcpyDeviceToHost));
+        *fresh_host = f;
+    }
+    return MP_OK;
+}
+
 // ------------------------------------------------------------------------------------------ measurement
 int mp_timing_enable(mp_handle* h, int on) {
     if (!h) return MP_ERR_INVALID;
@@ -1226,8 +1282,19 @@ int mp_device_error(mp_handle* h, int* code) {
     if (!h || !code) return MP_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->s_main));
-    HIPCHK(h, hipMemcpy(code, h->err_dev, sizeof(int), hipMemcpyDeviceToHost));
-    if (*code) HIPCHK(h, hipMemset(h->err_dev, 0, sizeof(int)));
+    *code = *(volatile int*)h->err_host;
+    *(volatile int*)h->err_host = 0;
+    return MP_OK;
+}
+
+namespace { MP_KERNEL void mp_poke_error(int* err, int code) { mp_set_error(err, code); } }
+
+int mp_debug_poke_error(mp_handle* h, int code) {
+    if (!h) return MP_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(mp_poke_error, dim3(1), dim3(1), 0, h->s_main, h->err_dev, code);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->s_main));
     return MP_OK;
 }
 

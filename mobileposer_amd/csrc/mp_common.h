@@ -110,6 +110,11 @@ void mp_launch_lstm_uni2(const LstmPersistArgs& a, hipStream_t s);
 void mp_launch_lstm_x3(const LstmPersistArgs& a, int KIN, int nslice, hipStream_t s);
 void mp_launch_lstm_x3w(const LstmPersistArgs& a, int KIN, hipStream_t s);   // four 512-register waves per workgroup (8 slices)
 void mp_launch_pack_w_x3(const float* w, float* dst, int K, int nslice, hipStream_t s);
+// Dynamic-LDS limits (80-160 KB) of the persistent kernels are per-DEVICE function attributes: mp_create sets them for
+// the handle's device after hipSetDevice, outside of any stream capture.
+hipError_t mp_lstm_persist_device_attrs();
+hipError_t mp_lstm_x3_device_attrs();
+hipError_t mp_lstm_x3w_device_attrs();
 
 // ---------------------------------------------------------------- K4/K5: kinematics
 void mp_launch_r6d_ik(const float* r6d, long N, float* pose, const int* parent_dev, hipStream_t s);

@@ -16,6 +16,12 @@ static __device__ __forceinline__ float tanhf_(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
+// A bounded wait gave up: leave a code in the handle's error word.  The word lives in pinned, coherent HOST memory (every
+// API entry reads it without synchronising), so this is a system-scope store, not a device atomic.
+static __device__ __forceinline__ void mp_set_error(int* err, int code) {
+    __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 static __device__ __forceinline__ u64 granule_load(const u64* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

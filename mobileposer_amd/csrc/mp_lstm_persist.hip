@@ -171,7 +171,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
             while (true) {
                 const u64 g = granule_load(xtab + lane);
                 if ((unsigned)(g >> 32) == XCC_TAG) { peer = (unsigned)g; break; }
-                if (++spins > spin_budget) { atomicExch(a.err, 1000000); peer = ~0u; break; }
+                if (++spins > spin_budget) { mp_set_error(a.err, 1000000); peer = ~0u; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
         }
@@ -312,7 +312,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
                 if (++spins > spin_budget) timed_out = true;
             }
             if (timed_out) {                                   // bounded: flag the error and never wait again
-                if (lane == 0) atomicExch(a.err, 1 + step);
+                if (lane == 0) mp_set_error(a.err, 1 + step);
                 spin_budget = 0;
             }
 #pragma unroll
@@ -486,7 +486,7 @@ MP_KERNEL __launch_bounds__(512, 1) void mp_lstm_fused_uni2(LstmPersistArgs a) {
             while (true) {
                 const u64 g = granule_load(xtab + lane);
                 if ((unsigned)(g >> 32) == XCC_TAG) { peer = (unsigned)g; break; }
-                if (++spins > spin_budget) { atomicExch(a.err, 1000000); peer = ~0u; break; }
+                if (++spins > spin_budget) { mp_set_error(a.err, 1000000); peer = ~0u; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
         }
@@ -547,7 +547,7 @@ MP_KERNEL __launch_bounds__(512, 1) void mp_lstm_fused_uni2(LstmPersistArgs a) {
             if (++spins > spin_budget) timed_out = true;
         }
         if (timed_out) {
-            if (lane == 0) atomicExch(a.err, 1 + step);
+            if (lane == 0) mp_set_error(a.err, 1 + step);
             spin_budget = 0;
         }
 #pragma unroll
@@ -672,22 +672,32 @@ MP_KERNEL void mp_pack_wih_persist(const float* __restrict__ wih, float* __restr
 }
 
 template <int H, int NSLICE, int KIN, int TW>
+constexpr size_t fused_lds() {
+    using C = Cfg<H, NSLICE, KIN, TW>;
+    return (size_t)C::RED_F4 * 16 + (size_t)C::NWV * C::XL * C::NTG * 64 * 16;
+}
+
+template <int H, int NSLICE, int KIN, int TW>
 void launch_fused(const LstmPersistArgs& a, hipStream_t s) {
     using C = Cfg<H, NSLICE, KIN, TW>;
-    const size_t lds = (size_t)C::RED_F4 * 16 + (size_t)C::NWV * C::XL * C::NTG * 64 * 16;
+    const size_t lds = fused_lds<H, NSLICE, KIN, TW>();
     const dim3 grid(((a.nslab * a.ndir + 7) / 8) * 8 * NSLICE);
-    if (a.prof) {
-        static bool once = (hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, TW, true>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-        (void)once;
-        hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, TW, true>), grid, dim3(64 * C::NWV), lds, s, a);
-    } else {
-        static bool once = (hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, TW, false>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-        (void)once;
-        hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, TW, false>), grid, dim3(64 * C::NWV), lds, s, a);
-    }
+    if (a.prof) hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, TW, true>), grid, dim3(64 * C::NWV), lds, s, a);
+    else hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, TW, false>), grid, dim3(64 * C::NWV), lds, s, a);
 }
+
+// the dynamic-LDS limit is a per-device function attribute: set for the CURRENT device, outside of any capture
+template <int H, int NSLICE, int KIN, int TW>
+hipError_t fused_attrs() {
+    const int lds = (int)fused_lds<H, NSLICE, KIN, TW>();
+    hipError_t e = hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, TW, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, TW, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
+
+constexpr size_t kUni2Lds = (size_t)(2 * 4 * 4 * 64 + 2 * 4 * (256 / 16) * 64) * 16;    // 32 KB + 2 x 64 KB
 
 }  // namespace
 
@@ -712,11 +722,20 @@ int mp_persist_max_wg(int H, int nslice) { return H == 256 && nslice == 16 ? 512
 
 // both layers of a unidirectional 2-layer LSTM (H = 256, 16-slice packing) as one wavefront launch
 void mp_launch_lstm_uni2(const LstmPersistArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)(2 * 4 * 4 * 64 + 2 * 4 * (256 / 16) * 64) * 16;    // 32 KB + 2 x 64 KB
-    static bool once = (hipFuncSetAttribute((const void*)mp_lstm_fused_uni2<256>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-    (void)once;
-    hipLaunchKernelGGL((mp_lstm_fused_uni2<256>), dim3(((a.nslab + 7) / 8) * 8 * 16), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((mp_lstm_fused_uni2<256>), dim3(((a.nslab + 7) / 8) * 8 * 16), dim3(512), kUni2Lds, s, a);
+}
+
+hipError_t mp_lstm_persist_device_attrs() {
+    hipError_t e = hipSuccess;
+    if (!e) e = fused_attrs<256, 16, 256, 1>();
+    if (!e) e = fused_attrs<256, 16, 512, 1>();
+    if (!e) e = fused_attrs<256, 8, 256, 2>();
+    if (!e) e = fused_attrs<256, 8, 512, 2>();
+    if (!e) e = fused_attrs<64, 4, 64, 1>();
+    if (!e) e = fused_attrs<64, 4, 128, 1>();
+    if (!e) e = hipFuncSetAttribute((const void*)mp_lstm_fused_uni2<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kUni2Lds);
+    return e;
 }
 
 void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice, hipStream_t s) {

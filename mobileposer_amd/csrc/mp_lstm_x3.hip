@@ -193,7 +193,7 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
             while (true) {
                 const u64 g = granule_load(xtab + lane);
                 if ((unsigned)(g >> 32) == XCC_TAG) { peer = (unsigned)g; break; }
-                if (++spins > spin_budget) { atomicExch(a.err, 1000000); peer = ~0u; break; }
+                if (++spins > spin_budget) { mp_set_error(a.err, 1000000); peer = ~0u; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
         }
@@ -427,7 +427,7 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
                 unsigned spins = 0;
                 do {
                     if (++spins > spin_budget) {                // bounded: flag the error and never wait again
-                        if (lane == 0) atomicExch(a.err, 1 + step);
+                        if (lane == 0) mp_set_error(a.err, 1 + step);
                         spin_budget = 0;
                         break;
                     }
@@ -601,17 +601,17 @@ void launch_x3(const LstmPersistArgs& a, hipStream_t s) {
     using C = CfgX<NSLICE, KIN>;
     const size_t lds = (size_t)C::LDS_BYTES;
     const dim3 grid(((a.nslab * a.ndir + 7) / 8) * 8 * NSLICE);
-    if (a.prof) {
-        static bool once = (hipFuncSetAttribute((const void*)mp_lstm_x3<NSLICE, KIN, true>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-        (void)once;
-        hipLaunchKernelGGL((mp_lstm_x3<NSLICE, KIN, true>), grid, dim3(64 * C::NWV), lds, s, a);
-    } else {
-        static bool once = (hipFuncSetAttribute((const void*)mp_lstm_x3<NSLICE, KIN, false>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-        (void)once;
-        hipLaunchKernelGGL((mp_lstm_x3<NSLICE, KIN, false>), grid, dim3(64 * C::NWV), lds, s, a);
-    }
+    if (a.prof) hipLaunchKernelGGL((mp_lstm_x3<NSLICE, KIN, true>), grid, dim3(64 * C::NWV), lds, s, a);
+    else hipLaunchKernelGGL((mp_lstm_x3<NSLICE, KIN, false>), grid, dim3(64 * C::NWV), lds, s, a);
+}
+
+template <int NSLICE, int KIN>
+hipError_t x3_attrs() {
+    const int lds = (int)CfgX<NSLICE, KIN>::LDS_BYTES;
+    hipError_t e = hipFuncSetAttribute((const void*)mp_lstm_x3<NSLICE, KIN, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)mp_lstm_x3<NSLICE, KIN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
 }  // namespace
@@ -630,4 +630,10 @@ void mp_launch_lstm_x3(const LstmPersistArgs& a, int KIN, int nslice, hipStream_
     (void)nslice;
     if (KIN == 256) launch_x3<8, 256>(a, s);
     else launch_x3<8, 512>(a, s);
+}
+
+// per-device dynamic-LDS limits of the kernels above (called by mp_create after hipSetDevice, outside of any capture)
+hipError_t mp_lstm_x3_device_attrs() {
+    hipError_t e = x3_attrs<8, 256>();
+    return e != hipSuccess ? e : x3_attrs<8, 512>();
 }

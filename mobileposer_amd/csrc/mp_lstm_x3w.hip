@@ -170,7 +170,7 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
             while (true) {
                 const u64 g = granule_load(xtab + lane);
                 if ((unsigned)(g >> 32) == XCC_TAG) { peer = (unsigned)g; break; }
-                if (++spins > spin_budget) { atomicExch(a.err, 1000000); peer = ~0u; break; }
+                if (++spins > spin_budget) { mp_set_error(a.err, 1000000); peer = ~0u; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
         }
@@ -314,7 +314,7 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
                 unsigned spins = 0;
                 do {
                     if (++spins > spin_budget) {
-                        if (lane == 0) atomicExch(a.err, 1 + step);
+                        if (lane == 0) mp_set_error(a.err, 1 + step);
                         spin_budget = 0;
                         break;
                     }
@@ -434,17 +434,16 @@ void launch_x3w(const LstmPersistArgs& a, hipStream_t s) {
     using C = CfgW<KIN>;
     const size_t lds = (size_t)C::LDS_BYTES;
     const dim3 grid(((a.nslab * a.ndir + 7) / 8) * 8 * 8);
-    if (a.prof) {
-        static bool once = (hipFuncSetAttribute((const void*)mp_lstm_x3w<KIN, true>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-        (void)once;
-        hipLaunchKernelGGL((mp_lstm_x3w<KIN, true>), grid, dim3(256), lds, s, a);
-    } else {
-        static bool once = (hipFuncSetAttribute((const void*)mp_lstm_x3w<KIN, false>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-        (void)once;
-        hipLaunchKernelGGL((mp_lstm_x3w<KIN, false>), grid, dim3(256), lds, s, a);
-    }
+    if (a.prof) hipLaunchKernelGGL((mp_lstm_x3w<KIN, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((mp_lstm_x3w<KIN, false>), grid, dim3(256), lds, s, a);
+}
+
+template <int KIN>
+hipError_t x3w_attrs() {
+    const int lds = (int)CfgW<KIN>::LDS_BYTES;
+    hipError_t e = hipFuncSetAttribute((const void*)mp_lstm_x3w<KIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)mp_lstm_x3w<KIN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
 }  // namespace
@@ -453,4 +452,10 @@ void launch_x3w(const LstmPersistArgs& a, hipStream_t s) {
 void mp_launch_lstm_x3w(const LstmPersistArgs& a, int KIN, hipStream_t s) {
     if (KIN == 256) launch_x3w<256>(a, s);
     else launch_x3w<512>(a, s);
+}
+
+// per-device dynamic-LDS limits (called by mp_create after hipSetDevice, outside of any capture)
+hipError_t mp_lstm_x3w_device_attrs() {
+    hipError_t e = x3w_attrs<256>();
+    return e != hipSuccess ? e : x3w_attrs<512>();
 }

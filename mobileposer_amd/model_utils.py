@@ -31,14 +31,40 @@ def blob_to_state_dict(blob):
     return out
 
 
-def load_model(model_path, smpl_file=None, device="cuda:0"):
-    """utils/model_utils.py:6-15.  ``model_path``: a ``torch.save``d state dict of the 72 tensors
-    (combine_weights.py:53-56) or a Lightning checkpoint holding it under 'state_dict'."""
-    import torch
-    from .net import MobilePoserNet
-    sd = torch.load(model_path, map_location="cpu")
-    if isinstance(sd, dict) and "state_dict" in sd:
+def normalise_state_dict(obj):
+    """What ``load_model`` accepts (utils/model_utils.py:6-15): the plain state dict of the 72 tensors written by
+    combine_weights.py:53-56, or a Lightning checkpoint (``MobilePoserNet.load_from_checkpoint``: the weights sit under
+    'state_dict', possibly behind a common wrapper prefix such as 'model.' / 'module.').  Extra entries are ignored
+    the way a non-strict load would; a missing weight raises."""
+    sd = obj
+    if isinstance(sd, dict) and "state_dict" in sd and not hasattr(sd["state_dict"], "shape"):
         sd = sd["state_dict"]
-    model = MobilePoserNet(smpl_file=smpl_file, device=device)
-    model.load_state_dict(sd)
+    if not isinstance(sd, dict):
+        raise TypeError("expected a state dict or a checkpoint dict, got %s" % type(obj).__name__)
+    man = state_dict_manifest()
+    first = next(iter(man))
+    if first not in sd:
+        hits = [k for k in sd if isinstance(k, str) and k.endswith(first)]
+        if len(hits) == 1:
+            prefix = hits[0][:-len(first)]
+            sd = {k[len(prefix):]: v for k, v in sd.items() if isinstance(k, str) and k.startswith(prefix)}
+    return {k: sd[k] for k in man if k in sd} if all(k in sd for k in man) else sd
+
+
+def load_model(model_path, smpl_file=None, device="cuda:0", smpl=None):
+    """utils/model_utils.py:6-15: ``load_model(path) -> MobilePoserNet`` with the weights of ``path`` (a ``torch.save``d
+    state dict, or a Lightning checkpoint as the reference's fallback branch reads).  ``smpl_file`` defaults to
+    ``config.paths.smpl_file`` when that file exists (the reference always reads it, net.py:37), else the synthetic body."""
+    import os
+    import torch
+    from .config import paths
+    from .net import MobilePoserNet
+    try:
+        obj = torch.load(model_path, map_location="cpu", weights_only=True)
+    except Exception:                       # Lightning checkpoints carry non-tensor objects (hyper-parameters)
+        obj = torch.load(model_path, map_location="cpu", weights_only=False)
+    if smpl is None and smpl_file is None and os.path.exists(str(paths.smpl_file)):
+        smpl_file = str(paths.smpl_file)
+    model = MobilePoserNet(smpl_file=smpl_file, smpl=smpl, device=device)
+    model.load_state_dict(normalise_state_dict(obj))
     return model

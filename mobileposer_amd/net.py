@@ -39,10 +39,18 @@ def _close_all():               # runs before interpreter finalisation, while th
 
 
 class _VelocityView:
-    """Stands in for ``model.velocity``: exposes the carried LSTM state as ``rnn_state`` (velocity.py:30,47)."""
+    """Stands in for ``model.velocity``: exposes the carried LSTM state as ``rnn_state`` (velocity.py:30,47).
+    Holds the net weakly: no reference cycle, so a net's native handle is released as soon as the net is."""
 
     def __init__(self, net):
-        self._net = net
+        self._ref = weakref.ref(net)
+
+    @property
+    def _net(self):
+        net = self._ref()
+        if net is None:
+            raise ReferenceError("the MobilePoserNet this velocity view belongs to is gone")
+        return net
 
     @property
     def rnn_state(self):
@@ -94,17 +102,13 @@ class MobilePoserNet:
         self.num_past_frames = model_config.past_frames
         self.num_future_frames = model_config.future_frames
         self.num_total_frames = self.num_past_frames + self.num_future_frames
-        # variables (net.py:59-64)
-        self.last_root_pos = torch.zeros(3, device=self.device)
-        self.current_root_y = 0
-        self.imu = None
+        # variables (net.py:59-64): last_root_pos / current_root_y / imu / last_{l,r}foot_pos live in the library's
+        # per-stream state on the device and are mirrored by the properties below
         self.rnn_state = None
         self.velocity = _VelocityView(self)
         self._h = None
         self._blob = None
-        self._io = {}
         self._stream_S = 0
-        self._online_started = False
         self.training = False
         parts = {"pose.": poser, "joints.": joints, "foot_contact.": foot_contact, "velocity.": velocity}
         if any(v is not None for v in parts.values()):
@@ -155,7 +159,6 @@ class MobilePoserNet:
         fp = (C.c_float * 6)()
         _lib.check(self._lib.mp_get_constants(self._h, C.byref(fy), fp), self._h)
         assert abs(fy.value - self.floor_y) < 1e-6
-        self._io = {}
         self._stream_S = 0
         self.n_vertex = 0
         bm = self.bodymodel
@@ -172,9 +175,16 @@ class MobilePoserNet:
         if h is not None:
             self._lib.mp_destroy(h)
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def __del__(self):
-        # at interpreter shutdown the HIP runtime may already be gone: native handles are then released by the atexit
-        # hook below (which runs first), never from a finalizer
+        # no reference cycles (the velocity view and the body model hold this object weakly), so this runs when the
+        # last reference goes -- never from the cyclic collector at an arbitrary allocation.  At interpreter shutdown
+        # the HIP runtime may already be gone: handles still alive then were released by the atexit hook above.
         try:
             if not sys.is_finalizing():
                 self.close()
@@ -213,12 +223,8 @@ class MobilePoserNet:
         """models/net.py:84-88.  Like the reference this does NOT clear ``velocity.rnn_state`` (SURVEY Q1);
         pass ``clear_velocity=True`` to ``reset_all`` or set ``model.velocity.rnn_state = None`` for that."""
         self.rnn_state = None
-        self.imu = None
-        self.current_root_y = 0
-        self.last_root_pos = torch.zeros(3, device=self.device)
-        if self._h is not None and self._stream_S:
+        if self._h is not None and self._stream_S:        # imu = None, current_root_y = 0, last_root_pos = 0
             _lib.check(self._lib.mp_stream_reset(self._h, None, 0), self._h)
-        self._online_started = False
 
     def reset_all(self, clear_velocity=True):
         self.reset()
@@ -240,22 +246,16 @@ class MobilePoserNet:
             raise RuntimeError("len(input_lengths) = %d but batch = %d" % (len(lens), B))
         return (C.c_int32 * B)(*lens)
 
-    def _buffers(self, B, T):
-        key = (B, T)
-        io = self._io.get(key)
-        if io is None:
-            dev, f32 = self.device, torch.float32
-            io = {
-                "imu": torch.empty(B, T, 60, device=dev, dtype=f32),
-                "pose": torch.empty(B * T, 24, 3, 3, device=dev, dtype=f32),
-                "joints": torch.empty(B, T, 72, device=dev, dtype=f32),
-                "vel": torch.empty(B, T, 72, device=dev, dtype=f32),
-                "contact": torch.empty(B, T, 2, device=dev, dtype=f32),
-                "r6d": torch.empty(B, T, 96, device=dev, dtype=f32),
-                "tran": torch.empty(B, T, 3, device=dev, dtype=f32),
-            }
-            self._io[key] = io
-        return io
+    def _input(self, x):
+        """The caller's tensor itself when it already is contiguous fp32 on this device (no copy)."""
+        if x.device == self.device and x.dtype == torch.float32 and x.is_contiguous():
+            return x
+        return x.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def _outputs(self, B, T, names):
+        shapes = {"pose": (B * T, 24, 3, 3), "joints": (B, T, 72), "vel": (B, T, 72), "contact": (B, T, 2),
+                  "r6d": (B, T, 96), "tran": (B, T, 3)}
+        return {n: torch.empty(shapes[n], device=self.device, dtype=torch.float32) for n in names}
 
     def forward_into(self, imu, lengths_c, pose, joints, vel, contact, r6d=None):
         """mp_forward on caller-owned contiguous fp32 cuda buffers (no allocation, no copies)."""
@@ -264,23 +264,20 @@ class MobilePoserNet:
                                   _ptr(contact), _ptr(r6d), self._stream())
         _lib.check(rc, self._h)
 
-    def _forward_buffers(self, batch, input_lengths):
+    def forward(self, batch, input_lengths=None, return_r6d=False):
+        """models/net.py:101-119 -> (pred_pose [B*T,24,3,3], pred_joints [B,T,72], pred_vel [B,T,72]
+        (batch dim squeezed when B == 1, net.py:117), foot_contact [B,T,2]); with ``return_r6d`` the Poser output
+        before net.py:110 ([B,T,96]) is appended.  Outputs are fresh tensors the library writes directly."""
         self._require_weights()
         if batch.dim() != 3 or batch.shape[-1] != model_config.n_imu:
             raise RuntimeError("expected batch of shape [B, T, 60], got %s" % (tuple(batch.shape),))
         B, T = int(batch.shape[0]), int(batch.shape[1])
         lens = self._lengths(input_lengths, B, T)
-        io = self._buffers(B, T)
-        io["imu"].copy_(batch.to(device=self.device, dtype=torch.float32))
-        self.forward_into(io["imu"], lens, io["pose"], io["joints"], io["vel"], io["contact"], io["r6d"])
-        return io, lens, B, T
-
-    def forward(self, batch, input_lengths=None):
-        """models/net.py:101-119 -> (pred_pose [B*T,24,3,3], pred_joints [B,T,72], pred_vel [B,T,72]
-        (batch dim squeezed when B == 1, net.py:117), foot_contact [B,T,2])."""
-        io, _, B, T = self._forward_buffers(batch, input_lengths)
-        vel = io["vel"].clone()
-        return io["pose"].clone(), io["joints"].clone(), vel.squeeze(0), io["contact"].clone()
+        x = self._input(batch)
+        o = self._outputs(B, T, ("pose", "joints", "vel", "contact") + (("r6d",) if return_r6d else ()))
+        self.forward_into(x, lens, o["pose"], o["joints"], o["vel"], o["contact"], o.get("r6d"))
+        out = (o["pose"], o["joints"], o["vel"].squeeze(0), o["contact"])
+        return out + (o["r6d"],) if return_r6d else out
 
     __call__ = forward
 
@@ -295,16 +292,14 @@ class MobilePoserNet:
             raise RuntimeError("expected imu of shape [B, T, 60], got %s" % (tuple(imu.shape),))
         B, T = int(imu.shape[0]), int(imu.shape[1])
         lens = self._lengths(input_lengths, B, T)
-        io = self._buffers(B, T)
-        io["imu"].copy_(imu.to(device=self.device, dtype=torch.float32))
-        rc = self._lib.mp_forward_offline(self._h, _ptr(io["imu"]), lens, B, T, _ptr(io["pose"]), _ptr(io["joints"]),
-                                          _ptr(io["vel"]), _ptr(io["contact"]), _ptr(io["tran"]), None, None, self._stream())
+        x = self._input(imu)
+        o = self._outputs(B, T, ("pose", "joints", "vel", "contact", "tran"))
+        rc = self._lib.mp_forward_offline(self._h, _ptr(x), lens, B, T, _ptr(o["pose"]), _ptr(o["joints"]),
+                                          _ptr(o["vel"]), _ptr(o["contact"]), _ptr(o["tran"]), None, None, self._stream())
         _lib.check(rc, self._h)
-        pose, joints = io["pose"].clone(), io["joints"].clone()
-        tran, contact = io["tran"].clone(), io["contact"].clone()
         if B == 1:
-            return pose, joints, tran[0], contact[0]
-        return pose, joints, tran, contact
+            return o["pose"], o["joints"], o["tran"][0], o["contact"][0]
+        return o["pose"], o["joints"], o["tran"], o["contact"]
 
     def translate_offline_into(self, joints, vel, contact, lengths_c, tran):
         B, T = joints.shape[0], joints.shape[1]
@@ -317,14 +312,6 @@ class MobilePoserNet:
         self._require_weights()
         _lib.check(self._lib.mp_stream_create(self._h, int(S)), self._h)
         self._stream_S = int(S)
-        dev, f32 = self.device, torch.float32
-        self._sio = {
-            "frames": torch.empty(S, 60, device=dev, dtype=f32),
-            "pose": torch.empty(S, 24, 9, device=dev, dtype=f32),
-            "joints": torch.empty(S, 45, 72, device=dev, dtype=f32),
-            "root": torch.empty(S, 3, device=dev, dtype=f32),
-            "contact": torch.empty(S, 2, device=dev, dtype=f32),
-        }
 
     def stream_step_into(self, frames, pose, joints, root, contact):
         rc = self._lib.mp_stream_step(self._h, _ptr(frames), _ptr(pose), _ptr(joints), _ptr(root), _ptr(contact),
@@ -333,10 +320,21 @@ class MobilePoserNet:
 
     def stream_step(self, frames):
         """One tick for all S streams: frames [S,60] -> (pose [S,24,9], joints [S,45,72], root_pos [S,3], contact [S,2])."""
-        io = self._sio
-        io["frames"].copy_(frames.to(device=self.device, dtype=torch.float32).reshape(self._stream_S, 60))
-        self.stream_step_into(io["frames"], io["pose"], io["joints"], io["root"], io["contact"])
-        return io["pose"].clone(), io["joints"].clone(), io["root"].clone(), io["contact"].clone()
+        S, dev, f32 = self._stream_S, self.device, torch.float32
+        x = self._input(frames.reshape(S, 60))
+        pose = torch.empty(S, 24, 9, device=dev, dtype=f32)
+        joints = torch.empty(S, 45, 72, device=dev, dtype=f32)
+        root = torch.empty(S, 3, device=dev, dtype=f32)
+        contact = torch.empty(S, 2, device=dev, dtype=f32)
+        self.stream_step_into(x, pose, joints, root, contact)
+        return pose, joints, root, contact
+
+    def stream_reset(self, mask=None, clear_velocity=False):
+        """reset() (net.py:84-88) for the streams whose ``mask`` entry is true (all when None)."""
+        m = None
+        if mask is not None:
+            m = (C.c_uint8 * self._stream_S)(*[1 if bool(v) else 0 for v in mask])
+        _lib.check(self._lib.mp_stream_reset(self._h, m, int(bool(clear_velocity))), self._h)
 
     @torch.no_grad()
     def forward_online(self, data, input_lengths=None):
@@ -348,9 +346,30 @@ class MobilePoserNet:
         if self._stream_S != 1:
             raise RuntimeError("forward_online drives a single stream; use stream_step for %d streams" % self._stream_S)
         pose, joints, root, contact = self.stream_step(data.reshape(1, 60))
-        self.last_root_pos = root[0]
-        self._online_started = True
-        return pose[0], joints[0], root[0].clone(), contact[0]
+        return pose[0], joints[0], root[0], contact[0]
+
+    # ---- the reference's state attributes (net.py:59-64,205-208), read back from the device ---------------
+    def stream_state(self, s=0):
+        """State of stream ``s``: dict(imu [45,60] or None before the first frame, current_root_y (float),
+        last_root_pos [3], last_lfoot_pos [3], last_rfoot_pos [3])."""
+        if self._h is None or not self._stream_S:
+            feet = self.feet_pos.to(self.device)
+            return {"imu": None, "current_root_y": 0, "last_root_pos": torch.zeros(3, device=self.device),
+                    "last_lfoot_pos": feet[0], "last_rfoot_pos": feet[1]}
+        win = torch.empty(45, 60, device=self.device, dtype=torch.float32)
+        feet = (C.c_float * 6)()
+        root = (C.c_float * 3)()
+        y, fresh = C.c_double(0), C.c_int(0)
+        _lib.check(self._lib.mp_stream_get_state(self._h, int(s), _ptr(win), feet, C.byref(y), root, C.byref(fresh)), self._h)
+        t = lambda a: torch.tensor(list(a), device=self.device, dtype=torch.float32)
+        return {"imu": None if fresh.value else win, "current_root_y": y.value if not fresh.value else 0,
+                "last_root_pos": t(root), "last_lfoot_pos": t(feet[0:3]), "last_rfoot_pos": t(feet[3:6])}
+
+    imu = property(lambda self: self.stream_state()["imu"])
+    current_root_y = property(lambda self: self.stream_state()["current_root_y"])
+    last_root_pos = property(lambda self: self.stream_state()["last_root_pos"])
+    last_lfoot_pos = property(lambda self: self.stream_state()["last_lfoot_pos"])
+    last_rfoot_pos = property(lambda self: self.stream_state()["last_rfoot_pos"])
 
     # ---- kinematics ----------------------------------------------------------------------------
     def _reduced_global_to_full(self, reduced_pose):
@@ -407,8 +426,8 @@ class MobilePoserNet:
         return n.value, ms.value, gf.value
 
     def set_lstm_mode(self, mode):
-        """3: fused persistent layers on split-bf16 MFMA operands (default); 1: the same on exact-fp32 operands;
-        2: mode 1 + two-layer wavefront velocity kernel; 0: per-step kernels.  (include/mobileposer_hip.h)"""
+        """1 (default): fused persistent layers on exact-fp32 MFMA operands; 3: the same on split-bf16 operands (opt-in
+        fast mode); 2: mode 1 + two-layer wavefront velocity kernel; 0: per-step kernels.  (include/mobileposer_hip.h)"""
         _lib.check(self._lib.mp_set_lstm_mode(self._h, int(mode)), self._h)
 
     def set_transport(self, force_remote):

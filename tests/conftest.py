@@ -51,3 +51,32 @@ def geodesic(Ra, Rb):
     # robust: angle = 2*asin(||D - I||_F / (2*sqrt(2)))
     n = np.linalg.norm(D - np.eye(3), axis=(-1, -2))
     return 2.0 * np.arcsin(np.clip(n / (2.0 * np.sqrt(2.0)), 0.0, 1.0))
+
+
+# ---- shared by the -m gpu test modules -----------------------------------------------------------
+@pytest.fixture(scope="session")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
+    return torch
+
+
+@pytest.fixture(params=["fp32", "x3"])
+def net(request, torch_mod, weights, smpl):
+    """Every parity test runs twice: exact-fp32 MFMA operands (LSTM mode 1, the library default and the reference's
+    arithmetic) and split-bf16 operands (mode 3, mp_lstm_x3.hip, opt-in) -- same goldens, same oracle, same tolerances.
+    The handle is closed when the test ends: one live native handle at a time unless a test builds more itself."""
+    from mobileposer_amd.net import MobilePoserNet
+    n = MobilePoserNet.from_numpy(weights, smpl, device="cuda:0")
+    n.lstm_mode = 3 if request.param == "x3" else 1
+    n.set_lstm_mode(n.lstm_mode)
+    yield n
+    n.close()
+
+
+def cu(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
