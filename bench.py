@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- IMU frames/s of the MobilePoser inference path on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one synthetic batch of 256 IMU windows x 125 frames that is
-already resident in HBM:  mp_forward_offline = forward (4 stacked-LSTM modules + 6D->SO(3) + global->local)
- + SMPL forward kinematics of the predicted pose + foot-contact/velocity translation solver, one captured graph.  With N > 1 every rank (one process per GPU, launched by torch.distributed.run) runs
-the same per-GPU workload on its own seeded batch (weak scaling); the only collective is the RCCL broadcast
-of the weight blob from rank 0 at start-up.
+One "step" = one pass of the hot path over one synthetic batch of IMU windows x 125 frames that is already resident in
+HBM:  mp_forward_offline = forward (4 stacked-LSTM modules + 6D->SO(3) + global->local) + SMPL forward kinematics of the
+predicted pose + foot-contact/velocity translation solver.  The headline `value` is measured in the library's default
+arithmetic -- exact-fp32 MFMA operands, the reference's arithmetic (`dtype` "f32"); the opt-in split-bf16 mode is timed
+in the same run and reported under `modes`.
 
-Prints ONE JSON line on rank 0 (see the field list in README / DESIGN.md section "Measurement").
+  --scaling weak   (default)  256 sequences per GPU (BASELINE metric: batch 256 x window 125 per GPU)
+  --scaling strong            BASELINE configs[3]: --global-batch (1024) sequences split over the ranks with
+                              dist.shard_range (128 per GPU on 8 GPUs)
+With N > 1 (one process per GPU, launched by torch.distributed.run) the only collective is ONE RCCL broadcast of the weight
+blob + SMPL constants from rank 0 at start-up; sequences never interact.
+
+Prints ONE JSON line on rank 0 (field list: DESIGN.md section "Measurement").
 """
 import argparse
 import ctypes as C
@@ -150,8 +156,10 @@ def bench_stream(args, net, dev, dist, rank, world):
             "value": round(world * S * ticks, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 / ticks, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[4]: %d concurrent streams per GPU, hipGraph-captured tick" % S,
+            "config": {"workload": "configs[4]: %d concurrent streams per GPU, one tick = one new frame per stream (%s)"
+                                   % (S, "hipGraph replay" if args.graph else "eager launches"),
                        "streams_per_gpu": S, "ticks_per_s": round(ticks, 2), "meets_60hz": ticks >= 60.0,
+                       "lstm_mode": args.lstm_mode, "graph": bool(args.graph),
                        "window_frames_per_s": round(world * S * 45 * ticks, 1)}}))
     if dist is not None:
         dist.destroy_process_group()
@@ -160,17 +168,20 @@ def bench_stream(args, net, dev, dist, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (default 300: a timed region of > 1 s)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay captured hipGraphs instead of eager launches (opt-in, "
+                    "see profiles/r02_hipgraph_segv.md)")
     ap.add_argument("--workload", choices=["offline", "stream"], default="offline",
                     help="offline (default, the BASELINE metric) or stream: config 5, S concurrent 45-frame windows per GPU")
     ap.add_argument("--streams", type=int, default=512)
-    ap.add_argument("--lstm-mode", choices=["fp32", "x3"], default="x3",
-                    help="MFMA operands of the H=256 LSTM layers for the headline value: x3 (the library default: every fp32 "
-                         "product as 3 bf16 products on v_mfma_f32_16x16x32_bf16, fp32 accumulate) or fp32 (exact "
-                         "v_mfma_f32_16x16x4_f32); the other mode is timed as well and reported beside it")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--global-batch", type=int, default=1024, help="--scaling strong: sequences of the whole job (configs[3])")
+    ap.add_argument("--lstm-mode", choices=["fp32", "x3"], default="fp32",
+                    help="MFMA operands of the H=256 LSTM layers for the headline value: fp32 (default = the library default: "
+                         "exact v_mfma_f32_16x16x4_f32 operands, the reference's arithmetic) or x3 (opt-in: every fp32 product "
+                         "as 3 bf16 products on v_mfma_f32_16x16x32_bf16, fp32 accumulate); the other mode is timed as well")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -196,23 +207,33 @@ def main():
             dist.barrier()
 
     from mobileposer_amd import synthetic
-    from mobileposer_amd.dist import broadcast_weights
+    from mobileposer_amd.dist import broadcast_model, gather_counts, shard_range
     from mobileposer_amd.net import MobilePoserNet
 
-    smpl = synthetic.synthetic_smpl()
-    if dist is not None:
-        blob = broadcast_weights(synthetic.make_weights(0) if rank == 0 else None, dev, src=0)
+    if dist is not None:    # ONE broadcast: weight blob + SMPL constants; ranks > 0 build from the blob in HBM
+        blob, smpl = broadcast_model(synthetic.make_weights(0) if rank == 0 else None,
+                                     synthetic.synthetic_smpl() if rank == 0 else None, dev, src=0)
         net = MobilePoserNet.from_device_blob(blob, smpl, device=dev)
     else:
-        net = MobilePoserNet.from_numpy(synthetic.make_weights(0), smpl, device=dev)
-    if args.no_graph:
-        net.set_graph_mode(False)
+        net = MobilePoserNet.from_numpy(synthetic.make_weights(0), synthetic.synthetic_smpl(), device=dev)
+    net.set_graph_mode(bool(args.graph))
 
     if args.workload == "stream":
+        net.set_lstm_mode({"fp32": 1, "x3": 3}[args.lstm_mode])
         return bench_stream(args, net, dev, dist, rank, world)
 
-    B, T = B_PER_GPU, T_WIN
-    imu = torch.from_numpy(synthetic.make_imu(B, T, seed=1 + rank)).to(dev)
+    T = T_WIN
+    if args.scaling == "strong":                     # configs[3]: a fixed global batch, contiguous shards
+        lo, hi = shard_range(args.global_batch, rank, world)
+        B, global_batch = hi - lo, args.global_batch
+        # every rank draws the SAME global batch and keeps its rows: the job's input does not depend on N
+        imu_all = synthetic.make_imu(global_batch, T, seed=1)
+        imu = torch.from_numpy(np.ascontiguousarray(imu_all[lo:hi])).to(dev)
+        del imu_all
+    else:
+        B, global_batch = B_PER_GPU, world * B_PER_GPU
+        lo, hi = rank * B, (rank + 1) * B
+        imu = torch.from_numpy(synthetic.make_imu(B, T, seed=1 + rank)).to(dev)
     f32 = torch.float32
     pose = torch.empty(B * T, 24, 3, 3, device=dev, dtype=f32)
     joints = torch.empty(B, T, 72, device=dev, dtype=f32)
@@ -229,7 +250,7 @@ def main():
     def step():
         lib.mp_reset_state(h, 1)            # every step is a fresh, independent batch
         rc = lib.mp_forward_offline(h, vp(imu), lens, B, T, vp(pose), vp(joints), vp(vel), vp(contact), vp(tran),
-                                    vp(rglob), vp(jglob), stream)       # forward + FK + translation solver, one graph
+                                    vp(rglob), vp(jglob), stream)       # forward + FK + translation solver
         if rc:
             raise RuntimeError(lib.mp_last_error(h).decode())
 
@@ -240,35 +261,86 @@ def main():
 
     MODE_ID = {"fp32": 1, "x3": 3}
 
-    def timed(mode):
-        """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks."""
+    def timed(mode, steps):
+        """W warm-up steps, then exactly `steps` steps between barrier + synchronize; max over ranks."""
         net.set_lstm_mode(MODE_ID[mode])
         for _ in range(args.warmup):
             step()
         sync()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step()
         sync()
-        dt = time.perf_counter() - t0
+        dt_local = time.perf_counter() - t0
+        dt = dt_local
         if dist is not None:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        return dt
+        return dt, dt_local
 
     other = "x3" if args.lstm_mode == "fp32" else "fp32"
-    elapsed_other = timed(other)
-    outs_other = [t.clone() for t in (joints, vel, contact, tran, pose)]
-    elapsed = timed(args.lstm_mode)                       # the headline measurement (its outputs stay in the buffers)
-    mode_dev = max(float((a - b).abs().max()) for a, b in zip(outs_other, (joints, vel, contact, tran, pose)))
+    elapsed, elapsed_local = timed(args.lstm_mode, args.steps)          # the headline measurement: exactly K steps
+    outs_head = [t.clone() for t in (joints, vel, contact, tran, pose)]
+    other_steps = max(20, args.steps // 4)
+    elapsed_other, _ = timed(other, other_steps)
+    mode_dev = max(float((a - b).abs().max()) for a, b in zip(outs_head, (joints, vel, contact, tran, pose)))
+    del outs_head
+    err = C.c_int(0)
+    lib.mp_device_error(h, C.byref(err))
+    if err.value:
+        raise RuntimeError("persistent-kernel wait timed out during the timed region (code %d)" % err.value)
+    per_rank = None
+    if dist is not None:
+        per_rank = gather_counts(B * T * args.steps, elapsed_local, dev)
+
+    # ---- BASELINE configs[3] beside the headline (weak-scaling runs only): GLOBAL batch 1024 split over the ranks ----
+    strong = None
+    if args.scaling == "weak":
+        g_batch = args.global_batch
+        lo3, hi3 = shard_range(g_batch, rank, world)
+        B3 = hi3 - lo3
+        imu3 = torch.from_numpy(np.ascontiguousarray(synthetic.make_imu(g_batch, T, seed=1)[lo3:hi3])).to(dev)
+        o3 = [torch.empty(B3 * T, 24, 3, 3, device=dev, dtype=f32), torch.empty(B3, T, 72, device=dev, dtype=f32),
+              torch.empty(B3, T, 72, device=dev, dtype=f32), torch.empty(B3, T, 2, device=dev, dtype=f32),
+              torch.empty(B3, T, 3, device=dev, dtype=f32), torch.empty(B3 * T, 24, 3, 3, device=dev, dtype=f32),
+              torch.empty(B3 * T, 24, 3, device=dev, dtype=f32)]
+        lens3 = (C.c_int32 * B3)(*([T] * B3))
+
+        def step3():
+            lib.mp_reset_state(h, 1)
+            rc = lib.mp_forward_offline(h, vp(imu3), lens3, B3, T, *[vp(t) for t in o3], stream)
+            if rc:
+                raise RuntimeError(lib.mp_last_error(h).decode())
+
+        net.set_lstm_mode(MODE_ID[args.lstm_mode])
+        steps3 = max(10, args.steps // 8)
+        for _ in range(3):
+            step3()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps3):
+            step3()
+        sync()
+        dt3 = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt3], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt3 = float(tt.item())
+        strong = {"workload": "configs[3]: global batch %d x %d split contiguously over %d GPU(s) (%d on rank 0)"
+                              % (g_batch, T, world, B3),
+                  "scaling": "strong", "value": round(g_batch * T * steps3 / dt3, 1), "unit": "frames/s",
+                  "ms_per_step": round(1e3 * dt3 / steps3, 4), "steps": steps3, "lstm_mode": args.lstm_mode}
+        del imu3, o3
+        lib.mp_reset_state(h, 1)
 
     # ---- per-kernel-class timing: HIP events around every launch, on the library stream that launches it ----
     kern, dominant = {}, None
     if rank == 0:
+        net.set_lstm_mode(MODE_ID[args.lstm_mode])
         net.timing_enable(True)
         acc = {c: [0, 0.0, 0.0] for c in list(KERNEL_CLASSES) + [3]}
-        reps = 3
+        reps = 5
         for _ in range(reps):
             lib.mp_reset_state(h, 1)
             lib.mp_forward(h, vp(imu), lens, B, T, vp(pose), vp(joints), vp(vel), vp(contact), None, stream)
@@ -289,7 +361,7 @@ def main():
             kern[name] = {"launches_per_forward": n // reps, "avg_launch_ms": round(ms / n, 4),
                           "ms_per_forward": round(ms / reps, 4), "gflop_per_launch": round(gf / n, 3),
                           "tflops": round(gf / ms, 2) if ms > 0 else None}
-        kern["forward_eager_ms"] = round(acc[3][1] / reps, 4)
+        kern["forward_event_timed_ms"] = round(acc[3][1] / reps, 4)
         # the kernel class with the largest share of the forward is the one the roofline line describes
         dominant = max((c for c in KERNEL_CLASSES if acc[c][0]), key=lambda c: acc[c][1])
     if dist is not None:
@@ -300,62 +372,66 @@ def main():
             dist.destroy_process_group()
         return
 
-    frames = world * B * T * args.steps
+    frames = global_batch * T * args.steps
     value = frames / elapsed
-    value_other = frames / elapsed_other
+    value_other = global_batch * T * other_steps / elapsed_other
     dn, dms, dgf = acc[dominant]
-    achieved = dgf / dms if dms > 0 else 0.0              # GFLOP / ms = TFLOP/s
+    achieved = dgf / dms if dms > 0 else 0.0              # GFLOP / ms = TFLOP/s: ALGORITHMIC flops / event-timed duration
     x3_dom = args.lstm_mode == "x3" and dominant in X3_NAMES
     if x3_dom:
-        # every algorithmic fp32 multiply-add is executed as 3 bf16 multiply-adds: price the EXECUTED MFMA flops
-        # against the dense bf16 peak (the algorithmic rate is reported beside it)
+        # opt-in mode: every algorithmic fp32 multiply-add is executed as 3 bf16 multiply-adds: price the EXECUTED MFMA
+        # flops against the dense bf16 peak (the algorithmic rate is reported beside it)
         roof_peak, roof_achieved = PEAK_BF16_MFMA_TFLOPS, 3.0 * achieved
         roof_note = ("3 x algorithmic FLOPs of the launch (each fp32 product = hi*hi + hi*lo + lo*hi on "
-                     "v_mfma_f32_16x16x32_bf16) / HIP-event duration, dense bf16 MFMA peak; the kernel is bound by the "
-                     "per-step hidden-state exchange latency, not by the matrix pipe (DESIGN.md)")
+                     "v_mfma_f32_16x16x32_bf16) / HIP-event duration, dense bf16 MFMA peak")
     else:
         roof_peak, roof_achieved = PEAK_FP32_MFMA_TFLOPS, achieved
-        roof_note = ("algorithmic FLOPs of the launch (input projection + recurrence, SURVEY.md 8(d)) / "
-                     "HIP-event duration of the launch, v_mfma_f32_16x16x4_f32 dense peak")
-    # HBM bytes per launch of that kernel from the separate rocprofv3 --pmc passes (profiles/r01_pmc_summary.json):
+        roof_note = ("algorithmic FLOPs of one launch (input projection + recurrence of one bidirectional layer, "
+                     "SURVEY.md 8(d): 2*4H*(K_in+H) per frame and direction) / HIP-event duration of the launch on the "
+                     "library stream, against the dense v_mfma_f32_16x16x4_f32 peak")
+    # HBM bytes per launch of that kernel from the separate rocprofv3 --pmc passes (profiles/*_pmc_summary.json):
     # (2*FETCH_SIZE + WRITE_SIZE)*1024, corrected as MI355X_MICROARCH.md prescribes; null when no profile is present
     traffic = None
-    try:
-        pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_summary.json")))["kernels"]
-        key = {1: "mp_lstm_fused<256, 8, 256, 2, false>", 4: "mp_lstm_fused<256, 8, 512, 2, false>",
-               5: "mp_lstm_fused<256, 16, 256, 1, false>", 0: "mp_gemm_f32<2, 2, 2, 2>"}.get(dominant)
-        if args.lstm_mode == "x3":
-            key = {1: "mp_lstm_x3<8, 256, false>", 4: "mp_lstm_x3w<512, false>", 5: "mp_lstm_x3<8, 256, false>",
-                   0: "mp_gemm_x3<128, 64>"}.get(dominant)
-        traffic = pmc[key]["hbm_bytes_per_launch_corrected"] if key in pmc else None
-    except Exception:
-        traffic = None
+    for prof in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        try:
+            pmc = json.load(open(os.path.join(REPO, "profiles", prof)))["kernels"]
+            key = {1: "mp_lstm_fused<256, 8, 256, 2, false>", 4: "mp_lstm_fused<256, 8, 512, 2, false>",
+                   5: "mp_lstm_fused<256, 16, 256, 1, false>", 0: "mp_gemm_f32<2, 2, 2, 2>"}.get(dominant)
+            if args.lstm_mode == "x3":
+                key = {1: "mp_lstm_x3<8, 256, false>", 4: "mp_lstm_x3w<512, false>", 5: "mp_lstm_x3<8, 256, false>",
+                       0: "mp_gemm_x3<128, 64>"}.get(dominant)
+            if key in pmc:
+                traffic = pmc[key]["hbm_bytes_per_launch_corrected"]
+                break
+        except Exception:
+            pass
+    cfg_name = ("configs[3]: full MobilePoserNet + r6d/IK + SMPL FK + offline translation solver, GLOBAL batch %d x T=%d "
+                "split contiguously over %d GPU(s) (%d sequences on rank 0)" % (global_batch, T, world, B)
+                if args.scaling == "strong" else
+                "configs[2]+solver: full MobilePoserNet (4 LSTM modules) + r6d/IK + SMPL FK + offline translation solver, "
+                "B=256 x T=125 per GPU")
     out = {
         "metric": "imu_frames_per_sec (MobilePoserNet fwd + FK + translation solver, batch 256 x window 125 per GPU)",
         "value": round(value, 1), "unit": "frames/s", "per_gpu": round(value / world, 1),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.lstm_mode == "fp32" else "f32 (LSTM and linear-layer matrix products as 3-term split-bf16 MFMA, fp32 accumulate)",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f32" if args.lstm_mode == "fp32" else "f32 state/accumulate, matrix products as 3-term split-bf16 MFMA (opt-in mode)",
         "data": "synthetic",
-        "config": {"workload": "configs[2]+solver: full MobilePoserNet (4 LSTM modules) + r6d/IK + SMPL FK + offline "
-                               "translation solver, B=256 x T=125 per GPU, seeded synthetic IMU (lw_rp combo), "
-                               "seeded random weights, synthetic SMPL constants",
-                   "batch_per_gpu": B, "window": T, "global_batch": world * B,
+        "config": {"workload": cfg_name + ", seeded synthetic IMU (lw_rp combo), seeded random weights, synthetic SMPL constants",
+                   "batch_per_gpu": B, "window": T, "global_batch": global_batch,
                    "parallelism": "independent sequences sharded, dp%d" % world,
-                   "graph": not args.no_graph, "lstm_mode": args.lstm_mode},
+                   "graph": bool(args.graph), "lstm_mode": args.lstm_mode},
         "modes": {
             args.lstm_mode: {"value": round(value, 1), "ms_per_step": round(1e3 * elapsed / args.steps, 4), "headline": True},
-            other: {"value": round(value_other, 1), "ms_per_step": round(1e3 * elapsed_other / args.steps, 4),
-                    "headline": False},
+            other: {"value": round(value_other, 1), "ms_per_step": round(1e3 * elapsed_other / other_steps, 4),
+                    "steps": other_steps, "headline": False},
             "max_abs_output_difference_between_modes": mode_dev,
-            "note": "fp32 = exact v_mfma_f32_16x16x4_f32 operands; x3 = each fp32 product as hi*hi+hi*lo+lo*hi of bf16 "
-                    "parts on v_mfma_f32_16x16x32_bf16 with fp32 accumulate and fp32 state (mp_set_lstm_mode(h, 3)); both "
-                    "pass the same parity tests at 1e-4 / 1 mm (tests/test_gpu_parity.py runs every test in both modes)"},
+            "note": "fp32 (library default) = exact v_mfma_f32_16x16x4_f32 operands; x3 (opt-in, mp_set_lstm_mode(h, 3)) = each "
+                    "fp32 product as hi*hi+hi*lo+lo*hi of bf16 parts on v_mfma_f32_16x16x32_bf16 with fp32 accumulate and fp32 "
+                    "state; both pass the same parity tests at 1e-4 / 1 mm"},
         "end_to_end": {"tflops": round(value * FLOP_PER_FRAME / 1e12, 3),      # algorithmic fp32 FLOPs of the 4 modules
                        "frac_of_fp32_mfma_peak": round(value / world * FLOP_PER_FRAME / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                       "frac_of_bf16_mfma_peak_executed": (round(3.0 * value / world * FLOP_PER_FRAME / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
-                                                           if args.lstm_mode != "fp32" else None),
                        "hbm_gbps_compulsory": round(value / world * BYTES_PER_FRAME / 1e9, 2)},
         "roofline": {"kernel": names[dominant], "bound": "mfma",
                      "achieved": round(roof_achieved, 2), "peak": roof_peak, "unit": "TFLOP/s",
@@ -364,6 +440,10 @@ def main():
                      "avg_launch_ms": round(dms / dn, 4), "note": roof_note},
         "kernels": kern,
     }
+    if strong is not None:
+        out["configs3_strong"] = strong
+    if per_rank is not None:
+        out["per_rank"] = [{"rank": r, "frames": int(v[0]), "seconds": round(float(v[1]), 6)} for r, v in enumerate(per_rank)]
     if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed on rank 0 of the single-GPU run only
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))
