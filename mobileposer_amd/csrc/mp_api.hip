@@ -92,6 +92,8 @@ struct ModuleW {
     float* wihP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // W_ih, persistent kernel layout
     float* whhX[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // split-bf16 kernel layout (H = 256 modules)
     float* wihX[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    float* whhP16[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // 16-slice packing for mp_lstm_pair (bidirectional H = 256
+    float* wihP16[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  //  blocks; a unidirectional block's whhP / wihP already is it)
     float* wihG1 = nullptr;          // unidirectional H=256 block: layer-1 W_ih in granule k-order (wavefront kernel)
 };
 struct ModuleWS {
@@ -166,8 +168,15 @@ struct mp_handle {
     bool x3 = false;                 // false (default, mode 1): H = 256 layers on exact-fp32 MFMA operands -- the reference's
                                      // arithmetic; true (mode 3, mp_set_lstm_mode(h, 3) / MP_LSTM_MODE=x3): the opt-in fast
                                      // mode, split-bf16 MFMA operands (mp_lstm_x3.hip)
+    bool slices16_ok = true;         // MP_SLICES16=0: bidirectional fp32 layers always on 8 slices
+    bool wide_ok = true;             // MP_WIDE=0: never run pose / velocity / foot-contact side by side (small batches)
     bool fuse_pv = true;             // MP_FUSE_PV=0: separate linear1 launches for pose and velocity
     Packed lin1_pv;                  // pose.linear1 and velocity.linear1 stacked (split-bf16 mode: one GEMM over the shared rows)
+    int pair_mask = 0;               // fp32 mode: bidirectional H = 256 layers run by the two-slabs-per-workgroup kernel
+                                     // mp_lstm_pair: bit 0 K_in = 512 layers, bit 1 K_in = 256 layers (env MP_PAIR).  Off:
+                                     // measured slower than mp_lstm_fused on every layer ("two slabs per
+                                     // workgroup"); kept, parity-tested, as the record of that experiment
+    int pair_mode = 1;               // bit 0: the two slabs of a workgroup take turns on the matrix pipe (env MP_PAIR_MODE)
     int x3w_mask = 2;                // split-bf16 layers run by the 4-wave kernel mp_lstm_x3w: bit 0 K_in = 256, bit 1 K_in = 512
                                      // (default: the K_in = 512 layers, measured 373 vs 391 us; K_in = 256: 300 vs 285 us; env MP_X3W)
     int nslice_env = 0;              // 0: pick per module (8 slices / 8 waves for bidirectional layers that fill the
@@ -243,6 +252,10 @@ int pack_weights(mp_handle* h, const float* blob) {
                 if (int rc = dev_alloc(h, (void**)&m.whhP[l][d], mp_whh_pack_floats(m.H) * sizeof(float))) return rc;
                 const int kin = l == 0 ? m.H : m.dirs * m.H;
                 if (int rc = dev_alloc(h, (void**)&m.wihP[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
+                if (m.H == 256 && m.nslice != 16) {
+                    if (int rc = dev_alloc(h, (void**)&m.whhP16[l][d], mp_whh_pack_floats(m.H) * sizeof(float))) return rc;
+                    if (int rc = dev_alloc(h, (void**)&m.wihP16[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
+                }
                 if (m.H == 256) {
                     if (int rc = dev_alloc(h, (void**)&m.whhX[l][d], (size_t)4 * m.H * m.H * sizeof(float))) return rc;
                     if (int rc = dev_alloc(h, (void**)&m.wihX[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
@@ -273,6 +286,10 @@ int pack_weights(mp_handle* h, const float* blob) {
                 mp_launch_pack_whh(find(s.id, K_WHH, l, d), m.whh[l][d], m.H, h->s_main);
                 mp_launch_pack_whh_persist(find(s.id, K_WHH, l, d), m.whhP[l][d], m.H, m.nslice, h->s_main);
                 mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP[l][d], m.H, m.ih[l].K, m.nslice, 0, h->s_main);
+                if (m.whhP16[l][d]) {
+                    mp_launch_pack_whh_persist(find(s.id, K_WHH, l, d), m.whhP16[l][d], m.H, 16, h->s_main);
+                    mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP16[l][d], m.H, m.ih[l].K, 16, 0, h->s_main);
+                }
                 if (m.H == 256) {
                     mp_launch_pack_w_x3(find(s.id, K_WHH, l, d), m.whhX[l][d], m.H, m.nsliceX, h->s_main);
                     mp_launch_pack_w_x3(find(s.id, K_WIH, l, d), m.wihX[l][d], m.ih[l].K, m.nsliceX, h->s_main);
@@ -346,6 +363,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     if (const char* e = getenv("MP_NO_GRAPH")) if (e[0] && e[0] != '0') h->use_graph = false;
     {   // dynamic-LDS limits of the persistent kernels are per-device attributes (and must not be set under capture)
         hipError_t ea = mp_lstm_persist_device_attrs();
+        if (ea == hipSuccess) ea = mp_lstm_pair_device_attrs();
         if (ea == hipSuccess) ea = mp_lstm_x3_device_attrs();
         if (ea == hipSuccess) ea = mp_lstm_x3w_device_attrs();
         if (ea != hipSuccess) { h->err = std::string("hipFuncSetAttribute failed: ") + hipGetErrorString(ea); return bail(MP_ERR_HIP); }
@@ -362,7 +380,11 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     }
     if (const char* e = getenv("MP_LSTM_UNI2")) h->uni2 = e[0] == '1';
     if (const char* e = getenv("MP_X3W")) h->x3w_mask = atoi(e) & 3;
+    if (const char* e = getenv("MP_PAIR")) h->pair_mask = atoi(e) & 3;
+    if (const char* e = getenv("MP_PAIR_MODE")) h->pair_mode = atoi(e);
     if (const char* e = getenv("MP_FUSE_PV")) h->fuse_pv = atoi(e) != 0;
+    if (const char* e = getenv("MP_WIDE")) h->wide_ok = atoi(e) != 0;
+    if (const char* e = getenv("MP_SLICES16")) h->slices16_ok = atoi(e) != 0;
     if (const char* e = getenv("MP_LSTM_SLICES")) h->nslice_env = atoi(e) == 8 ? 8 : (atoi(e) == 16 ? 16 : 0);
     if (getenv("MP_PERSIST_PROF")) {
         if (hipMalloc((void**)&h->prof_dev, kProfWords * sizeof(long long)) != hipSuccess) h->prof_dev = nullptr;
@@ -548,6 +570,21 @@ struct RnnJob {
 // split-bf16 operands for this module's LSTM layers?  (X1 and the layer-0 output are then stored as pairs)
 bool use_x3(const mp_handle* h, const ModuleW& m) { return h->persist && h->x3 && !h->uni2 && m.H == 256; }
 
+// Slices per slab of an exact-fp32 layer launch: a bidirectional H = 256 layer normally uses 8 slices (8-wave workgroups, one
+// per CU at B = 256); when the batch is small enough that 16 slices still fit the chip (B <= 128), the 16-slice / 4-wave
+// decomposition halves the matrix work per CU and step (7 600 instead of 11 900 cycles per step).
+int fp32_slices(const mp_handle* h, const ModuleW& m, int B) {
+    const int nslab = (B + 15) / 16;
+    const int cus = h->n_cu < 256 ? h->n_cu : 256;
+    if (m.H == 256 && m.nslice == 8 && m.whhP16[0][0] && h->slices16_ok && m.dirs * nslab * 16 <= cus) return 16;
+    return m.nslice;
+}
+
+int layer_workgroups(const mp_handle* h, const ModuleW& m, int B) {
+    const int nslab = (B + 15) / 16;
+    return m.dirs * nslab * (use_x3(h, m) ? m.nsliceX : fp32_slices(h, m, B));
+}
+
 float* x1_buffer(const mp_handle* h, const ModuleW& m, ModuleWS& w) {
     return (h->persist && h->uni2 && m.wihG1) ? w.out0 : w.out1;
 }
@@ -649,9 +686,16 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         // (split-bf16 kernels: the flags of layer 0's area were zeroed by the linear1 GEMM, those of layer 1's area by the layer-0 launch)
         if (!use_x3(h, m)) HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
         unsigned long long* hx_l = (use_x3(h, m) && l == 1) ? w.hx2 : w.hx;
-        const int nsl = use_x3(h, m) ? m.nsliceX : m.nslice;
+        // two slabs per workgroup (mp_lstm_pair): exact-fp32 H = 256 layers with at least one full pair of slabs
+        const int kin_l = l == 0 ? H : dirs * H;
+        const bool pair = !use_x3(h, m) && H == 256 && nslab >= 2 && dirs == 2 && m.whhP16[0][0] &&
+                          (h->pair_mask & (kin_l == 512 ? 1 : 2));
+        const int nsl = use_x3(h, m) ? m.nsliceX : fp32_slices(h, m, B);
+        const bool p16 = pair || (!use_x3(h, m) && nsl == 16 && m.nslice != 16);      // 16-slice packing of a bidirectional block
         const int cus = h->n_cu < 256 ? h->n_cu : 256;
-        const int chunk = cus / (dirs * nsl) > 0 ? cus / (dirs * nsl) : 1;   // slabs per launch: grid <= #CUs, one workgroup per CU
+        // slabs per launch: grid <= #CUs, one workgroup per CU (pair kernel: 16 workgroups per pair of slabs)
+        const int chunk = pair ? (cus / (dirs * 16) > 0 ? 2 * (cus / (dirs * 16)) : 2)
+                               : (cus / (dirs * nsl) > 0 ? cus / (dirs * nsl) : 1);
         const int kin = l == 0 ? H : dirs * H;
         // timing classes: 1 = H256 bidirectional K_in=256, 4 = H256 bidirectional K_in=512, 5 = H256 unidirectional
         const int cls = H != 256 ? 6 : (dirs == 1 ? 5 : (kin == 256 ? 1 : 4));
@@ -672,16 +716,18 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             a.out_pairs = x3 ? 1 : 0;                          // both layers feed split-bf16 consumers (layer 1 / linear2)
             for (int d = 0; d < dirs; ++d) {
                 LstmDir& dd = a.d[d];
-                dd.wpack = x3 ? m.whhX[l][d] : m.whhP[l][d]; dd.xproj = nullptr; dd.out = outp + (size_t)d * H;
+                dd.wpack = x3 ? m.whhX[l][d] : (p16 ? m.whhP16[l][d] : m.whhP[l][d]);
+                dd.xproj = nullptr; dd.out = outp + (size_t)d * H;
                 const bool inplace = j.out_h == j.in_h && j.out_h;
                 dd.hbuf = inplace ? j.out_h + (size_t)(l * dirs + d) * B * H : w.hbuf[l][d];
                 dd.cbuf = inplace ? j.out_c + (size_t)(l * dirs + d) * B * H : w.cbuf[l][d];
                 dd.xprojStride = 0; dd.outStride = dirs * H; dd.reverse = d;
-                dd.wihpack = x3 ? m.wihX[l][d] : m.wihP[l][d]; dd.bias = m.ih[l].bias + (size_t)d * 4 * H; dd.xin = xin;
+                dd.wihpack = x3 ? m.wihX[l][d] : (p16 ? m.wihP16[l][d] : m.wihP[l][d]); dd.bias = m.ih[l].bias + (size_t)d * 4 * H; dd.xin = xin;
             }
             if (dirs == 1) a.d[1] = a.d[0];
             if (x3 && nsl == 8 && (h->x3w_mask & (kin == 256 ? 1 : 2))) mp_launch_lstm_x3w(a, kin, s);
             else if (x3) mp_launch_lstm_x3(a, kin, nsl, s);
+            else if (pair) mp_launch_lstm_pair(a, kin, h->pair_mode, s);
             else mp_launch_lstm_persist(a, H, kin, nsl, s);
         }
     } else {
@@ -754,12 +800,20 @@ int ensure_vstate(mp_handle* h, VelState& v, int B) {
     return MP_OK;
 }
 
+// Workgroups of one persistent layer launch of module m at batch B (every one of them fits a CU of its own)
 // models/net.py:101-119 on the library's streams (eager or under capture).
-// Stream plan (persistent mode): the multi-workgroup persistent recurrences must never run concurrently
-// (their workgroups wait on each other, so two such grids that are each only partly resident could starve
-// one another), hence ALL H = 256 recurrences are serialised on s_main; the GEMM phases of pose / velocity
-// run beside them on s_gp / s_vel, and the foot-contact block (H = 64: one workgroup per slab, waits on
-// nobody) runs whole on s_foot.
+// Stream plan (persistent mode).  The persistent layer kernels are grids of clusters of workgroups that wait on each
+// other every step, so two such grids may only run concurrently when ALL their workgroups are resident at once;
+// otherwise two partly-resident grids could starve one another (the waits are bounded, so that would end in
+// MP_ERR_DEVICE rather than a hang, but it must not happen).
+//  * Batches whose pose + velocity + foot-contact launches together need no more workgroups than the device has CUs
+//    (B <= 64 with fp32 operands, B <= 128 split-bf16): net.py:106-117 makes the three blocks independent given the
+//    joints, so each runs whole on its own stream -- four dependent layer launches deep instead of six
+//    (16 x 125: 1.7 -> 1.2 ms; evaluate.py's [1, 3000, 60] call: 33 -> 22 ms).
+//  * Larger batches: the joints / pose layers fill the chip (one workgroup per CU, 160 KB of LDS), so all H = 256
+//    recurrences are serialised on s_main; the H = 64 foot-contact layers (4 slices per slab, 48 KB of LDS: they fit on
+//    a CU beside a velocity workgroup, LDS 80 + 48 KB, or on the half of the chip the split-bf16 velocity layers leave
+//    free) run on s_foot beside the velocity layers, the linear2 / IK / FK tail of pose on s_gp.
 int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long poseRows, long poseRowStride,
                  long poseRowOffset, float* joints, float* vel, float* contact, float* r6d, VelState& vs,
                  bool has_state, float* fk_rglobal = nullptr, float* fk_joint = nullptr) {
@@ -787,12 +841,20 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         if (fk_rglobal) mp_launch_fk(pose, nullptr, poseRows, h->bone_dev, h->parent_dev, h->depth_dev, fk_rglobal, fk_joint, sm);
         RC(run_rnn(V, sv));                                                               // net.py:117
         HIPCHK(h, hipEventRecord(h->ev_v, sv));
+    } else if (!h->uni2 && h->wide_ok &&
+               layer_workgroups(h, h->mod[MP_MOD_POSE], p->B) + layer_workgroups(h, h->mod[MP_MOD_VELOCITY], p->B) +
+                   layer_workgroups(h, h->mod[MP_MOD_FOOT_CONTACT], p->B) <= h->n_cu) {
+        // the three blocks side by side: every workgroup of the three concurrent layer launches has a CU of its own
+        HIPCHK(h, hipStreamWaitEvent(sv, h->ev_j, 0));
+        RC(run_rnn(F, sf));                                                               // net.py:113-114
+        HIPCHK(h, hipEventRecord(h->ev_f, sf));
+        RC(run_rnn(V, sv));                                                               // net.py:117
+        HIPCHK(h, hipEventRecord(h->ev_v, sv));
+        RC(run_rnn(P, sm));                                                               // net.py:106-107
+        { SegScope seg(h, sm, 2, 1);
+          mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sm); }   // net.py:110
+        if (fk_rglobal) mp_launch_fk(pose, nullptr, poseRows, h->bone_dev, h->parent_dev, h->depth_dev, fk_rglobal, fk_joint, sm);
     } else {
-        // Persistent fused layers are grids of clusters of workgroups that wait on each other; joints and pose
-        // need every CU (2 workgroups x 80 KB LDS each), so nothing that also waits may run beside them: they
-        // are serialised on s_main.  Velocity (unidirectional) leaves half the slots free, and the small
-        // foot-contact layers (H = 64, 48 KB) are started only then, beside it.  linear1 / linear2 GEMMs and
-        // the r6d/IK kernel go to side streams.
         auto rec = [&](int i, hipStream_t on) -> int { HIPCHK(h, hipEventRecord(h->ev_x[i], on)); return MP_OK; };
         auto wait = [&](int i, hipStream_t on) -> int { HIPCHK(h, hipStreamWaitEvent(on, h->ev_x[i], 0)); return MP_OK; };
         // (every cross-stream edge into a node of the critical chain costs 8-20 us of graph dependency resolution, so the
@@ -927,6 +989,8 @@ void mp_destroy(mp_handle* h) {
             if (m.whh[l][d]) (void)hipFree(m.whh[l][d]);
             if (m.whhP[l][d]) (void)hipFree(m.whhP[l][d]);
             if (m.wihP[l][d]) (void)hipFree(m.wihP[l][d]);
+            if (m.whhP16[l][d]) (void)hipFree(m.whhP16[l][d]);
+            if (m.wihP16[l][d]) (void)hipFree(m.wihP16[l][d]);
             if (m.whhX[l][d]) (void)hipFree(m.whhX[l][d]);
             if (m.wihX[l][d]) (void)hipFree(m.wihX[l][d]);
         }

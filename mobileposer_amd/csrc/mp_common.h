@@ -112,6 +112,9 @@ void mp_launch_lstm_x3w(const LstmPersistArgs& a, int KIN, hipStream_t s);   // 
 void mp_launch_pack_w_x3(const float* w, float* dst, int K, int nslice, hipStream_t s);
 // Dynamic-LDS limits (80-160 KB) of the persistent kernels are per-DEVICE function attributes: mp_create sets them for
 // the handle's device after hipSetDevice, outside of any stream capture.
+// two slabs per workgroup (mp_lstm_pair.hip): H = 256, weights in the 16-slice packing; mode bit 0 = matrix-pipe token
+void mp_launch_lstm_pair(const LstmPersistArgs& a, int KIN, int mode, hipStream_t s);
+hipError_t mp_lstm_pair_device_attrs();
 hipError_t mp_lstm_persist_device_attrs();
 hipError_t mp_lstm_x3_device_attrs();
 hipError_t mp_lstm_x3w_device_attrs();

@@ -459,3 +459,59 @@ def test_soak_bitwise_stable_under_concurrency(torch_mod, net):
             for a, b in zip(ref, outs):
                 assert torch_mod.equal(a, b), it
     assert net.device_error() == 0
+
+
+def test_small_batch_schedules_agree(torch_mod, weights, smpl, monkeypatch):
+    """Batches whose pose + velocity + foot-contact launches fit the chip together run the three blocks side by side
+    (MP_WIDE, default on): bitwise the same outputs as the serial schedule.  Exact-fp32 layers of small batches use 16
+    slices per slab instead of 8 (MP_SLICES16, default on): another summation order, same values to fp32 noise."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    outs = {}
+    for wide, s16 in ((1, 1), (0, 1), (1, 0)):
+        monkeypatch.setenv("MP_WIDE", str(wide))
+        monkeypatch.setenv("MP_SLICES16", str(s16))
+        with MobilePoserNet.from_numpy(weights, smpl) as n:
+            o = []
+            for mode in (1, 3):
+                n.set_lstm_mode(mode)
+                for B, T in ((1, 200), (40, 50), (64, 30)):
+                    x = cu(torch_mod, synthetic.make_imu(B, T, seed=B))
+                    L = [T] * B
+                    L[B // 2] = max(1, T // 3)
+                    n.reset_all()
+                    o += [t.clone() for t in n.forward_offline(x, L)]
+                    o += [t.clone() for t in n.forward_offline(x, L)]      # carried velocity state
+            assert n.device_error() == 0
+        outs[(wide, s16)] = o
+    for a, b in zip(outs[(1, 1)], outs[(0, 1)]):
+        assert torch_mod.equal(a, b)
+    for a, b in zip(outs[(1, 1)], outs[(1, 0)]):
+        assert float((a - b).abs().max()) < 5e-6
+
+
+def test_two_slab_kernel_matches(torch_mod, weights, smpl, monkeypatch):
+    """mp_lstm_pair (two slabs of 16 sequences per workgroup; off by default, MP_PAIR=3 turns it on for the bidirectional
+    fp32 layers): same arithmetic as mp_lstm_fused up to the summation order -- full-chip batch, an odd number of slabs,
+    ragged lengths, several launch groups."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    outs = {}
+    rng = np.random.default_rng(9)
+    shapes = ((256, 40), (300, 12), (40, 30))
+    lens = {s: [int(v) for v in rng.integers(1, s[1] + 1, size=s[0])] for s in shapes}
+    for mask in (0, 3):
+        monkeypatch.setenv("MP_PAIR", str(mask))
+        monkeypatch.setenv("MP_SLICES16", "0")
+        with MobilePoserNet.from_numpy(weights, smpl) as n:
+            n.set_lstm_mode(1)
+            o = []
+            for B, T in shapes:
+                L = list(lens[(B, T)])
+                L[0] = T
+                o += [t.clone() for t in n.forward_offline(cu(torch_mod, synthetic.make_imu(B, T, seed=B + 1)), L)]
+                n.reset_all()
+            assert n.device_error() == 0
+        outs[mask] = o
+    for a, b in zip(outs[0], outs[3]):
+        assert float((a - b).abs().max()) < 5e-6
