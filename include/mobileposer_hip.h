@@ -156,6 +156,17 @@ int mp_stream_reset(mp_handle* h, const uint8_t* mask_host, int clear_velocity);
 int mp_stream_get_state(mp_handle* h, int s, float* window_dev, float last_foot_host[6], double* root_y_host,
                         float root_pos_host[3], int* fresh_host);
 
+/* ---- live front-end: raw sensor samples -> network input frames, S streams per call --------------------------------
+ * The per-frame arithmetic between the sensor packets and forward_online in the reference's live demo
+ * (mobileposer/live_demo.py:213-236; calibration quantities from :161-174), batched over streams:
+ *   quat [S,5,4] wxyz (unnormalised), acc [S,5,3] m/s^2, smpl2imu [S,3,3], device2bone [S,5,3,3], acc_offsets [S,5,3]
+ *   -> frames [S,60] = [5 x 3 accelerations / acc_scale | 5 x 3x3 orientations], slots in network order (sensors
+ *   [1,4,3,0,2]); slots whose bit in keep_mask is clear are zero (device-location combo, config.py:60-73).
+ * The output is what mp_stream_step takes as frames_dev. */
+int mp_live_form_frames(mp_handle* h, const float* quat_dev, const float* acc_dev, const float* smpl2imu_dev,
+                        const float* device2bone_dev, const float* acc_offsets_dev, unsigned keep_mask, int S,
+                        float* frames_dev, void* stream);
+
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------------
  * With timing on, every call runs eagerly and brackets each kernel launch of the classes below
  * with HIP events on the library stream that launches it.  mp_timing_read returns, for the last call, the

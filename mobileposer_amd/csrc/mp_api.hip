@@ -1296,6 +1296,18 @@ int mp_stream_reset(mp_handle* h, const uint8_t* mask_host, int clear_velocity) 
     return MP_OK;
 }
 
+int mp_live_form_frames(mp_handle* h, const float* quat_dev, const float* acc_dev, const float* smpl2imu_dev,
+                        const float* device2bone_dev, const float* acc_offsets_dev, unsigned keep_mask, int S,
+                        float* frames_dev, void* stream) {
+    if (!h || !quat_dev || !acc_dev || !smpl2imu_dev || !device2bone_dev || !acc_offsets_dev || !frames_dev || S < 1)
+        return h ? fail(h, MP_ERR_INVALID, "mp_live_form_frames: bad argument") : MP_ERR_INVALID;
+    if (int rc = enter(h, stream)) return rc;
+    mp_launch_live_frames(quat_dev, acc_dev, smpl2imu_dev, device2bone_dev, acc_offsets_dev, keep_mask, 30.0f /* config.py:74 */,
+                          S, frames_dev, h->s_main);
+    HIPCHK(h, hipGetLastError());
+    return leave(h, stream);
+}
+
 int mp_stream_get_state(mp_handle* h, int s, float* window_dev, float last_foot_host[6], double* root_y_host,
                         float root_pos_host[3], int* fresh_host) {
     if (!h) return MP_ERR_INVALID;

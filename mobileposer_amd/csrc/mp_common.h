@@ -131,6 +131,11 @@ void mp_launch_fk(const float* pose, const float* tran, long N, const float* bon
 void mp_launch_lbs(const float* rglobal, const float* joint, const float* tran, long N, const float* jrest_dev,
                    const float* vrest_dev, const float* weights_dev, int V, float* vert, hipStream_t s);
 
+// ---------------------------------------------------------------- live front-end (mp_live.hip)
+// raw sensor samples of S streams -> network input frames [S,60] (live_demo.py:213-236)
+void mp_launch_live_frames(const float* quat, const float* acc, const float* smpl2imu, const float* device2bone,
+                           const float* acc_off, unsigned keep, float acc_scale, int S, float* frames, hipStream_t s);
+
 // ---------------------------------------------------------------- K6: translation solver
 void mp_launch_translate_offline(const float* joints, const float* vel, const float* contact, const int* lengths,
                                  int B, int T, float floor_y, float* tran, hipStream_t s);

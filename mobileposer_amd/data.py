@@ -1,51 +1,121 @@
-"""Dataset -> IMU-frame formation for evaluation: mirror of ``PoseDataset`` in eval mode
-(data.py:45-107 of the reference) -- the step immediately before the hot path.
+"""Dataset -> IMU-frame formation for evaluation: the ``PoseDataset`` the reference's ``evaluate.py`` builds
+(``PoseDataset(fold='test', evaluate='dip')``, data.py:19-107) -- the step immediately before the hot path.
 
-Host-side, load-time logic (torch CPU tensors).  On-disk format is the reference's: a ``.pt`` dict of lists
-``acc [N,6,3]``, ``ori [N,6,3,3]``, ``pose [N,24,3,3]``, ``tran [N,3]`` (process.py:116-127,285-295).
-Every sequence is expanded into the 12 device-location combos of ``amass.combos`` (config.py:60-73) by
-zero-masking absent devices (data.py:69-76); items are ``(imu [T,60], pose_r6d [T,144], joint [T,24,3], tran [T,3])``.
+Host-side, load-time logic (torch CPU tensors).  On-disk format is the reference's: ``paths.processed_datasets/eval/<file>``
+(config.py:33-34, datasets.test_datasets config.py:104-108), a ``.pt`` dict of lists ``acc [N,6,3]``, ``ori [N,6,3,3]``,
+``pose [N,24,3,3]``, ``tran [N,3]`` (process.py:116-127,285-295).  Every sequence appears once per device-location combo of
+``amass.combos`` (config.py:60-73): the accelerations / orientations of the devices a combo lacks are zero, the 60-d frame is
+[5 x 3 accelerations / acc_scale | 5 x 3 x 3 orientations]; items are ``(imu [T,60], pose_r6d [T,144], joint [T,24,3],
+tran [T,3])`` with the ground-truth pose kept LOCAL (data.py:65) and its joints from forward kinematics (data.py:64).
+
+Only the evaluation fold is in scope; the training fold (windows of 125, velocity / foot-contact
+targets, data.py:82-93) belongs to training and raises.
 """
+import numpy as np
 import torch
 
-from .config import amass
+from .config import SMPL_PARENT, amass, datasets, paths
 
 
 def rotation_matrix_to_r6d(r):
-    """articulate/math/angular.py:185-192: first two columns of R, column-major."""
-    return r.reshape(-1, 3, 3)[:, :, :2].transpose(1, 2).clone().reshape(-1, 6)
+    """articulate/math/angular.py:185-192: the six numbers are the first two COLUMNS of R, column after column."""
+    m = torch.as_tensor(r).reshape(-1, 3, 3)
+    return torch.cat((m[:, :, 0], m[:, :, 1]), dim=1)
+
+
+def forward_kinematics_host(pose, J, parent=SMPL_PARENT):
+    """Joint positions of a local pose [N,24,3,3] on the host (what data.py:64 needs at load time): the tree is walked
+    level by level, every joint's global rotation and position from its parent's (articulate/model.py:208-232, mean shape,
+    no translation).  Returns (R_global [N,24,3,3], joint [N,24,3])."""
+    pose = torch.as_tensor(pose, dtype=torch.float32).reshape(-1, 24, 3, 3)
+    j = torch.as_tensor(np.asarray(J, dtype=np.float32))
+    j = j - j[:1]
+    R = [None] * 24
+    p = [None] * 24
+    R[0] = pose[:, 0]
+    p[0] = j[0].expand(pose.shape[0], 3)
+    for i in range(1, 24):
+        a = parent[i]
+        R[i] = R[a] @ pose[:, i]
+        p[i] = p[a] + (R[a] @ (j[i] - j[a]).reshape(3, 1)).squeeze(-1)
+    return torch.stack(R, dim=1), torch.stack(p, dim=1)
+
+
+def combo_masks(combos=None):
+    """[n_combos, 5] 0/1 table: which of the 5 device slots a combo keeps (config.py:60-73)."""
+    combos = combos if combos is not None else amass.combos
+    m = torch.zeros(len(combos), 5)
+    for k, slots in enumerate(combos.values()):
+        m[k, list(slots)] = 1.0
+    return m
 
 
 class PoseDataset:
-    def __init__(self, data, fk=None, combos=None):
-        """``data``: path to a ``.pt`` file or an already-loaded dict of lists.
-        ``fk``: callable pose[N,24,3,3] -> (R_global, joint[N,24,3]) giving the ground-truth joints the
-        reference computes at data.py:64 (e.g. ``MobilePoserNet.forward_kinematics``); None -> joints omitted."""
-        if isinstance(data, (str, bytes)) or hasattr(data, "__fspath__"):
-            data = torch.load(data, map_location="cpu")
-        self.combos = list((combos or amass.combos).items())
-        self.items = []
-        poses = data["pose"]
-        for acc, ori, pose, tran in zip(data["acc"], data["ori"], poses, data["tran"]):
-            acc = torch.as_tensor(acc).float()
-            ori = torch.as_tensor(ori).float()
-            pose = torch.as_tensor(pose).float().view(-1, 24, 3, 3)
+    def __init__(self, fold='train', evaluate=None, finetune=None, data=None, fk=None, combos=None, smpl=None):
+        """Reference signature ``PoseDataset(fold, evaluate, finetune)`` (data.py:19).  Extras, all optional: ``data`` -- an
+        already-loaded dataset dict or a path instead of the configured file; ``fk`` -- callable pose -> (R_global, joint)
+        for the ground-truth joints (e.g. ``MobilePoserNet.forward_kinematics``: GPU); default is the host walk above on
+        the SMPL joints of ``smpl`` / ``paths.smpl_file`` / the synthetic body; ``combos`` -- a subset of ``amass.combos``."""
+        self.fold, self.evaluate, self.finetune = fold, evaluate, finetune
+        self.combos = list((combos if combos is not None else amass.combos).items())
+        self._fk = fk if fk is not None else self._host_fk(smpl)
+        self.data = {k: [] for k in ('imu_inputs', 'pose_outputs', 'joint_outputs', 'tran_outputs')}
+        for file_data in self._sources(data):
+            self._add_file(file_data, combo_masks(dict(self.combos)))
+
+    # ---- where the sequences come from (data.py:27-55) ------------------------------------------------------------
+    def _sources(self, data):
+        if data is not None:
+            yield torch.load(data, map_location="cpu", weights_only=False) if not isinstance(data, dict) else data
+            return
+        if self.fold == 'test':
+            if self.evaluate not in datasets.test_datasets:
+                raise ValueError(f"Test dataset: {self.evaluate} not found.")
+            names = [datasets.test_datasets[self.evaluate]]
+        elif self.fold == 'train':
+            raise NotImplementedError("the training fold (windows, velocity / contact targets) is outside the inference path")
+        else:
+            raise ValueError(f"Unknown data fold: {self.fold}.")
+        folder = paths.processed_datasets / ('eval' if (self.finetune or self.evaluate) else '')
+        for name in names:
+            try:                                                       # data.py:50-54: a bad file is reported, not fatal
+                yield torch.load(folder / name, map_location="cpu", weights_only=False)
+            except Exception as e:
+                print(f"Error processing {name}: {e}.")
+
+    @staticmethod
+    def _host_fk(smpl):
+        import os
+        from .body_model import ParametricModel
+        if smpl is None:
+            smpl = ParametricModel(str(paths.smpl_file)) if os.path.exists(str(paths.smpl_file)) else ParametricModel.synthetic()
+        elif not isinstance(smpl, ParametricModel):
+            smpl = ParametricModel(data=smpl)
+        J, parent = smpl.J, smpl.parent
+        return lambda pose: forward_kinematics_host(pose, J, parent)
+
+    # ---- one file: every sequence x every combo (data.py:57-85) -----------------------------------------------------
+    def _add_file(self, fd, masks):
+        for acc, ori, pose, tran in zip(fd['acc'], fd['ori'], fd['pose'], fd['tran']):
+            acc = torch.as_tensor(acc).float()[:, :5] / amass.acc_scale
+            ori = torch.as_tensor(ori).float()[:, :5]
+            pose = torch.as_tensor(pose).float().reshape(-1, 24, 3, 3)
             tran = torch.as_tensor(tran).float()
-            acc, ori = acc[:, :5] / amass.acc_scale, ori[:, :5]                       # data.py:62
-            joint = None
-            if fk is not None:
-                joint = fk(pose)[1].detach().cpu().view(-1, 24, 3)                       # data.py:63-66
-            for _, c in self.combos:                                                    # data.py:70-76
-                combo_acc = torch.zeros_like(acc)
-                combo_ori = torch.zeros_like(ori)
-                combo_acc[:, c] = acc[:, c]
-                combo_ori[:, c] = ori[:, c]
-                imu = torch.cat([combo_acc.flatten(1), combo_ori.flatten(1)], dim=1)    # [N,15] | [N,45] -> [N,60]
-                pose_r6d = rotation_matrix_to_r6d(pose).reshape(-1, 24 * 6)             # data.py:98 (local pose kept)
-                self.items.append((imu, pose_r6d, joint, tran))
+            joint = self._fk(pose)[1].detach().cpu().reshape(-1, 24, 3)
+            # all combos at once: [C,1,5,1] masks against [1,N,5,3] / [1,N,5,9]
+            m = masks.reshape(-1, 1, 5, 1)
+            imu = torch.cat(((acc.unsqueeze(0) * m).flatten(2), (ori.flatten(2).unsqueeze(0) * m).flatten(2)), dim=2)
+            for k in range(imu.shape[0]):
+                self.data['imu_inputs'].append(imu[k])
+                self.data['pose_outputs'].append(pose)
+                self.data['joint_outputs'].append(joint)
+                self.data['tran_outputs'].append(tran)
 
     def __len__(self):
-        return len(self.items)
+        return len(self.data['imu_inputs'])
 
     def __getitem__(self, idx):
-        return self.items[idx]
+        """(imu, pose as r6d of all 24 joints, joint, tran) -- data.py:94-102 for the evaluate / finetune folds."""
+        pose = rotation_matrix_to_r6d(self.data['pose_outputs'][idx]).reshape(-1, 24 * 6)
+        return (self.data['imu_inputs'][idx].float(), pose, self.data['joint_outputs'][idx].float(),
+                self.data['tran_outputs'][idx].float())

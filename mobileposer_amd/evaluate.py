@@ -1,15 +1,19 @@
-"""Evaluation harness: mirror of mobileposer/evaluate.py (PoseEvaluator :16-36, evaluate_pose :39-107, CLI :110-126).
+"""Evaluation harness with the reference's surface (mobileposer/evaluate.py): ``PoseEvaluator`` (:16-36),
+``evaluate_pose(model, dataset, num_past_frame=20, num_future_frame=5, evaluate_tran=False)`` (:39-107) and the CLI
+``python -m mobileposer_amd.evaluate --model W --dataset dip`` (:110-126, env ONLINE as in the reference).
 
-Per sequence: ``model.reset()`` -> ``forward_offline`` -> (env ONLINE=1: ``forward_online`` for every frame plus
-5 repeated tail frames, first 5 outputs dropped, evaluate.py:62-64) -> errors.  ``FullMotionEvaluator`` follows
-articulate/evaluator.py:292-343 with forward kinematics and mesh skinning on the GPU (mp_fk_mesh); rotation angles
-are 2*asin(|R_p^T R_t - I|_F / (2*sqrt 2)) instead of a per-matrix cv2.Rodrigues call (same value); the
-mean / std reductions of the error table are plain torch reductions on the device.
+Per sequence: ``model.reset()`` -> ``forward_offline`` -> (ONLINE=1: ``forward_online`` for every frame plus
+``num_future_frame`` repeats of the last one, the first ``num_future_frame`` outputs dropped, :62-64) -> error table.
+``FullMotionEvaluator`` follows articulate/evaluator.py:292-343 with forward kinematics and mesh skinning on the GPU
+(mp_fk_mesh); a rotation angle is 2*asin(|R_p^T R_t - I|_F / (2*sqrt 2)) instead of a per-matrix cv2.Rodrigues call (the
+same number); means / stds are torch reductions on the device.  Sequence tables are combined with ``mean`` exactly as
+the reference does -- a sequence shorter than one second makes the 1-s distance row NaN there, and here.
 """
 import argparse
 import math
 import os
 
+import numpy as np
 import torch
 
 from .config import datasets, joint_set
@@ -79,10 +83,17 @@ class FullMotionEvaluator:
         return torch.stack([ms(x) for x in rows])
 
 
+# The eight printed metrics (evaluate.py:29,33-35): label, row of the FullMotionEvaluator table it is taken from, unit factor.
+# Row 9 = masked global angle (joints 2, 5, 16, 20) serves "SIP" and "Masked Angular", row 3 = global angle, rows 0 / 7 / 1 =
+# joint / masked joint / vertex position (m -> cm), row 4 = predicted jitter (-> 100 m/s^3), row 6 = 1-s root distance error.
+METRICS = (("SIP Error (deg)", 9, 1.0), ("Angular Error (deg)", 3, 1.0), ("Masked Angular Error (deg)", 9, 1.0),
+           ("Positional Error (cm)", 0, 100.0), ("Masked Positional Error (cm)", 7, 100.0), ("Mesh Error (cm)", 1, 100.0),
+           ("Jitter Error (100m/s^3)", 4, 0.01), ("Distance Error (cm)", 6, 1.0))
+
+
 class PoseEvaluator:
-    """evaluate.py:16-36."""
-    names = ['SIP Error (deg)', 'Angular Error (deg)', 'Masked Angular Error (deg)', 'Positional Error (cm)',
-             'Masked Positional Error (cm)', 'Mesh Error (cm)', 'Jitter Error (100m/s^3)', 'Distance Error (cm)']
+    """evaluate.py:16-36.  ``model``: the MobilePoserNet whose handle runs FK / skinning (the reference builds its own
+    CPU body model from paths.smpl_file; here the constants already live on the GPU)."""
 
     def __init__(self, model, joint_mask=(2, 5, 16, 20), fps=datasets.fps):
         self.model = model
@@ -90,56 +101,110 @@ class PoseEvaluator:
 
     def eval(self, pose_p, pose_t, joint_p=None, tran_p=None, tran_t=None):
         dev = self.model.device
-        pose_p = pose_p.clone().view(-1, 24, 3, 3).to(dev)
-        pose_t = pose_t.clone().view(-1, 24, 3, 3).to(dev)
-        tran_p = tran_p.clone().view(-1, 3).to(dev)
-        tran_t = tran_t.clone().view(-1, 3).to(dev)
-        eye = torch.eye(3, device=dev)
-        pose_p[:, joint_set.ignored] = eye                                               # evaluate.py:25-26
-        pose_t[:, joint_set.ignored] = eye
-        errs = self._eval_fn(pose_p, pose_t, tran_p=tran_p, tran_t=tran_t)
-        # evaluate.py:29
-        return torch.stack([errs[9], errs[3], errs[9], errs[0] * 100, errs[7] * 100, errs[1] * 100, errs[4] / 100, errs[6]])
+        pose_p = pose_p.to(dev).reshape(-1, 24, 3, 3).clone()
+        pose_t = pose_t.to(dev).reshape(-1, 24, 3, 3).clone()
+        for pose in (pose_p, pose_t):                       # joints the network does not predict count as identity (:25-26)
+            pose[:, joint_set.ignored] = torch.eye(3, device=dev)
+        table = self._eval_fn(pose_p, pose_t, tran_p=tran_p.to(dev).reshape(-1, 3), tran_t=tran_t.to(dev).reshape(-1, 3))
+        return torch.stack([table[row] * scale for _, row, scale in METRICS])
 
-    @classmethod
-    def print(cls, errors):
-        for i, name in enumerate(cls.names):
-            print('%s: %.2f (+/- %.2f)' % (name, errors[i, 0], errors[i, 1]))
+    @staticmethod
+    def print(errors):
+        for (label, _, _), (mean, std) in zip(METRICS, errors.tolist()):
+            print('%s: %.2f (+/- %.2f)' % (label, mean, std))
+
+
+def distance_window_pairs(move_distance, window):
+    """evaluate.py:74-83: walking ``start`` over the frames, ``end`` = the first frame (never moving backwards) by which the
+    ground truth has travelled at least ``window`` metres since ``start``; a pair is kept when its ``end`` is new.
+    ``move_distance``: non-decreasing cumulative path length [N] (float32, as the reference accumulates it)."""
+    d = np.asarray(move_distance, dtype=np.float32)
+    n = d.shape[0]
+    if n < 2:
+        return []
+    # end(start) = first index e >= 1 with d[e] - d[start] >= window, evaluated in float32 like the reference's comparison
+    ends = np.empty(n, dtype=np.int64)
+    e = 1
+    for s in range(n):
+        while e < n and np.float32(d[e] - d[s]) < np.float32(window):
+            e += 1
+        ends[s] = e
+        if e >= n:
+            ends[s:] = n
+            break
+    pairs, last = [], -1
+    for s in range(n):
+        if ends[s] >= n:
+            break
+        if ends[s] != last:
+            pairs.append((s, int(ends[s])))
+            last = int(ends[s])
+    return pairs
+
+
+def translation_window_errors(tran_p, tran_t, windows=range(1, 8)):
+    """evaluate.py:66-91 for one sequence: {window: mean relative distance error over the pairs} (windows without a pair
+    are absent)."""
+    tran_t = torch.as_tensor(tran_t).float().cpu()
+    tran_p = torch.as_tensor(tran_p).float().cpu()
+    step = (tran_t[1:] - tran_t[:-1]).norm(dim=1).numpy()
+    dist = np.zeros(tran_t.shape[0], dtype=np.float32)
+    for j in range(step.shape[0]):                        # sequential float32 accumulation (:69-70)
+        dist[j + 1] = dist[j] + step[j]
+    out = {}
+    for w in windows:
+        pairs = distance_window_pairs(dist, w)
+        if not pairs:
+            continue
+        s = torch.tensor([p[0] for p in pairs])
+        e = torch.tensor([p[1] for p in pairs])
+        moved = torch.from_numpy(dist)[e] - torch.from_numpy(dist)[s]
+        err = ((tran_t[e] - tran_t[s]) - (tran_p[e] - tran_p[s])).norm(dim=1) / moved * w
+        out[w] = float(err.sum() / len(pairs))
+    return out
 
 
 @torch.no_grad()
-def evaluate_pose(model, dataset, num_future_frame=5, verbose=True):
-    """evaluate.py:39-107 (translation-window statistics of evaluate_tran omitted)."""
+def evaluate_pose(model, dataset, num_past_frame=20, num_future_frame=5, evaluate_tran=False, verbose=True):
+    """evaluate.py:39-107.  Returns {"offline": [8,2], "online": [8,2] (ONLINE=1), "tran": [8] (evaluate_tran)} and prints
+    what the reference prints."""
     dev = model.device
     evaluator = PoseEvaluator(model)
-    offline_errs, online_errs = [], []
+    tables = {"offline": [], "online": []}
+    tran_errors = {w: [] for w in range(1, 8)}
+    online = bool(getenv("ONLINE"))
     model.eval()
     for imu, pose_t, _joint, tran_t in dataset:
         x = imu.to(dev)
         model.reset()
-        pose_p, _joint_p, tran_p, _ = model.forward_offline(x.unsqueeze(0), [x.shape[0]])
-        pose_t_m = r6d_to_rotation_matrix_torch(pose_t.to(dev)).view(-1, 24, 3, 3)
-        offline_errs.append(evaluator.eval(pose_p, pose_t_m, tran_p=tran_p, tran_t=tran_t))
-        if getenv("ONLINE"):
-            frames = torch.cat((x, x[-1].repeat(num_future_frame, 1)))
-            res = [model.forward_online(f) for f in frames]
-            pose_o, _j, tran_o, _c = [torch.stack(_)[num_future_frame:] for _ in zip(*res)]
-            online_errs.append(evaluator.eval(pose_o, pose_t_m, tran_p=tran_o, tran_t=tran_t))
-    out = {"offline": torch.stack(offline_errs).nanmean(dim=0) if offline_errs else None}
-    if verbose:
-        print('============== offline ================')
-        PoseEvaluator.print(out["offline"])
-    if online_errs:
-        out["online"] = torch.stack(online_errs).nanmean(dim=0)
+        pose_p, _joints_p, tran_p, _contact = model.forward_offline(x.unsqueeze(0), [x.shape[0]])
+        pose_gt = r6d_to_rotation_matrix_torch(pose_t.to(dev)).view(-1, 24, 3, 3)
+        tables["offline"].append(evaluator.eval(pose_p, pose_gt, tran_p=tran_p, tran_t=tran_t))
+        if evaluate_tran:
+            for w, v in translation_window_errors(tran_p, tran_t).items():
+                tran_errors[w].append(v)
+        if online:
+            feed = torch.cat((x, x[-1:].expand(num_future_frame, -1)))
+            frames = [model.forward_online(f) for f in feed]
+            pose_o = torch.stack([fr[0] for fr in frames])[num_future_frame:]
+            tran_o = torch.stack([fr[2] for fr in frames])[num_future_frame:]
+            tables["online"].append(evaluator.eval(pose_o, pose_gt, tran_p=tran_o, tran_t=tran_t))
+    out = {}
+    for name in ("offline", "online"):
+        if tables[name]:
+            out[name] = torch.stack(tables[name]).mean(dim=0)                       # mean, as evaluate.py:99-102
+            if verbose:
+                print('============== %s ================' % name)
+                PoseEvaluator.print(out[name])
+    if evaluate_tran:
+        out["tran"] = [0] + [float(torch.tensor(v).mean()) if v else float("nan") for v in tran_errors.values()]
         if verbose:
-            print('============== online ================')
-            PoseEvaluator.print(out["online"])
+            print(out["tran"])
     return out
 
 
 def synthetic_dataset(n_seq=2, frames=90, seed=0):
     """A dataset dict in the reference's on-disk format, for smoke runs without the licensed data."""
-    import numpy as np
     from .synthetic import _random_rotations
     rng = np.random.Generator(np.random.PCG64(seed))
     d = {"acc": [], "ori": [], "pose": [], "tran": []}
@@ -152,31 +217,25 @@ def synthetic_dataset(n_seq=2, frames=90, seed=0):
 
 
 def main(argv=None):
+    """evaluate.py:110-126: ``--model`` and ``--dataset`` only; everything else comes from config.paths, as in the reference.
+    (``--model synthetic`` / ``--dataset synthetic`` are smoke-run conveniences for machines without the licensed files.)"""
     ap = argparse.ArgumentParser()
-    ap.add_argument('--model', type=str, required=True, help="weights .pth (state dict) or 'synthetic'")
+    ap.add_argument('--model', type=str, required=True)
     ap.add_argument('--dataset', type=str, default='dip')
-    ap.add_argument('--smpl', type=str, default=None, help="SMPL pickle; default: smpl/basicmodel_m.pkl or synthetic")
-    ap.add_argument('--data-dir', type=str, default='data/processed_datasets/eval')
-    ap.add_argument('--max-combos', type=int, default=None)
     args = ap.parse_args(argv)
+    from . import synthetic
     from .model_utils import load_model
     from .net import MobilePoserNet
-    from . import synthetic
-    smpl_file = args.smpl or ('smpl/basicmodel_m.pkl' if os.path.exists('smpl/basicmodel_m.pkl') else None)
     if args.model == 'synthetic':
-        model = MobilePoserNet(smpl_file=smpl_file)
-        model.load_state_dict(synthetic.make_weights(0))
+        model = MobilePoserNet().load_state_dict(synthetic.make_weights(0))
     else:
-        model = load_model(args.model, smpl_file=smpl_file)
+        model = load_model(args.model)
     if args.dataset == 'synthetic':
-        data = synthetic_dataset()
+        dataset = PoseDataset(fold='test', evaluate='dip', data=synthetic_dataset(), fk=model.forward_kinematics)
     else:
         if args.dataset not in datasets.test_datasets:
-            raise ValueError(f"Test dataset: {args.dataset} not found.")                 # evaluate.py:120-121
-        data = os.path.join(args.data_dir, datasets.test_datasets[args.dataset])
-    from .config import amass
-    combos = dict(list(amass.combos.items())[:args.max_combos]) if args.max_combos else None
-    dataset = PoseDataset(data, fk=model.forward_kinematics, combos=combos)
+            raise ValueError(f"Test dataset: {args.dataset} not found.")
+        dataset = PoseDataset(fold='test', evaluate=args.dataset, fk=model.forward_kinematics)
     print(f"Starting evaluation: {args.dataset.capitalize()}")
     evaluate_pose(model, dataset)
 

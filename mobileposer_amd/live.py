@@ -1,7 +1,8 @@
-"""Live streaming front-end math: what sits between the sensor packets and
-``forward_online`` / ``mp_stream_step`` in the reference's live demo, as pure host-side functions.
+"""Live streaming front-end: what sits between the sensor packets and
+``forward_online`` / ``mp_stream_step`` in the reference's live demo.  The per-tick arithmetic for S streams is a HIP
+kernel (csrc/mp_live.hip, ``LiveSession``); calibration, wire formats and a single-set host version are here.
 
-Mirrors, formula for formula: the UDP packet format ``acc#quat$`` (live_demo.py:64-75, sender side
+Contracts followed: the UDP packet format ``acc#quat$`` (live_demo.py:64-75, sender side
 utils/socket_utils.py:19-34), T-pose calibration (live_demo.py:161-174), per-frame frame formation
 (live_demo.py:213-236: sensor -> SMPL frame, channel re-order [1,4,3,0,2], /acc_scale, combo mask) and the
 ``pose#tran$`` output string (live_demo.py:243-256).  No sockets, threads or UI here -- those are out of scope;
@@ -16,14 +17,17 @@ CHANNEL_ORDER = [1, 4, 3, 0, 2]          # live_demo.py:219-220, combiner.py:14-
 
 
 def quaternion_to_rotation_matrix(q):
-    """articulate/math/angular.py:224-236: (unnormalised) wxyz quaternions [...,4] -> [N,3,3]."""
+    """(Unnormalised) wxyz quaternions [...,4] -> rotation matrices [N,3,3] (contract of articulate/math/angular.py:224-236).
+    With unit q = (w, v):  R = (w^2 - |v|^2) I + 2 v v^T + 2 w [v]x."""
     q = torch.as_tensor(q, dtype=torch.float32).reshape(-1, 4)
     q = q / q.norm(dim=1, keepdim=True)
-    a, b, c, d = q[:, 0:1], q[:, 1:2], q[:, 2:3], q[:, 3:4]
-    r = torch.cat((-2 * c * c - 2 * d * d + 1, 2 * b * c - 2 * a * d, 2 * a * c + 2 * b * d,
-                   2 * b * c + 2 * a * d, -2 * b * b - 2 * d * d + 1, 2 * c * d - 2 * a * b,
-                   2 * b * d - 2 * a * c, 2 * a * b + 2 * c * d, -2 * b * b - 2 * c * c + 1), dim=1)
-    return r.view(-1, 3, 3)
+    w, v = q[:, 0], q[:, 1:]
+    eye = torch.eye(3, dtype=q.dtype).expand(q.shape[0], 3, 3)
+    cross = torch.zeros(q.shape[0], 3, 3, dtype=q.dtype)                      # [v]x
+    cross[:, 0, 1], cross[:, 0, 2], cross[:, 1, 2] = -v[:, 2], v[:, 1], -v[:, 0]
+    cross = cross - cross.transpose(1, 2)
+    return (w * w - (v * v).sum(dim=1)).view(-1, 1, 1) * eye + 2.0 * v.unsqueeze(2) * v.unsqueeze(1) \
+        + 2.0 * w.view(-1, 1, 1) * cross
 
 
 def rotation_matrix_to_axis_angle(r):
@@ -92,33 +96,53 @@ class Calibration:
         return cls(smpl2imu, device2bone, acc_offsets)
 
 
+def combo_keep_mask(combo):
+    """Bit k set = network slot k (config.py:60-73) is part of the device combo."""
+    m = 0
+    for k in amass.combos[combo]:
+        m |= 1 << k
+    return m
+
+
 def form_frame(cal, quat_raw, acc_raw, combo='lw_rp', n_imus=5):
-    """live_demo.py:213-236: raw wxyz quaternions [F,5,4] / accelerations [F,5,3] -> network input [F,60]."""
-    ori_raw = quaternion_to_rotation_matrix(quat_raw).view(-1, n_imus, 3, 3)
-    acc_raw = torch.as_tensor(acc_raw, dtype=torch.float32)
-    glb_acc = (cal.smpl2imu.matmul(acc_raw.view(-1, n_imus, 3, 1)) - cal.acc_offsets).view(-1, n_imus, 3)
-    glb_ori = cal.smpl2imu.matmul(ori_raw).matmul(cal.device2bone)
-    _acc = glb_acc.view(-1, 5, 3)[:, CHANNEL_ORDER] / amass.acc_scale
-    _ori = glb_ori.view(-1, 5, 3, 3)[:, CHANNEL_ORDER]
-    acc = torch.zeros_like(_acc)
-    ori = torch.zeros_like(_ori)
-    c = amass.combos[combo]
-    acc[:, c] = _acc[:, c]
-    ori[:, c] = _ori[:, c]
-    return torch.cat([acc.flatten(1), ori.flatten(1)], dim=1)
+    """Host version of the frame formation (contract of live_demo.py:213-236): raw wxyz quaternions [F,5,4] and
+    accelerations [F,5,3] of ONE calibrated sensor set -> network input [F,60].  Per sensor: orientation
+    smpl2imu . R(q) . device2bone, acceleration smpl2imu . a - offset; then the sensors are gathered into network slot order
+    (CHANNEL_ORDER), accelerations divided by acc_scale, and slots outside the combo zeroed.
+    (LiveSession does the same for S sensor sets in one GPU launch, mp_live_form_frames.)"""
+    F = torch.as_tensor(quat_raw).reshape(-1, n_imus, 4).shape[0]
+    R = quaternion_to_rotation_matrix(quat_raw).view(F, n_imus, 3, 3)
+    a = torch.as_tensor(acc_raw, dtype=torch.float32).reshape(F, n_imus, 3)
+    M = cal.smpl2imu
+    ori = torch.einsum('ab,fsbc,scd->fsad', M, R, cal.device2bone)
+    acc = torch.einsum('ab,fsb->fsa', M, a) - cal.acc_offsets.reshape(1, n_imus, 3)
+    keep = torch.zeros(n_imus)
+    keep[amass.combos[combo]] = 1.0
+    acc = acc[:, CHANNEL_ORDER] / amass.acc_scale * keep.view(1, n_imus, 1)
+    ori = ori[:, CHANNEL_ORDER] * keep.view(1, n_imus, 1, 1)
+    return torch.cat((acc.reshape(F, -1), ori.reshape(F, -1)), dim=1)
 
 
 class LiveSession:
-    """S calibrated sensor sets -> one GPU streaming tick (mp_stream_step) per frame set."""
+    """S calibrated sensor sets -> one GPU launch that forms the S frames (mp_live_form_frames) -> one streaming tick
+    (mp_stream_step).  The calibrations live on the device for the lifetime of the session."""
 
     def __init__(self, model, calibrations, combo='lw_rp'):
         self.model, self.cals, self.combo = model, list(calibrations), combo
+        self.keep = combo_keep_mask(combo)
+        dev = model.device
+        self._M = torch.stack([c.smpl2imu for c in self.cals]).float().contiguous().to(dev)                 # [S,3,3]
+        self._D = torch.stack([c.device2bone for c in self.cals]).float().contiguous().to(dev)              # [S,5,3,3]
+        self._O = torch.stack([c.acc_offsets.reshape(5, 3) for c in self.cals]).float().contiguous().to(dev)  # [S,5,3]
         model.stream_create(len(self.cals))
 
+    def frames(self, quats, accs):
+        """quats [S,5,4], accs [S,5,3] (one raw sample per stream) -> frames [S,60] on the device."""
+        return self.model.live_form_frames(torch.as_tensor(quats), torch.as_tensor(accs), self._M, self._D, self._O, self.keep)
+
     def tick(self, quats, accs):
-        """quats [S,5,4], accs [S,5,3] (one raw sample per stream) -> (pose [S,24,9], root_pos [S,3], packets)."""
-        frames = torch.cat([form_frame(c, torch.as_tensor(quats[i])[None], torch.as_tensor(accs[i])[None], self.combo)
-                            for i, c in enumerate(self.cals)])
-        pose, _joints, root, _contact = self.model.stream_step(frames)
-        packets = [format_output(pose[i], root[i]) for i in range(len(self.cals))]
+        """-> (pose [S,24,9], root_pos [S,3], packets)."""
+        pose, _joints, root, _contact = self.model.stream_step(self.frames(quats, accs))
+        pose_h, root_h = pose.cpu(), root.cpu()
+        packets = [format_output(pose_h[i], root_h[i]) for i in range(len(self.cals))]
         return pose, root, packets

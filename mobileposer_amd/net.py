@@ -9,6 +9,7 @@ There is no CPU path: constructing the model without the built library raises.
 """
 import atexit
 import ctypes as C
+import os
 import sys
 import weakref
 
@@ -17,7 +18,7 @@ import torch
 
 from . import _lib
 from .body_model import ParametricModel
-from .config import joint_set, model_config
+from .config import joint_set, model_config, paths
 from .manifest import state_dict_manifest
 from .model_utils import blob_to_state_dict, state_dict_to_blob
 
@@ -90,7 +91,9 @@ class MobilePoserNet:
             self.bodymodel = smpl if isinstance(smpl, ParametricModel) else ParametricModel(data=smpl)
         elif smpl_file is not None:
             self.bodymodel = ParametricModel(smpl_file)
-        else:
+        elif os.path.exists(str(paths.smpl_file)):             # the reference always reads paths.smpl_file (net.py:37)
+            self.bodymodel = ParametricModel(str(paths.smpl_file))
+        else:                                                  # licensed file absent: synthetic body
             self.bodymodel = ParametricModel.synthetic()
         self.bodymodel.bind(self)
         # base joints (net.py:47-49)
@@ -328,6 +331,19 @@ class MobilePoserNet:
         contact = torch.empty(S, 2, device=dev, dtype=f32)
         self.stream_step_into(x, pose, joints, root, contact)
         return pose, joints, root, contact
+
+    def live_form_frames(self, quat, acc, smpl2imu, device2bone, acc_offsets, keep_mask):
+        """mp_live_form_frames: raw sensor samples of S streams -> frames [S,60] (live_demo.py:213-236 per stream)."""
+        self._require_weights()
+        f = lambda t: self._input(torch.as_tensor(t, dtype=torch.float32))
+        q, a, M, D, O = f(quat), f(acc), f(smpl2imu), f(device2bone), f(acc_offsets)
+        S = int(q.shape[0])
+        assert tuple(q.shape) == (S, 5, 4) and tuple(a.shape) == (S, 5, 3) and tuple(M.shape) == (S, 3, 3)
+        assert tuple(D.shape) == (S, 5, 3, 3) and O.numel() == S * 15
+        out = torch.empty(S, 60, device=self.device, dtype=torch.float32)
+        _lib.check(self._lib.mp_live_form_frames(self._h, _ptr(q), _ptr(a), _ptr(M), _ptr(D), _ptr(O), int(keep_mask), S,
+                                                 _ptr(out), self._stream()), self._h)
+        return out
 
     def stream_reset(self, mask=None, clear_velocity=False):
         """reset() (net.py:84-88) for the streams whose ``mask`` entry is true (all when None)."""

@@ -255,6 +255,61 @@ def main():
                         fq=fq.numpy(), fa=fa.numpy(), smpl2imu=smpl2imu.numpy(), device2bone=device2bone.numpy(),
                         acc_offsets=acc_offsets.numpy(), imu_input=imu_input.numpy(), rot=rot, axis_angle=aa.numpy())
 
+    # ---- G11 evaluate_pose incl. the translation-window statistics (evaluate.py:39-107, evaluate_tran=True) --------
+    # the reference's own evaluate_pose, driven with a stand-in model that returns canned predictions (what is pinned here
+    # is the harness: per-sequence loop, error table aggregation with mean(), the evaluate_tran pair search and averages)
+    import builtins
+    import mobileposer.evaluate as ref_eval            # noqa: E402
+    rng = np.random.Generator(np.random.PCG64(11))
+    seqs11 = []
+    for n in (150, 90, 20):                            # the 20-frame one is shorter than fps: its 1-s error row is NaN
+        pose_t = synthetic._random_rotations(rng, n * 24).reshape(n, 24, 3, 3).astype(np.float32)
+        noise = rng.standard_normal((n, 24, 3)) * 0.1
+        pose_p = np.einsum("njab,njbc->njac", pose_t, Rotation.from_rotvec(noise.reshape(-1, 3)).as_matrix()
+                           .reshape(n, 24, 3, 3)).astype(np.float32)
+        tran_t = np.cumsum(np.abs(rng.standard_normal((n, 3))) * np.array([0.06, 0.002, 0.05]), axis=0).astype(np.float32)
+        tran_p = (tran_t + np.cumsum(rng.standard_normal((n, 3)) * 0.004, axis=0)).astype(np.float32)
+        imu = rng.standard_normal((n, 60)).astype(np.float32)
+        seqs11.append(dict(imu=imu, pose_t=pose_t, pose_p=pose_p, tran_t=tran_t, tran_p=tran_p))
+
+    class _CannedModel:
+        def __init__(self):
+            self.k = -1
+
+        def eval(self):
+            return self
+
+        def reset(self):
+            self.k += 1
+
+        def forward_offline(self, x, lengths):
+            sq = seqs11[self.k]
+            return (torch.from_numpy(sq["pose_p"]), torch.zeros(1, x.shape[1], 72), torch.from_numpy(sq["tran_p"]),
+                    torch.zeros(x.shape[1], 2))
+
+    dataset11 = [(torch.from_numpy(sq["imu"]), art.math.rotation_matrix_to_r6d(torch.from_numpy(sq["pose_t"])).reshape(-1, 144),
+                  torch.zeros(sq["imu"].shape[0], 24, 3), torch.from_numpy(sq["tran_t"])) for sq in seqs11]
+    captured = {}
+    ref_eval.PoseEvaluator.print = staticmethod(lambda errors: captured.setdefault("table", errors.clone()))
+    real_print = builtins.print
+
+    def _capture_print(*a, **k):
+        if len(a) == 1 and isinstance(a[0], list):
+            captured["tran"] = [float(v) for v in a[0]]
+        else:
+            real_print(*a, **k)
+
+    builtins.print = _capture_print
+    try:
+        ref_eval.evaluate_pose(_CannedModel(), dataset11, evaluate_tran=True)
+    finally:
+        builtins.print = real_print
+    g11 = {"n_seq": np.int64(len(seqs11)), "table": captured["table"].numpy(), "tran_errors": np.array(captured["tran"], dtype=np.float64)}
+    for k, sq in enumerate(seqs11):
+        for name, v in sq.items():
+            g11[f"s{k}_{name}"] = v
+    np.savez_compressed(os.path.join(HERE, "g11_evaluate.npz"), **g11)
+
     print("golden vectors written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         print("  %-24s %8d B" % (fn, os.path.getsize(os.path.join(HERE, fn))))

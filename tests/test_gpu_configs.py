@@ -226,3 +226,33 @@ print("GRAPH_OK")
     env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "GRAPH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_live_frame_kernel_golden_and_host_version(torch_mod, weights, smpl):
+    """mp_live_form_frames (csrc/mp_live.hip) against golden G10 -- frames computed with the reference's own math functions,
+    live_demo.py:213-236 -- and, with a different calibration per stream and every device combo, against the host version."""
+    from conftest import load_golden
+    from mobileposer_amd import live
+    from mobileposer_amd.config import amass
+    from mobileposer_amd.net import MobilePoserNet
+    g = load_golden("g10_live.npz")
+    with MobilePoserNet.from_numpy(weights, smpl) as m:
+        F = g["fq"].shape[0]
+        rep = lambda a: torch_mod.from_numpy(np.ascontiguousarray(np.broadcast_to(a, (F,) + a.shape)))
+        got = m.live_form_frames(torch_mod.from_numpy(g["fq"]), torch_mod.from_numpy(g["fa"]), rep(g["smpl2imu"]),
+                                 rep(g["device2bone"]), rep(g["acc_offsets"].reshape(5, 3)), live.combo_keep_mask("lw_rp"))
+        assert np.abs(npy(got) - g["imu_input"]).max() < 1e-5
+        rng = np.random.default_rng(12)
+        S = 37
+        cals = [live.Calibration.from_measurements(torch_mod.from_numpy(rng.standard_normal(4)).float(),
+                                                   torch_mod.from_numpy(rng.standard_normal((5, 4))).float(),
+                                                   torch_mod.from_numpy(rng.standard_normal((5, 3)) * 9.8).float()) for _ in range(S)]
+        q = torch_mod.from_numpy(rng.standard_normal((S, 5, 4)) * 3).float()
+        a = torch_mod.from_numpy(rng.standard_normal((S, 5, 3)) * 9.8).float()
+        M = torch_mod.stack([c.smpl2imu for c in cals])
+        D = torch_mod.stack([c.device2bone for c in cals])
+        O = torch_mod.stack([c.acc_offsets.reshape(5, 3) for c in cals])
+        for combo in amass.combos:
+            got = npy(m.live_form_frames(q, a, M, D, O, live.combo_keep_mask(combo)))
+            want = torch_mod.cat([live.form_frame(c, q[i][None], a[i][None], combo) for i, c in enumerate(cals)]).numpy()
+            assert np.abs(got - want).max() < 2e-5, combo

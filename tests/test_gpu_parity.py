@@ -278,7 +278,8 @@ def test_evaluate_harness_offline_and_online(torch_mod, net, monkeypatch):
     from mobileposer_amd.evaluate import PoseEvaluator, evaluate_pose, synthetic_dataset
     from mobileposer_amd.config import amass
     data = synthetic_dataset(n_seq=1, frames=40, seed=3)
-    ds = PoseDataset(data, fk=net.forward_kinematics, combos=dict(list(amass.combos.items())[:2]))
+    ds = PoseDataset(fold='test', evaluate='dip', data=data, fk=net.forward_kinematics,
+                     combos=dict(list(amass.combos.items())[:2]))
     assert len(ds) == 2 and tuple(ds[0][0].shape) == (40, 60) and tuple(ds[0][2].shape) == (40, 24, 3)
     monkeypatch.setenv("ONLINE", "1")
     out = evaluate_pose(net, ds, verbose=False)
@@ -516,3 +517,35 @@ def test_two_slab_kernel_matches(torch_mod, weights, smpl, monkeypatch):
         outs[mask] = o
     for a, b in zip(outs[0], outs[3]):
         assert float((a - b).abs().max()) < 5e-6
+
+
+def test_g11_evaluate_pose_table_and_translation_statistics(torch_mod, net):
+    """evaluate_pose (evaluate.py:39-107) against the reference's own run on canned predictions (golden G11): the 8 x 2
+    table -- aggregated with mean(), so the sequence shorter than one second turns the 1-s distance row into NaN exactly
+    as upstream -- and the evaluate_tran list.  FK / skinning / angles / reductions run on the GPU."""
+    from mobileposer_amd.data import rotation_matrix_to_r6d
+    from mobileposer_amd.evaluate import evaluate_pose
+    g = load_golden("g11_evaluate.npz")
+    n_seq = int(g["n_seq"])
+
+    class Canned:                                   # the model under evaluation is not the point here: canned predictions
+        device, n_vertex = net.device, net.n_vertex
+        forward_kinematics = staticmethod(net.forward_kinematics)
+        k = -1
+
+        def eval(self):
+            return self
+
+        def reset(self):
+            self.k += 1
+
+        def forward_offline(self, x, lengths):
+            return (cu(torch_mod, g[f"s{self.k}_pose_p"]), None, cu(torch_mod, g[f"s{self.k}_tran_p"]), None)
+
+    ds = [(torch_mod.from_numpy(g[f"s{k}_imu"]), rotation_matrix_to_r6d(torch_mod.from_numpy(g[f"s{k}_pose_t"])).reshape(-1, 144),
+           None, torch_mod.from_numpy(g[f"s{k}_tran_t"])) for k in range(n_seq)]
+    out = evaluate_pose(Canned(), ds, evaluate_tran=True, verbose=False)
+    table = npy(out["offline"])
+    assert np.isnan(table[7]).all() and np.isnan(g["table"][7]).all()
+    np.testing.assert_allclose(table[:7], g["table"][:7], rtol=3e-4, atol=1e-4)
+    np.testing.assert_allclose(out["tran"], g["tran_errors"], rtol=1e-4, atol=1e-6)
