@@ -54,27 +54,23 @@ def main():
         f.write("# rocprofv3 --kernel-trace --stats (%s)\n\n" % tag)
         f.write("Command (MI355X, via gpurun): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
                 "--no-cpu-baseline %s --steps 20 --warmup 5`\n" % " ".join(extra))
-        f.write("(bench.py times BOTH LSTM operand modes in one process: 25 graph-replayed forwards per mode + 3 eager "
-                "event-timed forwards of the headline mode, B=256 x T=125; raw CSV next to this file)\n\n")
+        f.write("(bench.py in one process: 25 forwards of the headline mode (exact-fp32 operands, eager launches on the library's "
+                "streams), 23 of the opt-in split-bf16 mode, the configs[3] leg (B = 1024), 5 event-timed forwards of the "
+                "headline mode; B=256 x T=125; raw CSV next to this file)\n\n")
         if bench_line:
             f.write("bench line of this (profiled) run: %.4f ms/step = %.0f frames/s headline (%s); modes: %s\n\n"
                     % (bench_line["ms_per_step"], bench_line["value"], bench_line["config"].get("lstm_mode"),
                        json.dumps({k: v for k, v in bench_line["modes"].items() if isinstance(v, dict)})))
             f.write("roofline kernel (HIP events, live): %s: avg %.4f ms/launch\n\n"
                     % (bench_line["roofline"]["kernel"], bench_line["roofline"]["avg_launch_ms"]))
-        # the event-timed launches are the LAST eager forwards of the run; graph-replayed launches of the same kernel are
-        # shorter (no host launch gaps between the streams' kernels), so compare like with like
         trace = glob.glob(os.path.join(d, "**", "bench_kernel_trace.csv"), recursive=True)
         if bench_line and trace:
             want = bench_line["roofline"]["kernel"].split(" ")[0].replace(",", ", ").replace(">", ", false>")
             dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(trace[0]))
                    if want in r["Kernel_Name"]]
-            n_eager = 3 * bench_line["kernels"][bench_line["roofline"]["kernel"]]["launches_per_forward"]
-            if len(dur) > n_eager:
-                f.write("rocprof durations of `%s`: %d graph-replayed launches avg %.1f us; the %d eager launches that bench.py "
-                        "brackets with HIP events avg %.1f us (HIP events: %.1f us)\n\n"
-                        % (want, len(dur) - n_eager, sum(dur[:-n_eager]) / (len(dur) - n_eager), n_eager,
-                           sum(dur[-n_eager:]) / n_eager, 1e3 * bench_line["roofline"]["avg_launch_ms"]))
+            if dur:
+                f.write("rocprof durations of `%s`: %d launches, avg %.1f us (HIP events inside bench.py: %.1f us)\n\n"
+                        % (want, len(dur), sum(dur) / len(dur), 1e3 * bench_line["roofline"]["avg_launch_ms"]))
         f.write("| kernel | calls | total ms | % | avg us | min us | max us |\n|---|---|---|---|---|---|---|\n")
         for r in rows[:24]:
             f.write("| %s | %s | %.3f | %s | %.1f | %.1f | %.1f |\n" % (
