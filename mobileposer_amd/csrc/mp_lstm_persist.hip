@@ -193,13 +193,34 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
     // granules: the second half of x_t is then fetched at the top of step t (it is first used ~2000 cycles later).
     constexpr bool SPLIT_X = C::BIG;
     constexpr int XJ_PRE = SPLIT_X ? NXJ / 2 : NXJ;        // 16-byte pieces prefetched one step ahead
+    // LEAN (one wave per SIMD: the 16-slice / 4-wave and the H = 64 configurations): VALU instructions do not hide under
+    // MFMAs on this hardware (profiles/r02_persist_phases.md) and a lone wave has nobody to cover them, so the step is put on
+    // a VALU diet -- (1) x_t of this lane's row is read UNCONDITIONALLY from a clamped time index (a row past its length
+    // multiplies whatever finite values it finds there: row r of the A operand only reaches row r of the gates, and an
+    // inactive row's gates are discarded by the cell update; the zero fill cost 32 v_mov + exec juggling per step) through
+    // a pointer that is stepped, not re-multiplied: forward t = min(step, T-1), reverse t = max(len-1-step, 0); (2) the
+    // granules are requested on every step and feed the recurrent MFMAs straight from their low words (a load under a
+    // branch made `gr` a phi of defined / undefined values: 60-80 v_mov per step).  Measured, same box: velocity layers
+    // 577 -> 504-513 us, foot-contact layers 426-440 -> 408-414 us.  The two-waves-per-SIMD kernels keep the old code:
+    // there the same source changes made the K_in = 512 layer 12 % SLOWER (register allocation at the 256-VGPR limit).
+    constexpr bool LEAN = TW == 1;
+    const float* xp_cur = xbase + (size_t)(d.reverse ? (alen > 0 ? alen - 1 : 0) : 0) * xtstride;   // time index of `step`
+    const float* xp_nxt = xp_cur;                                                                  // ... of `step + 1`
     auto load_x = [&](int step, int j0, int j1) {
-        const bool on = step < alen;
-        const int t = on ? (d.reverse ? alen - 1 - step : step) : 0;
-        const float* p = xbase + (size_t)t * xtstride;
+        if (LEAN) {
+            const float* p = step & 0x40000000 ? xp_nxt : xp_cur;       // (bit 30 = "the prefetch of the next step")
 #pragma unroll
-        for (int j = 0; j < NXJ; ++j)
-            if (j >= j0 && j < j1) xa[j] = on ? *reinterpret_cast<const f32x4*>(p + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NXJ; ++j)
+                if (j >= j0 && j < j1) xa[j] = *reinterpret_cast<const f32x4*>(p + j * 16);
+        } else {
+            step &= 0x3fffffff;
+            const bool on = step < alen;
+            const int t = on ? (d.reverse ? alen - 1 - step : step) : 0;
+            const float* p = xbase + (size_t)t * xtstride;
+#pragma unroll
+            for (int j = 0; j < NXJ; ++j)
+                if (j >= j0 && j < j1) xa[j] = on ? *reinterpret_cast<const f32x4*>(p + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     };
     load_x(0, 0, XJ_PRE);
     __syncthreads();                                          // W_ih LDS image complete
@@ -214,6 +235,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
 
     for (int step = 0; step < T; ++step) {
         PROF_T(0);
+        if (LEAN) xp_cur = xp_nxt;
         if (SPLIT_X) load_x(step, XJ_PRE, NXJ);
         f32x4 acc[NTW];
 #pragma unroll
@@ -254,7 +276,8 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
         // (when part of W_ih lives in registers there is no room to hold 16 granules in flight beside it:
         //  request them after the projection instead; the second wave on the SIMD covers the L2 latency)
         constexpr bool EARLY_GATHER = !C::BIG;
-        if (EARLY_GATHER && step > 0) {
+        // (LEAN: requested on EVERY step, step 0 included -- there the words are simply not looked at)
+        if (EARLY_GATHER && (LEAN || step > 0)) {
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) gr[ks] = granule_load(srcp[ks / KSP] + (size_t)ks * 64);
         }
@@ -280,6 +303,9 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
         PROF_E(0); PROF_T(1);
 
         // ---- validate the granules; the slow path (cheap gate, then sweep) only runs when some were stale
+        // (K_in = 512: the registers are full -- the words are requested only now and only when they are needed, and the
+        //  recurrent A operand is extracted into 16 registers so that the 32 of `gr` die before the MFMAs)
+        constexpr bool DIRECT_GR = EARLY_GATHER && LEAN;       // recurrent MFMAs read the low words of `gr` directly
         if (step > 0) {
             if (!EARLY_GATHER) {
 #pragma unroll
@@ -315,18 +341,31 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
                 if (lane == 0) mp_set_error(a.err, 1 + step);
                 spin_budget = 0;
             }
+            if (!DIRECT_GR) {
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) av[ks] = __uint_as_float((unsigned)gr[ks]);
+                for (int ks = 0; ks < NKS; ++ks) av[ks] = __uint_as_float((unsigned)gr[ks]);
+            }
+        } else if (DIRECT_GR) {
+            // step 0: the recurrent A operand is the initial state; it takes the place of the (unused) words just loaded
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) gr[ks] = (u64)__float_as_uint(av[ks]);
         }
-        load_x(step + 1, 0, XJ_PRE);     // next step's x: issued only now so that the granule wait above does not
-                                         // also drain these HBM loads; they land under the MFMAs / cell update below
+        if (LEAN) {   // time index of step + 1, clamped
+            const bool adv = d.reverse ? (alen - 2 - step >= 0) : (step + 1 < T);
+            const long dlt = d.reverse ? -(long)xtstride : (long)xtstride;
+            xp_nxt = adv ? xp_cur + dlt : xp_cur;
+        }
+        load_x((step + 1) | 0x40000000, 0, XJ_PRE);   // next step's x: issued only now so that the granule wait above does not
+                                                      // also drain these HBM loads; they land under the MFMAs / cell update below
         PROF_E(1); PROF_T(2);
 
         // ---- recurrent part: h_{t-1} W_hh^T on top of the input projection
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], wv[ks][t], acc[t], 0, 0, 0);
+            for (int t = 0; t < NTW; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(DIRECT_GR ? __uint_as_float((unsigned)gr[ks]) : av[ks], wv[ks][t],
+                                                              acc[t], 0, 0, 0);
         PROF_E(2); PROF_T(3);
 
         // ---- K reduction through LDS: the 4 K-quarter waves of a tile group hand each finishing wave the 4 gate
