@@ -94,6 +94,8 @@ struct ModuleW {
     float* wihX[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     float* whhP16[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // 16-slice packing for mp_lstm_pair (bidirectional H = 256
     float* wihP16[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  //  blocks; a unidirectional block's whhP / wihP already is it)
+    float* whhPW[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // 8-slice / 4-wave (WREG) packing, bidirectional H = 256 blocks
+    float* wihPW[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     float* wihG1 = nullptr;          // unidirectional H=256 block: layer-1 W_ih in granule k-order (wavefront kernel)
 };
 struct ModuleWS {
@@ -172,6 +174,9 @@ struct mp_handle {
     bool wide_ok = true;             // MP_WIDE=0: never run pose / velocity / foot-contact side by side (small batches)
     bool fuse_pv = true;             // MP_FUSE_PV=0: separate linear1 launches for pose and velocity
     Packed lin1_pv;                  // pose.linear1 and velocity.linear1 stacked (split-bf16 mode: one GEMM over the shared rows)
+    int wreg_mask = 3;               // fp32 mode, 8-slice bidirectional layers on the four-wave / AccVGPR-weight configuration
+                                     // (mp_lstm_fused<256,8,KIN,1>): bit 0 K_in = 512, bit 1 K_in = 256 (env MP_WREG; 0 = the
+                                     // eight-wave kernels).  Measured on one box: 4.47 -> 4.35 ms per 256 x 125 forward.
     int pair_mask = 0;               // fp32 mode: bidirectional H = 256 layers run by the two-slabs-per-workgroup kernel
                                      // mp_lstm_pair: bit 0 K_in = 512 layers, bit 1 K_in = 256 layers (env MP_PAIR).  Off:
                                      // measured slower than mp_lstm_fused on every layer ("two slabs per
@@ -253,6 +258,8 @@ int pack_weights(mp_handle* h, const float* blob) {
                 const int kin = l == 0 ? m.H : m.dirs * m.H;
                 if (int rc = dev_alloc(h, (void**)&m.wihP[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
                 if (m.H == 256 && m.nslice != 16) {
+                    if (int rc = dev_alloc(h, (void**)&m.whhPW[l][d], mp_whh_pack_floats(m.H) * sizeof(float))) return rc;
+                    if (int rc = dev_alloc(h, (void**)&m.wihPW[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
                     if (int rc = dev_alloc(h, (void**)&m.whhP16[l][d], mp_whh_pack_floats(m.H) * sizeof(float))) return rc;
                     if (int rc = dev_alloc(h, (void**)&m.wihP16[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
                 }
@@ -286,6 +293,10 @@ int pack_weights(mp_handle* h, const float* blob) {
                 mp_launch_pack_whh(find(s.id, K_WHH, l, d), m.whh[l][d], m.H, h->s_main);
                 mp_launch_pack_whh_persist(find(s.id, K_WHH, l, d), m.whhP[l][d], m.H, m.nslice, h->s_main);
                 mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP[l][d], m.H, m.ih[l].K, m.nslice, 0, h->s_main);
+                if (m.whhPW[l][d]) {
+                    mp_launch_pack_whh_persist_w(find(s.id, K_WHH, l, d), m.whhPW[l][d], h->s_main);
+                    mp_launch_pack_wih_persist_w(find(s.id, K_WIH, l, d), m.wihPW[l][d], m.ih[l].K, h->s_main);
+                }
                 if (m.whhP16[l][d]) {
                     mp_launch_pack_whh_persist(find(s.id, K_WHH, l, d), m.whhP16[l][d], m.H, 16, h->s_main);
                     mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP16[l][d], m.H, m.ih[l].K, 16, 0, h->s_main);
@@ -381,6 +392,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     if (const char* e = getenv("MP_LSTM_UNI2")) h->uni2 = e[0] == '1';
     if (const char* e = getenv("MP_X3W")) h->x3w_mask = atoi(e) & 3;
     if (const char* e = getenv("MP_PAIR")) h->pair_mask = atoi(e) & 3;
+    if (const char* e = getenv("MP_WREG")) h->wreg_mask = atoi(e) & 3;
     if (const char* e = getenv("MP_PAIR_MODE")) h->pair_mode = atoi(e);
     if (const char* e = getenv("MP_FUSE_PV")) h->fuse_pv = atoi(e) != 0;
     if (const char* e = getenv("MP_WIDE")) h->wide_ok = atoi(e) != 0;
@@ -692,6 +704,8 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
                           (h->pair_mask & (kin_l == 512 ? 1 : 2));
         const int nsl = use_x3(h, m) ? m.nsliceX : fp32_slices(h, m, B);
         const bool p16 = pair || (!use_x3(h, m) && nsl == 16 && m.nslice != 16);      // 16-slice packing of a bidirectional block
+        const bool wreg = !use_x3(h, m) && !pair && H == 256 && nsl == 8 && m.whhPW[0][0] &&
+                          (h->wreg_mask & (kin_l == 512 ? 1 : 2));
         const int cus = h->n_cu < 256 ? h->n_cu : 256;
         // slabs per launch: grid <= #CUs, one workgroup per CU (pair kernel: 16 workgroups per pair of slabs)
         const int chunk = pair ? (cus / (dirs * 16) > 0 ? 2 * (cus / (dirs * 16)) : 2)
@@ -716,18 +730,19 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             a.out_pairs = x3 ? 1 : 0;                          // both layers feed split-bf16 consumers (layer 1 / linear2)
             for (int d = 0; d < dirs; ++d) {
                 LstmDir& dd = a.d[d];
-                dd.wpack = x3 ? m.whhX[l][d] : (p16 ? m.whhP16[l][d] : m.whhP[l][d]);
+                dd.wpack = x3 ? m.whhX[l][d] : (wreg ? m.whhPW[l][d] : (p16 ? m.whhP16[l][d] : m.whhP[l][d]));
                 dd.xproj = nullptr; dd.out = outp + (size_t)d * H;
                 const bool inplace = j.out_h == j.in_h && j.out_h;
                 dd.hbuf = inplace ? j.out_h + (size_t)(l * dirs + d) * B * H : w.hbuf[l][d];
                 dd.cbuf = inplace ? j.out_c + (size_t)(l * dirs + d) * B * H : w.cbuf[l][d];
                 dd.xprojStride = 0; dd.outStride = dirs * H; dd.reverse = d;
-                dd.wihpack = x3 ? m.wihX[l][d] : (p16 ? m.wihP16[l][d] : m.wihP[l][d]); dd.bias = m.ih[l].bias + (size_t)d * 4 * H; dd.xin = xin;
+                dd.wihpack = x3 ? m.wihX[l][d] : (wreg ? m.wihPW[l][d] : (p16 ? m.wihP16[l][d] : m.wihP[l][d])); dd.bias = m.ih[l].bias + (size_t)d * 4 * H; dd.xin = xin;
             }
             if (dirs == 1) a.d[1] = a.d[0];
             if (x3 && nsl == 8 && (h->x3w_mask & (kin == 256 ? 1 : 2))) mp_launch_lstm_x3w(a, kin, s);
             else if (x3) mp_launch_lstm_x3(a, kin, nsl, s);
             else if (pair) mp_launch_lstm_pair(a, kin, h->pair_mode, s);
+            else if (wreg) mp_launch_lstm_persist_w(a, kin, s);
             else mp_launch_lstm_persist(a, H, kin, nsl, s);
         }
     } else {
@@ -989,6 +1004,8 @@ void mp_destroy(mp_handle* h) {
             if (m.whh[l][d]) (void)hipFree(m.whh[l][d]);
             if (m.whhP[l][d]) (void)hipFree(m.whhP[l][d]);
             if (m.wihP[l][d]) (void)hipFree(m.wihP[l][d]);
+            if (m.whhPW[l][d]) (void)hipFree(m.whhPW[l][d]);
+            if (m.wihPW[l][d]) (void)hipFree(m.wihPW[l][d]);
             if (m.whhP16[l][d]) (void)hipFree(m.whhP16[l][d]);
             if (m.wihP16[l][d]) (void)hipFree(m.wihP16[l][d]);
             if (m.whhX[l][d]) (void)hipFree(m.whhX[l][d]);

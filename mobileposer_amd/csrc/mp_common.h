@@ -101,6 +101,10 @@ struct LstmPersistArgs {
 void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice, hipStream_t s);
 void mp_launch_pack_whh_persist(const float* whh, float* dst, int H, int nslice, hipStream_t s);
 void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, int nslice, int korder, hipStream_t s);
+// H = 256, 8 slices, four 512-register waves per workgroup with AccVGPR-resident weights (mp_lstm_fused<256,8,KIN,1>)
+void mp_launch_pack_whh_persist_w(const float* whh, float* dst, hipStream_t s);
+void mp_launch_pack_wih_persist_w(const float* wih, float* dst, int KIN, hipStream_t s);
+void mp_launch_lstm_persist_w(const LstmPersistArgs& a, int KIN, hipStream_t s);
 int mp_persist_max_wg(int H, int nslice);    // largest grid that is co-resident
 // both layers of a unidirectional 2-layer H = 256 LSTM as one wavefront launch (d[0] = layer 0, d[1] = layer 1)
 void mp_launch_lstm_uni2(const LstmPersistArgs& a, hipStream_t s);

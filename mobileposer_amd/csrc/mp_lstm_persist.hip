@@ -62,16 +62,42 @@ struct Cfg {
     static constexpr int STEP_BYTES = NWV * NTG * 64 * 16;                     // all waves, one k-step
     static constexpr int LDS_BUDGET = (NWV == 4 && NSLICE == 16) ? 80 * 1024 : 160 * 1024;   // 2 workgroups per CU
     static constexpr int LDS_STEPS_MAX = (LDS_BUDGET - RED_F4 * 16) / STEP_BYTES;
-    static constexpr int XL = NXS <= LDS_STEPS_MAX ? NXS : (LDS_STEPS_MAX / 4) * 4;  // x k-steps served from LDS
+    // (four-wave 8-slice configuration, K_in = 256: ALL of W_ih fits the AccVGPRs beside W_hh -- no weight comes from LDS)
+    static constexpr bool ALLREG = H == 256 && NSLICE == 8 && TW == 1 && KIN == 256;
+    static constexpr int XL = ALLREG ? 0 : (NXS <= LDS_STEPS_MAX ? NXS : (LDS_STEPS_MAX / 4) * 4);  // x k-steps served from LDS
     static constexpr int XR = NXS - XL;                                        // x k-steps served from registers
     static constexpr bool BIG = KIN > H;              // part of W_ih in registers: late gather, split x prefetch
     static constexpr int WG_PER_CU = NWV == 4 && NSLICE == 16 ? 2 : 1;         // co-resident workgroups wanted
     static_assert(TW == 1 || TW == NUB, "tile groups are whole unit blocks");
 };
 
+// WREG configuration (H = 256, 8 slices, FOUR waves with up to 512 registers each instead of eight with 256): the
+// register-resident weight fragments live in AccVGPRs and every MFMA is inline asm that names them as its B operand
+// (VOP3P-MAI encodes an AccVGPR source directly; left to itself the compiler parks the 256 weight registers in AccVGPRs
+// and copies each one back with a v_accvgpr_read -- a VALU instruction per MFMA).  The hazard recogniser does not look
+// inside asm, so the two hazards that exist here are handled by hand: accumulators start from an inline-constant C = 0
+// MFMA (no VALU-zeroed register is read as SrcC), and mfma_drain() supplies the wait states between the last MFMA
+// and the first VALU / LDS read of its result (8-pass MFMA: 11 by the ISA tables, 18 given).
+template <bool ZERO, bool WACC>
+__device__ __forceinline__ void mfma_asm(f32x4& c, float a, float w) {
+    if (ZERO) {
+        if (WACC) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(w));
+        else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(w));
+    } else {
+        if (WACC) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(w));
+        else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(w));
+    }
+}
+__device__ __forceinline__ void mfma_drain() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 1" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int H, int NSLICE, int KIN, int TW, bool PROF>
 MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void mp_lstm_fused(LstmPersistArgs a) {
     using C = Cfg<H, NSLICE, KIN, TW>;
+    constexpr bool WREG = H == 256 && NSLICE == 8 && TW == 1;
     constexpr int U = C::U, NUB = C::NUB, NWV = C::NWV, NTW = C::NTW, NTG = C::NTG, KW = C::KW, NKS = C::NKS, KQ = C::KQ;
     constexpr int NXS = C::NXS, NXJ = C::NXJ, NOWN = C::NOWN, XL = C::XL, XR = C::XR, NPW = C::NPW;
     constexpr bool PER_UB = C::PER_UB;
@@ -238,14 +264,16 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
         if (LEAN) xp_cur = xp_nxt;
         if (SPLIT_X) load_x(step, XJ_PRE, NXJ);
         f32x4 acc[NTW];
+        if (!WREG) {                                           // (WREG: the first MFMA of every tile has C = 0)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         // ---- first half of x_t W_ih^T (independent of h: this is what fills the wait for the peers)
         // (LDS-resident weights are fetched exactly one k-step ahead; the scheduling barriers keep the compiler
         //  from hoisting dozens of ds_reads -- and their 4 destination registers each -- to the top of the loop)
         f32x4 wl[NTG], wn[NTG];
 #pragma unroll
-        for (int tg = 0; tg < NTG; ++tg) wl[tg] = wxw[(size_t)tg * 64];
+        for (int tg = 0; tg < NTG; ++tg) wl[tg] = XL > 0 ? wxw[(size_t)tg * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < NXS / 2; ++s) {
             const float a_s = xa[s >> 2][s & 3];
@@ -257,8 +285,14 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
             for (int tg = 0; tg < NTG; ++tg) {
                 const f32x4 w4 = s < XL ? wl[tg] : wxr[s >= XL ? s - XL : 0][tg];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[tg * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, w4[i], acc[tg * 4 + i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    if (WREG) {
+                        if (s == 0) { if (s < XL) mfma_asm<true, false>(acc[tg * 4 + i], a_s, w4[i]); else mfma_asm<true, true>(acc[tg * 4 + i], a_s, w4[i]); }
+                        else { if (s < XL) mfma_asm<false, false>(acc[tg * 4 + i], a_s, w4[i]); else mfma_asm<false, true>(acc[tg * 4 + i], a_s, w4[i]); }
+                    } else {
+                        acc[tg * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, w4[i], acc[tg * 4 + i], 0, 0, 0);
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -275,7 +309,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
         constexpr int KSP = NKS / NPW;                          // k-steps per producer slice
         // (when part of W_ih lives in registers there is no room to hold 16 granules in flight beside it:
         //  request them after the projection instead; the second wave on the SIMD covers the L2 latency)
-        constexpr bool EARLY_GATHER = !C::BIG;
+        constexpr bool EARLY_GATHER = !C::BIG || WREG;         // (WREG: 512 registers per wave -- room for the granules)
         // (LEAN: requested on EVERY step, step 0 included -- there the words are simply not looked at)
         if (EARLY_GATHER && (LEAN || step > 0)) {
 #pragma unroll
@@ -293,8 +327,14 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
             for (int tg = 0; tg < NTG; ++tg) {
                 const f32x4 w4 = s < XL ? wl[tg] : wxr[s >= XL ? s - XL : 0][tg];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[tg * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, w4[i], acc[tg * 4 + i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    if (WREG) {
+                        if (s == 0) { if (s < XL) mfma_asm<true, false>(acc[tg * 4 + i], a_s, w4[i]); else mfma_asm<true, true>(acc[tg * 4 + i], a_s, w4[i]); }
+                        else { if (s < XL) mfma_asm<false, false>(acc[tg * 4 + i], a_s, w4[i]); else mfma_asm<false, true>(acc[tg * 4 + i], a_s, w4[i]); }
+                    } else {
+                        acc[tg * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, w4[i], acc[tg * 4 + i], 0, 0, 0);
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -360,12 +400,16 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
         PROF_E(1); PROF_T(2);
 
         // ---- recurrent part: h_{t-1} W_hh^T on top of the input projection
+        if (WREG) asm volatile("s_nop 3" ::: "memory");        // (step 0 writes the A operand with VALU moves just above)
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-            for (int t = 0; t < NTW; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(DIRECT_GR ? __uint_as_float((unsigned)gr[ks]) : av[ks], wv[ks][t],
-                                                              acc[t], 0, 0, 0);
+            for (int t = 0; t < NTW; ++t) {
+                const float a_h = DIRECT_GR ? __uint_as_float((unsigned)gr[ks]) : av[ks];
+                if (WREG) mfma_asm<false, true>(acc[t], a_h, wv[ks][t]);
+                else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_h, wv[ks][t], acc[t], 0, 0, 0);
+            }
+        if (WREG) mfma_drain();
         PROF_E(2); PROF_T(3);
 
         // ---- K reduction through LDS: the 4 K-quarter waves of a tile group hand each finishing wave the 4 gate
@@ -757,6 +801,20 @@ void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, in
     else hipLaunchKernelGGL((mp_pack_wih_persist<64, 4, 1>), dim3(grid), dim3(256), 0, s, wih, dst, KIN, korder);
 }
 
+// WREG configuration (H = 256, 8 slices, four 512-register waves): its own fragment order (TW = 1)
+void mp_launch_pack_whh_persist_w(const float* whh, float* dst, hipStream_t s) {
+    const size_t n = (size_t)4 * 256 * 256;
+    hipLaunchKernelGGL((mp_pack_whh_persist<256, 8, 1>), dim3((int)((n + 255) / 256)), dim3(256), 0, s, whh, dst);
+}
+void mp_launch_pack_wih_persist_w(const float* wih, float* dst, int KIN, hipStream_t s) {
+    const size_t n = (size_t)4 * 256 * KIN;
+    hipLaunchKernelGGL((mp_pack_wih_persist<256, 8, 1>), dim3((int)((n + 255) / 256)), dim3(256), 0, s, wih, dst, KIN, 0);
+}
+void mp_launch_lstm_persist_w(const LstmPersistArgs& a, int KIN, hipStream_t s) {
+    if (KIN == 256) launch_fused<256, 8, 256, 1>(a, s);
+    else launch_fused<256, 8, 512, 1>(a, s);
+}
+
 int mp_persist_max_wg(int H, int nslice) { return H == 256 && nslice == 16 ? 512 : 256; }
 
 // both layers of a unidirectional 2-layer LSTM (H = 256, 16-slice packing) as one wavefront launch
@@ -770,6 +828,8 @@ hipError_t mp_lstm_persist_device_attrs() {
     if (!e) e = fused_attrs<256, 16, 512, 1>();
     if (!e) e = fused_attrs<256, 8, 256, 2>();
     if (!e) e = fused_attrs<256, 8, 512, 2>();
+    if (!e) e = fused_attrs<256, 8, 256, 1>();
+    if (!e) e = fused_attrs<256, 8, 512, 1>();
     if (!e) e = fused_attrs<64, 4, 64, 1>();
     if (!e) e = fused_attrs<64, 4, 128, 1>();
     if (!e) e = hipFuncSetAttribute((const void*)mp_lstm_fused_uni2<256>, hipFuncAttributeMaxDynamicSharedMemorySize,

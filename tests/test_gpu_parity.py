@@ -549,3 +549,32 @@ def test_g11_evaluate_pose_table_and_translation_statistics(torch_mod, net):
     assert np.isnan(table[7]).all() and np.isnan(g["table"][7]).all()
     np.testing.assert_allclose(table[:7], g["table"][:7], rtol=3e-4, atol=1e-4)
     np.testing.assert_allclose(out["tran"], g["tran_errors"], rtol=1e-4, atol=1e-6)
+
+
+def test_four_wave_fp32_kernel_matches_eight_wave(torch_mod, weights, smpl, monkeypatch):
+    """mp_lstm_fused<256,8,KIN,1> (default for the 8-slice fp32 layers: four 512-register waves, weights in AccVGPRs, inline-asm
+    MFMAs with hand-placed wait states) against the eight-wave kernel it replaced (MP_WREG=0): full-chip batch, several
+    launch groups with an odd slab count, ragged lengths, carried velocity state.  Same K split and reduction order; the
+    cell update is contracted differently by the compiler, hence fp32-noise-level differences, not bitwise equality."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    rng = np.random.default_rng(21)
+    shapes = ((256, 60), (300, 15), (520, 9))
+    lens = {sh: [int(v) for v in rng.integers(1, sh[1] + 1, size=sh[0])] for sh in shapes}
+    outs = {}
+    for mask in (0, 3):
+        monkeypatch.setenv("MP_WREG", str(mask))
+        with MobilePoserNet.from_numpy(weights, smpl) as n:
+            n.set_lstm_mode(1)
+            o = []
+            for B, T in shapes:
+                L = list(lens[(B, T)])
+                L[0] = T
+                x = cu(torch_mod, synthetic.make_imu(B, T, seed=B + 3))
+                o += [t.clone() for t in n.forward_offline(x, L)]
+                o += [t.clone() for t in n.forward_offline(x, L)]
+                n.reset_all()
+            assert n.device_error() == 0
+        outs[mask] = o
+    for a, b in zip(outs[0], outs[3]):
+        assert float((a - b).abs().max()) < 5e-6
