@@ -44,8 +44,8 @@ X3_NAMES = {         # the same timing classes when the H = 256 blocks run on sp
 
 KERNEL_CLASSES = {   # timing classes of the C ABI (include/mobileposer_hip.h, mp_timing_read)
     0: "mp_gemm_f32 (linear1 / linear2)",
-    1: "mp_lstm_fused<256,8,256,2> bidirectional layer 0 (joints, pose)",
-    4: "mp_lstm_fused<256,8,512,2> bidirectional layer 1 (joints, pose)",
+    1: "mp_lstm_fused<256,8,256,1> bidirectional layer 0 (joints, pose)",
+    4: "mp_lstm_fused<256,8,512,1> bidirectional layer 1 (joints, pose)",
     5: "mp_lstm_fused<256,16,256,1> unidirectional layers (velocity)",
     6: "mp_lstm_fused<64,4,*,1> (foot contact)",
     7: "mp_lstm_step (per-step fallback)",
@@ -395,7 +395,7 @@ def main():
     for prof in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
         try:
             pmc = json.load(open(os.path.join(REPO, "profiles", prof)))["kernels"]
-            key = {1: "mp_lstm_fused<256, 8, 256, 2, false>", 4: "mp_lstm_fused<256, 8, 512, 2, false>",
+            key = {1: "mp_lstm_fused<256, 8, 256, 1, false>", 4: "mp_lstm_fused<256, 8, 512, 1, false>",
                    5: "mp_lstm_fused<256, 16, 256, 1, false>", 0: "mp_gemm_f32<2, 2, 2, 2>"}.get(dominant)
             if args.lstm_mode == "x3":
                 key = {1: "mp_lstm_x3<8, 256, false>", 4: "mp_lstm_x3w<512, false>", 5: "mp_lstm_x3<8, 256, false>",
