@@ -105,6 +105,7 @@ struct ModuleWS {
     unsigned long long* hx = nullptr;   // hidden-state exchange buffer of the persistent kernels (split-bf16 mode: of layer 0)
     unsigned long long* hx2 = nullptr;  // split-bf16 mode: exchange buffer of layer 1 (re-armed by the layer-0 launch)
     size_t hx_bytes = 0;
+    unsigned hx_epoch = 0;              // next epoch base of `hx` (mp_lstm_fused launches); 0 = must be zeroed first
 };
 struct VelState { float* h = nullptr; float* c = nullptr; int B = 0; int cap = 0; };   // [2][B][256] each
 
@@ -170,6 +171,8 @@ struct mp_handle {
     bool x3 = false;                 // false (default, mode 1): H = 256 layers on exact-fp32 MFMA operands -- the reference's
                                      // arithmetic; true (mode 3, mp_set_lstm_mode(h, 3) / MP_LSTM_MODE=x3): the opt-in fast
                                      // mode, split-bf16 MFMA operands (mp_lstm_x3.hip)
+    unsigned epoch_start = 1;        // first epoch base after a zeroing (test hook MP_EPOCH_START: start close to the wrap guard)
+    bool epoch_tags = true;          // MP_EPOCH_TAGS=0: zero the exchange area before every fp32 layer launch (as round 1 did)
     bool slices16_ok = true;         // MP_SLICES16=0: bidirectional fp32 layers always on 8 slices
     bool wide_ok = true;             // MP_WIDE=0: never run pose / velocity / foot-contact side by side (small batches)
     bool fuse_pv = true;             // MP_FUSE_PV=0: separate linear1 launches for pose and velocity
@@ -397,6 +400,8 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     if (const char* e = getenv("MP_FUSE_PV")) h->fuse_pv = atoi(e) != 0;
     if (const char* e = getenv("MP_WIDE")) h->wide_ok = atoi(e) != 0;
     if (const char* e = getenv("MP_SLICES16")) h->slices16_ok = atoi(e) != 0;
+    if (const char* e = getenv("MP_EPOCH_TAGS")) h->epoch_tags = atoi(e) != 0;
+    if (const char* e = getenv("MP_EPOCH_START")) { const unsigned long v = strtoul(e, nullptr, 0); if (v >= 1 && v < 0xf0000000ul) h->epoch_start = (unsigned)v; }
     if (const char* e = getenv("MP_LSTM_SLICES")) h->nslice_env = atoi(e) == 8 ? 8 : (atoi(e) == 16 ? 16 : 0);
     if (getenv("MP_PERSIST_PROF")) {
         if (hipMalloc((void**)&h->prof_dev, kProfWords * sizeof(long long)) != hipSuccess) h->prof_dev = nullptr;
@@ -671,6 +676,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         // two-layer wavefront launch: layer 0 and layer 1 together when asked for layer 0, nothing for layer 1
         if (l == 1) return MP_OK;
         HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
+        w.hx_epoch = 0;
         const int nslab = (B + 15) / 16;
         const int chunk = (h->n_cu < 256 ? h->n_cu : 256) / 16 > 0 ? (h->n_cu < 256 ? h->n_cu : 256) / 16 : 1;   // one workgroup per CU
         SegScope seg(h, s, 5, (nslab + chunk - 1) / chunk, 2.0 * (double)B * T * 4.0 * H * (4.0 * H));
@@ -696,12 +702,25 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         const int nslab = (B + 15) / 16;
         // every polled word is re-zeroed before every launch: all granules (fp32 kernels) or the flags (split-bf16 kernels)
         // (split-bf16 kernels: the flags of layer 0's area were zeroed by the linear1 GEMM, those of layer 1's area by the layer-0 launch)
-        if (!use_x3(h, m)) HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
-        unsigned long long* hx_l = (use_x3(h, m) && l == 1) ? w.hx2 : w.hx;
         // two slabs per workgroup (mp_lstm_pair): exact-fp32 H = 256 layers with at least one full pair of slabs
         const int kin_l = l == 0 ? H : dirs * H;
         const bool pair = !use_x3(h, m) && H == 256 && nslab >= 2 && dirs == 2 && m.whhP16[0][0] &&
                           (h->pair_mask & (kin_l == 512 ? 1 : 2));
+        // exact-fp32 kernels: mp_lstm_fused tags its granules with a per-launch epoch base, so the area is zeroed only when
+        // something else may have written to it (first use, another kernel family, graph capture -- replays repeat the same
+        // base -- or an imminent wrap of the 32-bit tag); the others (pair / split-bf16 re-arm themselves) as before
+        const bool epoch_ok = !use_x3(h, m) && !pair && !h->capturing && h->epoch_tags;
+        unsigned epoch_base = 0;
+        if (!use_x3(h, m)) {
+            if (!epoch_ok || w.hx_epoch == 0 || w.hx_epoch > 0xf0000000u) {
+                HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
+                w.hx_epoch = epoch_ok ? h->epoch_start : 0u;
+            }
+            epoch_base = epoch_ok ? w.hx_epoch : 0u;
+        } else {
+            w.hx_epoch = 0;                                   // split-bf16 words in there now
+        }
+        unsigned long long* hx_l = (use_x3(h, m) && l == 1) ? w.hx2 : w.hx;
         const int nsl = use_x3(h, m) ? m.nsliceX : fp32_slices(h, m, B);
         const bool p16 = pair || (!use_x3(h, m) && nsl == 16 && m.nslice != 16);      // 16-slice packing of a bidirectional block
         const bool wreg = !use_x3(h, m) && !pair && H == 256 && nsl == 8 && m.whhPW[0][0] &&
@@ -727,6 +746,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             a.err = h->err_dev; a.max_spin = 1u << 18; a.prof = (prof_layer < 0 || prof_layer == l) ? h->prof_dev : nullptr;
             a.zero_state = j.mode == STATE_ZERO ? 1 : 0; a.force_remote = h->force_remote ? 1 : 0;
             const bool x3 = use_x3(h, m);
+            a.epoch_base = epoch_base;
             a.out_pairs = x3 ? 1 : 0;                          // both layers feed split-bf16 consumers (layer 1 / linear2)
             for (int d = 0; d < dirs; ++d) {
                 LstmDir& dd = a.d[d];
@@ -745,6 +765,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             else if (wreg) mp_launch_lstm_persist_w(a, kin, s);
             else mp_launch_lstm_persist(a, H, kin, nsl, s);
         }
+        if (epoch_base) w.hx_epoch += (unsigned)T + 1u;       // tags base .. base + T are used up
     } else {
         SegScope seg(h, s, 7, T, 2.0 * dirs * (double)B * T * 4.0 * H * H);
         LstmStepArgs a;

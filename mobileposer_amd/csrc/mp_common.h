@@ -94,6 +94,11 @@ struct LstmPersistArgs {
     unsigned max_spin;
     long long* prof;              // optional [grid][6] cycle sums per phase (debug), else nullptr
     int out_pairs = 0;            // split-bf16 kernel only: write the layer output as pairs (it feeds another layer)
+    // mp_lstm_fused only: 0 = the area was zeroed before this launch (tags = step numbers); otherwise the area may hold
+    // anything earlier launches of THIS kernel family left there, all with tags < epoch_base: the launch tags its granules
+    // epoch_base + step (and its XCC table entries epoch_base), so nothing stale can match and no memset sits between two
+    // layers on the critical path.  The host advances the base by T + 1 per launch and re-zeroes before a wrap-around.
+    unsigned epoch_base = 0;
     unsigned long long* hx_next = nullptr;   // split-bf16 kernel only: exchange area of the NEXT layer's launch (same cluster
                                               // indexing), re-armed by this launch at its start
 };

@@ -190,13 +190,16 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
     for (int i = 0; i < NPW; ++i) src_local[i] = true;
     bool all_local = true;
     if (NSLICE > 1) {
-        if (threadIdx.x == 0) granule_store(xtab + slice, XCC_TAG, __uint_as_float(my_xcc));
+        // (epoch_base != 0: the exchange area is NOT zeroed between launches -- every launch uses tags nobody has written
+        //  there before: base + step, and base itself for the XCC table; see LstmPersistArgs::epoch_base)
+        const unsigned xtag = a.epoch_base ? a.epoch_base : XCC_TAG;
+        if (threadIdx.x == 0) granule_store(xtab + slice, xtag, __uint_as_float(my_xcc));
         unsigned peer = my_xcc;
         if (lane < NSLICE) {
             unsigned spins = 0;
             while (true) {
                 const u64 g = granule_load(xtab + lane);
-                if ((unsigned)(g >> 32) == XCC_TAG) { peer = (unsigned)g; break; }
+                if ((unsigned)(g >> 32) == xtag) { peer = (unsigned)g; break; }
                 if (++spins > spin_budget) { mp_set_error(a.err, 1000000); peer = ~0u; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
@@ -301,7 +304,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
 
         // ---- request h_{step-1}: granule (row r16, unit kq*KW + 4*ks + q), 512 contiguous bytes per instruction
         u64 gr[NKS];
-        const unsigned epoch = (unsigned)step;                 // written by the producers at the end of step-1
+        const unsigned epoch = a.epoch_base + (unsigned)step;  // written by the producers at the end of step-1
         const size_t goff = (size_t)((step + 1) & 1) * 16 * H + (size_t)kq * NKS * 64 + r16 * 4 + q;
         const u64* srcp[NPW];
 #pragma unroll
@@ -460,8 +463,8 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
                 oval = hst[o];
             }
             const int gi = granule_index(q * 4 + reg0 + o, jown);
-            granule_store_l2(hxL + doff + gi, (unsigned)(step + 1), hst[o]);
-            if (!all_local) granule_store(hxR + doff + gi, (unsigned)(step + 1), hst[o]);
+            granule_store_l2(hxL + doff + gi, a.epoch_base + (unsigned)(step + 1), hst[o]);
+            if (!all_local) granule_store(hxR + doff + gi, a.epoch_base + (unsigned)(step + 1), hst[o]);
             if (bidx[o] < B) d.out[((size_t)tt * B + bidx[o]) * d.outStride + jown] = oval;
         }
         PROF_E(4);

@@ -578,3 +578,42 @@ def test_four_wave_fp32_kernel_matches_eight_wave(torch_mod, weights, smpl, monk
         outs[mask] = o
     for a, b in zip(outs[0], outs[3]):
         assert float((a - b).abs().max()) < 5e-6
+
+
+def test_epoch_tagged_exchange_equals_zeroed_exchange(torch_mod, weights, smpl, monkeypatch):
+    """The fp32 layer kernels no longer get a zeroed hidden-state exchange area per launch: every launch tags its granules
+    with a fresh epoch base (base + step) and the host re-zeroes only before the 32-bit tag would wrap.  Bitwise the same
+    outputs as with a memset before every launch (MP_EPOCH_TAGS=0) -- over many launches on the same areas, different
+    shapes sharing a handle, both operand modes in turn (the split-bf16 kernels leave their own words in the area), and
+    with the counter started just below the wrap guard so that the re-zeroing path runs several times."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    rng = np.random.default_rng(33)
+    shapes = ((256, 40), (40, 25), (300, 9), (1, 60))
+    xs = {sh: cu(torch_mod, synthetic.make_imu(sh[0], sh[1], seed=sum(sh))) for sh in shapes}
+    lens = {}
+    for sh in shapes:
+        L = [int(v) for v in rng.integers(1, sh[1] + 1, size=sh[0])]
+        L[0] = sh[1]
+        lens[sh] = L
+    outs = {}
+    for tags, start in (("0", None), ("1", None), ("1", "0xEFFFFF00")):
+        monkeypatch.setenv("MP_EPOCH_TAGS", tags)
+        if start:
+            monkeypatch.setenv("MP_EPOCH_START", start)
+        with MobilePoserNet.from_numpy(weights, smpl) as n:
+            o = []
+            for rep in range(3):
+                for mode in (1, 3, 1):
+                    n.set_lstm_mode(mode)
+                    for sh in shapes:
+                        n.reset_all()
+                        o += [t.clone() for t in n.forward_offline(xs[sh], lens[sh])]
+                        o += [t.clone() for t in n.forward_offline(xs[sh], lens[sh])]
+            assert n.device_error() == 0
+        outs[(tags, start)] = o
+    ref = outs[("0", None)]
+    for key in (("1", None), ("1", "0xEFFFFF00")):
+        assert len(ref) == len(outs[key])
+        for a, b in zip(ref, outs[key]):
+            assert torch_mod.equal(a, b), key
