@@ -709,7 +709,11 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         // exact-fp32 kernels: mp_lstm_fused tags its granules with a per-launch epoch base, so the area is zeroed only when
         // something else may have written to it (first use, another kernel family, graph capture -- replays repeat the same
         // base -- or an imminent wrap of the 32-bit tag); the others (pair / split-bf16 re-arm themselves) as before
-        const bool epoch_ok = !use_x3(h, m) && !pair && !h->capturing && h->epoch_tags;
+        // (not for a 16-slice launch that fills the chip: its 4-wave workgroups can start on CUs where workgroups of the
+        //  previous layer launch are still finishing, and their start-up polling slows those down -- measured 3.05 -> 3.28 ms
+        //  at 128 x 125; the memset between the launches is the boundary that prevents it.  The 8-slice kernels own their CU.)
+        const bool crowded16 = !use_x3(h, m) && dirs == 2 && fp32_slices(h, m, B) == 16 && dirs * nslab * 16 > 128;
+        const bool epoch_ok = !use_x3(h, m) && !pair && !h->capturing && h->epoch_tags && !crowded16;
         unsigned epoch_base = 0;
         if (!use_x3(h, m)) {
             if (!epoch_ok || w.hx_epoch == 0 || w.hx_epoch > 0xf0000000u) {
