@@ -1,0 +1,35 @@
+"""Randomised shapes: the default fp32 configuration (four-wave AccVGPR kernels, epoch-tagged exchange, side-by-side schedule,
+16-slice small-batch layers) against the round-1 configuration of the same library (eight-wave kernels, memset per launch,
+serial schedule, 8 slices) -- two handles in one process, same inputs, repeated calls with carried velocity state."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from mobileposer_amd import synthetic
+from mobileposer_amd.net import MobilePoserNet
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+sd, smpl = synthetic.make_weights(0), synthetic.synthetic_smpl()
+new = MobilePoserNet.from_numpy(sd, smpl)
+for k, v in (("MP_WREG", "0"), ("MP_EPOCH_TAGS", "0"), ("MP_WIDE", "0"), ("MP_SLICES16", "0")):
+    os.environ[k] = v
+old = MobilePoserNet.from_numpy(sd, smpl)
+rng = np.random.default_rng(2024)
+worst = 0.0
+for case in range(n_cases):
+    B = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 64, 100, 128, 129, 255, 256, 257, 300, 511, 700])) if case % 3 else int(rng.integers(1, 400))
+    T = int(rng.integers(1, 90))
+    x = torch.from_numpy(synthetic.make_imu(B, T, seed=1000 + case)).cuda()
+    L = [int(v) for v in rng.integers(1, T + 1, size=B)]
+    L[int(rng.integers(0, B))] = T
+    outs = []
+    for net in (new, old):
+        net.reset_all()
+        o = [t.clone() for t in net.forward_offline(x, L)]
+        o += [t.clone() for t in net.forward_offline(x, L)]
+        assert net.device_error() == 0
+        outs.append(o)
+    d = max(float((a - b).abs().max()) for a, b in zip(*outs))
+    assert all(torch.isfinite(a).all() for a in outs[0])
+    worst = max(worst, d)
+    assert d < 2e-5, (case, B, T, d)
+print("fuzz: %d random (B, T, lengths) cases, new vs round-1 configuration: max abs difference %.2e" % (n_cases, worst))
+new.close(); old.close()
