@@ -31,6 +31,13 @@
 // timeout raises a device-side error word instead of hanging the GPU.
 #include "mp_lstm_dev.h"
 
+#ifndef MP_EXP
+#define MP_EXP 0          // timing experiments (tools/debug/build_exp.sh); 0 = the product
+#endif
+#ifndef MP_FLAGX
+#define MP_FLAGX 1        // 0: the WREG kernels exchange {epoch, value} granules like the others (A/B builds)
+#endif
+
 namespace {
 
 // granule index of (row, hidden unit j) inside one [16][H] slab-parity block
@@ -98,6 +105,7 @@ template <int H, int NSLICE, int KIN, int TW, bool PROF>
 MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void mp_lstm_fused(LstmPersistArgs a) {
     using C = Cfg<H, NSLICE, KIN, TW>;
     constexpr bool WREG = H == 256 && NSLICE == 8 && TW == 1;
+    constexpr bool FLAGX = WREG && MP_FLAGX;                          // flagged exchange (see "FLAGX" below)
     constexpr int U = C::U, NUB = C::NUB, NWV = C::NWV, NTW = C::NTW, NTG = C::NTG, KW = C::KW, NKS = C::NKS, KQ = C::KQ;
     constexpr int NXS = C::NXS, NXJ = C::NXJ, NOWN = C::NOWN, XL = C::XL, XR = C::XR, NPW = C::NPW;
     constexpr bool PER_UB = C::PER_UB;
@@ -183,6 +191,21 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
     u64* hxL = a.hx + (size_t)cl * SLABW;
     u64* hxR = hxL + (size_t)2 * 16 * H;
     u64* xtab = hxL + (size_t)4 * 16 * H;
+    // FLAGX (the four-wave 8-slice kernels): the same area holds plain 4-byte words h[parity][16 * H] for both transports
+    // and ONE flag word per (parity, producer slice, producer wave) instead of a tag in every granule.  A producer wave
+    // stores its values, waits until they are acknowledged (s_waitcnt vmcnt(0) -- under the first projection MFMAs of the
+    // next step, so nobody sits in that wait) and then stores epoch_base + step + 1 into its flag; a consumer wave reads
+    // the 8 flags of the two slices its K quarter comes from a quarter of the way through the projection, checks them half
+    // way (ONE compare; stale -> bounded poll) and only then requests the values: 4 x 16 bytes per lane instead of 16 x 8,
+    // nothing to validate afterwards.  Measured on the granule form (profiles/r03_flagx.md): the 16 requests cost 700
+    // cycles of issue inside the projection and their 16 compare / s_and pairs 600 cycles, while the words themselves were
+    // ALWAYS there at the first look -- the hand-off latency was never the problem, its instruction count was.
+    // Word (row, unit j) sits where consumer lane (q = j & 3, row) finds k-steps 4i .. 4i+3 of its K quarter in one
+    // 16-byte piece:  (((j >> 6) * 4 + ((j & 63) >> 4)) * 64 + (j & 3) * 16 + row) * 4 + ((j >> 2) & 3).
+    unsigned* hdL = reinterpret_cast<unsigned*>(hxL);                 // [2 parities][16 * H]
+    unsigned* hfL = hdL + (size_t)4 * 16 * H;                         // flags: L [2][NSLICE * 4], then R [2][NSLICE * 4]
+    constexpr unsigned HD_R = 2 * 16 * H * 4;                         // byte offset of the R copy of the values
+    constexpr unsigned HF_R = 2 * NSLICE * 4;                         // word offset of the R flags
     unsigned spin_budget = a.max_spin;
     const unsigned my_xcc = xcc_id();
     bool src_local[NPW];                   // is the producer slice of each part of this wave's K quarter on my XCD?
@@ -214,6 +237,26 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
 #pragma unroll
             for (int i = 0; i < NPW; ++i) src_local[i] = false;
         }
+    }
+
+    // ---- FLAGX: consumer offsets (values of producer slices 2kq, 2kq+1 -> pieces 0,1 and 2,3), flag pointer, store slots
+    __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(hdL, 0, 4 * 16 * H * 4, 0x00020000);
+    unsigned hvoff[2] = {0u, 0u};
+    const unsigned* hflag = hfL;
+    unsigned hslot[NOWN];
+    f32x4 hr[4];                                                       // recurrent A operand: k-steps 4i .. 4i+3 in hr[i]
+    unsigned hflags = 0;
+    if (FLAGX) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) hvoff[i] = (src_local[i % NPW] ? 0u : HD_R) + (unsigned)(((kq * 4 + 2 * i) * 64 + lane) * 16);
+        hflag = hfL + (src_local[((lane >> 2) & 1) % NPW] ? 0 : HF_R) + 8 * kq + (lane & 7);
+#pragma unroll
+        for (int o = 0; o < NOWN; ++o) {
+            const int row = q * 4 + reg0 + o;
+            hslot[o] = (unsigned)(((((jown >> 6) * 4 + ((jown & 63) >> 4)) * 64 + (jown & 3) * 16 + row) << 2) + ((jown >> 2) & 3));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hr[i] = f32x4{av[(4 * i) % NKS], av[(4 * i + 1) % NKS], av[(4 * i + 2) % NKS], av[(4 * i + 3) % NKS]};
     }
 
     // ---- x_0: this lane's A values of the input projection, k = kq*KQ + j*16 + q*4 + i  (x-step s = 4j+i)
@@ -265,7 +308,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
     for (int step = 0; step < T; ++step) {
         PROF_T(0);
         if (LEAN) xp_cur = xp_nxt;
-        if (SPLIT_X) load_x(step, XJ_PRE, NXJ);
+        if (SPLIT_X && !FLAGX) load_x(step, XJ_PRE, NXJ);
         f32x4 acc[NTW];
         if (!WREG) {                                           // (WREG: the first MFMA of every tile has C = 0)
 #pragma unroll
@@ -300,6 +343,24 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tg = 0; tg < NTG; ++tg) wl[tg] = wn[tg];
+            if (FLAGX) {
+                constexpr int PUB_S = 1, REQ_S = NXS / 4;
+                if (s == PUB_S) {
+                    // the values this wave stored at the end of step-1 have had two k-steps of MFMAs to be acknowledged:
+                    // wait for them, then raise the flag (parity of step-1 = the parity this step reads)
+                    if (step > 0) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0) {
+                            unsigned* f = hfL + ((step + 1) & 1) * (NSLICE * 4) + slice * 4 + wave;
+                            __hip_atomic_store(f, a.epoch_base + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (!all_local) __hip_atomic_store(f + HF_R, a.epoch_base + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    if (SPLIT_X) load_x(step, XJ_PRE, NXJ);          // (behind the wait above, not in front of it)
+                }
+                if (s == REQ_S) hflags = __hip_atomic_load(hflag + ((step + 1) & 1) * (NSLICE * 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 
         // ---- request h_{step-1}: granule (row r16, unit kq*KW + 4*ks + q), 512 contiguous bytes per instruction
@@ -314,9 +375,34 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
         //  request them after the projection instead; the second wave on the SIMD covers the L2 latency)
         constexpr bool EARLY_GATHER = !C::BIG || WREG;         // (WREG: 512 registers per wave -- room for the granules)
         // (LEAN: requested on EVERY step, step 0 included -- there the words are simply not looked at)
-        if (EARLY_GATHER && (LEAN || step > 0)) {
+        if (FLAGX) {
+            if (SPLIT_X) {
+                // second half of x_t (requested 14 k-steps ago): have the compiler wait for it HERE -- its own placement, one
+                // piece at a time inside the second half, would also wait for the h words requested just below
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) gr[ks] = granule_load(srcp[ks / KSP] + (size_t)ks * 64);
+                for (int j = XJ_PRE; j < NXJ; ++j) asm volatile("" : "+v"(xa[j]));
+            }
+            if (step > 0) {
+                bool ok = hflags == epoch;
+                unsigned spins = 0;
+                if (PROF && prof && !__all(ok)) pt[5] += 1;  // slow-path entries
+                while (!__all(ok)) {
+                    if (++spins > spin_budget) {               // bounded: flag the error and never wait again
+                        if (lane == 0) mp_set_error(a.err, 1 + step);
+                        spin_budget = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    ok = __hip_atomic_load(hflag + ((step + 1) & 1) * (NSLICE * 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+                }
+                const int par_off = ((step + 1) & 1) * (16 * H * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    hr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, hvoff[i >> 1] + (i & 1) * 1024, par_off, 16 /* sc1 */));
+            }
+        } else if (EARLY_GATHER && (LEAN || step > 0)) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) gr[ks] = MP_EXP == 3 ? (u64)(ks + lane) : granule_load(srcp[ks / KSP] + (size_t)ks * 64);
         }
         // ---- second half of the input projection
 #pragma unroll
@@ -348,8 +434,12 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
         // ---- validate the granules; the slow path (cheap gate, then sweep) only runs when some were stale
         // (K_in = 512: the registers are full -- the words are requested only now and only when they are needed, and the
         //  recurrent A operand is extracted into 16 registers so that the 32 of `gr` die before the MFMAs)
-        constexpr bool DIRECT_GR = EARLY_GATHER && LEAN;       // recurrent MFMAs read the low words of `gr` directly
-        if (step > 0) {
+        constexpr bool DIRECT_GR = EARLY_GATHER && LEAN && !FLAGX;   // recurrent MFMAs read the low words of `gr` directly
+        if (FLAGX) {
+            // the values were requested half a projection ago: make the compiler wait for them HERE, before the prefetch
+            // of x_{t+1} below is issued (a wait placed after it would also drain those HBM loads)
+            asm volatile("" : "+v"(hr[0]), "+v"(hr[1]), "+v"(hr[2]), "+v"(hr[3]));
+        } else if (step > 0) {
             if (!EARLY_GATHER) {
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) gr[ks] = granule_load(srcp[ks / KSP] + (size_t)ks * 64);
@@ -357,6 +447,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
             bool ok = true;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) ok = ok && ((unsigned)(gr[ks] >> 32) == epoch);
+            if (MP_EXP == 1 || MP_EXP == 3) ok = true;
             unsigned spins = 0;
             bool timed_out = false;
             if (PROF && prof && !__all(ok)) pt[5] += 1;      // slow-path entries
@@ -398,7 +489,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
             const long dlt = d.reverse ? -(long)xtstride : (long)xtstride;
             xp_nxt = adv ? xp_cur + dlt : xp_cur;
         }
-        load_x((step + 1) | 0x40000000, 0, XJ_PRE);   // next step's x: issued only now so that the granule wait above does not
+        if (MP_EXP != 2) load_x((step + 1) | 0x40000000, 0, XJ_PRE);   // next step's x: issued only now so that the granule wait above does not
                                                       // also drain these HBM loads; they land under the MFMAs / cell update below
         PROF_E(1); PROF_T(2);
 
@@ -408,10 +499,11 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
-                const float a_h = DIRECT_GR ? __uint_as_float((unsigned)gr[ks]) : av[ks];
+                const float a_h = FLAGX ? hr[(ks >> 2) & 3][ks & 3] : DIRECT_GR ? __uint_as_float((unsigned)gr[ks]) : av[ks];
                 if (WREG) mfma_asm<false, true>(acc[t], a_h, wv[ks][t]);
                 else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_h, wv[ks][t], acc[t], 0, 0, 0);
             }
+        if (MP_EXP == 2) load_x((step + 1) | 0x40000000, 0, XJ_PRE);
         if (WREG) mfma_drain();
         PROF_E(2); PROF_T(3);
 
@@ -462,9 +554,15 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
                 hst[o] = og * tanhf_(cst[o]);
                 oval = hst[o];
             }
+            if (FLAGX) {   // plain words; this wave's flag follows at the top of the next step
+                unsigned* hw = hdL + (size_t)(step & 1) * 16 * H + hslot[o];
+                __hip_atomic_store(hw, __float_as_uint(hst[o]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (!all_local) __hip_atomic_store(hw + HD_R / 4, __float_as_uint(hst[o]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
             const int gi = granule_index(q * 4 + reg0 + o, jown);
             granule_store_l2(hxL + doff + gi, a.epoch_base + (unsigned)(step + 1), hst[o]);
             if (!all_local) granule_store(hxR + doff + gi, a.epoch_base + (unsigned)(step + 1), hst[o]);
+            }
             if (bidx[o] < B) d.out[((size_t)tt * B + bidx[o]) * d.outStride + jown] = oval;
         }
         PROF_E(4);
