@@ -464,6 +464,9 @@ int get_plan(mp_handle* h, int B, int T, Plan** out) {
         }
         if (victim != h->plans.end()) { free_plan(h, victim->second); h->plans.erase(victim); }
     }
+    // (the layer kernels step through their output with a 32-bit row pitch: B * 512 floats must stay below 4 GB)
+    if ((size_t)B * 512 * sizeof(float) > 0xffffffffull)
+        return fail(h, MP_ERR_INVALID, "batch of %d sequences is beyond the supported 2^21 - 1; split it", B);
     Plan* p = new Plan();
     p->B = B; p->T = T; p->last_use = ++h->use_clock;
     h->plans[{B, T}] = p;

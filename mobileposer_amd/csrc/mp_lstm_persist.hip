@@ -35,7 +35,7 @@
 #define MP_EXP 0          // timing experiments (tools/debug/build_exp.sh); 0 = the product
 #endif
 #ifndef MP_FLAGX
-#define MP_FLAGX 1        // 0: the WREG kernels exchange {epoch, value} granules like the others (A/B builds)
+#define MP_FLAGX 3        // bit 0: flagged hand-off in the four-wave 8-slice kernels, bit 1: in the 16-slice kernels (A/B builds)
 #endif
 
 namespace {
@@ -105,10 +105,17 @@ template <int H, int NSLICE, int KIN, int TW, bool PROF>
 MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void mp_lstm_fused(LstmPersistArgs a) {
     using C = Cfg<H, NSLICE, KIN, TW>;
     constexpr bool WREG = H == 256 && NSLICE == 8 && TW == 1;
-    constexpr bool FLAGX = WREG && MP_FLAGX;                          // flagged exchange (see "FLAGX" below)
     constexpr int U = C::U, NUB = C::NUB, NWV = C::NWV, NTW = C::NTW, NTG = C::NTG, KW = C::KW, NKS = C::NKS, KQ = C::KQ;
     constexpr int NXS = C::NXS, NXJ = C::NXJ, NOWN = C::NOWN, XL = C::XL, XR = C::XR, NPW = C::NPW;
     constexpr bool PER_UB = C::PER_UB;
+    constexpr bool FLAGX = (WREG && (MP_FLAGX & 1)) || (H == 256 && NSLICE == 16 && TW == 1 && (MP_FLAGX & 2));   // flagged hand-off (below)
+    constexpr int NP = NKS / 4 > 0 ? NKS / 4 : 1;                     // FLAGX: 16-byte pieces of h per lane (4 k-steps each)
+    constexpr int PPP = NP / NPW > 0 ? NP / NPW : 1;                  //        pieces per producer slice
+    // FLAGX: k-steps of the projection in front of the flag request / of the flag check + value request.  One k-step is
+    // 256 cycles in the 8-slice kernels and 128 in the 16-slice ones, whose 16-step projection has to cover three memory
+    // round trips (the producer's store acknowledgement, the flag, the values) -- everything sits as late as it can there.
+    constexpr int REQ_S = (!WREG && NXS == 16) ? 6 : NXS / 4;
+    constexpr int XSPLIT = (FLAGX && !WREG && NXS == 16) ? 11 : NXS / 2;
     constexpr int NTHREADS = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* red = reinterpret_cast<f32x4*>(smem);                       // [finishing wave][source kq][o][lane]
@@ -161,10 +168,13 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
     const f32x4 bias4 = *reinterpret_cast<const f32x4*>(d.bias + 4 * jown);
     float cst[NOWN], hst[NOWN];
     int blen[NOWN], bidx[NOWN];
+    float* outb[NOWN];                                                   // &out[t = 0][sequence][jown]
+    const unsigned out_row_bytes = (unsigned)a.B * (unsigned)d.outStride * 4u;   // one time step of the layer output
 #pragma unroll
     for (int o = 0; o < NOWN; ++o) {
         const int b = brow0 + q * 4 + reg0 + o;
         bidx[o] = b;
+        outb[o] = d.out + (size_t)(b < B ? b : 0) * d.outStride + jown;
         const bool inb = b < B;
         blen[o] = inb ? a.lengths[b] : 0;
         cst[o] = (inb && !a.zero_state) ? d.cbuf[(size_t)b * H + jown] : 0.f;
@@ -239,24 +249,28 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
         }
     }
 
-    // ---- FLAGX: consumer offsets (values of producer slices 2kq, 2kq+1 -> pieces 0,1 and 2,3), flag pointer, store slots
+    // ---- FLAGX: consumer offsets (piece i comes from producer slice NPW*kq + i/PPP), flag pointer, store slots
     __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(hdL, 0, 4 * 16 * H * 4, 0x00020000);
-    unsigned hvoff[2] = {0u, 0u};
+    unsigned hvoff[NP];
     const unsigned* hflag = hfL;
     unsigned hslot[NOWN];
-    f32x4 hr[4];                                                       // recurrent A operand: k-steps 4i .. 4i+3 in hr[i]
+    f32x4 hr[NP];                                                      // recurrent A operand: k-steps 4i .. 4i+3 in hr[i]
     unsigned hflags = 0;
     if (FLAGX) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) hvoff[i] = (src_local[i % NPW] ? 0u : HD_R) + (unsigned)(((kq * 4 + 2 * i) * 64 + lane) * 16);
-        hflag = hfL + (src_local[((lane >> 2) & 1) % NPW] ? 0 : HF_R) + 8 * kq + (lane & 7);
+        for (int i = 0; i < NP; ++i) hvoff[i] = (src_local[(i / PPP) % NPW] ? 0u : HD_R) + (unsigned)(((kq * NP + i) * 64 + lane) * 16);
+        // (lane l watches wave l & 3 of producer slice NPW*kq + (l >> 2) % NPW: 4 * NPW flags, the other lanes see copies)
+        bool fl_local = src_local[0];
+#pragma unroll
+        for (int i = 1; i < NPW; ++i) fl_local = (((lane >> 2) & (NPW - 1)) == i) ? src_local[i] : fl_local;
+        hflag = hfL + (fl_local ? 0 : HF_R) + 4 * NPW * kq + (lane & (4 * NPW - 1));
 #pragma unroll
         for (int o = 0; o < NOWN; ++o) {
             const int row = q * 4 + reg0 + o;
-            hslot[o] = (unsigned)(((((jown >> 6) * 4 + ((jown & 63) >> 4)) * 64 + (jown & 3) * 16 + row) << 2) + ((jown >> 2) & 3));
+            hslot[o] = (unsigned)(((((jown / KW) * NP + ((jown % KW) >> 4)) * 64 + (jown & 3) * 16 + row) << 2) + ((jown >> 2) & 3));
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) hr[i] = f32x4{av[(4 * i) % NKS], av[(4 * i + 1) % NKS], av[(4 * i + 2) % NKS], av[(4 * i + 3) % NKS]};
+        for (int i = 0; i < NP; ++i) hr[i] = f32x4{av[(4 * i) % NKS], av[(4 * i + 1) % NKS], av[(4 * i + 2) % NKS], av[(4 * i + 3) % NKS]};
     }
 
     // ---- x_0: this lane's A values of the input projection, k = kq*KQ + j*16 + q*4 + i  (x-step s = 4j+i)
@@ -321,7 +335,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
 #pragma unroll
         for (int tg = 0; tg < NTG; ++tg) wl[tg] = XL > 0 ? wxw[(size_t)tg * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < NXS / 2; ++s) {
+        for (int s = 0; s < XSPLIT; ++s) {
             const float a_s = xa[s >> 2][s & 3];
             if (s + 1 < XL) {
 #pragma unroll
@@ -344,7 +358,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
 #pragma unroll
             for (int tg = 0; tg < NTG; ++tg) wl[tg] = wn[tg];
             if (FLAGX) {
-                constexpr int PUB_S = 1, REQ_S = NXS / 4;
+                constexpr int PUB_S = 1;
                 if (s == PUB_S) {
                     // the values this wave stored at the end of step-1 have had two k-steps of MFMAs to be acknowledged:
                     // wait for them, then raise the flag (parity of step-1 = the parity this step reads)
@@ -397,8 +411,8 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
                 }
                 const int par_off = ((step + 1) & 1) * (16 * H * 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    hr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, hvoff[i >> 1] + (i & 1) * 1024, par_off, 16 /* sc1 */));
+                for (int i = 0; i < NP; ++i)
+                    hr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, hvoff[i], par_off, 16 /* sc1 */));
             }
         } else if (EARLY_GATHER && (LEAN || step > 0)) {
 #pragma unroll
@@ -406,7 +420,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
         }
         // ---- second half of the input projection
 #pragma unroll
-        for (int s = NXS / 2; s < NXS; ++s) {
+        for (int s = XSPLIT; s < NXS; ++s) {
             const float a_s = xa[s >> 2][s & 3];
             if (s + 1 < XL) {
 #pragma unroll
@@ -438,7 +452,8 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
         if (FLAGX) {
             // the values were requested half a projection ago: make the compiler wait for them HERE, before the prefetch
             // of x_{t+1} below is issued (a wait placed after it would also drain those HBM loads)
-            asm volatile("" : "+v"(hr[0]), "+v"(hr[1]), "+v"(hr[2]), "+v"(hr[3]));
+#pragma unroll
+            for (int i = 0; i < NP; ++i) asm volatile("" : "+v"(hr[i]));
         } else if (step > 0) {
             if (!EARLY_GATHER) {
 #pragma unroll
@@ -499,7 +514,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
-                const float a_h = FLAGX ? hr[(ks >> 2) & 3][ks & 3] : DIRECT_GR ? __uint_as_float((unsigned)gr[ks]) : av[ks];
+                const float a_h = FLAGX ? hr[(ks >> 2) % NP][ks & 3] : DIRECT_GR ? __uint_as_float((unsigned)gr[ks]) : av[ks];
                 if (WREG) mfma_asm<false, true>(acc[t], a_h, wv[ks][t]);
                 else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_h, wv[ks][t], acc[t], 0, 0, 0);
             }
@@ -563,7 +578,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
             granule_store_l2(hxL + doff + gi, a.epoch_base + (unsigned)(step + 1), hst[o]);
             if (!all_local) granule_store(hxR + doff + gi, a.epoch_base + (unsigned)(step + 1), hst[o]);
             }
-            if (bidx[o] < B) d.out[((size_t)tt * B + bidx[o]) * d.outStride + jown] = oval;
+            if (bidx[o] < B) *reinterpret_cast<float*>(reinterpret_cast<char*>(outb[o]) + (size_t)(unsigned)tt * out_row_bytes) = oval;
         }
         PROF_E(4);
     }
