@@ -12,6 +12,7 @@
 // blockIdx -> tile mapping keeps all n-tiles of one m-tile on one XCD (same L2) so the A panel is fetched
 // from HBM once.
 #include "mp_lstm_dev.h"
+#include <cstdlib>
 
 namespace {
 
@@ -150,6 +151,129 @@ MP_KERNEL __launch_bounds__(256) void mp_gemm_f32(GemmArgs g, int nTilesM, int n
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// mp_gemm_f32_rows<TN, NK> -- the same GEMM for the linear2 shapes of this path (M = B*T rows in the tens of thousands,
+// K = 128 .. 512, N = 2 .. 96): no LDS, no barrier, every WAVE on its own.  A wave owns 32 rows x TN*32 columns and
+// streams K through registers: per 32-wide k-tile and lane 4 x 16 bytes of its A row and TN x 4 x 16 bytes of W rows
+// (W -- at most 0.2 MB -- is read by every wave and lives in L1 / L2), consumed in four slots of 4*TN MFMAs; the registers
+// of a slot are re-requested as soon as its MFMAs are issued (A two k-tiles ahead, W one).  With the LDS-staged kernel
+// above these launches are latency chains -- one workgroup per CU at most, load -> LDS -> barrier -> MFMA per k-tile.
+// Measured inside a 256 x 125 forward (tools/debug/timeline.py): linear2 of joints 63 -> 46 us, of velocity 49 -> 39 us,
+// of foot contact 13 -> 10 us; 1024 x 125: 15.6 -> 15.25 ms.  (Still 2x the 20 us of matrix work: a lane reads 16 bytes
+// per row and instruction, so every 128-byte line goes through the L1 tag lookup four times.)  The wide linear1 outputs
+// (N = 256) are store-bound and did no better this way (86 vs 54 us for pose's linear1): they stay on the staged kernel.
+// Same k pairing as above (lanes 0-31: k = s, lanes 32-63: k = 16 + s), so the summation order -- and every result
+// bit -- is that of mp_gemm_f32.
+template <int TN, int NK>
+MP_KERNEL __launch_bounds__(256, 2) void mp_gemm_f32_rows(GemmArgs g, int nTilesM, int nTilesN) {
+    __shared__ long rowOffC[4][32];
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int mt = (idx / nTilesN) * 8 + xcd;               // all n-tiles of an m-tile on one XCD (A panel from HBM once)
+    const int nt = idx % nTilesN;
+    if (mt >= nTilesM) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int m0 = mt * 128 + wave * 32, n0 = nt * (TN * 32);
+    if (m0 >= g.M) return;
+
+    // this lane's A row (clamped: rows past M are computed and not stored), its two segments
+    const int m = m0 + li < g.M ? m0 + li : g.M - 1;
+    const int rb = m % g.B, rt = m / g.B;
+    const float* pa0 = g.a0.base + (long)rb * g.a0.strideB + (long)rt * g.a0.strideT;
+    const float* pa1 = g.a1.base ? g.a1.base + (long)rb * g.a1.strideB + (long)rt * g.a1.strideT - g.a0.width : pa0;
+    if (lane < 32) rowOffC[wave][lane] = (long)rb * g.cStrideB + (long)rt * g.cStrideT;
+    const int w0 = g.a0.width, klast = g.K - 4;
+    // (k >= K only in the last k-tile: W is zero there, so A may be anything finite -- the row's last four values again)
+    auto a_piece = [&](int k) {
+        const int kk = k < klast ? k : klast;
+        return *reinterpret_cast<const f32x4*>((kk < w0 ? pa0 : pa1) + kk);
+    };
+    const float* pw = g.W + (long)(n0 + li) * g.Kpad + lh * 16;
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+    // The loads are inline asm and the waits are placed by hand: left to the compiler, the loop gets ONE s_waitcnt
+    // vmcnt(0) at its top, i.e. the full latency of the group requested last, once per k-tile.  Before the MFMAs of a
+    // group everything except the three younger groups must have arrived: vmcnt(3 * (1 + TN)).
+    // A comes from HBM (it is streamed once), W from L2: the A pieces are requested TWO k-tiles ahead, W one; two A buffers
+    // take turns (even / odd k-tiles) and every buffer is re-requested right after the MFMAs that read it.  The k loop is
+    // unrolled completely (NK is a template parameter): in straight-line code the compiler's s_waitcnt counts are exact
+    // (vmcnt(3 * (1 + TN)) in front of every slot); around a real loop it merges the states at the loop header into ONE
+    // vmcnt(0) at the top, which puts the latency of the group requested last on every k-tile.
+    f32x4 fa[2][4], fw[TN][4];
+    auto request_a = [&](f32x4& dst, int q, int k0) {            // A piece q of the k-tile at k0 (past K: the row's last piece)
+        const int k = k0 + lh * 16 + q * 4;
+        const int kk = k < klast ? k : klast;
+        dst = *reinterpret_cast<const f32x4*>((kk < w0 ? pa0 : pa1) + kk);
+    };
+    auto request_w = [&](int q, int k0) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b) fw[b][q] = *reinterpret_cast<const f32x4*>(pw + (long)b * 32 * g.Kpad + k0 + q * 4);
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) request_a(fa[0][q], q, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { request_w(q, 0); request_a(fa[1][q], q, BK); }
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kt & 1][q][s4], fw[b][q][s4], acc[b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 2 < NK) request_a(fa[kt & 1][q], q, (kt + 2) * BK);
+            if (kt + 1 < NK) request_w(q, (kt + 1) * BK);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // epilogue: D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]; bias (+ReLU), row-mapped store
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // rowOffC of this wave (written by its own lanes)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + b * 32 + li;
+        if (n >= g.N) continue;
+        const float bias = g.bias[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m0 + ml < g.M) {
+                float v = acc[b][r] + bias;
+                if (g.relu) v = fmaxf(v, 0.f);
+                g.C[rowOffC[wave][ml] + n] = g.pairOut ? __uint_as_float(pair_of(v)) : v;
+            }
+        }
+    }
+}
+
+template <int TN, int NK>
+void launch_rows(const GemmArgs& g, hipStream_t s) {
+    const int nTilesM = (g.M + 127) / 128;
+    const int nTilesN = (g.N + TN * 32 - 1) / (TN * 32);
+    const int grid = ((nTilesM + 7) / 8) * 8 * nTilesN;
+    hipLaunchKernelGGL((mp_gemm_f32_rows<TN, NK>), dim3(grid), dim3(256), 0, s, g, nTilesM, nTilesN);
+}
+
+// the linear2 shapes of the four modules (and foot contact's linear1): K = 512 / 256 / 128 / 132, N = 72 / 96 / 2 / 64
+template <int TN>
+bool launch_rows_k(const GemmArgs& g, hipStream_t s) {
+    switch (g.Kpad / BK) {
+        case 4: launch_rows<TN, 4>(g, s); return true;
+        case 5: launch_rows<TN, 5>(g, s); return true;
+        case 8: launch_rows<TN, 8>(g, s); return true;
+        case 16: launch_rows<TN, 16>(g, s); return true;
+        default: return false;
+    }
+}
+
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 void launch(const GemmArgs& g, hipStream_t s) {
     constexpr int BN = WAVES_N * TN * 32;
@@ -164,6 +288,13 @@ void launch(const GemmArgs& g, hipStream_t s) {
 int mp_gemm_pick_bn(int N) { return N > 96 ? 128 : (N > 32 ? 96 : 32); }
 
 void mp_launch_gemm(const GemmArgs& g, int bn, hipStream_t s) {
+    static const bool staged = getenv("MP_GEMM_STAGED") && atoi(getenv("MP_GEMM_STAGED")) != 0;   // the LDS-staged kernel (A/B runs)
+    // (row-streaming kernel for the linear2 shapes -- few columns, K >= 128)
+    if (!staged && g.N <= 96 && g.Kpad >= 128) {
+        // (W is padded to a multiple of bn rows: bn = 32 -> 1 tile, 96 -> up to 3)
+        const bool done = g.N > 64 ? launch_rows_k<3>(g, s) : g.N > 32 ? launch_rows_k<2>(g, s) : launch_rows_k<1>(g, s);
+        if (done) return;
+    }
     if (bn == 128) launch<2, 2, 2, 2>(g, s);
     else if (bn == 96) launch<4, 1, 1, 3>(g, s);
     else launch<4, 1, 1, 1>(g, s);

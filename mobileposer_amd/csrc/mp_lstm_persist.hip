@@ -416,7 +416,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
             }
         } else if (EARLY_GATHER && (LEAN || step > 0)) {
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) gr[ks] = MP_EXP == 3 ? (u64)(ks + lane) : granule_load(srcp[ks / KSP] + (size_t)ks * 64);
+            for (int ks = 0; ks < NKS; ++ks) gr[ks] = granule_load(srcp[ks / KSP] + (size_t)ks * 64);
         }
         // ---- second half of the input projection
 #pragma unroll
@@ -462,7 +462,6 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
             bool ok = true;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) ok = ok && ((unsigned)(gr[ks] >> 32) == epoch);
-            if (MP_EXP == 1 || MP_EXP == 3) ok = true;
             unsigned spins = 0;
             bool timed_out = false;
             if (PROF && prof && !__all(ok)) pt[5] += 1;      // slow-path entries
@@ -504,7 +503,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
             const long dlt = d.reverse ? -(long)xtstride : (long)xtstride;
             xp_nxt = adv ? xp_cur + dlt : xp_cur;
         }
-        if (MP_EXP != 2) load_x((step + 1) | 0x40000000, 0, XJ_PRE);   // next step's x: issued only now so that the granule wait above does not
+        load_x((step + 1) | 0x40000000, 0, XJ_PRE);   // next step's x: issued only now so that the granule wait above does not
                                                       // also drain these HBM loads; they land under the MFMAs / cell update below
         PROF_E(1); PROF_T(2);
 
@@ -518,7 +517,6 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
                 if (WREG) mfma_asm<false, true>(acc[t], a_h, wv[ks][t]);
                 else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_h, wv[ks][t], acc[t], 0, 0, 0);
             }
-        if (MP_EXP == 2) load_x((step + 1) | 0x40000000, 0, XJ_PRE);
         if (WREG) mfma_drain();
         PROF_E(2); PROF_T(3);
 
