@@ -207,7 +207,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
     // next step, so nobody sits in that wait) and then stores epoch_base + step + 1 into its flag; a consumer wave reads
     // the 8 flags of the two slices its K quarter comes from a quarter of the way through the projection, checks them half
     // way (ONE compare; stale -> bounded poll) and only then requests the values: 4 x 16 bytes per lane instead of 16 x 8,
-    // nothing to validate afterwards.  Measured on the granule form (profiles/r03_flagx.md): the 16 requests cost 700
+    // nothing to validate afterwards.  Measured on the granule form (profiles/r02_flagx.md): the 16 requests cost 700
     // cycles of issue inside the projection and their 16 compare / s_and pairs 600 cycles, while the words themselves were
     // ALWAYS there at the first look -- the hand-off latency was never the problem, its instruction count was.
     // Word (row, unit j) sits where consumer lane (q = j & 3, row) finds k-steps 4i .. 4i+3 of its K quarter in one
