@@ -390,12 +390,12 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
         constexpr bool EARLY_GATHER = !C::BIG || WREG;         // (WREG: 512 registers per wave -- room for the granules)
         // (LEAN: requested on EVERY step, step 0 included -- there the words are simply not looked at)
         if (FLAGX) {
-            if (SPLIT_X) {
-                // second half of x_t (requested 14 k-steps ago): have the compiler wait for it HERE -- its own placement, one
-                // piece at a time inside the second half, would also wait for the h words requested just below
+            // every piece of x_t has been requested long ago (the previous step's prefetch; the second half of a K_in = 512
+            // row 14 k-steps ago): have the compiler wait for them HERE -- its own placement, piece by piece inside the rest
+            // of the projection with counts that assume nothing younger is in flight, would also wait for the h words
+            // requested just below (measured in the K_in = 256 kernel: a full L2 round trip per step)
 #pragma unroll
-                for (int j = XJ_PRE; j < NXJ; ++j) asm volatile("" : "+v"(xa[j]));
-            }
+            for (int j = 0; j < NXJ; ++j) asm volatile("" : "+v"(xa[j]));
             if (step > 0) {
                 bool ok = hflags == epoch;
                 unsigned spins = 0;
