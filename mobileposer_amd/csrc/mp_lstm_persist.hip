@@ -277,7 +277,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
     f32x4 xa[NXJ];
     // With part of W_ih in registers (XR > 0) there is no room for a whole prefetched x row beside the
     // granules: the second half of x_t is then fetched at the top of step t (it is first used ~2000 cycles later).
-    constexpr bool SPLIT_X = C::BIG;
+    constexpr bool SPLIT_X = C::BIG && H == 256;            // (H = 64: registers to spare -- the whole row one step ahead)
     constexpr int XJ_PRE = SPLIT_X ? NXJ / 2 : NXJ;        // 16-byte pieces prefetched one step ahead
     // LEAN (one wave per SIMD: the 16-slice / 4-wave and the H = 64 configurations): VALU instructions do not hide under
     // MFMAs on this hardware (profiles/r02_persist_phases.md) and a lone wave has nobody to cover them, so the step is put on
@@ -310,6 +310,10 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
     };
     load_x(0, 0, XJ_PRE);
     __syncthreads();                                          // W_ih LDS image complete
+    // (x_0 has arrived before the loop is entered, x_{t+1} before the stores of step t are issued -- see the cell update --
+    //  so the compiler places no vector-memory wait at the top of the loop, where the previous step's stores are pending)
+#pragma unroll
+    for (int j = 0; j < XJ_PRE; ++j) asm volatile("" : "+v"(xa[j]));
 
     long long pt[6] = {0, 0, 0, 0, 0, 0};
     const bool prof = PROF && a.prof != nullptr && threadIdx.x == 0;
@@ -552,6 +556,11 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
         PROF_E(3); PROF_T(4);
 
         // ---- cell update (register-local), publish h_step, write the layer output
+        // (x_{t+1}, requested before the recurrent MFMAs, is waited for HERE, while only loads are in flight: vmcnt counts
+        //  loads and stores together and stores are acknowledged out of order, so once the stores below are pending the only
+        //  safe wait for a load is vmcnt(0) -- the top of the next step would sit out the acknowledgement of every store)
+#pragma unroll
+        for (int j = 0; j < XJ_PRE; ++j) asm volatile("" : "+v"(xa[j]));
         const size_t doff = (size_t)(step & 1) * 16 * H;
 #pragma unroll
         for (int o = 0; o < NOWN; ++o) {
