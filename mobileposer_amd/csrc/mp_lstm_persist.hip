@@ -562,6 +562,39 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
 #pragma unroll
         for (int j = 0; j < XJ_PRE; ++j) asm volatile("" : "+v"(xa[j]));
         const size_t doff = (size_t)(step & 1) * 16 * H;
+        if (WREG && FLAGX) {
+            // two cells per lane: both are computed first, branch-free (an inactive row's gates are whatever its clamped input
+            // row gives -- finite or not, they are never kept), and all stores follow -- one basic block, so the scheduler
+            // interleaves the two dependent exp / rcp chains instead of running them one after the other
+            float oval[NOWN];
+            int tt[NOWN];
+#pragma unroll
+            for (int o = 0; o < NOWN; ++o) {
+                const bool act = step < blen[o];
+                tt[o] = act ? (d.reverse ? blen[o] - 1 - step : step) : step;
+                const float ig = sigmoidf_(gate[o][0]);
+                const float fg = sigmoidf_(gate[o][1]);
+                const float gg = tanhf_(gate[o][2]);
+                const float og = sigmoidf_(gate[o][3]);
+                const float cnew = fg * cst[o] + ig * gg;
+                const float hnew = og * tanhf_(cnew);
+                cst[o] = act ? cnew : cst[o];
+                hst[o] = act ? hnew : hst[o];
+                oval[o] = act ? hnew : 0.f;
+            }
+            unsigned* hw = hdL + (size_t)(step & 1) * 16 * H;
+#pragma unroll
+            for (int o = 0; o < NOWN; ++o)
+                __hip_atomic_store(hw + hslot[o], __float_as_uint(hst[o]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!all_local) {
+#pragma unroll
+                for (int o = 0; o < NOWN; ++o)
+                    __hip_atomic_store(hw + HD_R / 4 + hslot[o], __float_as_uint(hst[o]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int o = 0; o < NOWN; ++o)
+                if (bidx[o] < B) *reinterpret_cast<float*>(reinterpret_cast<char*>(outb[o]) + (size_t)(unsigned)tt[o] * out_row_bytes) = oval[o];
+        } else
 #pragma unroll
         for (int o = 0; o < NOWN; ++o) {
             const bool act = step < blen[o];
