@@ -175,6 +175,8 @@ struct mp_handle {
     bool epoch_tags = true;          // MP_EPOCH_TAGS=0: zero the exchange area before every fp32 layer launch (as round 1 did)
     bool slices16_ok = true;         // MP_SLICES16=0: bidirectional fp32 layers always on 8 slices
     bool wide_ok = true;             // MP_WIDE=0: never run pose / velocity / foot-contact side by side (small batches)
+    bool exclusive_ok = true;        // MP_EXCLUSIVE=0: never pad the LDS request of concurrent persistent launches (below)
+    int excl_lds = 0;                // forward_body -> rnn_rec: LstmPersistArgs::min_lds of the launches being issued
     bool fuse_pv = true;             // MP_FUSE_PV=0: separate linear1 launches for pose and velocity
     Packed lin1_pv;                  // pose.linear1 and velocity.linear1 stacked (split-bf16 mode: one GEMM over the shared rows)
     int wreg_mask = 3;               // fp32 mode, 8-slice bidirectional layers on the four-wave / AccVGPR-weight configuration
@@ -399,6 +401,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     if (const char* e = getenv("MP_PAIR_MODE")) h->pair_mode = atoi(e);
     if (const char* e = getenv("MP_FUSE_PV")) h->fuse_pv = atoi(e) != 0;
     if (const char* e = getenv("MP_WIDE")) h->wide_ok = atoi(e) != 0;
+    if (const char* e = getenv("MP_EXCLUSIVE")) h->exclusive_ok = atoi(e) != 0;
     if (const char* e = getenv("MP_SLICES16")) h->slices16_ok = atoi(e) != 0;
     if (const char* e = getenv("MP_EPOCH_TAGS")) h->epoch_tags = atoi(e) != 0;
     if (const char* e = getenv("MP_EPOCH_START")) { const unsigned long v = strtoul(e, nullptr, 0); if (v >= 1 && v < 0xf0000000ul) h->epoch_start = (unsigned)v; }
@@ -546,6 +549,8 @@ struct SegScope {
     }
     ~SegScope() { if (on) (void)hipEventRecord(h->segs[idx].b, s); }
 };
+
+constexpr int kExclusiveLdsBytes = 84 * 1024;   // LstmPersistArgs::min_lds: more than half of a CU's 160 KB
 
 // ------------------------------------------------------------------------------------------ one RNN block
 enum StateMode { STATE_ZERO, STATE_FROM };
@@ -754,6 +759,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             a.zero_state = j.mode == STATE_ZERO ? 1 : 0; a.force_remote = h->force_remote ? 1 : 0;
             const bool x3 = use_x3(h, m);
             a.epoch_base = epoch_base;
+            a.min_lds = x3 ? 0 : h->excl_lds;
             a.out_pairs = x3 ? 1 : 0;                          // both layers feed split-bf16 consumers (layer 1 / linear2)
             for (int d = 0; d < dirs; ++d) {
                 LstmDir& dd = a.d[d];
@@ -887,13 +893,19 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
     } else if (!h->uni2 && h->wide_ok &&
                layer_workgroups(h, h->mod[MP_MOD_POSE], p->B) + layer_workgroups(h, h->mod[MP_MOD_VELOCITY], p->B) +
                    layer_workgroups(h, h->mod[MP_MOD_FOOT_CONTACT], p->B) <= h->n_cu) {
-        // the three blocks side by side: every workgroup of the three concurrent layer launches has a CU of its own
+        // the three blocks side by side: every workgroup of the three concurrent layer launches has a CU of its own --
+        // and gets one: the exact-fp32 launches ask for more than half a CU's LDS, so the dispatcher cannot put two
+        // persistent workgroups on one CU while others stand empty (it spreads every launch on its own, and a workgroup
+        // that shares its SIMDs slows its whole lock-stepped cluster)
         HIPCHK(h, hipStreamWaitEvent(sv, h->ev_j, 0));
-        RC(run_rnn(F, sf));                                                               // net.py:113-114
-        HIPCHK(h, hipEventRecord(h->ev_f, sf));
-        RC(run_rnn(V, sv));                                                               // net.py:117
-        HIPCHK(h, hipEventRecord(h->ev_v, sv));
-        RC(run_rnn(P, sm));                                                               // net.py:106-107
+        h->excl_lds = h->exclusive_ok ? kExclusiveLdsBytes : 0;
+        int rc_w = run_rnn(F, sf);                                                        // net.py:113-114
+        if (!rc_w) { hipError_t e_ = hipEventRecord(h->ev_f, sf); if (e_ != hipSuccess) rc_w = fail(h, MP_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(e_)); }
+        if (!rc_w) rc_w = run_rnn(V, sv);                                                 // net.py:117
+        if (!rc_w) { hipError_t e_ = hipEventRecord(h->ev_v, sv); if (e_ != hipSuccess) rc_w = fail(h, MP_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(e_)); }
+        if (!rc_w) rc_w = run_rnn(P, sm);                                                 // net.py:106-107
+        h->excl_lds = 0;
+        RC(rc_w);
         { SegScope seg(h, sm, 2, 1);
           mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sm); }   // net.py:110
         if (fk_rglobal) mp_launch_fk(pose, nullptr, poseRows, h->bone_dev, h->parent_dev, h->depth_dev, fk_rglobal, fk_joint, sm);
@@ -916,14 +928,29 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         // (captured BEFORE the side-stream work that hangs off the same event: the graph launches the successors of a
         //  node in creation order, and the velocity layers are the critical chain)
         if (!fused_pv) RC(wait(1, sm));
-        RC(rnn_rec(V, 0, sm)); RC(rnn_rec(V, 1, sm)); RC(rnn_g2(V, sm));                    // net.py:117
+        // velocity and foot contact run side by side: when together they need no more workgroups than there are CUs
+        // (B <= 128) each workgroup gets a CU of its own (see the side-by-side schedule above)
+        const int excl_vf = (h->exclusive_ok && layer_workgroups(h, h->mod[MP_MOD_VELOCITY], p->B) +
+                             layer_workgroups(h, h->mod[MP_MOD_FOOT_CONTACT], p->B) <= h->n_cu) ? kExclusiveLdsBytes : 0;
+        h->excl_lds = excl_vf;
+        int rc_v = rnn_rec(V, 0, sm);
+        if (!rc_v) rc_v = rnn_rec(V, 1, sm);
+        h->excl_lds = 0;
+        RC(rc_v);
+        RC(rnn_g2(V, sm));                                                                  // net.py:117
         HIPCHK(h, hipEventRecord(h->ev_v, sm));
         RC(wait(2, sp)); RC(rnn_g2(P, sp));
         { SegScope seg(h, sp, 2, 1);
           mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sp); }   // net.py:110
         if (fk_rglobal) mp_launch_fk(pose, nullptr, poseRows, h->bone_dev, h->parent_dev, h->depth_dev, fk_rglobal, fk_joint, sp);
         RC(rec(3, sp));
-        RC(wait(2, sf)); RC(rnn_rec(F, 0, sf)); RC(rnn_rec(F, 1, sf)); RC(rnn_g2(F, sf));   // net.py:113-114
+        RC(wait(2, sf));
+        h->excl_lds = excl_vf;
+        int rc_f = rnn_rec(F, 0, sf);
+        if (!rc_f) rc_f = rnn_rec(F, 1, sf);
+        h->excl_lds = 0;
+        RC(rc_f);
+        RC(rnn_g2(F, sf));                                                                  // net.py:113-114
         HIPCHK(h, hipEventRecord(h->ev_f, sf));
         RC(wait(3, sm));
     }

@@ -99,6 +99,10 @@ struct LstmPersistArgs {
     // epoch_base + step (and its XCC table entries epoch_base), so nothing stale can match and no memset sits between two
     // layers on the critical path.  The host advances the base by T + 1 per launch and re-zeroes before a wrap-around.
     unsigned epoch_base = 0;
+    // mp_lstm_fused, host side only: ask for at least this much dynamic LDS (bytes) although the kernel uses less.  With
+    // more than half a CU's LDS per workgroup no CU takes two persistent workgroups -- of this launch or of a launch
+    // running beside it -- as long as CUs are free: a workgroup that shares its SIMDs slows its whole lock-stepped cluster.
+    int min_lds = 0;
     unsigned long long* hx_next = nullptr;   // split-bf16 kernel only: exchange area of the NEXT layer's launch (same cluster
                                               // indexing), re-armed by this launch at its start
 };

@@ -910,6 +910,8 @@ MP_KERNEL void mp_pack_wih_persist(const float* __restrict__ wih, float* __restr
     dst[idx] = wih[(size_t)row * KIN + col];
 }
 
+constexpr int kExclusiveLds = 84 * 1024;                             // > half of a CU's 160 KB
+
 template <int H, int NSLICE, int KIN, int TW>
 constexpr size_t fused_lds() {
     using C = Cfg<H, NSLICE, KIN, TW>;
@@ -919,7 +921,8 @@ constexpr size_t fused_lds() {
 template <int H, int NSLICE, int KIN, int TW>
 void launch_fused(const LstmPersistArgs& a, hipStream_t s) {
     using C = Cfg<H, NSLICE, KIN, TW>;
-    const size_t lds = fused_lds<H, NSLICE, KIN, TW>();
+    size_t lds = fused_lds<H, NSLICE, KIN, TW>();
+    if ((size_t)a.min_lds > lds) lds = (size_t)a.min_lds;
     const dim3 grid(((a.nslab * a.ndir + 7) / 8) * 8 * NSLICE);
     if (a.prof) hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, TW, true>), grid, dim3(64 * C::NWV), lds, s, a);
     else hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, TW, false>), grid, dim3(64 * C::NWV), lds, s, a);
@@ -928,7 +931,8 @@ void launch_fused(const LstmPersistArgs& a, hipStream_t s) {
 // the dynamic-LDS limit is a per-device function attribute: set for the CURRENT device, outside of any capture
 template <int H, int NSLICE, int KIN, int TW>
 hipError_t fused_attrs() {
-    const int lds = (int)fused_lds<H, NSLICE, KIN, TW>();
+    int lds = (int)fused_lds<H, NSLICE, KIN, TW>();
+    if (lds < kExclusiveLds) lds = kExclusiveLds;                  // (LstmPersistArgs::min_lds)
     hipError_t e = hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, TW, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
