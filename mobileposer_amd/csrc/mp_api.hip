@@ -177,6 +177,11 @@ struct mp_handle {
     bool wide_ok = true;             // MP_WIDE=0: never run pose / velocity / foot-contact side by side (small batches)
     bool exclusive_ok = true;        // MP_EXCLUSIVE=0: never pad the LDS request of concurrent persistent launches (below)
     int excl_lds = 0;                // forward_body -> rnn_rec: LstmPersistArgs::min_lds of the launches being issued
+    bool pose_slices8 = false;       // forward_body -> fp32_slices: this call runs the pose layers on 8 slices per slab (below)
+    bool xcd_rr = false;             // probed at create: workgroups are dealt round robin over 8 XCDs
+    bool xcd_plan_on[4] = {false, false, false, false};   // forward_body -> rnn_rec: clusters per XCD of module id's layer launches
+    unsigned char xcd_plan[4][8] = {};
+    bool half_ok = true;             // MP_HALF=0: no pose-on-half-the-chip schedule for 64 < B <= 128
     bool fuse_pv = true;             // MP_FUSE_PV=0: separate linear1 launches for pose and velocity
     Packed lin1_pv;                  // pose.linear1 and velocity.linear1 stacked (split-bf16 mode: one GEMM over the shared rows)
     int wreg_mask = 3;               // fp32 mode, 8-slice bidirectional layers on the four-wave / AccVGPR-weight configuration
@@ -390,6 +395,25 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
         // a persistent layer needs at least one cluster (dirs x 16 workgroups) resident at one workgroup per CU
         if (h->n_cu < 32) h->persist = false;
     }
+    {
+        // side-by-side schedules place clusters XCD by XCD (place_clusters): only on a device that deals workgroups round
+        // robin over 8 XCDs of n_cu / 8 CUs each -- probed, not assumed
+        int* probe = nullptr;
+        h->xcd_rr = false;
+        if (h->n_cu % 8 == 0 && hipHostMalloc((void**)&probe, 64 * sizeof(int), hipHostMallocDefault) == hipSuccess) {
+            for (int i = 0; i < 64; ++i) probe[i] = -1;
+            mp_launch_xcc_probe(probe, h->s_main);
+            if (hipStreamSynchronize(h->s_main) == hipSuccess) {
+                unsigned seen = 0;
+                bool ok = true;
+                for (int b = 0; b < 64; ++b) ok = ok && probe[b] >= 0 && probe[b] < 8 && probe[b] == probe[b & 7];
+                for (int b = 0; b < 8 && ok; ++b) seen |= 1u << probe[b];
+                h->xcd_rr = ok && seen == 0xffu;
+            }
+            (void)hipHostFree(probe);
+        }
+        (void)hipGetLastError();
+    }
     if (const char* e = getenv("MP_LSTM_MODE")) {
         h->persist = strcmp(e, "step") != 0;
         h->x3 = h->persist && strcmp(e, "x3") == 0;            // "fp32" (default) | "x3" | "step"
@@ -402,6 +426,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     if (const char* e = getenv("MP_FUSE_PV")) h->fuse_pv = atoi(e) != 0;
     if (const char* e = getenv("MP_WIDE")) h->wide_ok = atoi(e) != 0;
     if (const char* e = getenv("MP_EXCLUSIVE")) h->exclusive_ok = atoi(e) != 0;
+    if (const char* e = getenv("MP_HALF")) h->half_ok = atoi(e) != 0;
     if (const char* e = getenv("MP_SLICES16")) h->slices16_ok = atoi(e) != 0;
     if (const char* e = getenv("MP_EPOCH_TAGS")) h->epoch_tags = atoi(e) != 0;
     if (const char* e = getenv("MP_EPOCH_START")) { const unsigned long v = strtoul(e, nullptr, 0); if (v >= 1 && v < 0xf0000000ul) h->epoch_start = (unsigned)v; }
@@ -601,6 +626,7 @@ bool use_x3(const mp_handle* h, const ModuleW& m) { return h->persist && h->x3 &
 int fp32_slices(const mp_handle* h, const ModuleW& m, int B) {
     const int nslab = (B + 15) / 16;
     const int cus = h->n_cu < 256 ? h->n_cu : 256;
+    if (h->pose_slices8 && &m == &h->mod[MP_MOD_POSE]) return m.nslice;
     if (m.H == 256 && m.nslice == 8 && m.whhP16[0][0] && h->slices16_ok && m.dirs * nslab * 16 <= cus) return 16;
     return m.nslice;
 }
@@ -760,6 +786,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             const bool x3 = use_x3(h, m);
             a.epoch_base = epoch_base;
             a.min_lds = x3 ? 0 : h->excl_lds;
+            if (!x3 && !pair && h->xcd_plan_on[j.id] && a.nslab == nslab) { mp_fill_xcd_table(a, h->xcd_plan[j.id]); a.xcd_physical = 1; }
             a.out_pairs = x3 ? 1 : 0;                          // both layers feed split-bf16 consumers (layer 1 / linear2)
             for (int d = 0; d < dirs; ++d) {
                 LstmDir& dd = a.d[d];
@@ -849,6 +876,61 @@ int ensure_vstate(mp_handle* h, VelState& v, int B) {
     return MP_OK;
 }
 
+// Clusters per XCD for persistent launches that run at the same time.  The dispatcher sends workgroup b to XCD b % 8 and
+// lets it wait there when no CU has room, whatever the other XCDs are doing (tools/micro/xcd_dispatch.hip), so "fewer
+// workgroups than CUs" is not enough: every XCD must hold its share.  Greedy: widest clusters first, each cluster to the
+// XCD with the most CUs left.  `load` (CUs taken per XCD) is updated; false = does not fit (nothing is assigned then).
+struct XcdJob { int id, ncl, wgs; };
+bool place_clusters(const mp_handle* h, const XcdJob* jobs, int njobs, int load[8], unsigned char cnt[4][8]) {
+    const int cap = h->n_cu / 8;
+    int ld[8]; unsigned char c[4][8] = {};
+    for (int x = 0; x < 8; ++x) ld[x] = load[x];
+    int order[4] = {0, 1, 2, 3};
+    for (int a = 0; a < njobs; ++a)
+        for (int b = a + 1; b < njobs; ++b)
+            if (jobs[order[b]].wgs > jobs[order[a]].wgs) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
+    for (int a = 0; a < njobs; ++a) {
+        const XcdJob& jb = jobs[order[a]];
+        for (int k = 0; k < jb.ncl; ++k) {
+            int best = 0;
+            for (int x = 1; x < 8; ++x) if (ld[x] < ld[best]) best = x;
+            if (ld[best] + jb.wgs > cap || c[jb.id][best] == 255) return false;
+            ld[best] += jb.wgs; ++c[jb.id][best];
+        }
+    }
+    for (int x = 0; x < 8; ++x) load[x] = ld[x];
+    for (int a = 0; a < njobs; ++a) memcpy(cnt[jobs[a].id], c[jobs[a].id], 8);
+    return true;
+}
+
+// Which side-by-side schedule (forward_body) fits batch B: 0 = none, 1 = pose / velocity / foot contact at once, 2 = the same
+// with the pose layers on 8 slices per slab, 3 = pose (8 slices) beside velocity, foot contact after velocity.  Fills the
+// per-XCD cluster tables of the three blocks (h->xcd_plan).
+int side_by_side_plan(mp_handle* h, int B) {
+    if (h->uni2 || !h->wide_ok) return 0;
+    const ModuleW& pm = h->mod[MP_MOD_POSE];
+    const ModuleW& vm = h->mod[MP_MOD_VELOCITY];
+    const ModuleW& fm = h->mod[MP_MOD_FOOT_CONTACT];
+    const int nslab = (B + 15) / 16;
+    const bool any_x3 = use_x3(h, pm) || use_x3(h, vm);
+    auto job = [&](int id, const ModuleW& m, int slices) { return XcdJob{id, m.dirs * nslab, slices}; };
+    const int pslices = use_x3(h, pm) ? pm.nsliceX : fp32_slices(h, pm, B);
+    const int vslices = use_x3(h, vm) ? vm.nsliceX : fp32_slices(h, vm, B);
+    XcdJob all[3] = {job(MP_MOD_POSE, pm, pslices), job(MP_MOD_VELOCITY, vm, vslices), job(MP_MOD_FOOT_CONTACT, fm, fm.nslice)};
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (any_x3 || !h->xcd_rr || !h->exclusive_ok)   // (no tables: the split-bf16 kernels spread their clusters themselves)
+        return layer_workgroups(h, pm, B) + layer_workgroups(h, vm, B) + layer_workgroups(h, fm, B) <= h->n_cu ? 1 : 0;
+    if (place_clusters(h, all, 3, load, h->xcd_plan)) return 1;
+    if (!h->half_ok || !pm.whhPW[0][0] || (h->wreg_mask & 3) != 3 || pslices != 16) return 0;
+    all[0].wgs = pm.nslice;                   // pose on 8 slices per slab (four-wave kernels)
+    for (int x = 0; x < 8; ++x) load[x] = 0;
+    if (place_clusters(h, all, 3, load, h->xcd_plan)) return 2;
+    for (int x = 0; x < 8; ++x) load[x] = 0;
+    if (!place_clusters(h, all, 2, load, h->xcd_plan)) return 0;          // pose + velocity
+    for (int x = 0; x < 8; ++x) load[x] -= h->xcd_plan[MP_MOD_VELOCITY][x] * vslices;   // foot contact takes over velocity's CUs
+    return place_clusters(h, all + 2, 1, load, h->xcd_plan) ? 3 : 0;
+}
+
 // Workgroups of one persistent layer launch of module m at batch B (every one of them fits a CU of its own)
 // models/net.py:101-119 on the library's streams (eager or under capture).
 // Stream plan (persistent mode).  The persistent layer kernels are grids of clusters of workgroups that wait on each
@@ -890,21 +972,45 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         if (fk_rglobal) mp_launch_fk(pose, nullptr, poseRows, h->bone_dev, h->parent_dev, h->depth_dev, fk_rglobal, fk_joint, sm);
         RC(run_rnn(V, sv));                                                               // net.py:117
         HIPCHK(h, hipEventRecord(h->ev_v, sv));
-    } else if (!h->uni2 && h->wide_ok &&
-               layer_workgroups(h, h->mod[MP_MOD_POSE], p->B) + layer_workgroups(h, h->mod[MP_MOD_VELOCITY], p->B) +
-                   layer_workgroups(h, h->mod[MP_MOD_FOOT_CONTACT], p->B) <= h->n_cu) {
-        // the three blocks side by side: every workgroup of the three concurrent layer launches has a CU of its own --
-        // and gets one: the exact-fp32 launches ask for more than half a CU's LDS, so the dispatcher cannot put two
-        // persistent workgroups on one CU while others stand empty (it spreads every launch on its own, and a workgroup
-        // that shares its SIMDs slows its whole lock-stepped cluster)
+    } else if (const int side = side_by_side_plan(h, p->B)) {
+        // the blocks side by side: every workgroup of the concurrent layer launches has a CU of its own -- and gets one: the
+        // exact-fp32 launches ask for more than half a CU's LDS, so the dispatcher cannot put two persistent workgroups on
+        // one CU while others stand empty (it spreads every launch on its own, and a workgroup that shares its SIMDs slows
+        // its whole lock-stepped cluster).
+        //   side 1 (B <= 64 fp32, <= 128 split-bf16): pose, velocity and foot contact at once;
+        //   side 2 (B <= 96, fp32): the same with the pose layers on 8 slices per slab (the four-wave kernels, 16 CUs per
+        //           slab and direction instead of 32): a longer pose chain (1.38 instead of 0.85 ms), but nothing after it;
+        //   side 3 (B <= 128, fp32): pose on 8 slices beside velocity; foot contact follows velocity on the CUs it vacates.
         HIPCHK(h, hipStreamWaitEvent(sv, h->ev_j, 0));
         h->excl_lds = h->exclusive_ok ? kExclusiveLdsBytes : 0;
-        int rc_w = run_rnn(F, sf);                                                        // net.py:113-114
-        if (!rc_w) { hipError_t e_ = hipEventRecord(h->ev_f, sf); if (e_ != hipSuccess) rc_w = fail(h, MP_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(e_)); }
-        if (!rc_w) rc_w = run_rnn(V, sv);                                                 // net.py:117
-        if (!rc_w) { hipError_t e_ = hipEventRecord(h->ev_v, sv); if (e_ != hipSuccess) rc_w = fail(h, MP_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(e_)); }
+        h->pose_slices8 = side >= 2;
+        const bool tables = h->exclusive_ok && h->xcd_rr && !use_x3(h, h->mod[MP_MOD_POSE]) && !use_x3(h, h->mod[MP_MOD_VELOCITY]);
+        h->xcd_plan_on[MP_MOD_POSE] = h->xcd_plan_on[MP_MOD_VELOCITY] = h->xcd_plan_on[MP_MOD_FOOT_CONTACT] = tables;
+        auto ev = [&](hipEvent_t e, hipStream_t on) -> int {
+            hipError_t r = hipEventRecord(e, on);
+            return r == hipSuccess ? MP_OK : fail(h, MP_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(r));
+        };
+        int rc_w = MP_OK;
+        if (side == 3) {
+            rc_w = rnn_g0(F, sf);                                                         // linear1 right away
+            if (!rc_w) rc_w = run_rnn(V, sv);                                             // net.py:117
+            if (!rc_w) rc_w = ev(h->ev_v, sv);
+            if (!rc_w) { hipError_t r = hipStreamWaitEvent(sf, h->ev_v, 0); if (r != hipSuccess) rc_w = fail(h, MP_ERR_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(r)); }
+            if (!rc_w) rc_w = rnn_rec(F, 0, sf);                                          // net.py:113-114
+            if (!rc_w) rc_w = rnn_g1(F, sf);
+            if (!rc_w) rc_w = rnn_rec(F, 1, sf);
+            if (!rc_w) rc_w = rnn_g2(F, sf);
+            if (!rc_w) rc_w = ev(h->ev_f, sf);
+        } else {
+            rc_w = run_rnn(F, sf);                                                        // net.py:113-114
+            if (!rc_w) rc_w = ev(h->ev_f, sf);
+            if (!rc_w) rc_w = run_rnn(V, sv);                                             // net.py:117
+            if (!rc_w) rc_w = ev(h->ev_v, sv);
+        }
         if (!rc_w) rc_w = run_rnn(P, sm);                                                 // net.py:106-107
         h->excl_lds = 0;
+        h->pose_slices8 = false;
+        h->xcd_plan_on[MP_MOD_POSE] = h->xcd_plan_on[MP_MOD_VELOCITY] = h->xcd_plan_on[MP_MOD_FOOT_CONTACT] = false;
         RC(rc_w);
         { SegScope seg(h, sm, 2, 1);
           mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sm); }   // net.py:110
@@ -930,12 +1036,24 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         if (!fused_pv) RC(wait(1, sm));
         // velocity and foot contact run side by side: when together they need no more workgroups than there are CUs
         // (B <= 128) each workgroup gets a CU of its own (see the side-by-side schedule above)
-        const int excl_vf = (h->exclusive_ok && layer_workgroups(h, h->mod[MP_MOD_VELOCITY], p->B) +
-                             layer_workgroups(h, h->mod[MP_MOD_FOOT_CONTACT], p->B) <= h->n_cu) ? kExclusiveLdsBytes : 0;
+        int excl_vf = 0;
+        bool vf_tables = false;
+        if (h->exclusive_ok && !use_x3(h, h->mod[MP_MOD_VELOCITY]) && !h->xcd_rr) {
+            if (layer_workgroups(h, h->mod[MP_MOD_VELOCITY], p->B) + layer_workgroups(h, h->mod[MP_MOD_FOOT_CONTACT], p->B) <= h->n_cu)
+                excl_vf = kExclusiveLdsBytes;
+        } else if (h->exclusive_ok && !use_x3(h, h->mod[MP_MOD_VELOCITY])) {
+            const int nslab = (p->B + 15) / 16;
+            const XcdJob vf[2] = {{MP_MOD_VELOCITY, h->mod[MP_MOD_VELOCITY].dirs * nslab, fp32_slices(h, h->mod[MP_MOD_VELOCITY], p->B)},
+                                  {MP_MOD_FOOT_CONTACT, h->mod[MP_MOD_FOOT_CONTACT].dirs * nslab, h->mod[MP_MOD_FOOT_CONTACT].nslice}};
+            int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (place_clusters(h, vf, 2, load, h->xcd_plan)) { excl_vf = kExclusiveLdsBytes; vf_tables = true; }
+        }
         h->excl_lds = excl_vf;
+        h->xcd_plan_on[MP_MOD_VELOCITY] = vf_tables;
         int rc_v = rnn_rec(V, 0, sm);
         if (!rc_v) rc_v = rnn_rec(V, 1, sm);
         h->excl_lds = 0;
+        h->xcd_plan_on[MP_MOD_VELOCITY] = false;
         RC(rc_v);
         RC(rnn_g2(V, sm));                                                                  // net.py:117
         HIPCHK(h, hipEventRecord(h->ev_v, sm));
@@ -946,9 +1064,11 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         RC(rec(3, sp));
         RC(wait(2, sf));
         h->excl_lds = excl_vf;
+        h->xcd_plan_on[MP_MOD_FOOT_CONTACT] = vf_tables;
         int rc_f = rnn_rec(F, 0, sf);
         if (!rc_f) rc_f = rnn_rec(F, 1, sf);
         h->excl_lds = 0;
+        h->xcd_plan_on[MP_MOD_FOOT_CONTACT] = false;
         RC(rc_f);
         RC(rnn_g2(F, sf));                                                                  // net.py:113-114
         HIPCHK(h, hipEventRecord(h->ev_f, sf));

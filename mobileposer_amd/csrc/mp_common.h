@@ -103,11 +103,24 @@ struct LstmPersistArgs {
     // more than half a CU's LDS per workgroup no CU takes two persistent workgroups -- of this launch or of a launch
     // running beside it -- as long as CUs are free: a workgroup that shares its SIMDs slows its whole lock-stepped cluster.
     int min_lds = 0;
+    // mp_lstm_fused: which clusters ((direction, slab) pairs, 0 .. ndir*nslab-1) run on which XCD.  The dispatcher sends
+    // workgroup b to XCD b % 8 -- strictly: a workgroup whose XCD has no CU left for it WAITS, even while other XCDs stand
+    // empty (tools/micro/xcd_dispatch.hip) -- and a cluster's workgroups share an XCD (their hand-off lives in its L2).  XCD x
+    // runs clusters xcd_base[x] .. xcd_base[x] + xcd_cnt[x] - 1; all zero = spread round robin (mp_fill_xcd_table).
+    unsigned char xcd_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned short xcd_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // 1: the table is indexed by the XCD a workgroup really runs on (its XCC id), not by blockIdx % 8 -- the round robin
+    // does not start at XCD 0 for every launch (another stream's launch of the same micro-benchmark started at XCD 7), and
+    // tables of launches that run side by side must mean the same XCDs.  Only when the device was probed (mp_create) to
+    // deal workgroups b, b + 8, ... onto one XCD and 8 consecutive ones onto 8 different XCDs.
+    int xcd_physical = 0;
     unsigned long long* hx_next = nullptr;   // split-bf16 kernel only: exchange area of the NEXT layer's launch (same cluster
                                               // indexing), re-armed by this launch at its start
 };
 // nslice: workgroups sharing one slab of an H = 256 layer: 16 (4-wave workgroups, two per CU) or 8 (8-wave, one per CU)
 void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice, hipStream_t s);
+void mp_fill_xcd_table(LstmPersistArgs& a, const unsigned char* cnt);   // LstmPersistArgs::xcd_cnt / xcd_base
+void mp_launch_xcc_probe(int* out64, hipStream_t s);                    // 64 workgroups -> their XCC ids
 void mp_launch_pack_whh_persist(const float* whh, float* dst, int H, int nslice, hipStream_t s);
 void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, int nslice, int korder, hipStream_t s);
 // H = 256, 8 slices, four 512-register waves per workgroup with AccVGPR-resident weights (mp_lstm_fused<256,8,KIN,1>)

@@ -121,13 +121,16 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
     f32x4* red = reinterpret_cast<f32x4*>(smem);                       // [finishing wave][source kq][o][lane]
     f32x4* wxl = reinterpret_cast<f32x4*>(smem) + C::RED_F4;           // [wave][x-step < XL][tile group][lane]
 
-    // 1-D grid of 8 * ceil(ncl/8) * NSLICE blocks over (cluster = (direction, slab), slice).  The NSLICE workgroups
-    // of a cluster get block ids that are congruent mod 8, i.e. (observed dispatch: block b -> XCD b % 8) they
-    // share an XCD and its L2 -- speed only, never correctness (the transport is chosen from the real XCC ids).
-    // Blocks whose cluster index falls beyond ncl (ncl not a multiple of 8) exit at once.
+    // 1-D grid of 8 * max(xcd_cnt) * NSLICE blocks over (cluster = (direction, slab), slice).  The NSLICE workgroups
+    // of a cluster get block ids that are congruent mod 8, i.e. (dispatch: block b -> XCD b % 8) they share an XCD and
+    // its L2 -- speed only, never correctness (the transport is chosen from the real XCC ids); which clusters an XCD
+    // runs is the host's table (LstmPersistArgs::xcd_cnt / xcd_base).  Blocks beyond their XCD's count exit at once.
     const int ncl = a.ndir * a.nslab;
-    const int cl = ((int)(blockIdx.x >> 3) / NSLICE) * 8 + (int)(blockIdx.x & 7);
+    const int xcd = a.xcd_physical ? (int)(xcc_id() & 7) : (int)(blockIdx.x & 7);
+    const int kth = (int)(blockIdx.x >> 3) / NSLICE;                                     // the XCD's kth cluster
     const int slice = (int)(blockIdx.x >> 3) % NSLICE;
+    if (kth >= (int)a.xcd_cnt[xcd]) return;
+    const int cl = (int)a.xcd_base[xcd] + kth;
     if (cl >= ncl) return;
     const int dir = cl / a.nslab, slab = cl % a.nslab;
     const LstmDir d = a.d[dir];
@@ -923,9 +926,16 @@ void launch_fused(const LstmPersistArgs& a, hipStream_t s) {
     using C = Cfg<H, NSLICE, KIN, TW>;
     size_t lds = fused_lds<H, NSLICE, KIN, TW>();
     if ((size_t)a.min_lds > lds) lds = (size_t)a.min_lds;
-    const dim3 grid(((a.nslab * a.ndir + 7) / 8) * 8 * NSLICE);
-    if (a.prof) hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, TW, true>), grid, dim3(64 * C::NWV), lds, s, a);
-    else hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, TW, false>), grid, dim3(64 * C::NWV), lds, s, a);
+    LstmPersistArgs b = a;
+    int most = 0, total = 0;
+    for (int x = 0; x < 8; ++x) { most = b.xcd_cnt[x] > most ? b.xcd_cnt[x] : most; total += b.xcd_cnt[x]; }
+    if (total != a.nslab * a.ndir) {                      // no table (or not one for this launch): round robin
+        mp_fill_xcd_table(b, nullptr);
+        most = (a.nslab * a.ndir + 7) / 8;
+    }
+    const dim3 grid(8 * most * NSLICE);
+    if (a.prof) hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, TW, true>), grid, dim3(64 * C::NWV), lds, s, b);
+    else hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, TW, false>), grid, dim3(64 * C::NWV), lds, s, b);
 }
 
 // the dynamic-LDS limit is a per-device function attribute: set for the CURRENT device, outside of any capture
@@ -1007,3 +1017,22 @@ void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice
     } else if (KIN == 64) launch_fused<64, 4, 64, 1>(a, s);      // H = 64 (foot contact): 4 slices of 16 units, small
     else launch_fused<64, 4, 128, 1>(a, s);                       // footprint so that it fits beside the velocity layers
 }
+
+
+// cnt[x] clusters on XCD x (nullptr: the ndir * nslab clusters spread round robin), bases = running sum
+void mp_fill_xcd_table(LstmPersistArgs& a, const unsigned char* cnt) {
+    const int ncl = a.ndir * a.nslab;
+    int base = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int c = cnt ? cnt[x] : (ncl + 7 - x) / 8;
+        a.xcd_cnt[x] = (unsigned char)c;
+        a.xcd_base[x] = (unsigned short)base;
+        base += c;
+    }
+}
+
+// ---- does this device deal workgroups round robin over 8 XCDs?  (64 workgroups report their XCC ids)
+namespace {
+MP_KERNEL void mp_xcc_probe(int* out) { if (threadIdx.x == 0) out[blockIdx.x] = (int)xcc_id(); }
+}
+void mp_launch_xcc_probe(int* out64, hipStream_t s) { hipLaunchKernelGGL(mp_xcc_probe, dim3(64), dim3(64), 0, s, out64); }

@@ -492,6 +492,35 @@ def test_small_batch_schedules_agree(torch_mod, weights, smpl, monkeypatch):
         assert float((a - b).abs().max()) < 5e-6
 
 
+def test_half_chip_schedules_agree(torch_mod, weights, smpl, monkeypatch):
+    """64 < B <= 128, exact-fp32 operands: the pose layers run on 8 slices per slab (half the chip) beside velocity (and foot
+    contact, B <= 96; after velocity otherwise), every cluster on an XCD chosen by the host (MP_HALF, default on).  Same
+    values as the serial schedule to fp32 noise (pose on 8 instead of 16 slices: another summation order in the cell
+    update); joints / velocity / foot contact use the same kernels in both and must agree bitwise."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    outs = {}
+    for half in (1, 0):
+        monkeypatch.setenv("MP_HALF", str(half))
+        with MobilePoserNet.from_numpy(weights, smpl) as n:
+            o = []
+            for B, T in ((80, 24), (96, 20), (128, 16), (100, 30)):
+                x = cu(torch_mod, synthetic.make_imu(B, T, seed=B))
+                L = [T] * B
+                L[B // 2] = max(1, T // 3)
+                L[-1] = max(1, T - 2)
+                n.reset_all()
+                o += [t.clone() for t in n.forward_offline(x, L)]
+                o += [t.clone() for t in n.forward_offline(x, L)]          # carried velocity state
+            assert n.device_error() == 0
+        outs[half] = o
+    for i, (a, b) in enumerate(zip(outs[1], outs[0])):
+        if i % 4 == 0:                                         # pose: 8-slice against 16-slice kernels
+            assert float((a - b).abs().max()) < 5e-6
+        else:                                                  # joints, translation, contact: the same kernels
+            assert torch_mod.equal(a, b)
+
+
 def test_two_slab_kernel_matches(torch_mod, weights, smpl, monkeypatch):
     """mp_lstm_pair (two slabs of 16 sequences per workgroup; off by default, MP_PAIR=3 turns it on for the bidirectional
     fp32 layers): same arithmetic as mp_lstm_fused up to the summation order -- full-chip batch, an odd number of slabs,
