@@ -1,6 +1,8 @@
-// Does the workgroup dispatcher of MI355X map workgroup id -> XCD strictly (id mod 8), even when that XCD has no CU left
-// for the workgroup while other XCDs stand empty?  40 workgroups that each need more than half a CU's LDS (one per CU)
-// all have id = 0 mod 8; every one records its XCC id, its start time and spins for ~100 us.
+// Two facts about the workgroup dispatcher of MI355X that the side-by-side schedules of mp_api.hip rest on:
+//  1. workgroup id -> XCD is a strict round robin: a workgroup whose XCD has no CU left for it WAITS, even while other XCDs
+//     stand empty.  40 workgroups that each need more than half a CU's LDS (one per CU) all have id = 0 mod 8; every one
+//     records its XCC id, its start time and spins for ~100 us: all 40 land on one XCD, 8 of them start 100 us late.
+//  2. the round robin does not start at XCD 0 for every launch: the same launch on another stream starts elsewhere.
 //   hipcc --offload-arch=gfx950 -O3 tools/micro/xcd_dispatch.hip -o tools/micro/xcd_dispatch && tools/micro/xcd_dispatch
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -59,36 +61,24 @@ int main() {
     for (int x = 0; x < 8; ++x) printf(" %d", per_xcc[x]);
     printf("\nstarted more than 50 us after the first: %d of %d\n", late, n);
 
-    // ---- part 2: head-of-line blocking.  Kernel A fills XCD 0 (32 workgroups, 600 us).  Kernel B on another stream, started
-    // while A runs: its workgroups 0, 8, 16, ... belong on XCD 0 (no room), 1, 9, 17, ... on XCD 1 (empty).  Do B's XCD-1
-    // workgroups start at once, or only after its first XCD-0 workgroup has found a CU?
-    hipStream_t sa, sb;
-    hipStreamCreateWithFlags(&sa, hipStreamNonBlocking);
-    hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
-    unsigned long long *da, *db;
-    hipMalloc(&da, sizeof(unsigned long long) * 3 * 64);
-    hipMalloc(&db, sizeof(unsigned long long) * 3 * 64);
+    // ---- part 2: where does the round robin start?  The same 16-workgroup launch on three streams, twice each.
+    hipStream_t st[3] = {nullptr, nullptr, nullptr};
+    hipStreamCreateWithFlags(&st[1], hipStreamNonBlocking);
+    hipStreamCreateWithFlags(&st[2], hipStreamNonBlocking);
+    unsigned long long* d2;
+    hipMalloc(&d2, sizeof(unsigned long long) * 3 * 64);
     hipFuncSetAttribute((const void*)probe2, hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024);
-    for (int rep = 0; rep < 2; ++rep) {
-        hipMemset(da, 0xff, sizeof(unsigned long long) * 3 * 64);
-        hipMemset(db, 0xff, sizeof(unsigned long long) * 3 * 64);
-        hipDeviceSynchronize();
-        hipLaunchKernelGGL(probe2, dim3(8 * 32), dim3(256), 84 * 1024, sa, da, 600, 1);        // mask 1: only XCD 0 works
-        { const auto t = std::chrono::steady_clock::now();                                      // let A settle in first
-          while (std::chrono::steady_clock::now() - t < std::chrono::microseconds(100)) {} }
-        hipLaunchKernelGGL(probe2, dim3(8 * 8), dim3(256), 84 * 1024, sb, db, 20, 3);          // mask 3: XCD 0 and XCD 1 work
-        hipDeviceSynchronize();
-    }
-    std::vector<unsigned long long> ha(3 * 64), hb(3 * 64);
-    hipMemcpy(ha.data(), da, sizeof(unsigned long long) * 3 * 64, hipMemcpyDeviceToHost);
-    hipMemcpy(hb.data(), db, sizeof(unsigned long long) * 3 * 64, hipMemcpyDeviceToHost);
-    // (A records its first 64 block ids only: blocks 0, 8, ..., 56 are 8 of its 32 XCD-0 workgroups)
-    unsigned long long a0 = ~0ull, a1 = 0;
-    int na = 0;
-    for (int i = 0; i < 64; i += 8) if (ha[3 * i] != ~0ull) { a0 = std::min(a0, ha[3 * i + 1]); a1 = std::max(a1, ha[3 * i + 1]); ++na; }
-    printf("\nkernel A: %d recorded XCD-0 workgroups, xcc of the first %llu, starts within %.1f us\n", na, ha[0], (double)(a1 - a0) / 100.0);
-    printf("\nkernel B (8 workgroups per XCD, XCDs 0 and 1 work 20 us) beside kernel A (XCD 0 full for 600 us; B launched ~100 us after A):\n");
-    for (int i = 0; i < 64; ++i)
-        if (hb[3 * i] != ~0ull) printf("  B workgroup %2d: xcc %llu  start +%.1f us after A\n", i, hb[3 * i], (double)(hb[3 * i + 1] - a0) / 100.0);
+    for (int rep = 0; rep < 2; ++rep)
+        for (int k = 0; k < 3; ++k) {
+            hipMemset(d2, 0xff, sizeof(unsigned long long) * 3 * 64);
+            hipDeviceSynchronize();
+            hipLaunchKernelGGL(probe2, dim3(16), dim3(256), 84 * 1024, st[k], d2, 5, 0xff);
+            hipDeviceSynchronize();
+            std::vector<unsigned long long> h2(3 * 64);
+            hipMemcpy(h2.data(), d2, sizeof(unsigned long long) * 3 * 64, hipMemcpyDeviceToHost);
+            printf("stream %d, launch %d: workgroups 0..15 ran on XCCs", k, rep);
+            for (int i = 0; i < 16; ++i) printf(" %llu", h2[3 * i]);
+            printf("\n");
+        }
     return 0;
 }
