@@ -16,9 +16,12 @@
 //   * W_ih slice: LDS (up to 128 KB as 16-byte B-fragment groups) and, when K_in = 2H, the rest in registers;
 //   * c_t and the lane's own h_t: registers for all T steps;
 //   * x_{t+1}: prefetched from HBM into registers while step t finishes (16-byte loads, 64-byte segments).
-// h_t crosses workgroups (the NSLICE slices of a slab need each other's units every step) as 8-byte
-// {epoch, value} granules -- the data is its own flag, no fence / barrier / flag word (cdna_hip_programming.md
-// Guideline 16, form R2).  Two transports, chosen per PRODUCER from where it really runs (its XCC id,
+// h_t crosses workgroups (the NSLICE slices of a slab need each other's units every step) in one of two forms:
+//   * 8-byte {epoch, value} granules -- the data is its own flag, no fence / barrier / flag word (cdna_hip_programming.md
+//     Guideline 16, form R2): the H = 64 kernels and the eight-wave kernels (described in this header);
+//   * plain words + one flag per producer wave ("FLAGX" in the kernel body): the H = 256 kernels with one wave per SIMD,
+//     where 16 granule loads + 16 tag compares per lane and step cost more than the hand-off latency they hid.
+// Two transports, chosen per PRODUCER from where it really runs (its XCC id,
 // published once at kernel start), so the result never depends on placement, only the speed does:
 //   R: write-through (sc1) stores + sc1 loads -- coherent for any placement (fabric round trip, ~1 us);
 //   L: ordinary stores + L1-bypassing (sc1) loads -- producer and consumer share an XCD (one L2), ~4x faster.
