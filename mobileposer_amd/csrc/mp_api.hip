@@ -439,7 +439,12 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     e = e ? e : hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking);
     e = e ? e : hipStreamCreateWithFlags(&h->s_vel, hipStreamNonBlocking);
     e = e ? e : hipStreamCreateWithFlags(&h->s_foot, hipStreamNonBlocking);
-    e = e ? e : hipStreamCreateWithFlags(&h->s_gp, hipStreamNonBlocking);
+    // (three streams, not four: with the caller's own stream that makes four -- the number of hardware queues the HIP runtime
+    //  multiplexes a process's streams onto by default (GPU_MAX_HW_QUEUES).  Two streams on one queue are serialised: with a
+    //  fourth library stream the foot-contact chain was seen queued behind pose's linear2 / IK for 110 us,
+    //  profiles/r02_timeline_256x125.txt.  The pose tail (serial schedule) and the velocity chain (side-by-side schedules)
+    //  never run in the same call, so they share s_vel.)
+    h->s_gp = h->s_vel;
     for (hipEvent_t& ev : h->ev_x) e = e ? e : hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (!e) e = hipHostMalloc((void**)&h->err_host, 64, hipHostMallocMapped | hipHostMallocCoherent);
     if (!e) { *h->err_host = 0; e = hipHostGetDevicePointer((void**)&h->err_dev, h->err_host, 0); }
@@ -1197,7 +1202,7 @@ void mp_destroy(mp_handle* h) {
     hipEvent_t evs[5] = {h->ev_in, h->ev_out, h->ev_j, h->ev_v, h->ev_f};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_x) if (e) (void)hipEventDestroy(e);
-    hipStream_t ss[4] = {h->s_main, h->s_vel, h->s_foot, h->s_gp};
+    hipStream_t ss[3] = {h->s_main, h->s_vel, h->s_foot};             // (s_gp is s_vel)
     for (hipStream_t s : ss) if (s) (void)hipStreamDestroy(s);
     delete h;
 }
