@@ -64,6 +64,13 @@ def load():
         raise RuntimeError(
             "mobileposer_amd: %s not found -- build it with `python __graft_entry__.py` (hipcc, gfx950). "
             "There is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm ships its own libamdhip64; this library must bind to the runtime instance torch uses (the caller's
+    # tensors and streams live there), so torch is loaded first when it is installed.  Loaded the other way round, the
+    # library resolves the system ROCm's libamdhip64 and its first hipSetDevice fails once torch's copy is in the process.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
