@@ -176,7 +176,7 @@ int mp_live_form_frames(mp_handle* h, const float* quat_dev, const float* acc_de
  *   6 = fused LSTM layer H=64,   7 = per-step LSTM kernels (fallback mode),   2 = r6d/IK,   3 = whole call. */
 int mp_timing_enable(mp_handle* h, int on);
 int mp_timing_read(mp_handle* h, int cls, int* launches, float* ms, double* gflop);
-/* 0 (default): eager launches on the library's four streams; 1 (env MP_GRAPH=1): capture every (entry point, shape,
+/* 0 (default): eager launches on the library's three streams; 1 (env MP_GRAPH=1): capture every (entry point, shape,
  * buffer set) once into a hipGraph and replay it.  Opt-in because the multi-branch graph executor of the HIP runtime
  * in this image can crash in hipGraphLaunch depending on the hardware-queue placement of the streams a process has
  * created (profiles/r02_hipgraph_segv.md; GPU_MAX_HW_QUEUES=8 avoids it); outputs are bitwise identical either way. */

@@ -14,7 +14,7 @@
 // the launch stream's queue (GPU_MAX_HW_QUEUES = 4 by default, so this depends on every stream the process has ever
 // created) it reads past the end of the vector and the process dies with SIGSEGV inside hipGraphLaunch
 // (profiles/r02_hipgraph_segv.md: backtrace, disassembly, and the GPU_MAX_HW_QUEUES experiment).  Eager launches on
-// the library's four streams measure 1.755 vs 1.716 ms (split-bf16 mode) and 4.46 vs 4.57 ms (fp32 mode) per
+// the library's streams measure 1.755 vs 1.716 ms (split-bf16 mode) and 4.46 vs 4.57 ms (fp32 mode) per
 // 256 x 125 batch, i.e. nothing is lost.
 #include "../../include/mobileposer_hip.h"
 #include "mp_common.h"
@@ -949,7 +949,7 @@ int side_by_side_plan(mp_handle* h, int B) {
 //  * Larger batches: the joints / pose layers fill the chip (one workgroup per CU, 160 KB of LDS), so all H = 256
 //    recurrences are serialised on s_main; the H = 64 foot-contact layers (4 slices per slab, 48 KB of LDS: they fit on
 //    a CU beside a velocity workgroup, LDS 80 + 48 KB, or on the half of the chip the split-bf16 velocity layers leave
-//    free) run on s_foot beside the velocity layers, the linear2 / IK / FK tail of pose on s_gp.
+//    free) run on s_foot beside the velocity layers, the linear2 / IK / FK tail of pose on s_gp (= s_vel, idle by then).
 int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long poseRows, long poseRowStride,
                  long poseRowOffset, float* joints, float* vel, float* contact, float* r6d, VelState& vs,
                  bool has_state, float* fk_rglobal = nullptr, float* fk_joint = nullptr) {
