@@ -29,6 +29,10 @@ __global__ __launch_bounds__(256, 1) void k(long long* out, float* sink, const f
                 if (KIND == 4) asm volatile("ds_read_b128 %0, %1" : "=v"(l) : "v"((unsigned)(threadIdx.x * 16)));
                 if (KIND == 5) asm volatile("global_load_dword %0, %1, off" : "=v"(gl) : "v"(g + threadIdx.x));
                 if (KIND == 6) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sa));
+                if (KIND == 7) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(l) : "v"(g + threadIdx.x * 4));     // 1 KB per wave
+                if (KIND == 8)     // the same 1 KB per wave straight into LDS (no VGPR destination)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + threadIdx.x * 4),
+                                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -40,11 +44,12 @@ __global__ __launch_bounds__(256, 1) void k(long long* out, float* sink, const f
     sink[threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + v0 + v1 + v2 + v3 + l[0] + gl + sa;
 }
 int main() {
-    long long* d; float *s, *g; hipMalloc(&d, 64); hipMalloc(&s, 1024); hipMalloc(&g, 4096);
-    const char* names[7] = {"nothing", "1 VALU", "2 VALU", "4 VALU", "1 ds_read_b128", "1 global_load", "1 SALU"};
+    long long* d; float *s, *g; hipMalloc(&d, 64); hipMalloc(&s, 1024); hipMalloc(&g, 16384);
+    const char* names[9] = {"nothing", "1 VALU", "2 VALU", "4 VALU", "1 ds_read_b128", "1 global_load", "1 SALU",
+                            "1 global_load_dwordx4", "1 global_load_lds x4"};
     long long h;
 #define RUN(K) hipLaunchKernelGGL(k<K>, dim3(1), dim3(256), 0, 0, d, s, g, 100); hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost); \
-    printf("after every MFMA: %-15s -> %.1f cycles per MFMA\n", names[K], h / 64.0);
-    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6)
+    printf("after every MFMA: %-22s -> %.1f cycles per MFMA\n", names[K], h / 64.0);
+    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8)
     return 0;
 }
