@@ -96,6 +96,8 @@ struct ModuleW {
     float* wihP16[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  //  blocks; a unidirectional block's whhP / wihP already is it)
     float* whhPW[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // 8-slice / 4-wave (WREG) packing, bidirectional H = 256 blocks
     float* wihPW[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    float* whhU8[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // 32 slices of 8 units (mp_lstm_u8): small batches, H = 256 blocks
+    float* wihU8[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     float* wihG1 = nullptr;          // unidirectional H=256 block: layer-1 W_ih in granule k-order (wavefront kernel)
 };
 struct ModuleWS {
@@ -174,6 +176,7 @@ struct mp_handle {
     unsigned epoch_start = 1;        // first epoch base after a zeroing (test hook MP_EPOCH_START: start close to the wrap guard)
     bool epoch_tags = true;          // MP_EPOCH_TAGS=0: zero the exchange area before every fp32 layer launch (as round 1 did)
     bool slices16_ok = true;         // MP_SLICES16=0: bidirectional fp32 layers always on 8 slices
+    bool slices32_ok = true;         // MP_SLICES32=0: no 32-slice kernels for batches of one or two slabs
     bool wide_ok = true;             // MP_WIDE=0: never run pose / velocity / foot-contact side by side (small batches)
     bool exclusive_ok = true;        // MP_EXCLUSIVE=0: never pad the LDS request of concurrent persistent launches (below)
     int excl_lds = 0;                // forward_body -> rnn_rec: LstmPersistArgs::min_lds of the launches being issued
@@ -267,6 +270,10 @@ int pack_weights(mp_handle* h, const float* blob) {
                 if (int rc = dev_alloc(h, (void**)&m.whhP[l][d], mp_whh_pack_floats(m.H) * sizeof(float))) return rc;
                 const int kin = l == 0 ? m.H : m.dirs * m.H;
                 if (int rc = dev_alloc(h, (void**)&m.wihP[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
+                if (m.H == 256) {
+                    if (int rc = dev_alloc(h, (void**)&m.whhU8[l][d], (size_t)4 * m.H * m.H * sizeof(float))) return rc;
+                    if (int rc = dev_alloc(h, (void**)&m.wihU8[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
+                }
                 if (m.H == 256 && m.nslice != 16) {
                     if (int rc = dev_alloc(h, (void**)&m.whhPW[l][d], mp_whh_pack_floats(m.H) * sizeof(float))) return rc;
                     if (int rc = dev_alloc(h, (void**)&m.wihPW[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
@@ -303,6 +310,10 @@ int pack_weights(mp_handle* h, const float* blob) {
                 mp_launch_pack_whh(find(s.id, K_WHH, l, d), m.whh[l][d], m.H, h->s_main);
                 mp_launch_pack_whh_persist(find(s.id, K_WHH, l, d), m.whhP[l][d], m.H, m.nslice, h->s_main);
                 mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP[l][d], m.H, m.ih[l].K, m.nslice, 0, h->s_main);
+                if (m.whhU8[l][d]) {
+                    mp_launch_pack_w_u8(find(s.id, K_WHH, l, d), m.whhU8[l][d], m.H, h->s_main);
+                    mp_launch_pack_w_u8(find(s.id, K_WIH, l, d), m.wihU8[l][d], m.ih[l].K, h->s_main);
+                }
                 if (m.whhPW[l][d]) {
                     mp_launch_pack_whh_persist_w(find(s.id, K_WHH, l, d), m.whhPW[l][d], h->s_main);
                     mp_launch_pack_wih_persist_w(find(s.id, K_WIH, l, d), m.wihPW[l][d], m.ih[l].K, h->s_main);
@@ -385,6 +396,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     {   // dynamic-LDS limits of the persistent kernels are per-device attributes (and must not be set under capture)
         hipError_t ea = mp_lstm_persist_device_attrs();
         if (ea == hipSuccess) ea = mp_lstm_pair_device_attrs();
+        if (ea == hipSuccess) ea = mp_lstm_u8_device_attrs();
         if (ea == hipSuccess) ea = mp_lstm_x3_device_attrs();
         if (ea == hipSuccess) ea = mp_lstm_x3w_device_attrs();
         if (ea != hipSuccess) { h->err = std::string("hipFuncSetAttribute failed: ") + hipGetErrorString(ea); return bail(MP_ERR_HIP); }
@@ -428,6 +440,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     if (const char* e = getenv("MP_EXCLUSIVE")) h->exclusive_ok = atoi(e) != 0;
     if (const char* e = getenv("MP_HALF")) h->half_ok = atoi(e) != 0;
     if (const char* e = getenv("MP_SLICES16")) h->slices16_ok = atoi(e) != 0;
+    if (const char* e = getenv("MP_SLICES32")) h->slices32_ok = atoi(e) != 0;
     if (const char* e = getenv("MP_EPOCH_TAGS")) h->epoch_tags = atoi(e) != 0;
     if (const char* e = getenv("MP_EPOCH_START")) { const unsigned long v = strtoul(e, nullptr, 0); if (v >= 1 && v < 0xf0000000ul) h->epoch_start = (unsigned)v; }
     if (const char* e = getenv("MP_LSTM_SLICES")) h->nslice_env = atoi(e) == 8 ? 8 : (atoi(e) == 16 ? 16 : 0);
@@ -632,6 +645,9 @@ int fp32_slices(const mp_handle* h, const ModuleW& m, int B) {
     const int nslab = (B + 15) / 16;
     const int cus = h->n_cu < 256 ? h->n_cu : 256;
     if (h->pose_slices8 && &m == &h->mod[MP_MOD_POSE]) return m.nslice;
+    // one or two slabs (B <= 32): 32 slices of 8 units, every (direction, slab) cluster on an XCD of its own (mp_lstm_u8.hip) --
+    // at most 4 + 2 clusters of pose and velocity side by side, foot contact on the two XCDs that are left
+    if (m.H == 256 && m.whhU8[0][0] && h->slices32_ok && h->slices16_ok && nslab <= 2 && cus == 256 && !h->uni2) return 32;
     if (m.H == 256 && m.nslice == 8 && m.whhP16[0][0] && h->slices16_ok && m.dirs * nslab * 16 <= cus) return 16;
     return m.nslice;
 }
@@ -768,6 +784,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         const bool p16 = pair || (!use_x3(h, m) && nsl == 16 && m.nslice != 16);      // 16-slice packing of a bidirectional block
         const bool wreg = !use_x3(h, m) && !pair && H == 256 && nsl == 8 && m.whhPW[0][0] &&
                           (h->wreg_mask & (kin_l == 512 ? 1 : 2));
+        const bool u8 = !use_x3(h, m) && !pair && H == 256 && nsl == 32;
         const int cus = h->n_cu < 256 ? h->n_cu : 256;
         // slabs per launch: grid <= #CUs, one workgroup per CU (pair kernel: 16 workgroups per pair of slabs)
         const int chunk = pair ? (cus / (dirs * 16) > 0 ? 2 * (cus / (dirs * 16)) : 2)
@@ -795,18 +812,19 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             a.out_pairs = x3 ? 1 : 0;                          // both layers feed split-bf16 consumers (layer 1 / linear2)
             for (int d = 0; d < dirs; ++d) {
                 LstmDir& dd = a.d[d];
-                dd.wpack = x3 ? m.whhX[l][d] : (wreg ? m.whhPW[l][d] : (p16 ? m.whhP16[l][d] : m.whhP[l][d]));
+                dd.wpack = x3 ? m.whhX[l][d] : (u8 ? m.whhU8[l][d] : wreg ? m.whhPW[l][d] : (p16 ? m.whhP16[l][d] : m.whhP[l][d]));
                 dd.xproj = nullptr; dd.out = outp + (size_t)d * H;
                 const bool inplace = j.out_h == j.in_h && j.out_h;
                 dd.hbuf = inplace ? j.out_h + (size_t)(l * dirs + d) * B * H : w.hbuf[l][d];
                 dd.cbuf = inplace ? j.out_c + (size_t)(l * dirs + d) * B * H : w.cbuf[l][d];
                 dd.xprojStride = 0; dd.outStride = dirs * H; dd.reverse = d;
-                dd.wihpack = x3 ? m.wihX[l][d] : (wreg ? m.wihPW[l][d] : (p16 ? m.wihP16[l][d] : m.wihP[l][d])); dd.bias = m.ih[l].bias + (size_t)d * 4 * H; dd.xin = xin;
+                dd.wihpack = x3 ? m.wihX[l][d] : (u8 ? m.wihU8[l][d] : wreg ? m.wihPW[l][d] : (p16 ? m.wihP16[l][d] : m.wihP[l][d])); dd.bias = m.ih[l].bias + (size_t)d * 4 * H; dd.xin = xin;
             }
             if (dirs == 1) a.d[1] = a.d[0];
             if (x3 && nsl == 8 && (h->x3w_mask & (kin == 256 ? 1 : 2))) mp_launch_lstm_x3w(a, kin, s);
             else if (x3) mp_launch_lstm_x3(a, kin, nsl, s);
             else if (pair) mp_launch_lstm_pair(a, kin, h->pair_mode, s);
+            else if (u8) mp_launch_lstm_u8(a, kin, s);
             else if (wreg) mp_launch_lstm_persist_w(a, kin, s);
             else mp_launch_lstm_persist(a, H, kin, nsl, s);
         }
@@ -1186,6 +1204,8 @@ void mp_destroy(mp_handle* h) {
             if (m.wihP[l][d]) (void)hipFree(m.wihP[l][d]);
             if (m.whhPW[l][d]) (void)hipFree(m.whhPW[l][d]);
             if (m.wihPW[l][d]) (void)hipFree(m.wihPW[l][d]);
+            if (m.whhU8[l][d]) (void)hipFree(m.whhU8[l][d]);
+            if (m.wihU8[l][d]) (void)hipFree(m.wihU8[l][d]);
             if (m.whhP16[l][d]) (void)hipFree(m.whhP16[l][d]);
             if (m.wihP16[l][d]) (void)hipFree(m.wihP16[l][d]);
             if (m.whhX[l][d]) (void)hipFree(m.whhX[l][d]);

@@ -121,6 +121,10 @@ struct LstmPersistArgs {
 void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice, hipStream_t s);
 void mp_fill_xcd_table(LstmPersistArgs& a, const unsigned char* cnt);   // LstmPersistArgs::xcd_cnt / xcd_base
 void mp_launch_xcc_probe(int* out64, hipStream_t s);                    // 64 workgroups -> their XCC ids
+// 32 slices of 8 units per slab (mp_lstm_u8.hip): small batches; wpack / wihpack from mp_launch_pack_w_u8 (K = 256 / K_in)
+void mp_launch_lstm_u8(const LstmPersistArgs& a, int KIN, hipStream_t s);
+void mp_launch_pack_w_u8(const float* w, float* dst, int K, hipStream_t s);
+hipError_t mp_lstm_u8_device_attrs();
 void mp_launch_pack_whh_persist(const float* whh, float* dst, int H, int nslice, hipStream_t s);
 void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, int nslice, int korder, hipStream_t s);
 // H = 256, 8 slices, four 512-register waves per workgroup with AccVGPR-resident weights (mp_lstm_fused<256,8,KIN,1>)
