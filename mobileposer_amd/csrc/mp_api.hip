@@ -647,7 +647,9 @@ int fp32_slices(const mp_handle* h, const ModuleW& m, int B) {
     if (h->pose_slices8 && &m == &h->mod[MP_MOD_POSE]) return m.nslice;
     // one or two slabs (B <= 32): 32 slices of 8 units, every (direction, slab) cluster on an XCD of its own (mp_lstm_u8.hip) --
     // at most 4 + 2 clusters of pose and velocity side by side, foot contact on the two XCDs that are left
-    if (m.H == 256 && m.whhU8[0][0] && h->slices32_ok && h->slices16_ok && nslab <= 2 && cus == 256 && !h->uni2) return 32;
+    // (the joints block always has the chip to itself: 32 slices while its 2 * nslab clusters find an XCD each, B <= 64)
+    const int max32 = &m == &h->mod[MP_MOD_JOINTS] ? 4 : 2;
+    if (m.H == 256 && m.whhU8[0][0] && h->slices32_ok && h->slices16_ok && nslab <= max32 && cus == 256 && !h->uni2) return 32;
     if (m.H == 256 && m.nslice == 8 && m.whhP16[0][0] && h->slices16_ok && m.dirs * nslab * 16 <= cus) return 16;
     return m.nslice;
 }

@@ -6,7 +6,7 @@ os.environ["MP_PERSIST_PROF"] = "1"
 from mobileposer_amd import synthetic
 from mobileposer_amd.net import MobilePoserNet
 net = MobilePoserNet.from_numpy(synthetic.make_weights(0), synthetic.synthetic_smpl())
-B, T = 256, 125
+B, T = (int(sys.argv[2]) if len(sys.argv) > 2 else 256), 125
 x = torch.from_numpy(synthetic.make_imu(B, T, seed=1)).cuda()
 mod = sys.argv[1] if len(sys.argv) > 1 else "joints"
 xin = x if mod == "joints" else torch.randn(B, T, 132, device="cuda") * 0.3
