@@ -15,7 +15,7 @@
 //     transposes them: finishing wave w takes rows 4 q + w, lane (q, t, u) the cell of unit 8 slice + 4 t + u.
 // Same packed-sequence semantics, transports, bounded waits / error word and XCD table as mp_lstm_fused.  Sums run over k in
 // another order than in the 8 / 16-slice kernels: equal to fp32 rounding, not bitwise
-// (tests/test_gpu_parity.py::test_small_batch_schedules_agree).
+// (tests/test_gpu_parity.py::test_32_slice_fp32_kernel_matches_16_slice).
 #include "mp_lstm_dev.h"
 
 namespace {

@@ -609,6 +609,39 @@ def test_four_wave_fp32_kernel_matches_eight_wave(torch_mod, weights, smpl, monk
         assert float((a - b).abs().max()) < 5e-6
 
 
+def test_32_slice_fp32_kernel_matches_16_slice(torch_mod, weights, smpl, monkeypatch):
+    """mp_lstm_u8 (B <= 32, joints block up to B = 64: 32 slices of 8 units per slab, MFMA tiles of 4 gates x 4 units, K reduction
+    and gate transpose in one LDS pass, one XCD per cluster) against the 16-slice kernels (MP_SLICES32=0): one sequence, partly
+    filled and full slabs, ragged lengths, carried velocity state, a long sequence, both transports.  Another order of
+    summation: equal to fp32 rounding."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    rng = np.random.default_rng(23)
+    shapes = ((1, 40), (7, 33), (16, 25), (17, 20), (32, 31), (50, 12), (64, 9), (2, 700))
+    lens = {sh: [int(v) for v in rng.integers(1, sh[1] + 1, size=sh[0])] for sh in shapes}
+    outs = {}
+    for s32, remote in ((0, 0), (1, 0), (1, 1)):
+        monkeypatch.setenv("MP_SLICES32", str(s32))
+        with MobilePoserNet.from_numpy(weights, smpl) as n:
+            n.set_lstm_mode(1)
+            if remote:
+                n.set_transport(True)
+            o = []
+            for B, T in shapes:
+                L = list(lens[(B, T)])
+                L[0] = T
+                x = cu(torch_mod, synthetic.make_imu(B, T, seed=B + 7))
+                o += [t.clone() for t in n.forward_offline(x, L)]
+                o += [t.clone() for t in n.forward_offline(x, L)]      # carried velocity state
+                n.reset_all()
+            assert n.device_error() == 0
+        outs[(s32, remote)] = o
+    for a, b in zip(outs[(0, 0)], outs[(1, 0)]):
+        assert float((a - b).abs().max()) < 5e-6
+    for a, b in zip(outs[(1, 0)], outs[(1, 1)]):
+        assert torch_mod.equal(a, b)                       # the transport never changes a bit
+
+
 def test_epoch_tagged_exchange_equals_zeroed_exchange(torch_mod, weights, smpl, monkeypatch):
     """The fp32 layer kernels no longer get a zeroed hidden-state exchange area per launch: every launch tags its granules
     with a fresh epoch base (base + step) and the host re-zeroes only before the 32-bit tag would wrap.  Bitwise the same
