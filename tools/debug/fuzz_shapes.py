@@ -10,13 +10,13 @@ from mobileposer_amd.net import MobilePoserNet
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 sd, smpl = synthetic.make_weights(0), synthetic.synthetic_smpl()
 new = MobilePoserNet.from_numpy(sd, smpl)
-for k, v in (("MP_WREG", "0"), ("MP_EPOCH_TAGS", "0"), ("MP_WIDE", "0"), ("MP_SLICES16", "0"), ("MP_EXCLUSIVE", "0"), ("MP_HALF", "0")):
+for k, v in (("MP_WREG", "0"), ("MP_EPOCH_TAGS", "0"), ("MP_WIDE", "0"), ("MP_SLICES16", "0"), ("MP_EXCLUSIVE", "0"), ("MP_HALF", "0"), ("MP_SLICES32", "0")):
     os.environ[k] = v
 old = MobilePoserNet.from_numpy(sd, smpl)
 rng = np.random.default_rng(2024)
 worst = 0.0
 for case in range(n_cases):
-    B = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 64, 65, 80, 96, 97, 100, 112, 128, 129, 255, 256, 257, 300, 511, 700])) if case % 3 else int(rng.integers(1, 400))
+    B = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 48, 64, 65, 80, 96, 97, 100, 112, 128, 129, 255, 256, 257, 300, 511, 700])) if case % 3 else int(rng.integers(1, 400))
     T = int(rng.integers(1, 90))
     x = torch.from_numpy(synthetic.make_imu(B, T, seed=1000 + case)).cuda()
     L = [int(v) for v in rng.integers(1, T + 1, size=B)]
