@@ -69,6 +69,12 @@ int mp_create(mp_handle** out, int device, const float* weights_host, size_t n_f
 int mp_create_from_device(mp_handle** out, int device, const float* weights_dev, size_t n_floats,
                           const int32_t parent[24], const float J[72]);
 
+/* A body-only instance: the SMPL constants without network weights.  Serves the kinematics entry points (mp_fk,
+ * mp_set_mesh, mp_fk_mesh, mp_reduced_global_to_full, mp_translate_offline); the network entry points return
+ * MP_ERR_INVALID on it.  Replaces: a stand-alone ParametricModel(paths.smpl_file) as data.py:24 and
+ * articulate/evaluator.py:293 build it (articulate/model.py:20-39). */
+int mp_create_body(mp_handle** out, int device, const int32_t parent[24], const float J[72]);
+
 void mp_destroy(mp_handle* h);
 const char* mp_last_error(const mp_handle* h);   /* h may be NULL: error of a failed mp_create */
 
@@ -127,6 +133,17 @@ int mp_set_mesh(mp_handle* h, const float* v_template_host, const float* weights
  * FullMotionEvaluator.__call__ runs on prediction and ground truth (articulate/evaluator.py:319-320). */
 int mp_fk_mesh(mp_handle* h, const float* pose_dev, const float* tran_dev, int64_t N,
                float* rglobal_dev, float* joint_dev, float* vert_dev, void* stream);
+
+/* Shape space of ParametricModel (articulate/model.py:29,31): shapedirs [V,3,10] and the DENSE J_regressor [24,V]
+ * (the pickle holds it scipy-sparse; model.py:29 densifies it), host pointers, V as given to mp_set_mesh. */
+int mp_set_shape_space(mp_handle* h, const float* shapedirs_host, const float* j_regressor_host);
+
+/* ParametricModel.forward_kinematics with shape != None (articulate/model.py:208-240 through
+ * get_zero_pose_joint_and_vertex(shape), :84-89): v = shapedirs.shape + v_template, j = J_regressor v, both aligned to
+ * j[0]; then as mp_fk / mp_fk_mesh on that body.  shape_dev [n_shape,10] with n_shape == 1 (one body for all frames) or
+ * n_shape == N (a body per frame); vert_dev [N,V,3] optional (NULL = calc_mesh False). */
+int mp_fk_shape(mp_handle* h, const float* pose_dev, const float* shape_dev, int n_shape, const float* tran_dev,
+                int64_t N, float* rglobal_dev, float* joint_dev, float* vert_dev, void* stream);
 
 /* MobilePoserNet.reset (models/net.py:84-88) clears nothing this library owns for the batch path;
  * clear_velocity != 0 additionally drops the carried velocity LSTM state (what setting

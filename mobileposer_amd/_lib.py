@@ -23,6 +23,7 @@ SIGNATURES = {
     "mp_manifest_entry": (_i, [_i, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_i64), C.POINTER(_sz)]),
     "mp_create": (_i, [C.POINTER(_vp), _i, _fp, _sz, _ip, _fp]),
     "mp_create_from_device": (_i, [C.POINTER(_vp), _i, _vp, _sz, _ip, _fp]),
+    "mp_create_body": (_i, [C.POINTER(_vp), _i, _ip, _fp]),
     "mp_destroy": (None, [_vp]),
     "mp_last_error": (C.c_char_p, [_vp]),
     "mp_get_constants": (_i, [_vp, _fp, _fp]),
@@ -34,6 +35,8 @@ SIGNATURES = {
     "mp_fk": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "mp_set_mesh": (_i, [_vp, _fp, _fp, _i]),
     "mp_fk_mesh": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "mp_set_shape_space": (_i, [_vp, _fp, _fp]),
+    "mp_fk_shape": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
     "mp_reset_state": (_i, [_vp, _i]),
     "mp_get_velocity_state": (_i, [_vp, _vp, C.POINTER(_i)]),
     "mp_set_velocity_state": (_i, [_vp, _vp, _i]),

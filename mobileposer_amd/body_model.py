@@ -1,45 +1,71 @@
-"""SMPL constants the inference path needs, and the GPU forward kinematics facade.
+"""SMPL body model on the GPU: the subset of ``ParametricModel`` (articulate/model.py:20-39,77-92,208-240) that
+MobilePoserNet, PoseDataset and the evaluator use -- ``parent``, zero-pose joints / vertices, ``forward_kinematics``
+(joints, optional mesh, optional shape).
 
-Mirror of the subset of ``ParametricModel`` (articulate/model.py:20-39,77-92,208-232) used by
-MobilePoserNet and the evaluator: ``parent``, zero-pose joints, ``forward_kinematics`` (no mesh).
+All arithmetic runs in the HIP library (mp_fk / mp_fk_mesh / mp_fk_shape).  A model that belongs to a MobilePoserNet
+uses that net's handle; a stand-alone one (``ParametricModel(paths.smpl_file)`` as data.py:24 and
+articulate/evaluator.py:293 build it) owns a body-only handle (mp_create_body).  There is no host implementation.
 """
+import ctypes as C
 import pickle
 import weakref
 
 import numpy as np
+import torch
 
+from . import _lib
 from .config import SMPL_PARENT
 
 
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _dense(a):
+    return np.asarray(a.toarray() if hasattr(a, "toarray") else a, dtype=np.float32)
+
+
 class ParametricModel:
-    def __init__(self, official_model_file=None, data=None):
-        """From an SMPL pickle (articulate/model.py:26-37) or an already-loaded dict with the same keys."""
+    def __init__(self, official_model_file=None, use_pose_blendshape=False, device="cuda:0", data=None):
+        """From an SMPL pickle (articulate/model.py:26-37: latin1 pickle, scipy-sparse ``J_regressor``, ``kintree_table``)
+        or an already-loaded dict with the same keys."""
+        if use_pose_blendshape:
+            raise NotImplementedError("pose blend shapes are outside the inference path (the reference's callers leave "
+                                      "use_pose_blendshape at False: net.py:37, evaluator.py:293, data.py:24)")
         if data is None:
             with open(official_model_file, "rb") as f:
                 data = pickle.load(f, encoding="latin1")
-        self._J = np.asarray(data["J"], dtype=np.float32)
+        self._J = np.ascontiguousarray(np.asarray(data["J"], dtype=np.float32))
         kt = np.asarray(data["kintree_table"])[0].tolist()
         self.parent = [-1] + [int(p) for p in kt[1:]]          # parent[0] = None in the reference (model.py:37)
         self._v_template = np.asarray(data["v_template"], dtype=np.float32) if "v_template" in data else None
         self._skinning_weights = np.asarray(data["weights"], dtype=np.float32) if "weights" in data else None
+        self._shapedirs = np.asarray(data["shapedirs"], dtype=np.float32) if "shapedirs" in data else None
+        self._J_regressor = _dense(data["J_regressor"]) if "J_regressor" in data else None
         self.face = data.get("f")
+        self.use_pose_blendshape = False
+        self.device = torch.device(device)
         self._net_ref = None
+        self._own = None              # body-only native handle (created on first use when not bound to a net)
 
     @classmethod
-    def synthetic(cls):
+    def synthetic(cls, device="cuda:0"):
         from .synthetic import synthetic_smpl
-        return cls(data=synthetic_smpl())
+        return cls(data=synthetic_smpl(), device=device)
 
     @property
     def J(self):
         return self._J
 
-    def get_zero_pose_joint_and_vertex(self):
-        """articulate/model.py:77-92 with shape=None: root-aligned joints and vertices."""
+    def get_zero_pose_joint_and_vertex(self, shape=None):
+        """articulate/model.py:77-92 with shape=None: root-aligned joints and vertices (host constants)."""
+        if shape is not None:
+            raise NotImplementedError("zero-pose joints for a given shape are computed on the GPU inside forward_kinematics")
         j = self._J - self._J[:1]
         v = None if self._v_template is None else self._v_template - self._J[:1]
         return j, v
 
+    # ---- native handle ---------------------------------------------------------------------------------------------
     def bind(self, net):
         """Attach the MobilePoserNet whose library handle (holding these constants on the GPU) runs FK.
         Held weakly: the net owns the body model, not the other way round."""
@@ -49,13 +75,89 @@ class ParametricModel:
     def _net(self):
         return self._net_ref() if self._net_ref is not None else None
 
+    def _handle(self):
+        """(lib, handle, device) of the native instance that holds this body's constants."""
+        net = self._net
+        if net is not None and net._h is not None:
+            return net._lib, net._h, net.device
+        if self._own is None:
+            lib = _lib.load()                                  # raises when the HIP library is not built
+            if self.device.type != "cuda":
+                raise RuntimeError("mobileposer_amd runs on an AMD GPU only (device=%s)" % self.device)
+            h = C.c_void_p()
+            parent = (C.c_int32 * 24)(*self.parent)
+            idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            _lib.check(lib.mp_create_body(C.byref(h), idx, parent, self._J.reshape(-1).ctypes.data_as(C.POINTER(C.c_float))), None)
+            self._own = h
+            self._own_state = {}
+            weakref.finalize(self, _destroy, lib, h)
+            upload_mesh(lib, h, self, self._own_state)
+        return _lib.load(), self._own, self.device
+
+    def close(self):
+        h, self._own = self._own, None
+        if h is not None:
+            _lib.load().mp_destroy(h)
+
     def forward_kinematics(self, pose, shape=None, tran=None, calc_mesh=False):
-        """articulate/model.py:208-240 on the GPU (mp_fk / mp_fk_mesh).  pose [N,24,3,3] (or reshapeable) cuda tensor."""
-        if shape is not None:
-            raise NotImplementedError("shape blend shapes are outside the hot path (mean shape only)")
-        if self._net is None:
-            raise RuntimeError("ParametricModel is not bound to a MobilePoserNet (no GPU handle)")
-        return self._net.forward_kinematics(pose, tran, calc_mesh=calc_mesh)
+        """articulate/model.py:208-240 on the GPU.  pose [N,24,3,3] (or reshapeable); shape None | [10] | [1,10] | [N,10];
+        tran None | [N,3] -> (R_global [N,24,3,3], joint [N,24,3]) and, with ``calc_mesh``, vertices [N,V,3]."""
+        lib, h, dev = self._handle()
+        net = self._net
+        state = net._mesh_state if (net is not None and net._h is not None) else self._own_state
+        return fk_call(lib, h, dev, state, pose, shape, tran, calc_mesh)
+
+
+def _destroy(lib, h):
+    try:
+        lib.mp_destroy(h)
+    except Exception:
+        pass
+
+
+def upload_mesh(lib, h, bm, state):
+    """mp_set_mesh / mp_set_shape_space for the handle ``h`` from the body model's constants; ``state`` records what the
+    handle holds (n_vertex, has_shape)."""
+    state["n_vertex"], state["has_shape"] = 0, False
+    if bm._v_template is None or bm._skinning_weights is None:
+        return
+    fp = C.POINTER(C.c_float)
+    vt = np.ascontiguousarray(bm._v_template, dtype=np.float32)
+    sw = np.ascontiguousarray(bm._skinning_weights, dtype=np.float32)
+    _lib.check(lib.mp_set_mesh(h, vt.ctypes.data_as(fp), sw.ctypes.data_as(fp), vt.shape[0]), h)
+    state["n_vertex"] = int(vt.shape[0])
+    if bm._shapedirs is not None and bm._J_regressor is not None:
+        sd = np.ascontiguousarray(bm._shapedirs, dtype=np.float32)
+        jr = np.ascontiguousarray(bm._J_regressor, dtype=np.float32)
+        if sd.shape == (vt.shape[0], 3, 10) and jr.shape == (24, vt.shape[0]):
+            _lib.check(lib.mp_set_shape_space(h, sd.ctypes.data_as(fp), jr.ctypes.data_as(fp)), h)
+            state["has_shape"] = True
+
+
+def fk_call(lib, h, dev, state, pose, shape, tran, calc_mesh):
+    f32 = torch.float32
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    p = torch.as_tensor(pose).to(device=dev, dtype=f32).reshape(-1, 24, 3, 3).contiguous()
+    N = p.shape[0]
+    t = None if tran is None else torch.as_tensor(tran).to(device=dev, dtype=f32).reshape(N, 3).contiguous()
+    Rg = torch.empty(N, 24, 3, 3, device=dev, dtype=f32)
+    jg = torch.empty(N, 24, 3, device=dev, dtype=f32)
+    V = state.get("n_vertex", 0)
+    if calc_mesh and not V:
+        raise RuntimeError("the body model has no mesh (v_template / weights) loaded")
+    vg = torch.empty(N, V, 3, device=dev, dtype=f32) if calc_mesh else None
+    if shape is not None:
+        if not state.get("has_shape"):
+            raise RuntimeError("the body model has no shape space (shapedirs / J_regressor) loaded")
+        sh = torch.as_tensor(shape).to(device=dev, dtype=f32).reshape(-1, 10).contiguous()
+        if sh.shape[0] not in (1, N):
+            raise RuntimeError("shape must expand to [%d, 10], got %s" % (N, tuple(sh.shape)))
+        _lib.check(lib.mp_fk_shape(h, _ptr(p), _ptr(sh), int(sh.shape[0]), _ptr(t), N, _ptr(Rg), _ptr(jg), _ptr(vg), stream), h)
+    elif calc_mesh:
+        _lib.check(lib.mp_fk_mesh(h, _ptr(p), _ptr(t), N, _ptr(Rg), _ptr(jg), _ptr(vg), stream), h)
+    else:
+        _lib.check(lib.mp_fk(h, _ptr(p), _ptr(t), N, _ptr(Rg), _ptr(jg), stream), h)
+    return (Rg, jg, vg) if calc_mesh else (Rg, jg)
 
 
 assert SMPL_PARENT[0] == -1

@@ -145,6 +145,7 @@ struct StreamCtx {
 struct mp_handle {
     int device = 0;
     std::string err;
+    bool has_weights = true;         // false: body-only handle (mp_create_body) -- kinematics entry points only
     ModuleW mod[4];
     int* parent_dev = nullptr;
     int* depth_dev = nullptr;
@@ -152,6 +153,11 @@ struct mp_handle {
     float* jrest_dev = nullptr;      // root-aligned rest joints [24,3]
     float* vrest_dev = nullptr;      // root-aligned template vertices [V,3] (mp_set_mesh)
     float* skinw_dev = nullptr;      // skinning weights [V,24]
+    float* vtpl_dev = nullptr;       // raw template vertices [V,3] (shape blending starts from these, model.py:86)
+    float* shapedirs_dev = nullptr;  // [V,3,10] (mp_set_shape_space)
+    float* jreg_dev = nullptr;       // dense J_regressor [24,V]
+    float* shape_ws = nullptr;       // mp_fk_shape workspace: vrest [ns][V][3] | jraw | jrest | bone [ns][72] each
+    size_t shape_ws_floats = 0;
     int n_vertex = 0;
     float J0[3] = {0, 0, 0};
     float floor_y = 0.f;
@@ -384,11 +390,13 @@ int setup_smpl(mp_handle* h, const int32_t parent[24], const float J[72]) {
 
 int create_common(mp_handle** out, int device, const float* blob, bool blob_on_device, size_t n_floats,
                   const int32_t parent[24], const float J[72]) {
-    if (!out || !blob || !parent || !J) return fail(nullptr, MP_ERR_INVALID, "mp_create: NULL argument");
-    if (n_floats != manifest_floats())
+    if (!out || !parent || !J) return fail(nullptr, MP_ERR_INVALID, "mp_create: NULL argument");
+    const bool body_only = blob == nullptr && n_floats == 0;
+    if (!body_only && (!blob || n_floats != manifest_floats()))
         return fail(nullptr, MP_ERR_INVALID, "mp_create: weight blob has %zu floats, expected %zu", n_floats, manifest_floats());
     mp_handle* h = new mp_handle();
     h->device = device;
+    h->has_weights = !body_only;
     auto bail = [&](int rc) { g_create_error = h->err; mp_destroy(h); return rc; };
     if (hipSetDevice(device) != hipSuccess) { h->err = "hipSetDevice failed"; return bail(MP_ERR_HIP); }
     if (const char* e = getenv("MP_GRAPH")) h->use_graph = e[0] && e[0] != '0';
@@ -466,6 +474,12 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     if (e != hipSuccess) { h->err = std::string("stream/event creation failed: ") + hipGetErrorString(e); return bail(MP_ERR_HIP); }
     float* staging = nullptr;
     const float* dev_blob = blob;
+    if (body_only) {
+        int rc_b = setup_smpl(h, parent, J);
+        if (rc_b) return bail(rc_b);
+        *out = h;
+        return MP_OK;
+    }
     if (!blob_on_device) {
         if (hipMalloc((void**)&staging, n_floats * sizeof(float)) != hipSuccess ||
             hipMemcpy(staging, blob, n_floats * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
@@ -1145,6 +1159,11 @@ int pending_device_error(mp_handle* h, const char* where) {
                 where, code);
 }
 
+int need_weights(mp_handle* h, const char* what) {
+    if (h->has_weights) return MP_OK;
+    return fail(h, MP_ERR_INVALID, "%s: this is a body-only handle (mp_create_body): it has no network weights", what);
+}
+
 int enter(mp_handle* h, void* stream) {
     if (int rc = pending_device_error(h, "mobileposer")) return rc;
     HIPCHK(h, hipSetDevice(h->device));
@@ -1186,6 +1205,10 @@ int mp_create_from_device(mp_handle** out, int device, const float* weights_dev,
     return create_common(out, device, weights_dev, true, n_floats, parent, J);
 }
 
+int mp_create_body(mp_handle** out, int device, const int32_t parent[24], const float J[72]) {
+    return create_common(out, device, nullptr, false, 0, parent, J);
+}
+
 void mp_destroy(mp_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
@@ -1217,7 +1240,8 @@ void mp_destroy(mp_handle* h) {
     }
     void* misc[] = {h->parent_dev, h->depth_dev, h->bone_dev, h->vstate.h, h->vstate.c, h->sc.window, h->sc.fresh,
                     h->sc.mask_dev, h->sc.st.last_foot, h->sc.st.root_y, h->sc.st.root_pos, h->sc.joints, h->sc.vel,
-                    h->sc.contact, h->jrest_dev, h->vrest_dev, h->skinw_dev, h->lin1_pv.Wp, h->lin1_pv.bias, h->prof_dev};
+                    h->sc.contact, h->jrest_dev, h->vrest_dev, h->skinw_dev, h->lin1_pv.Wp, h->lin1_pv.bias, h->prof_dev,
+                    h->vtpl_dev, h->shapedirs_dev, h->jreg_dev, h->shape_ws};
     for (void* p : misc) if (p) (void)hipFree(p);
     if (h->err_host) (void)hipHostFree(h->err_host);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -1241,6 +1265,7 @@ int mp_get_constants(const mp_handle* h, float* floor_y, float feet_pos[6]) {
 int mp_forward(mp_handle* h, const float* imu_dev, const int32_t* lengths_host, int B, int T, float* pose_dev,
                float* joints_dev, float* vel_dev, float* contact_dev, float* r6d_dev, void* stream) {
     if (!h) return MP_ERR_INVALID;
+    if (int rc = need_weights(h, "mp_forward")) return rc;
     if (!imu_dev || !lengths_host || !pose_dev || !joints_dev || !vel_dev || !contact_dev || B < 1 || T < 1)
         return fail(h, MP_ERR_INVALID, "mp_forward: NULL buffer or non-positive shape");
     if (h->vstate.B != 0 && h->vstate.B != B)
@@ -1276,6 +1301,7 @@ int mp_forward_offline(mp_handle* h, const float* imu_dev, const int32_t* length
                        float* joints_dev, float* vel_dev, float* contact_dev, float* tran_dev, float* rglobal_dev,
                        float* joint_dev, void* stream) {
     if (!h) return MP_ERR_INVALID;
+    if (int rc = need_weights(h, "mp_forward_offline")) return rc;
     if (!imu_dev || !lengths_host || !pose_dev || !joints_dev || !vel_dev || !contact_dev || !tran_dev || B < 1 || T < 1 ||
         ((rglobal_dev == nullptr) != (joint_dev == nullptr)))
         return fail(h, MP_ERR_INVALID, "mp_forward_offline: NULL buffer or non-positive shape");
@@ -1313,6 +1339,7 @@ int mp_forward_offline(mp_handle* h, const float* imu_dev, const int32_t* length
 int mp_rnn_forward(mp_handle* h, int module, const float* x_dev, const int32_t* lengths_host, int B, int T,
                    float* y_dev, const float* state_in_dev, float* state_out_dev, void* stream) {
     if (!h) return MP_ERR_INVALID;
+    if (int rc = need_weights(h, "mp_rnn_forward")) return rc;
     if (module < 0 || module > 3 || !x_dev || !y_dev || !lengths_host || B < 1 || T < 1)
         return fail(h, MP_ERR_INVALID, "mp_rnn_forward: bad argument");
     if (int rc = enter(h, stream)) return rc;
@@ -1365,9 +1392,11 @@ int mp_set_mesh(mp_handle* h, const float* v_template_host, const float* weights
     if (!h || !v_template_host || !weights_host || n_vertex < 1) return h ? fail(h, MP_ERR_INVALID, "mp_set_mesh: bad argument") : MP_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());
-    if (h->vrest_dev) (void)hipFree(h->vrest_dev);
-    if (h->skinw_dev) (void)hipFree(h->skinw_dev);
-    h->vrest_dev = h->skinw_dev = nullptr; h->n_vertex = 0;
+    for (float** q : {&h->vrest_dev, &h->skinw_dev, &h->vtpl_dev, &h->shapedirs_dev, &h->jreg_dev}) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
+    h->n_vertex = 0;
     std::vector<float> v((size_t)n_vertex * 3);
     for (int i = 0; i < n_vertex; ++i)
         for (int c = 0; c < 3; ++c) v[(size_t)i * 3 + c] = v_template_host[(size_t)i * 3 + c] - h->J0[c];   // model.py:87
@@ -1375,8 +1404,60 @@ int mp_set_mesh(mp_handle* h, const float* v_template_host, const float* weights
     if (int rc = dev_alloc(h, (void**)&h->skinw_dev, (size_t)n_vertex * 24 * sizeof(float))) return rc;
     HIPCHK(h, hipMemcpy(h->vrest_dev, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->skinw_dev, weights_host, (size_t)n_vertex * 24 * sizeof(float), hipMemcpyHostToDevice));
+    if (int rc = dev_alloc(h, (void**)&h->vtpl_dev, v.size() * sizeof(float))) return rc;
+    HIPCHK(h, hipMemcpy(h->vtpl_dev, v_template_host, v.size() * sizeof(float), hipMemcpyHostToDevice));
     h->n_vertex = n_vertex;
     return MP_OK;
+}
+
+int mp_set_shape_space(mp_handle* h, const float* shapedirs_host, const float* j_regressor_host) {
+    if (!h || !shapedirs_host || !j_regressor_host) return h ? fail(h, MP_ERR_INVALID, "mp_set_shape_space: bad argument") : MP_ERR_INVALID;
+    if (!h->n_vertex) return fail(h, MP_ERR_INVALID, "mp_set_shape_space before mp_set_mesh");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    for (float** q : {&h->shapedirs_dev, &h->jreg_dev}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    const size_t V = (size_t)h->n_vertex;
+    if (int rc = dev_alloc(h, (void**)&h->shapedirs_dev, V * 30 * sizeof(float))) return rc;
+    if (int rc = dev_alloc(h, (void**)&h->jreg_dev, V * 24 * sizeof(float))) return rc;
+    HIPCHK(h, hipMemcpy(h->shapedirs_dev, shapedirs_host, V * 30 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->jreg_dev, j_regressor_host, V * 24 * sizeof(float), hipMemcpyHostToDevice));
+    return MP_OK;
+}
+
+int mp_fk_shape(mp_handle* h, const float* pose_dev, const float* shape_dev, int n_shape, const float* tran_dev, int64_t N,
+                float* rglobal_dev, float* joint_dev, float* vert_dev, void* stream) {
+    if (!h || !pose_dev || !shape_dev || !rglobal_dev || !joint_dev || N < 0 || !(n_shape == 1 || n_shape == N))
+        return h ? fail(h, MP_ERR_INVALID, "mp_fk_shape: bad argument (n_shape must be 1 or N)") : MP_ERR_INVALID;
+    if (!h->shapedirs_dev) return fail(h, MP_ERR_INVALID, "mp_fk_shape before mp_set_shape_space");
+    if (N == 0) return MP_OK;
+    const size_t V = (size_t)h->n_vertex, ns = (size_t)n_shape;
+    const size_t need = ns * (V * 3 + 3 * 72);
+    if (need > h->shape_ws_floats) {
+        HIPCHK(h, hipSetDevice(h->device));
+        HIPCHK(h, hipDeviceSynchronize());
+        if (h->shape_ws) (void)hipFree(h->shape_ws);
+        h->shape_ws = nullptr; h->shape_ws_floats = 0;
+        if (int rc = dev_alloc(h, (void**)&h->shape_ws, need * sizeof(float))) return rc;
+        h->shape_ws_floats = need;
+    }
+    if (int rc = enter(h, stream)) return rc;
+    float* vrest = h->shape_ws;
+    float* jraw = vrest + ns * V * 3;
+    float* jrest = jraw + ns * 72;
+    float* bone = jrest + ns * 72;
+    mp_launch_shape_body(shape_dev, n_shape, h->shapedirs_dev, h->vtpl_dev, h->jreg_dev, h->parent_dev, h->n_vertex, vrest,
+                         jraw, jrest, bone, h->s_main);                                       // model.py:84-89
+    const long bstride = n_shape == 1 ? 0 : 72, vstride = n_shape == 1 ? 0 : (long)V * 3;
+    mp_launch_fk(pose_dev, tran_dev, (long)N, bone, h->parent_dev, h->depth_dev, rglobal_dev, joint_dev, h->s_main, bstride);
+    if (vert_dev)
+        for (int64_t n0 = 0; n0 < N; n0 += 32768) {
+            const long cnt = (long)(N - n0 < 32768 ? N - n0 : 32768);
+            mp_launch_lbs(rglobal_dev + n0 * 216, joint_dev + n0 * 72, tran_dev ? tran_dev + n0 * 3 : nullptr, cnt,
+                          jrest + n0 * bstride, bstride, vrest + n0 * vstride, vstride, h->skinw_dev, h->n_vertex,
+                          vert_dev + n0 * h->n_vertex * 3, h->s_main);
+        }
+    HIPCHK(h, hipGetLastError());
+    return leave(h, stream);
 }
 
 int mp_fk_mesh(mp_handle* h, const float* pose_dev, const float* tran_dev, int64_t N, float* rglobal_dev, float* joint_dev,
@@ -1388,7 +1469,7 @@ int mp_fk_mesh(mp_handle* h, const float* pose_dev, const float* tran_dev, int64
     for (int64_t n0 = 0; n0 < N; n0 += 32768) {                   // grid.y limit
         const long cnt = (long)(N - n0 < 32768 ? N - n0 : 32768);
         mp_launch_lbs(rglobal_dev + n0 * 216, joint_dev + n0 * 72, tran_dev ? tran_dev + n0 * 3 : nullptr, cnt, h->jrest_dev,
-                      h->vrest_dev, h->skinw_dev, h->n_vertex, vert_dev + n0 * h->n_vertex * 3, h->s_main);
+                      0, h->vrest_dev, 0, h->skinw_dev, h->n_vertex, vert_dev + n0 * h->n_vertex * 3, h->s_main);
     }
     HIPCHK(h, hipGetLastError());
     return leave(h, stream);
@@ -1427,6 +1508,7 @@ int mp_set_velocity_state(mp_handle* h, const float* state_dev, int batch) {
 // ------------------------------------------------------------------------------------------ streaming
 int mp_stream_create(mp_handle* h, int S) {
     if (!h || S < 1) return h ? fail(h, MP_ERR_INVALID, "mp_stream_create: S must be positive") : MP_ERR_INVALID;
+    if (int rc = need_weights(h, "mp_stream_create")) return rc;
     HIPCHK(h, hipSetDevice(h->device));
     StreamCtx& c = h->sc;
     if (c.S) return fail(h, MP_ERR_INVALID, "streams already created (S = %d)", c.S);

@@ -154,12 +154,20 @@ void mp_launch_r6d_ik(const float* r6d, long N, float* pose, const int* parent_d
 // frame n reads its 96 numbers at r6d + n*rowStride + rowOffset
 void mp_launch_r6d_ik_strided(const float* r6d, long N, long rowStride, long rowOffset, float* pose,
                               const int* parent_dev, hipStream_t s);
+// boneStride: 0 = one body (bone_dev [24][3]) for all frames, 72 = frame n uses bone_dev + n*72 (per-frame shapes)
 void mp_launch_fk(const float* pose, const float* tran, long N, const float* bone_dev, const int* parent_dev,
-                  const int* depth_dev, float* rglobal, float* joint, hipStream_t s);
+                  const int* depth_dev, float* rglobal, float* joint, hipStream_t s, long boneStride = 0);
 
-// linear blend skinning on mp_fk's outputs (joint already translated by tran); grid.y = N frames (<= 65535 per launch)
+// linear blend skinning on mp_fk's outputs (joint already translated by tran); grid.y = N frames (<= 65535 per launch);
+// jrestStride / vrestStride: floats between the rest joints / rest vertices of consecutive frames (0 = shared body)
 void mp_launch_lbs(const float* rglobal, const float* joint, const float* tran, long N, const float* jrest_dev,
-                   const float* vrest_dev, const float* weights_dev, int V, float* vert, hipStream_t s);
+                   long jrestStride, const float* vrest_dev, long vrestStride, const float* weights_dev, int V,
+                   float* vert, hipStream_t s);
+// zero-pose bodies of ns shapes (articulate/model.py:84-89): vrest [ns][V][3] and jrest [ns][24][3] root-aligned,
+// bone [ns][24][3]; jraw [ns][24][3] is scratch
+void mp_launch_shape_body(const float* shape, int ns, const float* shapedirs, const float* vtemplate_raw,
+                          const float* jreg, const int* parent_dev, int V, float* vrest, float* jraw, float* jrest,
+                          float* bone, hipStream_t s);
 
 // ---------------------------------------------------------------- live front-end (mp_live.hip)
 // raw sensor samples of S streams -> network input frames [S,60] (live_demo.py:213-236)

@@ -86,8 +86,10 @@ MP_KERNEL __launch_bounds__(256) void mp_r6d_ik(const float* __restrict__ r6d, l
 }
 
 // lanes = joints, 2 frames per wave; bone[24][3] = j_i - j_parent(i) (bone[0] = j_0 = 0), depth[24]
+// (boneStride: 0 = one body for all frames; 72 = frame n uses bone + n*72, forward_kinematics with per-frame shapes)
 MP_KERNEL __launch_bounds__(256) void mp_fk(const float* __restrict__ pose, const float* __restrict__ tran, long N,
-                                              const float* __restrict__ bone, const int* __restrict__ parent,
+                                              const float* __restrict__ bone, long boneStride,
+                                              const int* __restrict__ parent,
                                               const int* __restrict__ depth, float* __restrict__ rglobal,
                                               float* __restrict__ joint) {
     const int lane = threadIdx.x & 63;
@@ -100,7 +102,8 @@ MP_KERNEL __launch_bounds__(256) void mp_fk(const float* __restrict__ pose, cons
         const float* src = pose + (n * 24 + i) * 9;
 #pragma unroll
         for (int k = 0; k < 9; ++k) { L[k] = src[k]; G[k] = L[k]; }
-        bv[0] = bone[i * 3 + 0]; bv[1] = bone[i * 3 + 1]; bv[2] = bone[i * 3 + 2];
+        const float* bn = bone + n * boneStride;
+        bv[0] = bn[i * 3 + 0]; bv[1] = bn[i * 3 + 1]; bv[2] = bn[i * 3 + 2];
         p[0] = bv[0]; p[1] = bv[1]; p[2] = bv[2];
         par = i > 0 ? parent[i] : 0;
         dep = depth[i];
@@ -144,10 +147,13 @@ MP_KERNEL __launch_bounds__(256) void mp_fk(const float* __restrict__ pose, cons
 // 12 B per vertex written, weights / template stay in L2.
 MP_KERNEL __launch_bounds__(256) void mp_lbs(const float* __restrict__ rglobal, const float* __restrict__ joint,
                                                const float* __restrict__ tran, const float* __restrict__ jrest,
-                                               const float* __restrict__ vrest, const float* __restrict__ weights,
+                                               long jrestStride, const float* __restrict__ vrest, long vrestStride,
+                                               const float* __restrict__ weights,
                                                int V, float* __restrict__ vert) {
     __shared__ float T[24 * 12];
     const long n = blockIdx.y;
+    jrest += n * jrestStride;
+    vrest += n * vrestStride;
     float tx = 0.f, ty = 0.f, tz = 0.f;
     if (tran) { tx = tran[n * 3 + 0]; ty = tran[n * 3 + 1]; tz = tran[n * 3 + 2]; }
     if (threadIdx.x < 24) {
@@ -182,13 +188,82 @@ MP_KERNEL __launch_bounds__(256) void mp_lbs(const float* __restrict__ rglobal, 
     o[2] = m[8] * vx + m[9] * vy + m[10] * vz + m[11] + tz;
 }
 
+// ---- zero-pose body of a given shape: ParametricModel.get_zero_pose_joint_and_vertex(shape) (articulate/model.py:84-89)
+//   v = shapedirs . shape + v_template;  j = J_regressor v;  j, v = j - j[0], v - j[0];  bone_i = j_i - j_parent(i)
+// three small kernels per call (ns = 1 or N bodies); the results feed mp_fk / mp_lbs through their per-frame strides.
+MP_KERNEL __launch_bounds__(256) void mp_shape_verts(const float* __restrict__ shape, int ns,
+                                                       const float* __restrict__ shapedirs,
+                                                       const float* __restrict__ vtemplate, int V,
+                                                       float* __restrict__ vraw) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;        // (body, vertex, component)
+    if (gid >= (long)ns * V * 3) return;
+    const long sidx = gid / ((long)V * 3);
+    const long vc = gid - sidx * (long)V * 3;
+    const float* sd = shapedirs + vc * 10;
+    const float* sh = shape + sidx * 10;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc += sh[k] * sd[k];
+    vraw[gid] = acc + vtemplate[vc];
+}
+
+MP_KERNEL __launch_bounds__(256) void mp_shape_joints(const float* __restrict__ vraw, const float* __restrict__ jreg,
+                                                        int V, float* __restrict__ jraw) {
+    __shared__ float red[3][256];
+    const int j = blockIdx.x;                          // joint
+    const long sidx = blockIdx.y;                      // body
+    const float* v = vraw + sidx * (long)V * 3;
+    const float* w = jreg + (long)j * V;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int k = threadIdx.x; k < V; k += 256) {
+        const float wk = w[k];
+        a0 += wk * v[k * 3 + 0]; a1 += wk * v[k * 3 + 1]; a2 += wk * v[k * 3 + 2];
+    }
+    red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1; red[2][threadIdx.x] = a2;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st)
+            for (int c = 0; c < 3; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) jraw[(sidx * 24 + j) * 3 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+MP_KERNEL __launch_bounds__(256) void mp_shape_align(float* __restrict__ v, const float* __restrict__ jraw,
+                                                       const int* __restrict__ parent, int V,
+                                                       float* __restrict__ jrest, float* __restrict__ bone) {
+    const long sidx = blockIdx.y;
+    const float* jr = jraw + sidx * 72;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < V * 3) v[sidx * (long)V * 3 + k] -= jr[k % 3];
+    if (blockIdx.x == 0 && threadIdx.x < 72) {
+        const int i = threadIdx.x / 3, c = threadIdx.x % 3;
+        const float ji = jr[i * 3 + c] - jr[c];
+        jrest[sidx * 72 + threadIdx.x] = ji;
+        bone[sidx * 72 + threadIdx.x] = i == 0 ? ji : ji - (jr[parent[i] * 3 + c] - jr[c]);
+    }
+}
+
 }  // namespace
 
+void mp_launch_shape_body(const float* shape, int ns, const float* shapedirs, const float* vtemplate_raw,
+                          const float* jreg, const int* parent_dev, int V, float* vrest, float* jraw, float* jrest,
+                          float* bone, hipStream_t s) {
+    if (ns <= 0 || V <= 0) return;
+    const long n = (long)ns * V * 3;
+    hipLaunchKernelGGL(mp_shape_verts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, shape, ns, shapedirs,
+                       vtemplate_raw, V, vrest);
+    hipLaunchKernelGGL(mp_shape_joints, dim3(24, (unsigned)ns), dim3(256), 0, s, vrest, jreg, V, jraw);
+    hipLaunchKernelGGL(mp_shape_align, dim3((V * 3 + 255) / 256, (unsigned)ns), dim3(256), 0, s, vrest, jraw, parent_dev,
+                       V, jrest, bone);
+}
+
 void mp_launch_lbs(const float* rglobal, const float* joint, const float* tran, long N, const float* jrest_dev,
-                   const float* vrest_dev, const float* weights_dev, int V, float* vert, hipStream_t s) {
+                   long jrestStride, const float* vrest_dev, long vrestStride, const float* weights_dev, int V,
+                   float* vert, hipStream_t s) {
     if (N <= 0 || V <= 0) return;
     hipLaunchKernelGGL(mp_lbs, dim3((V + 255) / 256, (unsigned)N), dim3(256), 0, s, rglobal, joint, tran, jrest_dev,
-                       vrest_dev, weights_dev, V, vert);
+                       jrestStride, vrest_dev, vrestStride, weights_dev, V, vert);
 }
 
 void mp_launch_r6d_ik_strided(const float* r6d, long N, long rowStride, long rowOffset, float* pose,
@@ -204,9 +279,9 @@ void mp_launch_r6d_ik(const float* r6d, long N, float* pose, const int* parent_d
 }
 
 void mp_launch_fk(const float* pose, const float* tran, long N, const float* bone_dev, const int* parent_dev,
-                  const int* depth_dev, float* rglobal, float* joint, hipStream_t s) {
+                  const int* depth_dev, float* rglobal, float* joint, hipStream_t s, long boneStride) {
     if (N <= 0) return;
     const long blocks = (N + 7) / 8;   // 4 waves x 2 frames per block
-    hipLaunchKernelGGL(mp_fk, dim3((unsigned)blocks), dim3(256), 0, s, pose, tran, N, bone_dev, parent_dev, depth_dev,
-                       rglobal, joint);
+    hipLaunchKernelGGL(mp_fk, dim3((unsigned)blocks), dim3(256), 0, s, pose, tran, N, bone_dev, boneStride, parent_dev,
+                       depth_dev, rglobal, joint);
 }

@@ -14,31 +14,13 @@ targets, data.py:82-93) belongs to training and raises.
 import numpy as np
 import torch
 
-from .config import SMPL_PARENT, amass, datasets, paths
+from .config import amass, datasets, paths
 
 
 def rotation_matrix_to_r6d(r):
     """articulate/math/angular.py:185-192: the six numbers are the first two COLUMNS of R, column after column."""
     m = torch.as_tensor(r).reshape(-1, 3, 3)
     return torch.cat((m[:, :, 0], m[:, :, 1]), dim=1)
-
-
-def forward_kinematics_host(pose, J, parent=SMPL_PARENT):
-    """Joint positions of a local pose [N,24,3,3] on the host (what data.py:64 needs at load time): the tree is walked
-    level by level, every joint's global rotation and position from its parent's (articulate/model.py:208-232, mean shape,
-    no translation).  Returns (R_global [N,24,3,3], joint [N,24,3])."""
-    pose = torch.as_tensor(pose, dtype=torch.float32).reshape(-1, 24, 3, 3)
-    j = torch.as_tensor(np.asarray(J, dtype=np.float32))
-    j = j - j[:1]
-    R = [None] * 24
-    p = [None] * 24
-    R[0] = pose[:, 0]
-    p[0] = j[0].expand(pose.shape[0], 3)
-    for i in range(1, 24):
-        a = parent[i]
-        R[i] = R[a] @ pose[:, i]
-        p[i] = p[a] + (R[a] @ (j[i] - j[a]).reshape(3, 1)).squeeze(-1)
-    return torch.stack(R, dim=1), torch.stack(p, dim=1)
 
 
 def combo_masks(combos=None):
@@ -54,11 +36,13 @@ class PoseDataset:
     def __init__(self, fold='train', evaluate=None, finetune=None, data=None, fk=None, combos=None, smpl=None):
         """Reference signature ``PoseDataset(fold, evaluate, finetune)`` (data.py:19).  Extras, all optional: ``data`` -- an
         already-loaded dataset dict or a path instead of the configured file; ``fk`` -- callable pose -> (R_global, joint)
-        for the ground-truth joints (e.g. ``MobilePoserNet.forward_kinematics``: GPU); default is the host walk above on
-        the SMPL joints of ``smpl`` / ``paths.smpl_file`` / the synthetic body; ``combos`` -- a subset of ``amass.combos``."""
+        for the ground-truth joints (e.g. ``MobilePoserNet.forward_kinematics``); default: what the reference does at
+        data.py:24,64 -- a ``ParametricModel`` of ``smpl`` / ``paths.smpl_file`` (synthetic body when that file is absent)
+        whose forward kinematics run on the GPU (mp_fk); ``combos`` -- a subset of ``amass.combos``."""
         self.fold, self.evaluate, self.finetune = fold, evaluate, finetune
         self.combos = list((combos if combos is not None else amass.combos).items())
-        self._fk = fk if fk is not None else self._host_fk(smpl)
+        self.bodymodel = None
+        self._fk = fk if fk is not None else self._body_fk(smpl)
         self.data = {k: [] for k in ('imu_inputs', 'pose_outputs', 'joint_outputs', 'tran_outputs')}
         for file_data in self._sources(data):
             self._add_file(file_data, combo_masks(dict(self.combos)))
@@ -83,16 +67,15 @@ class PoseDataset:
             except Exception as e:
                 print(f"Error processing {name}: {e}.")
 
-    @staticmethod
-    def _host_fk(smpl):
+    def _body_fk(self, smpl):
         import os
         from .body_model import ParametricModel
         if smpl is None:
             smpl = ParametricModel(str(paths.smpl_file)) if os.path.exists(str(paths.smpl_file)) else ParametricModel.synthetic()
         elif not isinstance(smpl, ParametricModel):
             smpl = ParametricModel(data=smpl)
-        J, parent = smpl.J, smpl.parent
-        return lambda pose: forward_kinematics_host(pose, J, parent)
+        self.bodymodel = smpl                                           # data.py:24
+        return smpl.forward_kinematics
 
     # ---- one file: every sequence x every combo (data.py:57-85) -----------------------------------------------------
     def _add_file(self, fd, masks):

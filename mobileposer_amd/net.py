@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .body_model import ParametricModel
+from .body_model import ParametricModel, fk_call, upload_mesh
 from .config import joint_set, model_config, paths
 from .manifest import state_dict_manifest
 from .model_utils import blob_to_state_dict, state_dict_to_blob
@@ -88,13 +88,13 @@ class MobilePoserNet:
         self.finetune = finetune
         # body model (net.py:37-38)
         if smpl is not None:
-            self.bodymodel = smpl if isinstance(smpl, ParametricModel) else ParametricModel(data=smpl)
+            self.bodymodel = smpl if isinstance(smpl, ParametricModel) else ParametricModel(data=smpl, device=device)
         elif smpl_file is not None:
-            self.bodymodel = ParametricModel(smpl_file)
+            self.bodymodel = ParametricModel(smpl_file, device=device)
         elif os.path.exists(str(paths.smpl_file)):             # the reference always reads paths.smpl_file (net.py:37)
-            self.bodymodel = ParametricModel(str(paths.smpl_file))
+            self.bodymodel = ParametricModel(str(paths.smpl_file), device=device)
         else:                                                  # licensed file absent: synthetic body
-            self.bodymodel = ParametricModel.synthetic()
+            self.bodymodel = ParametricModel.synthetic(device=device)
         self.bodymodel.bind(self)
         # base joints (net.py:47-49)
         self.j, _ = self.bodymodel.get_zero_pose_joint_and_vertex()
@@ -163,14 +163,9 @@ class MobilePoserNet:
         _lib.check(self._lib.mp_get_constants(self._h, C.byref(fy), fp), self._h)
         assert abs(fy.value - self.floor_y) < 1e-6
         self._stream_S = 0
-        self.n_vertex = 0
-        bm = self.bodymodel
-        if getattr(bm, "_v_template", None) is not None and getattr(bm, "_skinning_weights", None) is not None:
-            vt = np.ascontiguousarray(bm._v_template, dtype=np.float32)
-            sw = np.ascontiguousarray(bm._skinning_weights, dtype=np.float32)
-            _lib.check(self._lib.mp_set_mesh(self._h, vt.ctypes.data_as(C.POINTER(C.c_float)),
-                                             sw.ctypes.data_as(C.POINTER(C.c_float)), vt.shape[0]), self._h)
-            self.n_vertex = int(vt.shape[0])
+        self._mesh_state = {}
+        upload_mesh(self._lib, self._h, self.bodymodel, self._mesh_state)
+        self.n_vertex = self._mesh_state["n_vertex"]
 
     def close(self):
         """Release the native handle (weights, workspaces, streams, graphs).  Idempotent."""
@@ -396,23 +391,12 @@ class MobilePoserNet:
         _lib.check(self._lib.mp_reduced_global_to_full(self._h, _ptr(r), r.shape[0], _ptr(out), self._stream()), self._h)
         return out
 
-    def forward_kinematics(self, pose, tran=None, calc_mesh=False):
+    def forward_kinematics(self, pose, tran=None, calc_mesh=False, shape=None):
         """articulate/model.py:208-240: local pose [N,24,3,3] -> (R_global [N,24,3,3], joint [N,24,3])
-        and, with ``calc_mesh``, the skinned vertices [N,V,3] (mean shape, no pose blendshape)."""
+        and, with ``calc_mesh``, the skinned vertices [N,V,3] (no pose blendshape); ``shape`` [10] | [1,10] | [N,10]
+        selects the body (None = mean shape)."""
         self._require_weights()
-        p = pose.to(device=self.device, dtype=torch.float32).reshape(-1, 24, 3, 3).contiguous()
-        N = p.shape[0]
-        t = None if tran is None else tran.to(device=self.device, dtype=torch.float32).reshape(N, 3).contiguous()
-        Rg = torch.empty(N, 24, 3, 3, device=self.device, dtype=torch.float32)
-        jg = torch.empty(N, 24, 3, device=self.device, dtype=torch.float32)
-        if not calc_mesh:
-            _lib.check(self._lib.mp_fk(self._h, _ptr(p), _ptr(t), N, _ptr(Rg), _ptr(jg), self._stream()), self._h)
-            return Rg, jg
-        if not self.n_vertex:
-            raise RuntimeError("the body model has no mesh (v_template / weights) loaded")
-        vg = torch.empty(N, self.n_vertex, 3, device=self.device, dtype=torch.float32)
-        _lib.check(self._lib.mp_fk_mesh(self._h, _ptr(p), _ptr(t), N, _ptr(Rg), _ptr(jg), _ptr(vg), self._stream()), self._h)
-        return Rg, jg, vg
+        return fk_call(self._lib, self._h, self.device, self._mesh_state, pose, shape, tran, calc_mesh)
 
     def rnn_forward(self, module, x, input_lengths, state=None):
         """RNN.forward of one sub-module (models/rnn.py:20-33): -> (y [B,T,n_out], (h_n, c_n))."""

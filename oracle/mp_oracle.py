@@ -207,6 +207,49 @@ def forward_kinematics_mesh(pose, smpl, parent=PARENT, tran=None):
     return Rg, pg, vert
 
 
+def shaped_body(smpl, shape):
+    """ParametricModel.get_zero_pose_joint_and_vertex(shape) (articulate/model.py:84-89):
+    v = shapedirs . shape + v_template;  j = J_regressor v;  j, v = j - j[0], v - j[0].
+    shape [S,10] -> (j [S,24,3], v [S,V,3]), both root-aligned."""
+    shape = np.asarray(shape, dtype=F32).reshape(-1, 10)
+    sd = np.asarray(smpl["shapedirs"], dtype=F32)                              # [V,3,10]
+    jreg = smpl["J_regressor"]
+    jreg = np.asarray(jreg.toarray() if hasattr(jreg, "toarray") else jreg, dtype=F32)   # model.py:29
+    v = (np.einsum("sk,vck->svc", shape, sd) + np.asarray(smpl["v_template"], dtype=F32)).astype(F32)
+    j = np.einsum("jv,svc->sjc", jreg, v).astype(F32)
+    return (j - j[:, :1]).astype(F32), (v - j[:, :1]).astype(F32)
+
+
+def forward_kinematics_shape(pose, smpl, shape, parent=PARENT, tran=None):
+    """ParametricModel.forward_kinematics with shape != None, calc_mesh=True (articulate/model.py:208-240).
+    shape [10] | [1,10] | [N,10].  Returns R_global [N,24,3,3], joint [N,24,3], vert [N,V,3]."""
+    pose = np.asarray(pose, dtype=F32).reshape(-1, 24, 3, 3)
+    N = pose.shape[0]
+    j, v = shaped_body(smpl, shape)
+    j = np.broadcast_to(j, (N, 24, 3))
+    v = np.broadcast_to(v, (N,) + v.shape[1:])
+    bone = j.copy()
+    for i in range(1, 24):
+        bone[:, i] = j[:, i] - j[:, parent[i]]
+    Rg = np.empty((N, 24, 3, 3), dtype=F32)
+    pg = np.empty((N, 24, 3), dtype=F32)
+    Rg[:, 0] = pose[:, 0]
+    pg[:, 0] = bone[:, 0]
+    for i in range(1, 24):
+        p = parent[i]
+        Rg[:, i] = np.matmul(Rg[:, p], pose[:, i])
+        pg[:, i] = (np.einsum("nab,nb->na", Rg[:, p], bone[:, i]) + pg[:, p]).astype(F32)
+    tg = pg - np.einsum("njab,njb->nja", Rg, j)
+    W = np.asarray(smpl["weights"], dtype=F32)
+    Rv = np.einsum("njab,vj->nvab", Rg, W)
+    tv = np.einsum("nja,vj->nva", tg, W)
+    vert = (np.einsum("nvab,nvb->nva", Rv, v) + tv).astype(F32)
+    if tran is not None:
+        t = np.asarray(tran, dtype=F32).reshape(-1, 1, 3)
+        pg, vert = pg + t, vert + t
+    return Rg, pg, vert
+
+
 # --------------------------------------------------------------------------------------------
 # a6/a8/a9: the orchestrator with its state (models/net.py)
 # --------------------------------------------------------------------------------------------

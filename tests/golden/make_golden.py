@@ -310,6 +310,22 @@ def main():
             g11[f"s{k}_{name}"] = v
     np.savez_compressed(os.path.join(HERE, "g11_evaluate.npz"), **g11)
 
+    # ---- G12 forward kinematics with shape blending (articulate/model.py:84-89,208-240) -------------------------
+    rng = np.random.Generator(np.random.PCG64(12))
+    n12 = 9
+    pose12 = synthetic._random_rotations(rng, n12 * 24).reshape(n12, 24, 3, 3).astype(np.float32)
+    tran12 = rng.standard_normal((n12, 3)).astype(np.float32)
+    g12 = {"pose": pose12, "tran": tran12}
+    with torch.no_grad():
+        for tag, shp in (("one", (rng.standard_normal(10) * 1.5).astype(np.float32)),
+                         ("per", (rng.standard_normal((n12, 10)) * 1.5).astype(np.float32))):
+            Rg, jg, vg = net.bodymodel.forward_kinematics(torch.from_numpy(pose12), shape=torch.from_numpy(shp),
+                                                          tran=torch.from_numpy(tran12), calc_mesh=True)
+            _, jg0 = net.bodymodel.forward_kinematics(torch.from_numpy(pose12), shape=torch.from_numpy(shp))
+            g12[f"{tag}_shape"], g12[f"{tag}_R"], g12[f"{tag}_joint"] = shp, Rg.numpy(), jg.numpy()
+            g12[f"{tag}_vert"], g12[f"{tag}_joint_notran"] = vg.numpy(), jg0.numpy()
+    np.savez_compressed(os.path.join(HERE, "g12_fk_shape.npz"), **g12)
+
     print("golden vectors written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         print("  %-24s %8d B" % (fn, os.path.getsize(os.path.join(HERE, fn))))

@@ -30,16 +30,20 @@ def test_g8_dataset_formation(smpl):
 
 def test_reference_constructor_reads_the_configured_file(smpl, tmp_path, monkeypatch):
     """PoseDataset(fold='test', evaluate='dip') as evaluate.py:124 calls it: resolves
-    paths.processed_datasets/eval/dip_test.pt (config.py:33-34,104-108) and computes the ground-truth joints with the host
-    tree walk (no GPU, no callable)."""
+    paths.processed_datasets/eval/dip_test.pt (config.py:33-34,104-108).  The ground-truth joints come from a callable
+    here (the oracle, test-side): the default -- a GPU ParametricModel -- is exercised by tests/test_gpu_boundary.py."""
     from mobileposer_amd import config
-    from mobileposer_amd.data import forward_kinematics_host
     g = load_golden("g8_dataset.npz")
     data = {k: [torch.from_numpy(g[f"in{i}_{k}"]) for i in range(2)] for k in ("acc", "ori", "pose", "tran")}
     (tmp_path / "eval").mkdir()
     torch.save(data, tmp_path / "eval" / "dip_test.pt")
     monkeypatch.setattr(config.paths, "processed_datasets", tmp_path)
-    ds = PoseDataset(fold='test', evaluate='dip', smpl=smpl)
+
+    def fk(pose):
+        Rg, jg = O.forward_kinematics(pose.numpy(), smpl["J"])
+        return torch.from_numpy(Rg), torch.from_numpy(jg)
+
+    ds = PoseDataset(fold='test', evaluate='dip', fk=fk)
     assert len(ds) == 24
     for idx in (0, 5, 13, 23):
         imu, pose, joint, tran = ds[idx]
@@ -48,10 +52,6 @@ def test_reference_constructor_reads_the_configured_file(smpl, tmp_path, monkeyp
         assert np.abs(joint.numpy() - g[f"item{idx}_joint"]).max() < 1e-5
     import pytest
     with pytest.raises(ValueError):
-        PoseDataset(fold='test', evaluate='nope')
+        PoseDataset(fold='test', evaluate='nope', fk=fk)
     with pytest.raises(ValueError):
-        PoseDataset(fold='dev')
-    # the host tree walk against the reference's FK golden
-    g6 = load_golden("g6_fk.npz")
-    Rg, jg = forward_kinematics_host(torch.from_numpy(g6["pose"]), smpl["J"])
-    assert np.abs(Rg.numpy() - g6["R_global"]).max() < 1e-5 and np.abs(jg.numpy() - g6["joint"]).max() < 1e-5
+        PoseDataset(fold='dev', fk=fk)

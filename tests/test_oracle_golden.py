@@ -136,6 +136,18 @@ def test_g6_fk(smpl):
     assert np.abs(vg2 - g["vert_tran"]).max() < TIGHT
 
 
+def test_g12_fk_with_shape(smpl):
+    """forward_kinematics(pose, shape, tran, calc_mesh=True) -- one shared shape and a shape per frame."""
+    g = load_golden("g12_fk_shape.npz")
+    for tag in ("one", "per"):
+        Rg, jg, vg = O.forward_kinematics_shape(g["pose"], smpl, g[f"{tag}_shape"], tran=g["tran"])
+        assert np.abs(Rg - g[f"{tag}_R"]).max() < TIGHT
+        assert np.abs(jg - g[f"{tag}_joint"]).max() < TIGHT
+        assert np.abs(vg - g[f"{tag}_vert"]).max() < TIGHT
+        _, jg2, _ = O.forward_kinematics_shape(g["pose"], smpl, g[f"{tag}_shape"])
+        assert np.abs(jg2 - g[f"{tag}_joint_notran"]).max() < TIGHT
+
+
 @pytest.mark.parametrize("tag", ["eq", "rag"])
 def test_torch_baseline_restatement_matches_golden(weights, smpl, tag):
     """oracle/torch_ref.py (the torch-CPU leg of bench.py's cpu_baseline) against the reference's own outputs."""
