@@ -10,8 +10,12 @@ in the same run and reported under `modes`.
   --scaling weak   (default)  256 sequences per GPU (BASELINE metric: batch 256 x window 125 per GPU)
   --scaling strong            BASELINE configs[3]: --global-batch (1024) sequences split over the ranks with
                               dist.shard_range (128 per GPU on 8 GPUs)
-With N > 1 (one process per GPU, launched by torch.distributed.run) the only collective is ONE RCCL broadcast of the weight
-blob + SMPL constants from rank 0 at start-up; sequences never interact.
+With N > 1 the job is one process per GPU: `python bench.py --gpus N` starts the N ranks itself (torch.distributed.run,
+rendezvous on 127.0.0.1) unless it already runs under a launcher (WORLD_SIZE set), and every rank checks that
+WORLD_SIZE == --gpus.  The only collective on the data path is ONE RCCL broadcast of the weight blob + SMPL constants from
+rank 0 at start-up; sequences never interact.  `n_ranks_seen` in the JSON line is the number of ranks an all-gather reached.
+  --dry-run   the same launcher / rendezvous / broadcast / shard / barrier / max-over-ranks / gather path on CPU over gloo
+              with a stand-in step (no kernels, `dry_run: true` in the line): what tests/test_bench_launcher_cpu.py runs.
 
 Prints ONE JSON line on rank 0 (field list: DESIGN.md section "Measurement").
 """
@@ -53,12 +57,29 @@ KERNEL_CLASSES = {   # timing classes of the C ABI (include/mobileposer_hip.h, m
 }
 
 
-def cpu_baseline(seconds=10.0):
-    """The numpy oracle (a port of the reference's CPU path) on a bounded sample of the same workload."""
+def host_cores():
+    """(logical CPUs, physical cores, 'sockets x cores x threads' text) of this box from lscpu (os.cpu_count as fallback)."""
+    import subprocess
+    n_log = os.cpu_count() or 1
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        get = lambda key: int([l.split(":")[1] for l in txt.splitlines() if l.startswith(key)][0])
+        sockets, cps, tpc = get("Socket(s)"), get("Core(s) per socket"), get("Thread(s) per core")
+        return n_log, max(1, sockets * cps), "%d socket(s) x %d cores x %d thread(s) (lscpu), %d logical CPUs" % (sockets, cps, tpc, n_log)
+    except Exception:
+        return n_log, n_log, "%d logical CPUs (os.cpu_count; lscpu unavailable)" % n_log
+
+
+def cpu_baseline(seconds=5.0):
+    """The CPU path beside the GPU number, on bounded samples of the same workload (about 25 s in all):
+    torch's own CPU nn.LSTM / nn.Linear (what the reference calls; oracle/torch_ref.py) + numpy FK / translation at
+    1 thread, at all physical cores and at the thread count ATen scales best to here (<= 32), 3 timed reps after one
+    warm-up each; the numpy oracle (`kind: "port"`) for `seconds`.  The headline `value` is the best of them."""
     from mobileposer_amd import synthetic
     from oracle import mp_oracle as O
     sd = synthetic.make_weights(0)
     smpl = synthetic.synthetic_smpl()
+    n_log, n_phys, cores_txt = host_cores()
     Bs = 32
     imu = synthetic.make_imu(Bs, T_WIN, seed=1)[:Bs]
     ref = O.OracleNet(sd, smpl["J"])
@@ -78,45 +99,49 @@ def cpu_baseline(seconds=10.0):
         dt = time.perf_counter() - t0
         if dt >= seconds or reps >= 50:
             break
-    out = {"value": round(reps * Bs * T_WIN / dt, 1), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
-           "sample": "%d reps of %d sequences x %d frames (numpy oracle: forward + FK + translation), %.1f s"
-                     % (reps, Bs, T_WIN, dt)}
-    # the same workload through torch's own CPU nn.LSTM / nn.Linear (what the reference calls): the full 256 x 125
-    # batch, a thread count ATen scales to (more threads than that are slower on these small GEMMs)
+    numpy_leg = {"value": round(reps * Bs * T_WIN / dt, 1), "unit": "frames/s", "cores": n_log,
+                 "sample": "%d reps of %d sequences x %d frames (numpy oracle: forward + FK + translation; BLAS threads as "
+                           "numpy chooses), %.1f s" % (reps, Bs, T_WIN, dt)}
+    legs = {}
     try:
         from oracle.torch_ref import TorchNet
-        nthr = max(1, min(32, os.cpu_count() or 1))
-        torch.set_num_threads(nthr)
-        tnet = TorchNet(sd, smpl["J"])
         imu_full = synthetic.make_imu(B_PER_GPU, T_WIN, seed=1)
+        # (threads, sequences per rep): one thread gets a 32-sequence sample so that 1 + 3 reps stay within a few seconds
+        plan = [(1, 32)]
+        if n_phys > 1:
+            plan.append((n_phys, B_PER_GPU))
+        if min(32, n_log) not in (1, n_phys):
+            plan.append((min(32, n_log), B_PER_GPU))
+        for nthr, nb in plan:
+            torch.set_num_threads(nthr)
+            tnet = TorchNet(sd, smpl["J"])
+            x = imu_full[:nb]
 
-        def one_t():
-            tnet.vel_state = None
-            pose, joints, vel, contact, _ = tnet.forward(imu_full, [T_WIN] * B_PER_GPU)
-            O.forward_kinematics(pose, smpl["J"])
-            for b in range(B_PER_GPU):
-                O.translate_offline(joints[b].reshape(T_WIN, 24, 3), vel[b], contact[b], tnet.floor_y)
+            def one_t():
+                tnet.vel_state = None
+                pose, joints, vel, contact, _ = tnet.forward(x, [T_WIN] * nb)
+                O.forward_kinematics(pose, smpl["J"])
+                for b in range(nb):
+                    O.translate_offline(joints[b].reshape(T_WIN, 24, 3), vel[b], contact[b], tnet.floor_y)
 
-        one_t()
-        reps_t, t0 = 0, time.perf_counter()
-        while True:
-            one_t()
-            reps_t += 1
+            one_t()                                                   # 1 warm-up
+            t0 = time.perf_counter()
+            for _ in range(3):                                        # 3 timed reps
+                one_t()
             dt_t = time.perf_counter() - t0
-            if dt_t >= seconds or reps_t >= 50:
-                break
-        out["torch_cpu"] = {"value": round(reps_t * B_PER_GPU * T_WIN / dt_t, 1), "unit": "frames/s", "threads": nthr,
-                            "sample": "%d reps of %d sequences x %d frames through torch CPU nn.LSTM "
-                                      "(oracle/torch_ref.py) + numpy FK / translation, %.1f s"
-                                      % (reps_t, B_PER_GPU, T_WIN, dt_t)}
+            legs["torch_%dthr" % nthr] = {
+                "value": round(3 * nb * T_WIN / dt_t, 1), "unit": "frames/s", "threads": nthr,
+                "sample": "3 reps (after 1 warm-up) of %d sequences x %d frames through torch CPU nn.LSTM "
+                          "(oracle/torch_ref.py) + numpy FK / translation, %.1f s" % (nb, T_WIN, dt_t)}
     except Exception as e:
-        out["torch_cpu"] = {"error": str(e)}
-    # report the stronger CPU figure as the baseline proper, keep the other one beside it
-    t = out.get("torch_cpu", {})
-    if "value" in t and t["value"] > out["value"]:
-        numpy_leg = {k: out[k] for k in ("value", "unit", "cores", "sample")}
-        out = {"value": t["value"], "unit": "frames/s", "cores": t["threads"], "kind": "port", "sample": t["sample"],
-               "numpy_oracle": numpy_leg}
+        legs["error"] = str(e)
+    best = max((v for v in legs.values() if isinstance(v, dict) and "value" in v), key=lambda v: v["value"], default=None)
+    out = {"kind": "port", "host": cores_txt, "physical_cores": n_phys, "logical_cpus": n_log,
+           "legs": legs, "numpy_oracle": numpy_leg}
+    if best is not None and best["value"] > numpy_leg["value"]:
+        out.update(value=best["value"], unit="frames/s", cores=best["threads"], sample=best["sample"])
+    else:
+        out.update(value=numpy_leg["value"], unit="frames/s", cores=numpy_leg["cores"], sample=numpy_leg["sample"])
     return out
 
 
@@ -165,6 +190,96 @@ def bench_stream(args, net, dev, dist, rank, world):
         dist.destroy_process_group()
 
 
+def relaunch_with_ranks(n):
+    """`python bench.py --gpus N` outside of a launcher: start N ranks of this very command, one per GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL across processes)
+    return subprocess.call(cmd, env=env)
+
+
+def ranks_seen(dist, dev):
+    """How many ranks an all-gather actually reaches (1 without a process group)."""
+    if dist is None:
+        return 1
+    t = torch.ones(1, dtype=torch.int32, device=dev)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return int(sum(int(o.item()) for o in out))
+
+
+def timed_region(step, steps, warmup, sync, dist, dev):
+    """W untimed warm-up steps, then exactly `steps` steps between barrier + synchronize on both sides;
+    returns (max over ranks, local) seconds."""
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    dt_local = time.perf_counter() - t0
+    dt = dt_local
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt, dt_local
+
+
+def metric_label(scaling):
+    if scaling == "strong":
+        return "imu_frames_per_sec (MobilePoserNet fwd + FK + translation solver, global batch split over the GPUs, window 125)"
+    return "imu_frames_per_sec (MobilePoserNet fwd + FK + translation solver, batch 256 x window 125 per GPU)"
+
+
+def bench_dry(args, dist, rank, world):
+    """--dry-run: everything bench.py does around the kernels, on CPU over gloo."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.dist import broadcast_model, gather_counts, shard_range
+    from mobileposer_amd.model_utils import state_dict_to_blob
+    dev = torch.device("cpu")
+    ok_blob = True
+    if dist is not None:
+        blob, smpl = broadcast_model(synthetic.make_weights(0) if rank == 0 else None,
+                                     synthetic.synthetic_smpl() if rank == 0 else None, dev, src=0)
+        ok_blob = bool(np.array_equal(blob.numpy(), state_dict_to_blob(synthetic.make_weights(0))))
+    T = T_WIN
+    if args.scaling == "strong":
+        lo, hi = shard_range(args.global_batch, rank, world)
+        B, global_batch = hi - lo, args.global_batch
+    else:
+        B, global_batch = B_PER_GPU, world * B_PER_GPU
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+
+    elapsed, elapsed_local = timed_region(lambda: time.sleep(0.002), args.steps, args.warmup, sync, dist, dev)
+    per_rank = gather_counts(B * T * args.steps, elapsed_local, dev) if dist is not None else None
+    seen = ranks_seen(dist, dev)
+    if rank == 0:
+        out = {"metric": metric_label(args.scaling), "value": round(global_batch * T * args.steps / elapsed, 1),
+               "unit": "frames/s", "n_gpus": world, "n_ranks_seen": seen, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": args.scaling,
+               "vs_baseline": None, "dtype": "f32", "data": "none (dry run: stand-in step, no kernels)", "dry_run": True,
+               "weights_broadcast_ok": ok_blob,
+               "config": {"workload": "dry run of the launcher / rendezvous / broadcast / shard / timing path (gloo, CPU)",
+                          "batch_per_gpu": B, "window": T, "global_batch": global_batch,
+                          "parallelism": "independent sequences sharded, dp%d" % world}}
+        if per_rank is not None:
+            out["per_rank"] = [{"rank": r, "frames": int(v[0]), "seconds": round(float(v[1]), 6)} for r, v in enumerate(per_rank)]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,19 +297,33 @@ def main():
                     help="MFMA operands of the H=256 LSTM layers for the headline value: fp32 (default = the library default: "
                          "exact v_mfma_f32_16x16x4_f32 operands, the reference's arithmetic) or x3 (opt-in: every fp32 product "
                          "as 3 bf16 products on v_mfma_f32_16x16x32_bf16, fp32 accumulate); the other mode is timed as well")
+    ap.add_argument("--dry-run", action="store_true", help="CPU / gloo run of the launcher, rendezvous, broadcast, shard and "
+                    "timing path with a stand-in step (no GPU, no kernels); the JSON line says dry_run: true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:     # plain `python bench.py --gpus N`: become N ranks
+        sys.exit(relaunch_with_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU "
+                 "(python bench.py --gpus N does it by itself; or torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
     dist = None
-    if world > 1 or "RANK" in os.environ:           # launched by torch.distributed.run: one process per GPU over RCCL
+    if world > 1 or "RANK" in os.environ:           # one process per GPU over RCCL (gloo for --dry-run)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
+        if args.dry_run:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if args.dry_run:
+        return bench_dry(args, dist, rank, world)
+    if dist is None:
         torch.cuda.set_device(0)
         local_rank = 0
     dev = torch.device("cuda", local_rank)
@@ -264,20 +393,7 @@ def main():
     def timed(mode, steps):
         """W warm-up steps, then exactly `steps` steps between barrier + synchronize; max over ranks."""
         net.set_lstm_mode(MODE_ID[mode])
-        for _ in range(args.warmup):
-            step()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        sync()
-        dt_local = time.perf_counter() - t0
-        dt = dt_local
-        if dist is not None:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        return dt, dt_local
+        return timed_region(step, steps, args.warmup, sync, dist, dev)
 
     other = "x3" if args.lstm_mode == "fp32" else "fp32"
     elapsed, elapsed_local = timed(args.lstm_mode, args.steps)          # the headline measurement: exactly K steps
@@ -293,6 +409,7 @@ def main():
     per_rank = None
     if dist is not None:
         per_rank = gather_counts(B * T * args.steps, elapsed_local, dev)
+    seen = ranks_seen(dist, dev)
 
     # ---- BASELINE configs[3] beside the headline (weak-scaling runs only): GLOBAL batch 1024 split over the ranks ----
     strong = None
@@ -411,9 +528,9 @@ def main():
                 "configs[2]+solver: full MobilePoserNet (4 LSTM modules) + r6d/IK + SMPL FK + offline translation solver, "
                 "B=256 x T=125 per GPU")
     out = {
-        "metric": "imu_frames_per_sec (MobilePoserNet fwd + FK + translation solver, batch 256 x window 125 per GPU)",
+        "metric": metric_label(args.scaling),
         "value": round(value, 1), "unit": "frames/s", "per_gpu": round(value / world, 1),
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "n_ranks_seen": seen, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4),
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32" if args.lstm_mode == "fp32" else "f32 state/accumulate, matrix products as 3-term split-bf16 MFMA (opt-in mode)",

@@ -1,0 +1,63 @@
+"""bench.py's own multi-rank launcher, end to end on CPU: `python bench.py --gpus 2 --dry-run` must start two ranks by itself
+(torch.distributed.run, rendezvous on 127.0.0.1), run the broadcast / shard / barrier / max-over-ranks / gather path over gloo
+and print ONE JSON line whose n_gpus and n_ranks_seen say 2.  (--dry-run replaces only the step: no GPU here.)"""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import REPO
+
+
+def _run(argv, env_extra=None, timeout=300):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + argv, cwd=REPO, env=env,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_launches_two_ranks_by_itself():
+    r = _run(["--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["dry_run"] is True
+    assert out["weights_broadcast_ok"] is True
+    assert out["steps"] == 5 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 512 and out["config"]["batch_per_gpu"] == 256
+    assert [p["rank"] for p in out["per_rank"]] == [0, 1]
+    assert all(p["frames"] == 256 * 125 * 5 for p in out["per_rank"])
+    # value = whole-job frames / max-over-ranks seconds
+    assert abs(out["value"] - 512 * 125 * 5 / (out["ms_per_step"] * 5e-3)) < 1e-3 * out["value"]
+    assert out["ms_per_step"] * 5e-3 >= max(p["seconds"] for p in out["per_rank"]) - 1e-4
+
+
+def test_bench_strong_scaling_shards_the_global_batch():
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "0", "--dry-run", "--scaling", "strong", "--global-batch", "1023"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = _json_line(r.stdout)
+    assert out["n_ranks_seen"] == 2 and out["scaling"] == "strong" and out["config"]["global_batch"] == 1023
+    assert [p["frames"] for p in out["per_rank"]] == [512 * 125 * 3, 511 * 125 * 3]
+    assert "global batch" in out["metric"]
+
+
+def test_bench_single_rank_line_has_the_same_fields():
+    r = _run(["--steps", "3", "--warmup", "0", "--dry-run"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 1 and out["n_ranks_seen"] == 1 and "per_rank" not in out
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    r = _run(["--gpus", "2", "--dry-run"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+    r = _run(["--gpus", "1", "--dry-run"], env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0",
+                                                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
