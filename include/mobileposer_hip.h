@@ -40,9 +40,10 @@ typedef enum mp_status {
     MP_ERR_NO_STREAMS = -4,  /* mp_stream_* called before mp_stream_create                           */
     MP_ERR_LENGTHS = -5,     /* lengths[] not in 1..T or max(lengths) != T (the reference's           */
                              /* torch.cat at models/net.py:106 fails in that case)                    */
-    MP_ERR_DEVICE = -6       /* a persistent LSTM kernel of an EARLIER call gave up a bounded wait    */
-                             /* (its grid was starved of CUs): that call's outputs are invalid.       */
-                             /* Reported once by the next API entry, or by mp_device_error().         */
+    MP_ERR_DEVICE = -6       /* a persistent LSTM kernel gave up a time-bounded wait (its grid was    */
+                             /* starved of CUs) and recovery is off or failed: the affected outputs   */
+                             /* are NaN.  With recovery on (the default) the call repairs itself and  */
+                             /* returns MP_OK; see mp_set_recovery / mp_finish.                        */
 } mp_status;
 
 /* module ids for mp_rnn_forward: the four RNN blocks built at models/net.py:40-43 */
@@ -173,6 +174,11 @@ int mp_stream_reset(mp_handle* h, const uint8_t* mask_host, int clear_velocity);
 int mp_stream_get_state(mp_handle* h, int s, float* window_dev, float last_foot_host[6], double* root_y_host,
                         float root_pos_host[3], int* fresh_host);
 
+/* The counterpart: assignments to those variables (`model.last_root_pos = ...`, `model.imu = None` -> fresh != 0, as
+ * viewer / live code resets them).  Every pointer optional; synchronises the library stream. */
+int mp_stream_set_state(mp_handle* h, int s, const float* window_dev, const float last_foot_host[6],
+                        const double* root_y_host, const float root_pos_host[3], const int* fresh_host);
+
 /* ---- live front-end: raw sensor samples -> network input frames, S streams per call --------------------------------
  * The per-frame arithmetic between the sensor packets and forward_online in the reference's live demo
  * (mobileposer/live_demo.py:213-236; calibration quantities from :161-174), batched over streams:
@@ -194,7 +200,8 @@ int mp_live_form_frames(mp_handle* h, const float* quat_dev, const float* acc_de
 int mp_timing_enable(mp_handle* h, int on);
 int mp_timing_read(mp_handle* h, int cls, int* launches, float* ms, double* gflop);
 /* 0 (default): eager launches on the library's three streams; 1 (env MP_GRAPH=1): capture every (entry point, shape,
- * buffer set) once into a hipGraph and replay it.  Opt-in because the multi-branch graph executor of the HIP runtime
+ * buffer set) once into a hipGraph and replay it; 2: the same as a SINGLE-BRANCH graph (every launch captured on one
+ * stream, no parallel branches -- nothing for the graph executor's stream assignment to get wrong).  Opt-in because the multi-branch graph executor of the HIP runtime
  * in this image can crash in hipGraphLaunch depending on the hardware-queue placement of the streams a process has
  * created (profiles/r02_hipgraph_segv.md; GPU_MAX_HW_QUEUES=8 avoids it); outputs are bitwise identical either way. */
 int mp_set_graph_mode(mp_handle* h, int on);
@@ -208,19 +215,31 @@ int mp_set_graph_mode(mp_handle* h, int on);
  *   2: mode 1 plus the unidirectional velocity block as ONE two-layer wavefront launch;
  *   0 (env MP_LSTM_MODE=step): input-projection GEMM + one launch per time step. */
 int mp_set_lstm_mode(mp_handle* h, int mode);
-/* Test hook for the hidden-state exchange of the persistent kernels: 0 = pick the transport per producer from
- * its real XCC id (default), 1 = always use the any-placement write-through (sc1) transport. */
-int mp_set_transport(mp_handle* h, int force_remote);
+/* ---- error behaviour of the persistent LSTM kernels ---------------------------------------------------------------
+ * A fused layer launch is a grid of workgroups that wait for each other's hidden state every time step; all of them
+ * must be resident at once.  The library plans its launches for a GPU it has to itself; when something else (another
+ * process, another handle on another host thread) occupies CUs, a wait can starve.  Every wait is bounded in TIME
+ * (0.25 s of the device's constant clock).  A wave that gives up (1) stores 1+step (1000000 = start-up handshake) into
+ * the handle's error word and (2) turns its cell state into NaN, so that its slab's rows of every output of the call
+ * become NaN -- a starved call never returns plausible numbers (the reference's PyTorch path never returns wrong
+ * numbers silently either).
+ *
+ * mp_set_recovery(h, 1) -- the DEFAULT: mp_forward, mp_forward_offline, mp_rnn_forward and mp_stream_step wait for
+ * their own completion before they return (the reference's calls are synchronous too) and, if the error word is set,
+ * restore the carried state the call started from and run the call again with per-step kernels (LSTM mode 0: no
+ * cross-workgroup waits, parity-tested like the fused kernels).  The call then returns MP_OK, mp_last_error() holds a
+ * warning, mp_recovery_count() counts such calls, and the handle stops using physical-XCD placement tables.
+ * mp_set_recovery(h, 0): calls return as soon as their work is enqueued (throughput loops); an error is reported as
+ * MP_ERR_DEVICE by the next API entry, by mp_finish() or read by mp_device_error(); the outputs of the failed call are NaN. */
+int mp_set_recovery(mp_handle* h, int on);
+/* Number of calls that were repaired by the mode-0 re-run since mp_create. */
+int mp_recovery_count(const mp_handle* h);
+/* Waits for everything the handle has enqueued; MP_OK, or MP_ERR_DEVICE if a kernel gave up a wait since the last
+ * report (cleared).  What a caller with recovery off runs before it trusts the outputs of its last call. */
+int mp_finish(mp_handle* h);
 /* Synchronises the library's stream and returns (and clears) the error word of the persistent kernels:
- * 0 = ok, 1+step = a bounded wait for another workgroup's hidden state timed out (results invalid).
- * Without this call the same condition is reported as MP_ERR_DEVICE by the next API entry. */
+ * 0 = ok, 1+step = a bounded wait for another workgroup's hidden state timed out (1000000: start-up handshake). */
 int mp_device_error(mp_handle* h, int* code);
-/* Test hook: make a kernel store `code` into the error word exactly as a timed-out persistent kernel would. */
-int mp_debug_poke_error(mp_handle* h, int code);
-/* Debug (env MP_PERSIST_PROF=1 at mp_create): per-workgroup cycle sums [grid][6] of the phases of the last
- * persistent-kernel launch: wait, sweep, mfma, reduce, cell+publish, steps. */
-int mp_debug_read_prof(mp_handle* h, long long* out, int n_words);
-
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,8 @@ _vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
 
-# name -> (restype, argtypes): every symbol include/mobileposer_hip.h declares
+# name -> (restype, argtypes): every symbol include/mobileposer_hip.h declares, and the test / debug hooks of
+# include/mobileposer_hip_internal.h (mp_set_transport, mp_debug_*)
 SIGNATURES = {
     "mp_weight_count": (_sz, []),
     "mp_manifest_entry": (_i, [_i, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_i64), C.POINTER(_sz)]),
@@ -45,14 +46,19 @@ SIGNATURES = {
     "mp_stream_reset": (_i, [_vp, C.POINTER(C.c_uint8), _i]),
     "mp_live_form_frames": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint, _i, _vp, _vp]),
     "mp_stream_get_state": (_i, [_vp, _i, _vp, _fp, C.POINTER(C.c_double), _fp, C.POINTER(_i)]),
+    "mp_stream_set_state": (_i, [_vp, _i, _vp, _fp, C.POINTER(C.c_double), _fp, C.POINTER(_i)]),
     "mp_timing_enable": (_i, [_vp, _i]),
     "mp_timing_read": (_i, [_vp, _i, C.POINTER(_i), _fp, C.POINTER(C.c_double)]),
     "mp_set_graph_mode": (_i, [_vp, _i]),
     "mp_set_lstm_mode": (_i, [_vp, _i]),
     "mp_set_transport": (_i, [_vp, _i]),
     "mp_device_error": (_i, [_vp, C.POINTER(_i)]),
+    "mp_finish": (_i, [_vp]),
+    "mp_set_recovery": (_i, [_vp, _i]),
+    "mp_recovery_count": (_i, [_vp]),
     "mp_debug_poke_error": (_i, [_vp, _i]),
     "mp_debug_read_prof": (_i, [_vp, C.POINTER(C.c_longlong), _i]),
+    "mp_debug_occupy": (_i, [_vp, _i, _i, C.c_double]),
 }
 
 _lib = None

@@ -16,7 +16,7 @@
 // (profiles/r02_hipgraph_segv.md: backtrace, disassembly, and the GPU_MAX_HW_QUEUES experiment).  Eager launches on
 // the library's streams measure 1.755 vs 1.716 ms (split-bf16 mode) and 4.46 vs 4.57 ms (fp32 mode) per
 // 256 x 125 batch, i.e. nothing is lost.
-#include "../../include/mobileposer_hip.h"
+#include "../../include/mobileposer_hip_internal.h"
 #include "mp_common.h"
 #include "mp_lstm_dev.h"
 
@@ -92,8 +92,8 @@ struct ModuleW {
     float* wihP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // W_ih, persistent kernel layout
     float* whhX[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // split-bf16 kernel layout (H = 256 modules)
     float* wihX[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    float* whhP16[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // 16-slice packing for mp_lstm_pair (bidirectional H = 256
-    float* wihP16[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  //  blocks; a unidirectional block's whhP / wihP already is it)
+    float* whhP16[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // 16-slice packing of the bidirectional H = 256 blocks (small
+    float* wihP16[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  //  batches; a unidirectional block's whhP / wihP already is it)
     float* whhPW[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // 8-slice / 4-wave (WREG) packing, bidirectional H = 256 blocks
     float* wihPW[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     float* whhU8[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // 32 slices of 8 units (mp_lstm_u8): small batches, H = 256 blocks
@@ -170,46 +170,48 @@ struct mp_handle {
                                      // look at it without synchronising anything
     long long* prof_dev = nullptr;   // debug: per-workgroup phase cycle sums of the last persistent launch
     bool force_remote = false;       // test hook (mp_set_transport)
+    unsigned long long wait_ticks = 25000000ull;   // bound of every wait inside a persistent kernel: 0.25 s of the 100 MHz
+                                     // constant clock (env MP_WAIT_MS: tests of the starvation path shorten it)
     int n_cu = 256;                  // compute units of this device: bounds the co-resident persistent grids
     bool persist = true;
     bool uni2 = false;               // velocity block as ONE two-layer wavefront launch (mp_set_lstm_mode(h, 2) / env
-                                     // MP_LSTM_UNI2=1).  Off by default: it is 20 % faster than two launches but fills every
+                                     // MP_VARIANT uni2=1).  Off by default: it is 20 % faster than two launches but fills every
                                      // CU's registers and LDS, so the foot-contact layers and pose's linear2 / IK / FK can no
                                      // longer run beside the velocity block and the forward as a whole gets slower.
     bool x3 = false;                 // false (default, mode 1): H = 256 layers on exact-fp32 MFMA operands -- the reference's
                                      // arithmetic; true (mode 3, mp_set_lstm_mode(h, 3) / MP_LSTM_MODE=x3): the opt-in fast
                                      // mode, split-bf16 MFMA operands (mp_lstm_x3.hip)
-    unsigned epoch_start = 1;        // first epoch base after a zeroing (test hook MP_EPOCH_START: start close to the wrap guard)
-    bool epoch_tags = true;          // MP_EPOCH_TAGS=0: zero the exchange area before every fp32 layer launch (as round 1 did)
-    bool slices16_ok = true;         // MP_SLICES16=0: bidirectional fp32 layers always on 8 slices
-    bool slices32_ok = true;         // MP_SLICES32=0: no 32-slice kernels for batches of one or two slabs
-    bool wide_ok = true;             // MP_WIDE=0: never run pose / velocity / foot-contact side by side (small batches)
-    bool exclusive_ok = true;        // MP_EXCLUSIVE=0: never pad the LDS request of concurrent persistent launches (below)
+    unsigned epoch_start = 1;        // first epoch base after a zeroing (MP_VARIANT epoch_start: start close to the wrap guard)
+    bool epoch_tags = true;          // MP_VARIANT epoch_tags=0: zero the exchange area before every fp32 layer launch (as round 1 did)
+    bool slices16_ok = true;         // MP_VARIANT slices16=0: bidirectional fp32 layers always on 8 slices
+    bool slices32_ok = true;         // MP_VARIANT slices32=0: no 32-slice kernels for batches of one or two slabs
+    bool wide_ok = true;             // MP_VARIANT wide=0: never run pose / velocity / foot-contact side by side (small batches)
+    bool exclusive_ok = true;        // MP_VARIANT exclusive=0: never pad the LDS request of concurrent persistent launches (below)
     int excl_lds = 0;                // forward_body -> rnn_rec: LstmPersistArgs::min_lds of the launches being issued
     bool pose_slices8 = false;       // forward_body -> fp32_slices: this call runs the pose layers on 8 slices per slab (below)
     bool xcd_rr = false;             // probed at create: workgroups are dealt round robin over 8 XCDs
     bool xcd_plan_on[4] = {false, false, false, false};   // forward_body -> rnn_rec: clusters per XCD of module id's layer launches
     unsigned char xcd_plan[4][8] = {};
-    bool half_ok = true;             // MP_HALF=0: no pose-on-half-the-chip schedule for 64 < B <= 128
-    bool fuse_pv = true;             // MP_FUSE_PV=0: separate linear1 launches for pose and velocity
+    bool half_ok = true;             // MP_VARIANT half=0: no pose-on-half-the-chip schedule for 64 < B <= 128
+    bool fuse_pv = true;             // MP_VARIANT fuse_pv=0: separate linear1 launches for pose and velocity
     Packed lin1_pv;                  // pose.linear1 and velocity.linear1 stacked (split-bf16 mode: one GEMM over the shared rows)
     int wreg_mask = 3;               // fp32 mode, 8-slice bidirectional layers on the four-wave / AccVGPR-weight configuration
-                                     // (mp_lstm_fused<256,8,KIN,1>): bit 0 K_in = 512, bit 1 K_in = 256 (env MP_WREG; 0 = the
+                                     // (mp_lstm_fused<256,8,KIN,1>): bit 0 K_in = 512, bit 1 K_in = 256 (MP_VARIANT wreg; 0 = the
                                      // eight-wave kernels).  Measured on one box: 4.47 -> 4.35 ms per 256 x 125 forward.
-    int pair_mask = 0;               // fp32 mode: bidirectional H = 256 layers run by the two-slabs-per-workgroup kernel
-                                     // mp_lstm_pair: bit 0 K_in = 512 layers, bit 1 K_in = 256 layers (env MP_PAIR).  Off:
-                                     // measured slower than mp_lstm_fused on every layer ("two slabs per
-                                     // workgroup"); kept, parity-tested, as the record of that experiment
-    int pair_mode = 1;               // bit 0: the two slabs of a workgroup take turns on the matrix pipe (env MP_PAIR_MODE)
     int x3w_mask = 2;                // split-bf16 layers run by the 4-wave kernel mp_lstm_x3w: bit 0 K_in = 256, bit 1 K_in = 512
-                                     // (default: the K_in = 512 layers, measured 373 vs 391 us; K_in = 256: 300 vs 285 us; env MP_X3W)
+                                     // (default: the K_in = 512 layers, measured 373 vs 391 us; K_in = 256: 300 vs 285 us; MP_VARIANT x3w)
     int nslice_env = 0;              // 0: pick per module (8 slices / 8 waves for bidirectional layers that fill the
-                                     // chip, 16 slices / 4 waves for unidirectional ones); env MP_LSTM_SLICES=8|16 forces one             // LSTM recurrence: persistent kernel (default) or per-step launches
+                                     // chip, 16 slices / 4 waves for unidirectional ones); MP_VARIANT slices=8|16 forces one             // LSTM recurrence: persistent kernel (default) or per-step launches
     std::map<std::pair<int, int>, Plan*> plans;
     std::map<GraphKey, hipGraphExec_t> graphs;
     unsigned long long use_clock = 0;
     VelState vstate;
+    VelState vsnap;                  // recovery: the carried velocity state a call started from
     StreamCtx sc;
+    OnlineState st_snap;             // recovery: per-stream solver state a streaming tick started from
+    bool recovery = true;            // mp_set_recovery: calls wait for themselves and repair a starved run in LSTM mode 0
+    int recoveries = 0;
+    hipStream_t s_dbg = nullptr;     // mp_debug_occupy
     bool use_graph = false;          // opt-in (mp_set_graph_mode / MP_GRAPH=1): see the note at the top of this file
     bool timing = false;
     std::vector<Seg> segs;
@@ -264,7 +266,7 @@ int pack_weights(mp_handle* h, const float* blob) {
         // split-bf16 kernels: 8 slices (8-wave workgroups) for every H = 256 layer -- the unidirectional velocity
         // layers then occupy 128 CUs and leave the other half of the chip to the foot-contact block (measured:
         // 312 vs 326 us per velocity layer, foot-contact layers 200 vs 265 us)
-        m.nsliceX = 8;                                   // (MP_LSTM_SLICES only concerns the fp32 kernels)
+        m.nsliceX = 8;                                   // (MP_VARIANT slices only concerns the fp32 kernels)
         if (int rc = alloc_packed(h, m.lin1, m.H, m.n_in)) return rc;
         if (int rc = alloc_packed(h, m.ih[0], m.dirs * 4 * m.H, m.H)) return rc;
         if (int rc = alloc_packed(h, m.ih[1], m.dirs * 4 * m.H, m.dirs * m.H)) return rc;
@@ -400,10 +402,8 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     auto bail = [&](int rc) { g_create_error = h->err; mp_destroy(h); return rc; };
     if (hipSetDevice(device) != hipSuccess) { h->err = "hipSetDevice failed"; return bail(MP_ERR_HIP); }
     if (const char* e = getenv("MP_GRAPH")) h->use_graph = e[0] && e[0] != '0';
-    if (const char* e = getenv("MP_NO_GRAPH")) if (e[0] && e[0] != '0') h->use_graph = false;
     {   // dynamic-LDS limits of the persistent kernels are per-device attributes (and must not be set under capture)
         hipError_t ea = mp_lstm_persist_device_attrs();
-        if (ea == hipSuccess) ea = mp_lstm_pair_device_attrs();
         if (ea == hipSuccess) ea = mp_lstm_u8_device_attrs();
         if (ea == hipSuccess) ea = mp_lstm_x3_device_attrs();
         if (ea == hipSuccess) ea = mp_lstm_x3w_device_attrs();
@@ -438,20 +438,44 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
         h->persist = strcmp(e, "step") != 0;
         h->x3 = h->persist && strcmp(e, "x3") == 0;            // "fp32" (default) | "x3" | "step"
     }
-    if (const char* e = getenv("MP_LSTM_UNI2")) h->uni2 = e[0] == '1';
-    if (const char* e = getenv("MP_X3W")) h->x3w_mask = atoi(e) & 3;
-    if (const char* e = getenv("MP_PAIR")) h->pair_mask = atoi(e) & 3;
-    if (const char* e = getenv("MP_WREG")) h->wreg_mask = atoi(e) & 3;
-    if (const char* e = getenv("MP_PAIR_MODE")) h->pair_mode = atoi(e);
-    if (const char* e = getenv("MP_FUSE_PV")) h->fuse_pv = atoi(e) != 0;
-    if (const char* e = getenv("MP_WIDE")) h->wide_ok = atoi(e) != 0;
-    if (const char* e = getenv("MP_EXCLUSIVE")) h->exclusive_ok = atoi(e) != 0;
-    if (const char* e = getenv("MP_HALF")) h->half_ok = atoi(e) != 0;
-    if (const char* e = getenv("MP_SLICES16")) h->slices16_ok = atoi(e) != 0;
-    if (const char* e = getenv("MP_SLICES32")) h->slices32_ok = atoi(e) != 0;
-    if (const char* e = getenv("MP_EPOCH_TAGS")) h->epoch_tags = atoi(e) != 0;
-    if (const char* e = getenv("MP_EPOCH_START")) { const unsigned long v = strtoul(e, nullptr, 0); if (v >= 1 && v < 0xf0000000ul) h->epoch_start = (unsigned)v; }
-    if (const char* e = getenv("MP_LSTM_SLICES")) h->nslice_env = atoi(e) == 8 ? 8 : (atoi(e) == 16 ? 16 : 0);
+    if (const char* e = getenv("MP_WAIT_MS")) { const double ms = atof(e); if (ms > 0.0 && ms < 60000.0) h->wait_ticks = (unsigned long long)(ms * 1e5); }
+    // MP_VARIANT: ONE debug switch for the kernel / schedule variants kept for cross-checks and A/B runs -- a comma-separated
+    // list of key=value (tests/test_gpu_parity.py exercises them; nothing here changes results beyond summation order):
+    //   wreg=0..3      8-slice bidirectional fp32 layers on the four-wave / AccVGPR kernels: bit 0 K_in=512, bit 1 K_in=256 (3)
+    //   x3w=0..3       split-bf16 layers on the four-wave kernel: bit 0 K_in=256, bit 1 K_in=512 (2)
+    //   slices=8|16    force the slices per slab of the fp32 H=256 layers;  slices16=0 / slices32=0: no 16- / 32-slice kernels
+    //   wide=0         never run pose / velocity / foot contact side by side;  half=0: no pose-on-half-the-chip schedule
+    //   exclusive=0    no LDS padding / XCD tables for concurrent persistent launches;  fuse_pv=0: separate linear1 launches
+    //   epoch_tags=0   zero the exchange area before every fp32 layer launch;  epoch_start=N: first epoch base (wrap tests)
+    //   uni2=1         velocity block as one two-layer wavefront launch (= mp_set_lstm_mode(h, 2))
+    if (const char* e = getenv("MP_VARIANT")) {
+        std::string all(e);
+        size_t pos = 0;
+        while (pos < all.size()) {
+            size_t end = all.find(',', pos);
+            if (end == std::string::npos) end = all.size();
+            const std::string tok = all.substr(pos, end - pos);
+            pos = end + 1;
+            const size_t eq = tok.find('=');
+            if (eq == std::string::npos) continue;
+            const std::string key = tok.substr(0, eq);
+            const unsigned long v = strtoul(tok.c_str() + eq + 1, nullptr, 0);
+            if (key == "wreg") h->wreg_mask = (int)(v & 3);
+            else if (key == "x3w") h->x3w_mask = (int)(v & 3);
+            else if (key == "slices") h->nslice_env = v == 8 ? 8 : (v == 16 ? 16 : 0);
+            else if (key == "slices16") h->slices16_ok = v != 0;
+            else if (key == "slices32") h->slices32_ok = v != 0;
+            else if (key == "wide") h->wide_ok = v != 0;
+            else if (key == "half") h->half_ok = v != 0;
+            else if (key == "exclusive") h->exclusive_ok = v != 0;
+            else if (key == "fuse_pv") h->fuse_pv = v != 0;
+            else if (key == "epoch_tags") h->epoch_tags = v != 0;
+            else if (key == "epoch_start") { if (v >= 1 && v < 0xf0000000ul) h->epoch_start = (unsigned)v; }
+            else if (key == "uni2") h->uni2 = v != 0;
+            else if (key == "gemm_staged") {}                  // read by mp_launch_gemm
+            else { h->err = "MP_VARIANT: unknown key '" + key + "'"; return bail(MP_ERR_INVALID); }
+        }
+    }
     if (getenv("MP_PERSIST_PROF")) {
         if (hipMalloc((void**)&h->prof_dev, kProfWords * sizeof(long long)) != hipSuccess) h->prof_dev = nullptr;
         else (void)hipMemset(h->prof_dev, 0, kProfWords * sizeof(long long));
@@ -757,7 +781,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             a.lengths = j.p->lengths_dev; a.ndir = 2; a.B = B; a.T = T;
             a.slab0 = s0; a.nslab = nslab - s0 < chunk ? nslab - s0 : chunk;
             a.hx = w.hx + (size_t)2 * s0 * ((size_t)4 * 16 * H + 16);
-            a.err = h->err_dev; a.max_spin = 1u << 18; a.prof = nullptr;
+            a.err = h->err_dev; a.max_spin = 1u; a.max_ticks = h->wait_ticks; a.prof = nullptr;
             a.zero_state = j.mode == STATE_ZERO ? 1 : 0; a.force_remote = h->force_remote ? 1 : 0;
             for (int ll = 0; ll < 2; ++ll) {
                 LstmDir& dd = a.d[ll];
@@ -773,18 +797,15 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         const int nslab = (B + 15) / 16;
         // every polled word is re-zeroed before every launch: all granules (fp32 kernels) or the flags (split-bf16 kernels)
         // (split-bf16 kernels: the flags of layer 0's area were zeroed by the linear1 GEMM, those of layer 1's area by the layer-0 launch)
-        // two slabs per workgroup (mp_lstm_pair): exact-fp32 H = 256 layers with at least one full pair of slabs
         const int kin_l = l == 0 ? H : dirs * H;
-        const bool pair = !use_x3(h, m) && H == 256 && nslab >= 2 && dirs == 2 && m.whhP16[0][0] &&
-                          (h->pair_mask & (kin_l == 512 ? 1 : 2));
         // exact-fp32 kernels: mp_lstm_fused tags its granules with a per-launch epoch base, so the area is zeroed only when
         // something else may have written to it (first use, another kernel family, graph capture -- replays repeat the same
-        // base -- or an imminent wrap of the 32-bit tag); the others (pair / split-bf16 re-arm themselves) as before
+        // base -- or an imminent wrap of the 32-bit tag); the split-bf16 kernels re-arm themselves
         // (not for a 16-slice launch that fills the chip: its 4-wave workgroups can start on CUs where workgroups of the
         //  previous layer launch are still finishing, and their start-up polling slows those down -- measured 3.05 -> 3.28 ms
         //  at 128 x 125; the memset between the launches is the boundary that prevents it.  The 8-slice kernels own their CU.)
         const bool crowded16 = !use_x3(h, m) && dirs == 2 && fp32_slices(h, m, B) == 16 && dirs * nslab * 16 > 128;
-        const bool epoch_ok = !use_x3(h, m) && !pair && !h->capturing && h->epoch_tags && !crowded16;
+        const bool epoch_ok = !use_x3(h, m) && !h->capturing && h->epoch_tags && !crowded16;
         unsigned epoch_base = 0;
         if (!use_x3(h, m)) {
             if (!epoch_ok || w.hx_epoch == 0 || w.hx_epoch > 0xf0000000u) {
@@ -797,14 +818,13 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         }
         unsigned long long* hx_l = (use_x3(h, m) && l == 1) ? w.hx2 : w.hx;
         const int nsl = use_x3(h, m) ? m.nsliceX : fp32_slices(h, m, B);
-        const bool p16 = pair || (!use_x3(h, m) && nsl == 16 && m.nslice != 16);      // 16-slice packing of a bidirectional block
-        const bool wreg = !use_x3(h, m) && !pair && H == 256 && nsl == 8 && m.whhPW[0][0] &&
+        const bool p16 = !use_x3(h, m) && nsl == 16 && m.nslice != 16;      // 16-slice packing of a bidirectional block
+        const bool wreg = !use_x3(h, m) && H == 256 && nsl == 8 && m.whhPW[0][0] &&
                           (h->wreg_mask & (kin_l == 512 ? 1 : 2));
-        const bool u8 = !use_x3(h, m) && !pair && H == 256 && nsl == 32;
+        const bool u8 = !use_x3(h, m) && H == 256 && nsl == 32;
         const int cus = h->n_cu < 256 ? h->n_cu : 256;
-        // slabs per launch: grid <= #CUs, one workgroup per CU (pair kernel: 16 workgroups per pair of slabs)
-        const int chunk = pair ? (cus / (dirs * 16) > 0 ? 2 * (cus / (dirs * 16)) : 2)
-                               : (cus / (dirs * nsl) > 0 ? cus / (dirs * nsl) : 1);
+        // slabs per launch: grid <= #CUs, one workgroup per CU
+        const int chunk = cus / (dirs * nsl) > 0 ? cus / (dirs * nsl) : 1;
         const int kin = l == 0 ? H : dirs * H;
         // timing classes: 1 = H256 bidirectional K_in=256, 4 = H256 bidirectional K_in=512, 5 = H256 unidirectional
         const int cls = H != 256 ? 6 : (dirs == 1 ? 5 : (kin == 256 ? 1 : 4));
@@ -819,12 +839,13 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             a.hx = hx_l + (size_t)dirs * s0 * ((size_t)4 * 16 * H + 16);
             a.hx_next = (use_x3(h, m) && l == 0) ? w.hx2 + (size_t)dirs * s0 * ((size_t)4 * 16 * H + 16) : nullptr;
             static const int prof_layer = getenv("MP_PERSIST_PROF_LAYER") ? atoi(getenv("MP_PERSIST_PROF_LAYER")) : -1;
-            a.err = h->err_dev; a.max_spin = 1u << 18; a.prof = (prof_layer < 0 || prof_layer == l) ? h->prof_dev : nullptr;
+            a.err = h->err_dev; a.max_spin = 1u; a.max_ticks = h->wait_ticks;
+            a.prof = (prof_layer < 0 || prof_layer == l) ? h->prof_dev : nullptr;
             a.zero_state = j.mode == STATE_ZERO ? 1 : 0; a.force_remote = h->force_remote ? 1 : 0;
             const bool x3 = use_x3(h, m);
             a.epoch_base = epoch_base;
             a.min_lds = x3 ? 0 : h->excl_lds;
-            if (!x3 && !pair && h->xcd_plan_on[j.id] && a.nslab == nslab) { mp_fill_xcd_table(a, h->xcd_plan[j.id]); a.xcd_physical = 1; }
+            if (!x3 && h->xcd_plan_on[j.id] && a.nslab == nslab) { mp_fill_xcd_table(a, h->xcd_plan[j.id]); a.xcd_physical = 1; }
             a.out_pairs = x3 ? 1 : 0;                          // both layers feed split-bf16 consumers (layer 1 / linear2)
             for (int d = 0; d < dirs; ++d) {
                 LstmDir& dd = a.d[d];
@@ -839,7 +860,6 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             if (dirs == 1) a.d[1] = a.d[0];
             if (x3 && nsl == 8 && (h->x3w_mask & (kin == 256 ? 1 : 2))) mp_launch_lstm_x3w(a, kin, s);
             else if (x3) mp_launch_lstm_x3(a, kin, nsl, s);
-            else if (pair) mp_launch_lstm_pair(a, kin, h->pair_mode, s);
             else if (u8) mp_launch_lstm_u8(a, kin, s);
             else if (wreg) mp_launch_lstm_persist_w(a, kin, s);
             else mp_launch_lstm_persist(a, H, kin, nsl, s);
@@ -1150,13 +1170,19 @@ int run_maybe_graph(mp_handle* h, const GraphKey& key, Body body) {
 
 // A bounded wait inside a persistent kernel of an EARLIER call timed out (the grid was starved of CUs -- e.g. the GPU is
 // shared with another process): the results of that call are invalid.  Reported once, by the next API entry.
+// The side-by-side schedules address clusters by the XCD a workgroup really lands on, which rests on a probed but
+// undocumented dispatcher order.  After any device error the handle stops relying on it: launches fall back to the
+// blockIdx % 8 round robin (placement then only affects speed, never which (cluster, slice) a workgroup takes).
+void disable_xcd_tables(mp_handle* h) { h->xcd_rr = false; }
+
 int pending_device_error(mp_handle* h, const char* where) {
     const int code = h->err_host ? *(volatile int*)h->err_host : 0;
     if (!code) return MP_OK;
     *(volatile int*)h->err_host = 0;
-    return fail(h, MP_ERR_DEVICE, "%s: a previous call's persistent LSTM kernel timed out waiting for another workgroup's "
-                "hidden state (code %d: 1+step, or 1000000 = start-up handshake); the outputs of that call are invalid",
-                where, code);
+    disable_xcd_tables(h);
+    return fail(h, MP_ERR_DEVICE, "%s: a previous call's persistent LSTM kernel gave up a wait for another workgroup's "
+                "hidden state (code %d: 1+step, or 1000000 = start-up handshake; the GPU was shared?); the affected "
+                "outputs of that call are NaN.  Physical-XCD placement tables are now off for this handle", where, code);
 }
 
 int need_weights(mp_handle* h, const char* what) {
@@ -1174,6 +1200,51 @@ int enter(mp_handle* h, void* stream) {
 int leave(mp_handle* h, void* stream) {
     HIPCHK(h, hipEventRecord(h->ev_out, h->s_main));
     HIPCHK(h, hipStreamWaitEvent((hipStream_t)stream, h->ev_out, 0));
+    return MP_OK;
+}
+
+
+// ---- recovery (mp_set_recovery) ------------------------------------------------------------------------------------
+// snapshot / restore of the carried velocity state around a call (the fused kernels update it in place)
+int snapshot_vstate(mp_handle* h, int B, bool has_state) {
+    if (!h->recovery || !has_state) return MP_OK;
+    if (int rc = ensure_vstate(h, h->vsnap, B)) return rc;
+    const size_t n = (size_t)2 * B * 256 * sizeof(float);
+    HIPCHK(h, hipMemcpyAsync(h->vsnap.h, h->vstate.h, n, hipMemcpyDeviceToDevice, h->s_main));
+    HIPCHK(h, hipMemcpyAsync(h->vsnap.c, h->vstate.c, n, hipMemcpyDeviceToDevice, h->s_main));
+    return MP_OK;
+}
+int restore_vstate(mp_handle* h, int B, bool has_state) {
+    if (!has_state) return MP_OK;                      // the call started from zero state: nothing to restore
+    const size_t n = (size_t)2 * B * 256 * sizeof(float);
+    HIPCHK(h, hipMemcpyAsync(h->vstate.h, h->vsnap.h, n, hipMemcpyDeviceToDevice, h->s_main));
+    HIPCHK(h, hipMemcpyAsync(h->vstate.c, h->vsnap.c, n, hipMemcpyDeviceToDevice, h->s_main));
+    return MP_OK;
+}
+
+// After `first` has been enqueued: wait for it; if a persistent kernel gave up a wait, `restore()` puts back the state
+// the call started from and `again()` runs the call with per-step kernels (eager).  MP_OK + a warning when repaired.
+template <class Restore, class Again>
+int finish_or_recover(mp_handle* h, Plan* p, const char* what, Restore restore, Again again) {
+    if (!h->recovery || h->capturing) return MP_OK;
+    HIPCHK(h, hipStreamSynchronize(h->s_main));
+    const int code = h->err_host ? *(volatile int*)h->err_host : 0;
+    if (!code) return MP_OK;
+    *(volatile int*)h->err_host = 0;
+    disable_xcd_tables(h);
+    const bool persist = h->persist, uni2 = h->uni2, x3 = h->x3, graph = h->use_graph;
+    h->persist = false; h->uni2 = false; h->x3 = false; h->use_graph = false;
+    int rc = p ? ensure_step_ws(h, p) : MP_OK;
+    if (!rc) rc = restore();
+    if (!rc) rc = again();
+    h->persist = persist; h->uni2 = uni2; h->x3 = x3; h->use_graph = graph;
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->s_main));
+    ++h->recoveries;
+    char buf[400];
+    snprintf(buf, sizeof(buf), "warning: %s: a fused LSTM layer grid was starved of compute units (code %d; is the GPU shared?); "
+             "the call was run again with per-step kernels and its results are valid (recovery #%d)", what, code, h->recoveries);
+    h->err = buf;
     return MP_OK;
 }
 
@@ -1213,6 +1284,9 @@ void mp_destroy(mp_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
+    if (h->err_host && *(volatile int*)h->err_host)     // nobody asked (mp_finish / mp_device_error / a later call): say it
+        fprintf(stderr, "libmobileposer_hip: mp_destroy: an unreported device error was pending (code %d): a persistent LSTM "
+                        "kernel gave up a wait; the affected outputs of that call were NaN\n", *(volatile int*)h->err_host);
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     for (auto& kv : h->plans) {
         for (void* p : kv.second->allocs) (void)hipFree(p);
@@ -1241,14 +1315,15 @@ void mp_destroy(mp_handle* h) {
     void* misc[] = {h->parent_dev, h->depth_dev, h->bone_dev, h->vstate.h, h->vstate.c, h->sc.window, h->sc.fresh,
                     h->sc.mask_dev, h->sc.st.last_foot, h->sc.st.root_y, h->sc.st.root_pos, h->sc.joints, h->sc.vel,
                     h->sc.contact, h->jrest_dev, h->vrest_dev, h->skinw_dev, h->lin1_pv.Wp, h->lin1_pv.bias, h->prof_dev,
-                    h->vtpl_dev, h->shapedirs_dev, h->jreg_dev, h->shape_ws};
+                    h->vtpl_dev, h->shapedirs_dev, h->jreg_dev, h->shape_ws,
+                    h->vsnap.h, h->vsnap.c, h->st_snap.last_foot, h->st_snap.root_y, h->st_snap.root_pos};
     for (void* p : misc) if (p) (void)hipFree(p);
     if (h->err_host) (void)hipHostFree(h->err_host);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     hipEvent_t evs[5] = {h->ev_in, h->ev_out, h->ev_j, h->ev_v, h->ev_f};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_x) if (e) (void)hipEventDestroy(e);
-    hipStream_t ss[3] = {h->s_main, h->s_vel, h->s_foot};             // (s_gp is s_vel)
+    hipStream_t ss[4] = {h->s_main, h->s_vel, h->s_foot, h->s_dbg};   // (s_gp is s_vel)
     for (hipStream_t s : ss) if (s) (void)hipStreamDestroy(s);
     delete h;
 }
@@ -1279,20 +1354,23 @@ int mp_forward(mp_handle* h, const float* imu_dev, const int32_t* lengths_host, 
     const bool has_state = h->vstate.B == B;
     float* r6d = r6d_dev ? r6d_dev : p->r6d;
     h->segs.clear(); h->ev_used = 0;
+    if (int rc = snapshot_vstate(h, B, has_state)) return rc;
     GraphKey key;
     memset(&key, 0, sizeof(key));
     key.kind = 0; key.B = B; key.T = T; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0) | (h->uni2 ? 4 : 0) | (h->x3 ? 8 : 0);
     key.p[0] = imu_dev; key.p[1] = pose_dev; key.p[2] = joints_dev; key.p[3] = vel_dev; key.p[4] = contact_dev;
     key.p[5] = r6d; key.p[6] = h->vstate.h;
+    auto body = [&]() {
+        return forward_body(h, p, imu_dev, pose_dev, (long)B * T, 96, 0, joints_dev, vel_dev, contact_dev, r6d,
+                            h->vstate, has_state);
+    };
     int rc;
     {
         SegScope whole(h, h->s_main, 3, 1);
-        rc = run_maybe_graph(h, key, [&]() {
-            return forward_body(h, p, imu_dev, pose_dev, (long)B * T, 96, 0, joints_dev, vel_dev, contact_dev, r6d,
-                                h->vstate, has_state);
-        });
+        rc = run_maybe_graph(h, key, body);
     }
     if (rc) return rc;
+    if (int rc2 = finish_or_recover(h, p, "mp_forward", [&]() { return restore_vstate(h, B, has_state); }, body)) return rc2;
     h->vstate.B = B;
     return leave(h, stream);
 }
@@ -1314,24 +1392,27 @@ int mp_forward_offline(mp_handle* h, const float* imu_dev, const int32_t* length
     if (int rc = ensure_vstate(h, h->vstate, B)) return rc;
     const bool has_state = h->vstate.B == B;
     h->segs.clear(); h->ev_used = 0;
+    if (int rc = snapshot_vstate(h, B, has_state)) return rc;
     GraphKey key;
     memset(&key, 0, sizeof(key));
     key.kind = 2; key.B = B; key.T = T; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0) | (h->uni2 ? 4 : 0) | (h->x3 ? 8 : 0);
     key.p[0] = imu_dev; key.p[1] = pose_dev; key.p[2] = joints_dev; key.p[3] = vel_dev; key.p[4] = contact_dev;
     key.p[5] = tran_dev; key.p[6] = h->vstate.h; key.p[7] = rglobal_dev;
+    auto body = [&]() {
+        if (int r = forward_body(h, p, imu_dev, pose_dev, (long)B * T, 96, 0, joints_dev, vel_dev, contact_dev, p->r6d,
+                                 h->vstate, has_state, rglobal_dev, joint_dev)) return r;
+        mp_launch_translate_offline(joints_dev, vel_dev, contact_dev, p->lengths_dev, B, T, h->floor_y, tran_dev,
+                                    h->s_main);                                       // net.py:130-154
+        HIPCHK(h, hipGetLastError());
+        return (int)MP_OK;
+    };
     int rc;
     {
         SegScope whole(h, h->s_main, 3, 1);
-        rc = run_maybe_graph(h, key, [&]() {
-            if (int r = forward_body(h, p, imu_dev, pose_dev, (long)B * T, 96, 0, joints_dev, vel_dev, contact_dev, p->r6d,
-                                     h->vstate, has_state, rglobal_dev, joint_dev)) return r;
-            mp_launch_translate_offline(joints_dev, vel_dev, contact_dev, p->lengths_dev, B, T, h->floor_y, tran_dev,
-                                        h->s_main);                                       // net.py:130-154
-            HIPCHK(h, hipGetLastError());
-            return (int)MP_OK;
-        });
+        rc = run_maybe_graph(h, key, body);
     }
     if (rc) return rc;
+    if (int rc2 = finish_or_recover(h, p, "mp_forward_offline", [&]() { return restore_vstate(h, B, has_state); }, body)) return rc2;
     h->vstate.B = B;
     return leave(h, stream);
 }
@@ -1355,6 +1436,7 @@ int mp_rnn_forward(mp_handle* h, int module, const float* x_dev, const int32_t* 
                state_out_dev, state_out_dev ? state_out_dev + half : nullptr};
     int rc = run_rnn(job, h->s_main);
     if (rc) return rc;
+    if (int rc2 = finish_or_recover(h, p, "mp_rnn_forward", []() { return (int)MP_OK; }, [&]() { return run_rnn(job, h->s_main); })) return rc2;
     return leave(h, stream);
 }
 
@@ -1519,6 +1601,9 @@ int mp_stream_create(mp_handle* h, int S) {
     if (int rc = dev_alloc(h, (void**)&c.st.last_foot, (size_t)S * 6 * sizeof(float))) return rc;
     if (int rc = dev_alloc(h, (void**)&c.st.root_y, (size_t)S * sizeof(double))) return rc;
     if (int rc = dev_alloc(h, (void**)&c.st.root_pos, (size_t)S * 3 * sizeof(float))) return rc;
+    if (int rc = dev_alloc(h, (void**)&h->st_snap.last_foot, (size_t)S * 6 * sizeof(float))) return rc;
+    if (int rc = dev_alloc(h, (void**)&h->st_snap.root_y, (size_t)S * sizeof(double))) return rc;
+    if (int rc = dev_alloc(h, (void**)&h->st_snap.root_pos, (size_t)S * 3 * sizeof(float))) return rc;
     if (int rc = dev_alloc(h, (void**)&c.joints, (size_t)S * W * 72 * sizeof(float))) return rc;
     if (int rc = dev_alloc(h, (void**)&c.vel, (size_t)S * W * 72 * sizeof(float))) return rc;
     if (int rc = dev_alloc(h, (void**)&c.contact, (size_t)S * W * 2 * sizeof(float))) return rc;
@@ -1558,26 +1643,43 @@ int mp_stream_step(mp_handle* h, const float* frames_dev, float* pose_dev, float
     float* joints = joints_dev ? joints_dev : c.joints;
     const bool has_state = h->vstate.B == S;
     h->segs.clear(); h->ev_used = 0;
+    if (int rc = snapshot_vstate(h, S, has_state)) return rc;
+    if (h->recovery) {      // the solver state of the tick (net.py:59-64): last foot positions, root height, root position
+        HIPCHK(h, hipMemcpyAsync(h->st_snap.last_foot, c.st.last_foot, (size_t)S * 6 * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+        HIPCHK(h, hipMemcpyAsync(h->st_snap.root_y, c.st.root_y, (size_t)S * sizeof(double), hipMemcpyDeviceToDevice, h->s_main));
+        HIPCHK(h, hipMemcpyAsync(h->st_snap.root_pos, c.st.root_pos, (size_t)S * 3 * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+    }
     GraphKey key;
     memset(&key, 0, sizeof(key));
     key.kind = 1; key.B = S; key.T = W; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0) | (h->uni2 ? 4 : 0) | (h->x3 ? 8 : 0);
     key.p[0] = frames_dev; key.p[1] = pose_dev; key.p[2] = joints; key.p[3] = root_pos_dev; key.p[4] = contact_dev;
     key.p[6] = h->vstate.h;
+    auto net_and_solver = [&]() {
+        // forward on the 45-frame window (net.py:178); pose only for index 40 (net.py:181)
+        if (int r = forward_body(h, p, c.window, pose_dev, S, (long)W * 96, (long)PAST * 96, joints, c.vel, c.contact,
+                                 p->r6d, h->vstate, has_state)) return r;
+        mp_launch_translate_online(joints, c.vel, c.contact, S, W, PAST, h->floor_y, c.st, root_pos_dev, contact_dev,
+                                   h->s_main);                                                // net.py:186-208
+        HIPCHK(h, hipGetLastError());
+        return (int)MP_OK;
+    };
     int rc;
     {
         SegScope whole(h, h->s_main, 3, 1);
         rc = run_maybe_graph(h, key, [&]() {
             mp_launch_window_push(c.window, frames_dev, c.fresh, S, W, h->s_main);               // net.py:175
-            // forward on the 45-frame window (net.py:178); pose only for index 40 (net.py:181)
-            if (int r = forward_body(h, p, c.window, pose_dev, S, (long)W * 96, (long)PAST * 96, joints, c.vel, c.contact,
-                                     p->r6d, h->vstate, has_state)) return r;
-            mp_launch_translate_online(joints, c.vel, c.contact, S, W, PAST, h->floor_y, c.st, root_pos_dev, contact_dev,
-                                       h->s_main);                                                // net.py:186-208
-            HIPCHK(h, hipGetLastError());
-            return (int)MP_OK;
+            return net_and_solver();
         });
     }
     if (rc) return rc;
+    // (a repaired tick does not push the frame again: the window already holds it -- only network and solver are redone)
+    if (int rc2 = finish_or_recover(h, p, "mp_stream_step", [&]() {
+            if (int r = restore_vstate(h, S, has_state)) return r;
+            HIPCHK(h, hipMemcpyAsync(c.st.last_foot, h->st_snap.last_foot, (size_t)S * 6 * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+            HIPCHK(h, hipMemcpyAsync(c.st.root_y, h->st_snap.root_y, (size_t)S * sizeof(double), hipMemcpyDeviceToDevice, h->s_main));
+            HIPCHK(h, hipMemcpyAsync(c.st.root_pos, h->st_snap.root_pos, (size_t)S * 3 * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+            return (int)MP_OK;
+        }, net_and_solver)) return rc2;
     h->vstate.B = S;
     return leave(h, stream);
 }
@@ -1630,6 +1732,26 @@ int mp_stream_get_state(mp_handle* h, int s, float* window_dev, float last_foot_
     return MP_OK;
 }
 
+int mp_stream_set_state(mp_handle* h, int s, const float* window_dev, const float last_foot_host[6], const double* root_y_host,
+                        const float root_pos_host[3], const int* fresh_host) {
+    if (!h) return MP_ERR_INVALID;
+    StreamCtx& c = h->sc;
+    if (!c.S) return fail(h, MP_ERR_NO_STREAMS, "mp_stream_set_state before mp_stream_create");
+    if (s < 0 || s >= c.S) return fail(h, MP_ERR_INVALID, "mp_stream_set_state: stream %d outside 0..%d", s, c.S - 1);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->s_main));
+    if (window_dev)
+        HIPCHK(h, hipMemcpy(c.window + (size_t)s * 45 * 60, window_dev, (size_t)45 * 60 * sizeof(float), hipMemcpyDeviceToDevice));
+    if (last_foot_host) HIPCHK(h, hipMemcpy(c.st.last_foot + (size_t)s * 6, last_foot_host, 6 * sizeof(float), hipMemcpyHostToDevice));
+    if (root_y_host) HIPCHK(h, hipMemcpy(c.st.root_y + s, root_y_host, sizeof(double), hipMemcpyHostToDevice));
+    if (root_pos_host) HIPCHK(h, hipMemcpy(c.st.root_pos + (size_t)s * 3, root_pos_host, 3 * sizeof(float), hipMemcpyHostToDevice));
+    if (fresh_host) {
+        const uint8_t f = *fresh_host ? 1 : 0;
+        HIPCHK(h, hipMemcpy(c.fresh + s, &f, 1, hipMemcpyHostToDevice));
+    }
+    return MP_OK;
+}
+
 // ------------------------------------------------------------------------------------------ measurement
 int mp_timing_enable(mp_handle* h, int on) {
     if (!h) return MP_ERR_INVALID;
@@ -1664,7 +1786,41 @@ int mp_device_error(mp_handle* h, int* code) {
     return MP_OK;
 }
 
-namespace { MP_KERNEL void mp_poke_error(int* err, int code) { mp_set_error(err, code); } }
+int mp_finish(mp_handle* h) {
+    if (!h) return MP_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->s_main));
+    return pending_device_error(h, "mp_finish");
+}
+
+int mp_set_recovery(mp_handle* h, int on) {
+    if (!h) return MP_ERR_INVALID;
+    h->recovery = on != 0;
+    return MP_OK;
+}
+
+int mp_recovery_count(const mp_handle* h) { return h ? h->recoveries : 0; }
+
+namespace {
+MP_KERNEL void mp_poke_error(int* err, int code) { mp_set_error(err, code); }
+// holds a compute unit (one workgroup with `lds` bytes of LDS) for `ticks` of the 100 MHz clock
+MP_KERNEL void mp_occupy(unsigned long long ticks) {
+    extern __shared__ float occ_lds[];
+    if (threadIdx.x == 0) occ_lds[0] = 0.f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+}
+
+int mp_debug_occupy(mp_handle* h, int n_wg, int lds_bytes, double ms) {
+    if (!h || n_wg < 1 || lds_bytes < 0 || lds_bytes > 160 * 1024 || ms <= 0.0 || ms > 5000.0) return MP_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->s_dbg) HIPCHK(h, hipStreamCreateWithFlags(&h->s_dbg, hipStreamNonBlocking));
+    HIPCHK(h, hipFuncSetAttribute((const void*)mp_occupy, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(mp_occupy, dim3(n_wg), dim3(64), (size_t)lds_bytes, h->s_dbg, (unsigned long long)(ms * 1e5));
+    HIPCHK(h, hipGetLastError());
+    return MP_OK;
+}
 
 int mp_debug_poke_error(mp_handle* h, int code) {
     if (!h) return MP_ERR_INVALID;

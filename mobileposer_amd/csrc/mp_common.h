@@ -3,12 +3,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// gfx950 co-execution erratum observed on MI355X (DESIGN.md "packed-fp32 beside bf16 MFMA"): a wave's
-// packed-fp32 VALU results (v_pk_mul/add/fma_f32) come out wrong in lanes 48..63, at random, while another wave
-// on the same CU issues v_mfma_f32_16x16x32_bf16.  Every kernel of this library can run beside the split-bf16
-// LSTM layers, so none of them may contain packed-fp32 instructions: the build passes
-// `-Xclang -target-feature -Xclang -packed-fp32-ops` for all device code (__graft_entry__.build) and
-// tests/test_cabi_cpu.py disassembles the library to check that none slipped in.
+// No kernel of this library contains packed-fp32 VALU instructions (v_pk_mul/add/fma_f32): the build passes
+// `-Xclang -target-feature -Xclang -packed-fp32-ops` for all device code (__graft_entry__.build) and tests/test_cabi_cpu.py
+// disassembles the library to check that none slipped in.  Insurance, not a claimed hardware erratum: some historical
+// revisions of the split-bf16 LSTM kernels disturbed such results (lanes 48..63) of a kernel running beside them, the
+// current ones do not, and no trigger could be named (profiles/r02_coexec_glitch.md).
 #define MP_KERNEL __global__
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -91,7 +90,8 @@ struct LstmPersistArgs {
     int ndir, B, T, slab0, nslab;
     int zero_state;               // 1: start from h = c = 0 without reading hbuf / cbuf
     int force_remote;             // test hook: use the any-placement (sc1) transport even inside one XCD
-    unsigned max_spin;
+    unsigned max_spin;            // 0: never wait (a test hook); otherwise waits are allowed, bounded by max_ticks
+    unsigned long long max_ticks; // bound of every wait in ticks of the constant 100 MHz clock (s_memrealtime); mp_api: 0.25 s
     long long* prof;              // optional [grid][6] cycle sums per phase (debug), else nullptr
     int out_pairs = 0;            // split-bf16 kernel only: write the layer output as pairs (it feeds another layer)
     // mp_lstm_fused only: 0 = the area was zeroed before this launch (tags = step numbers); otherwise the area may hold
@@ -142,9 +142,6 @@ void mp_launch_lstm_x3w(const LstmPersistArgs& a, int KIN, hipStream_t s);   // 
 void mp_launch_pack_w_x3(const float* w, float* dst, int K, int nslice, hipStream_t s);
 // Dynamic-LDS limits (80-160 KB) of the persistent kernels are per-DEVICE function attributes: mp_create sets them for
 // the handle's device after hipSetDevice, outside of any stream capture.
-// two slabs per workgroup (mp_lstm_pair.hip): H = 256, weights in the 16-slice packing; mode bit 0 = matrix-pipe token
-void mp_launch_lstm_pair(const LstmPersistArgs& a, int KIN, int mode, hipStream_t s);
-hipError_t mp_lstm_pair_device_attrs();
 hipError_t mp_lstm_persist_device_attrs();
 hipError_t mp_lstm_x3_device_attrs();
 hipError_t mp_lstm_x3w_device_attrs();

@@ -13,6 +13,7 @@
 // from HBM once.
 #include "mp_lstm_dev.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -288,7 +289,7 @@ void launch(const GemmArgs& g, hipStream_t s) {
 int mp_gemm_pick_bn(int N) { return N > 96 ? 128 : (N > 32 ? 96 : 32); }
 
 void mp_launch_gemm(const GemmArgs& g, int bn, hipStream_t s) {
-    static const bool staged = getenv("MP_GEMM_STAGED") && atoi(getenv("MP_GEMM_STAGED")) != 0;   // the LDS-staged kernel (A/B runs)
+    static const bool staged = getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "gemm_staged=1");   // A/B runs: the LDS-staged kernel
     // (row-streaming kernel for the linear2 shapes -- few columns, K >= 128)
     if (!staged && g.N <= 96 && g.Kpad >= 128) {
         // (W is padded to a multiple of bn rows: bn = 32 -> 1 tile, 96 -> up to 3)

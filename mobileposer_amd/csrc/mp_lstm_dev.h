@@ -22,6 +22,26 @@ static __device__ __forceinline__ void mp_set_error(int* err, int code) {
     __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Every wait of a persistent kernel is bounded in TIME: a poll loop gives up once `max_ticks` of the constant 100 MHz clock
+// (s_memrealtime) have passed since its first look at the clock (one look per 32 polls: the clock is a scalar memory read).
+// budget == 0: an earlier wait of this wave already gave up -- never wait again.  Only ever reached on a slow path.
+static __device__ __forceinline__ bool wait_over(unsigned& spins, unsigned budget, u64& t0, u64 max_ticks) {
+    if (budget == 0) return true;
+    if ((++spins & 31u) != 1u) return false;
+    const u64 now = __builtin_amdgcn_s_memrealtime();
+    if (spins == 1u) { t0 = now; return false; }
+    return now - t0 > max_ticks;
+}
+// A wave that gave up a wait makes its cell state NaN: every h it publishes from now on, its rows of the layer output, the
+// final state and -- through the peers that consume its h -- the whole slab's output turn NaN within a step.  A starved
+// grid therefore never leaves plausible numbers behind (the error word says why).  Slow path only.
+template <int N>
+static __device__ __forceinline__ void poison_cells(float (&c)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) c[i] = __builtin_nanf("");
+}
+static __device__ __forceinline__ void poison_cells(float& c) { c = __builtin_nanf(""); }
+
 static __device__ __forceinline__ u64 granule_load(const u64* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

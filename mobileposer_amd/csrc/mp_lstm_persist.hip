@@ -235,11 +235,11 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
         if (threadIdx.x == 0) granule_store(xtab + slice, xtag, __uint_as_float(my_xcc));
         unsigned peer = my_xcc;
         if (lane < NSLICE) {
-            unsigned spins = 0;
+            unsigned spins = 0; u64 wt0 = 0;
             while (true) {
                 const u64 g = granule_load(xtab + lane);
                 if ((unsigned)(g >> 32) == xtag) { peer = (unsigned)g; break; }
-                if (++spins > spin_budget) { mp_set_error(a.err, 1000000); peer = ~0u; break; }
+                if (wait_over(spins, spin_budget, wt0, a.max_ticks)) { mp_set_error(a.err, 1000000); peer = ~0u; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
         }
@@ -247,7 +247,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
         all_local = (same & ((1ull << NSLICE) - 1)) == ((1ull << NSLICE) - 1);
 #pragma unroll
         for (int i = 0; i < NPW; ++i) src_local[i] = (same >> (NPW * kq + i)) & 1;   // k-steps of part i come from slice NPW*kq+i
-        if (__ballot(peer == ~0u)) spin_budget = 0;
+        if (__ballot(peer == ~0u)) { spin_budget = 0; poison_cells(cst); }
         if (a.force_remote) {                               // test hook: exercise the any-placement transport
             all_local = false;
 #pragma unroll
@@ -408,12 +408,12 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
             for (int j = 0; j < NXJ; ++j) asm volatile("" : "+v"(xa[j]));
             if (step > 0) {
                 bool ok = hflags == epoch;
-                unsigned spins = 0;
+                unsigned spins = 0; u64 wt0 = 0;
                 if (PROF && prof && !__all(ok)) pt[5] += 1;  // slow-path entries
                 while (!__all(ok)) {
-                    if (++spins > spin_budget) {               // bounded: flag the error and never wait again
+                    if (wait_over(spins, spin_budget, wt0, a.max_ticks)) {               // bounded: flag the error and never wait again
                         if (lane == 0) mp_set_error(a.err, 1 + step);
-                        spin_budget = 0;
+                        spin_budget = 0; poison_cells(cst);
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
@@ -472,7 +472,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
             bool ok = true;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) ok = ok && ((unsigned)(gr[ks] >> 32) == epoch);
-            unsigned spins = 0;
+            unsigned spins = 0; u64 wt0 = 0;
             bool timed_out = false;
             if (PROF && prof && !__all(ok)) pt[5] += 1;      // slow-path entries
             while (!__all(ok) && !timed_out) {
@@ -484,7 +484,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
                     for (int i = 0; i < NPW; ++i)
                         if (lane == i) ready = (unsigned)(granule_load(srcp[i] + (size_t)(i * KSP) * 64) >> 32) == epoch;
                     if (__all(ready)) break;
-                    if (++spins > spin_budget) { timed_out = true; break; }
+                    if (wait_over(spins, spin_budget, wt0, a.max_ticks)) { timed_out = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 ok = true;
@@ -493,11 +493,11 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
                     gr[ks] = granule_load(srcp[ks / KSP] + (size_t)ks * 64);
                     ok = ok && ((unsigned)(gr[ks] >> 32) == epoch);
                 }
-                if (++spins > spin_budget) timed_out = true;
+                if (wait_over(spins, spin_budget, wt0, a.max_ticks)) timed_out = true;
             }
             if (timed_out) {                                   // bounded: flag the error and never wait again
                 if (lane == 0) mp_set_error(a.err, 1 + step);
-                spin_budget = 0;
+                spin_budget = 0; poison_cells(cst);
             }
             if (!DIRECT_GR) {
 #pragma unroll
@@ -727,11 +727,11 @@ MP_KERNEL __launch_bounds__(512, 1) void mp_lstm_fused_uni2(LstmPersistArgs a) {
         if (threadIdx.x == 0) granule_store(xtab + slice, XCC_TAG, __uint_as_float(my_xcc));
         unsigned peer = my_xcc;
         if (lane < NSLICE) {
-            unsigned spins = 0;
+            unsigned spins = 0; u64 wt0 = 0;
             while (true) {
                 const u64 g = granule_load(xtab + lane);
                 if ((unsigned)(g >> 32) == XCC_TAG) { peer = (unsigned)g; break; }
-                if (++spins > spin_budget) { mp_set_error(a.err, 1000000); peer = ~0u; break; }
+                if (wait_over(spins, spin_budget, wt0, a.max_ticks)) { mp_set_error(a.err, 1000000); peer = ~0u; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
         }
@@ -739,7 +739,7 @@ MP_KERNEL __launch_bounds__(512, 1) void mp_lstm_fused_uni2(LstmPersistArgs a) {
         all_local = (same & 0xFFFFull) == 0xFFFFull;
 #pragma unroll
         for (int i = 0; i < NPW; ++i) src_local[i] = (same >> (NPW * kq + i)) & 1;
-        if (__ballot(peer == ~0u)) spin_budget = 0;
+        if (__ballot(peer == ~0u)) { spin_budget = 0; poison_cells(cst); }
         if (a.force_remote) {
             all_local = false;
 #pragma unroll
@@ -771,7 +771,7 @@ MP_KERNEL __launch_bounds__(512, 1) void mp_lstm_fused_uni2(LstmPersistArgs a) {
         for (int ks = 0; ks < NKS; ++ks) g[ks] = granule_load(sp[ks / KSP] + (size_t)ks * 64);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) ok = ok && ((unsigned)(g[ks] >> 32) == epoch);
-        unsigned spins = 0;
+        unsigned spins = 0; u64 wt0 = 0;
         bool timed_out = false;
         while (!__all(ok) && !timed_out) {
             while (true) {                                            // cheap gate: one granule per producer
@@ -780,7 +780,7 @@ MP_KERNEL __launch_bounds__(512, 1) void mp_lstm_fused_uni2(LstmPersistArgs a) {
                 for (int i = 0; i < NPW; ++i)
                     if (lane == i) ready = (unsigned)(granule_load(sp[i] + (size_t)(i * KSP) * 64) >> 32) == epoch;
                 if (__all(ready)) break;
-                if (++spins > spin_budget) { timed_out = true; break; }
+                if (wait_over(spins, spin_budget, wt0, a.max_ticks)) { timed_out = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
             ok = true;
@@ -789,11 +789,11 @@ MP_KERNEL __launch_bounds__(512, 1) void mp_lstm_fused_uni2(LstmPersistArgs a) {
                 g[ks] = granule_load(sp[ks / KSP] + (size_t)ks * 64);
                 ok = ok && ((unsigned)(g[ks] >> 32) == epoch);
             }
-            if (++spins > spin_budget) timed_out = true;
+            if (wait_over(spins, spin_budget, wt0, a.max_ticks)) timed_out = true;
         }
         if (timed_out) {
             if (lane == 0) mp_set_error(a.err, 1 + step);
-            spin_budget = 0;
+            spin_budget = 0; poison_cells(cst);
         }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) out[ks] = __uint_as_float((unsigned)g[ks]);

@@ -101,17 +101,17 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_u8(LstmPersistArgs a) {
         if (threadIdx.x == 0) granule_store(xtab + slice, xtag, __uint_as_float(my_xcc));
         unsigned peer = my_xcc;
         if (lane < NSLICE) {
-            unsigned spins = 0;
+            unsigned spins = 0; u64 wt0 = 0;
             while (true) {
                 const u64 gw = granule_load(xtab + lane);
                 if ((unsigned)(gw >> 32) == xtag) { peer = (unsigned)gw; break; }
-                if (++spins > spin_budget) { mp_set_error(a.err, 1000000); peer = ~0u; break; }
+                if (wait_over(spins, spin_budget, wt0, a.max_ticks)) { mp_set_error(a.err, 1000000); peer = ~0u; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
         }
         same = __ballot(peer == my_xcc) | ~0xffffffffull;              // bit s: producer slice s is on my XCD
         all_local = (same & 0xffffffffull) == 0xffffffffull;
-        if (__ballot(peer == ~0u)) spin_budget = 0;
+        if (__ballot(peer == ~0u)) { spin_budget = 0; poison_cells(cst); }
         if (a.force_remote) { all_local = false; same = 0; }
     }
     __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(hdL, 0, 4 * 16 * H * 4, 0x00020000);
@@ -172,12 +172,12 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_u8(LstmPersistArgs a) {
                 for (int i = 0; i < NXG; ++i) asm volatile("" : "+v"(xa[i]));   // (all of x_t waited for before h is requested)
                 if (step > 0) {
                     bool ok = hflags == epoch;
-                    unsigned spins = 0;
+                    unsigned spins = 0; u64 wt0 = 0;
                     if (PROF && prof && !__all(ok)) pt[5] += 1;
                     while (!__all(ok)) {
-                        if (++spins > spin_budget) {                    // bounded: flag the error and never wait again
+                        if (wait_over(spins, spin_budget, wt0, a.max_ticks)) {                    // bounded: flag the error and never wait again
                             if (lane == 0) mp_set_error(a.err, 1 + step);
-                            spin_budget = 0;
+                            spin_budget = 0; poison_cells(cst);
                             break;
                         }
                         __builtin_amdgcn_s_sleep(1);

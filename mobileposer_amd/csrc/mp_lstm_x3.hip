@@ -189,17 +189,17 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         if (threadIdx.x == 0) granule_store(xtab + slice, XCC_TAG, __uint_as_float(my_xcc));
         unsigned peer = my_xcc;
         if (lane < NSLICE) {
-            unsigned spins = 0;
+            unsigned spins = 0; u64 wt0 = 0;
             while (true) {
                 const u64 g = granule_load(xtab + lane);
                 if ((unsigned)(g >> 32) == XCC_TAG) { peer = (unsigned)g; break; }
-                if (++spins > spin_budget) { mp_set_error(a.err, 1000000); peer = ~0u; break; }
+                if (wait_over(spins, spin_budget, wt0, a.max_ticks)) { mp_set_error(a.err, 1000000); peer = ~0u; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
         }
         same = __ballot(peer == my_xcc);
         all_local = (same & ((1ull << NSLICE) - 1)) == ((1ull << NSLICE) - 1);
-        if (__ballot(peer == ~0u)) spin_budget = 0;
+        if (__ballot(peer == ~0u)) { spin_budget = 0; poison_cells(cst); }
         if (a.force_remote) { all_local = false; same = 0; }      // test hook: exercise the any-placement transport
     }
     // consumer role of this lane: producer slice PPW*wave + lane/LPB; inside its [16 rows][U units] block this lane
@@ -424,11 +424,11 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
             bool late = stale();
             if (!__all(!late)) {
                 if (PROF && prof) pt[5] += 1;                   // steps whose optimistic fetch came too early
-                unsigned spins = 0;
+                unsigned spins = 0; u64 wt0 = 0;
                 do {
-                    if (++spins > spin_budget) {                // bounded: flag the error and never wait again
+                    if (wait_over(spins, spin_budget, wt0, a.max_ticks)) {                // bounded: flag the error and never wait again
                         if (lane == 0) mp_set_error(a.err, 1 + step);
-                        spin_budget = 0;
+                        spin_budget = 0; poison_cells(cst);
                         break;
                     }
                     if (late) {

@@ -189,6 +189,8 @@ def evaluate_pose(model, dataset, num_past_frame=20, num_future_frame=5, evaluat
             pose_o = torch.stack([fr[0] for fr in frames])[num_future_frame:]
             tran_o = torch.stack([fr[2] for fr in frames])[num_future_frame:]
             tables["online"].append(evaluator.eval(pose_o, pose_gt, tran_p=tran_o, tran_t=tran_t))
+        if hasattr(model, "finish"):
+            model.finish()          # raises if a kernel of this sequence gave up a wait and was not repaired (recovery off)
     out = {}
     for name in ("offline", "online"):
         if tables[name]:

@@ -11,6 +11,7 @@ import atexit
 import ctypes as C
 import os
 import sys
+import warnings
 import weakref
 
 import numpy as np
@@ -112,6 +113,8 @@ class MobilePoserNet:
         self._h = None
         self._blob = None
         self._stream_S = 0
+        self._tick = 0                  # bumped by everything that changes per-stream state (cache key of stream_state)
+        self._state_cache = {}
         self.training = False
         parts = {"pose.": poser, "joints.": joints, "foot_contact.": foot_contact, "velocity.": velocity}
         if any(v is not None for v in parts.values()):
@@ -157,6 +160,8 @@ class MobilePoserNet:
             self._blob = blob_host
         _lib.check(rc, None)
         self._h = h
+        self._recoveries = 0
+        self._state_cache = {}
         _LIVE.add(self)
         fy = C.c_float()
         fp = (C.c_float * 6)()
@@ -168,10 +173,36 @@ class MobilePoserNet:
         self.n_vertex = self._mesh_state["n_vertex"]
 
     def close(self):
-        """Release the native handle (weights, workspaces, streams, graphs).  Idempotent."""
+        """Release the native handle (weights, workspaces, streams, graphs).  Idempotent.  Raises if a device error of
+        an earlier call was never reported (possible only with recovery off: the affected outputs were NaN)."""
         h, self._h = getattr(self, "_h", None), None
         if h is not None:
+            rc = self._lib.mp_finish(h)
+            msg = _lib.last_error(h) if rc else ""
             self._lib.mp_destroy(h)
+            if rc and not sys.is_finalizing():
+                raise RuntimeError("libmobileposer_hip: %s (status %d)" % (msg, rc))
+
+    def _after_call(self):
+        """A call that was repaired by the library's recovery path (include/mobileposer_hip.h, mp_set_recovery) is
+        reported as a Python warning: its results are valid, but the GPU is evidently shared."""
+        n = self._lib.mp_recovery_count(self._h)
+        if n != self._recoveries:
+            self._recoveries = n
+            warnings.warn(_lib.last_error(self._h), RuntimeWarning, stacklevel=3)
+
+    def set_recovery(self, on):
+        """True (default): every network call waits for itself and repairs a starved fused-LSTM launch by re-running with
+        per-step kernels; False: asynchronous calls, errors surface at the next call / ``finish()`` / ``close()``."""
+        _lib.check(self._lib.mp_set_recovery(self._h, int(bool(on))), self._h)
+
+    def finish(self):
+        """Wait for everything enqueued; raises if a persistent kernel gave up a wait (recovery off)."""
+        _lib.check(self._lib.mp_finish(self._h), self._h)
+
+    @property
+    def recovery_count(self):
+        return int(self._lib.mp_recovery_count(self._h)) if self._h is not None else 0
 
     def __enter__(self):
         return self
@@ -223,6 +254,7 @@ class MobilePoserNet:
         self.rnn_state = None
         if self._h is not None and self._stream_S:        # imu = None, current_root_y = 0, last_root_pos = 0
             _lib.check(self._lib.mp_stream_reset(self._h, None, 0), self._h)
+            self._tick += 1
 
     def reset_all(self, clear_velocity=True):
         self.reset()
@@ -261,6 +293,7 @@ class MobilePoserNet:
         rc = self._lib.mp_forward(self._h, _ptr(imu), lengths_c, B, T, _ptr(pose), _ptr(joints), _ptr(vel),
                                   _ptr(contact), _ptr(r6d), self._stream())
         _lib.check(rc, self._h)
+        self._after_call()
 
     def forward(self, batch, input_lengths=None, return_r6d=False):
         """models/net.py:101-119 -> (pred_pose [B*T,24,3,3], pred_joints [B,T,72], pred_vel [B,T,72]
@@ -295,6 +328,7 @@ class MobilePoserNet:
         rc = self._lib.mp_forward_offline(self._h, _ptr(x), lens, B, T, _ptr(o["pose"]), _ptr(o["joints"]),
                                           _ptr(o["vel"]), _ptr(o["contact"]), _ptr(o["tran"]), None, None, self._stream())
         _lib.check(rc, self._h)
+        self._after_call()
         if B == 1:
             return o["pose"], o["joints"], o["tran"][0], o["contact"][0]
         return o["pose"], o["joints"], o["tran"], o["contact"]
@@ -315,6 +349,8 @@ class MobilePoserNet:
         rc = self._lib.mp_stream_step(self._h, _ptr(frames), _ptr(pose), _ptr(joints), _ptr(root), _ptr(contact),
                                       self._stream())
         _lib.check(rc, self._h)
+        self._tick += 1
+        self._after_call()
 
     def stream_step(self, frames):
         """One tick for all S streams: frames [S,60] -> (pose [S,24,9], joints [S,45,72], root_pos [S,3], contact [S,2])."""
@@ -346,6 +382,7 @@ class MobilePoserNet:
         if mask is not None:
             m = (C.c_uint8 * self._stream_S)(*[1 if bool(v) else 0 for v in mask])
         _lib.check(self._lib.mp_stream_reset(self._h, m, int(bool(clear_velocity))), self._h)
+        self._tick += 1
 
     @torch.no_grad()
     def forward_online(self, data, input_lengths=None):
@@ -362,25 +399,61 @@ class MobilePoserNet:
     # ---- the reference's state attributes (net.py:59-64,205-208), read back from the device ---------------
     def stream_state(self, s=0):
         """State of stream ``s``: dict(imu [45,60] or None before the first frame, current_root_y (float),
-        last_root_pos [3], last_lfoot_pos [3], last_rfoot_pos [3])."""
+        last_root_pos [3], last_lfoot_pos [3], last_rfoot_pos [3]).  Read back once per tick: repeated attribute reads
+        between two ticks share one round trip to the device."""
         if self._h is None or not self._stream_S:
             feet = self.feet_pos.to(self.device)
             return {"imu": None, "current_root_y": 0, "last_root_pos": torch.zeros(3, device=self.device),
                     "last_lfoot_pos": feet[0], "last_rfoot_pos": feet[1]}
+        hit = self._state_cache.get(s)
+        if hit is not None and hit[0] == self._tick:
+            return hit[1]
         win = torch.empty(45, 60, device=self.device, dtype=torch.float32)
         feet = (C.c_float * 6)()
         root = (C.c_float * 3)()
         y, fresh = C.c_double(0), C.c_int(0)
         _lib.check(self._lib.mp_stream_get_state(self._h, int(s), _ptr(win), feet, C.byref(y), root, C.byref(fresh)), self._h)
         t = lambda a: torch.tensor(list(a), device=self.device, dtype=torch.float32)
-        return {"imu": None if fresh.value else win, "current_root_y": y.value if not fresh.value else 0,
-                "last_root_pos": t(root), "last_lfoot_pos": t(feet[0:3]), "last_rfoot_pos": t(feet[3:6])}
+        st = {"imu": None if fresh.value else win, "current_root_y": y.value if not fresh.value else 0,
+              "last_root_pos": t(root), "last_lfoot_pos": t(feet[0:3]), "last_rfoot_pos": t(feet[3:6])}
+        self._state_cache[s] = (self._tick, st)
+        return st
 
-    imu = property(lambda self: self.stream_state()["imu"])
-    current_root_y = property(lambda self: self.stream_state()["current_root_y"])
-    last_root_pos = property(lambda self: self.stream_state()["last_root_pos"])
-    last_lfoot_pos = property(lambda self: self.stream_state()["last_lfoot_pos"])
-    last_rfoot_pos = property(lambda self: self.stream_state()["last_rfoot_pos"])
+    def _set_stream_state(self, name, value, s=0):
+        """Assignment to one of the reference's state attributes (net.py:59-64) -> mp_stream_set_state."""
+        self._require_weights()
+        if self._stream_S == 0:
+            self.stream_create(1)
+        win = feet = y = root = fresh = None
+        f3 = lambda v: (C.c_float * 3)(*[float(x) for x in torch.as_tensor(v).reshape(3).tolist()])
+        if name == "imu":
+            if value is None:
+                fresh = C.c_int(1)
+            else:
+                win = torch.as_tensor(value).to(device=self.device, dtype=torch.float32).reshape(45, 60).contiguous()
+                fresh = C.c_int(0)
+        elif name == "current_root_y":
+            y = C.c_double(float(value))
+        elif name == "last_root_pos":
+            root = f3(value)
+        else:                                   # one foot: read the pair, replace one half
+            cur = self.stream_state(s)
+            l = value if name == "last_lfoot_pos" else cur["last_lfoot_pos"]
+            r = value if name == "last_rfoot_pos" else cur["last_rfoot_pos"]
+            feet = (C.c_float * 6)(*(list(f3(l)) + list(f3(r))))
+        _lib.check(self._lib.mp_stream_set_state(self._h, int(s), _ptr(win), feet, C.byref(y) if y is not None else None,
+                                                 root, C.byref(fresh) if fresh is not None else None), self._h)
+        self._tick += 1                         # invalidates the read-back cache
+
+    def _state_property(name):
+        return property(lambda self: self.stream_state()[name], lambda self, v: self._set_stream_state(name, v))
+
+    imu = _state_property("imu")
+    current_root_y = _state_property("current_root_y")
+    last_root_pos = _state_property("last_root_pos")
+    last_lfoot_pos = _state_property("last_lfoot_pos")
+    last_rfoot_pos = _state_property("last_rfoot_pos")
+    del _state_property
 
     # ---- kinematics ----------------------------------------------------------------------------
     def _reduced_global_to_full(self, reduced_pose):
@@ -413,6 +486,7 @@ class MobilePoserNet:
             st_in = torch.stack((state[0], state[1])).to(device=self.device, dtype=torch.float32).contiguous()
         rc = self._lib.mp_rnn_forward(self._h, mod, _ptr(x), lens, B, T, _ptr(y), _ptr(st_in), _ptr(st_out), self._stream())
         _lib.check(rc, self._h)
+        self._after_call()
         return y, (st_out[0], st_out[1])
 
     # ---- measurement hooks -----------------------------------------------------------------------

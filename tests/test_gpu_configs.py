@@ -174,25 +174,6 @@ def test_load_model_state_dict_and_checkpoint(torch_mod, weights, smpl, tmp_path
         load_model(str(p1), smpl=smpl)
 
 
-def test_device_error_is_reported_by_next_call(torch_mod, weights, smpl):
-    """A persistent kernel that gives up a bounded wait leaves a code in the handle's error word; the NEXT API entry
-    returns MP_ERR_DEVICE (once).  Simulated by poking the word the way the kernels do (system-scope store into the
-    pinned host word), since a healthy GPU never times out."""
-    import ctypes as C
-    from mobileposer_amd import synthetic
-    from mobileposer_amd.net import MobilePoserNet
-    x = cu(torch_mod, synthetic.make_imu(2, 8, seed=1))
-    with MobilePoserNet.from_numpy(weights, smpl) as m:
-        m.forward(x, [8, 8])
-        assert m.device_error() == 0
-        _lib = m._lib
-        assert _lib.mp_debug_poke_error(m._h, 43) == 0
-        with pytest.raises(RuntimeError, match="timed out"):
-            m.forward(x, [8, 8])
-        m.forward(x, [8, 8])                          # reported once; the handle stays usable
-        assert m.device_error() == 0
-
-
 def test_graph_replay_equals_eager_in_subprocess():
     """Opt-in hipGraph mode (mp_set_graph_mode(h, 1)): replay == eager, bitwise, for the batch path and the streaming
     tick.  In its own process with GPU_MAX_HW_QUEUES=8: the multi-branch graph executor of this ROCm's HIP runtime can

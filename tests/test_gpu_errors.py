@@ -1,0 +1,145 @@
+"""Error behaviour of the fused (persistent) LSTM launches -- include/mobileposer_hip.h, "error behaviour":
+a starved grid gives up its waits after a TIME bound, leaves NaN (never plausible numbers) and an error word behind;
+with recovery on (default) the call repairs itself with per-step kernels and returns valid results; with recovery off
+the error surfaces at the next entry / mp_finish / close().  Starvation is produced for real: a test hook parks spinning
+workgroups with a large LDS request on 64 compute units while a 256-workgroup layer grid is launched."""
+import ctypes as C
+import time
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import cu, npy
+
+pytestmark = pytest.mark.gpu
+
+
+def test_poked_error_is_reported_once_by_the_next_entry(torch_mod, weights, smpl):
+    """The error word of an EARLIER call (poked the way a kernel stores it: system-scope store into the pinned host word)
+    makes the next API entry return MP_ERR_DEVICE once; the handle stays usable."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    x = cu(torch_mod, synthetic.make_imu(2, 8, seed=1))
+    with MobilePoserNet.from_numpy(weights, smpl) as m:
+        m.forward(x, [8, 8])
+        assert m.device_error() == 0
+        assert m._lib.mp_debug_poke_error(m._h, 43) == 0
+        with pytest.raises(RuntimeError, match="gave up a wait"):
+            m.forward(x, [8, 8])
+        m.forward(x, [8, 8])                          # reported once
+        assert m.device_error() == 0
+        assert m._lib.mp_debug_poke_error(m._h, 44) == 0
+        with pytest.raises(RuntimeError, match="code 44"):
+            m.finish()
+        m.finish()
+
+
+def _starve(m, ms=400.0):
+    """Park 64 workgroups x 100 KB of LDS on 64 CUs for `ms`: a 256-workgroup persistent grid cannot be resident."""
+    assert m._lib.mp_debug_occupy(m._h, 64, 100 * 1024, C.c_double(ms)) == 0
+    time.sleep(0.005)
+
+
+@pytest.mark.parametrize("mode", [1, 3])
+def test_starved_call_repairs_itself(torch_mod, weights, smpl, monkeypatch, mode):
+    """Recovery on (default): the starved forward_offline returns the same values as an undisturbed one (to the
+    difference between the fused and the per-step kernels), warns, and counts one recovery; the carried velocity state
+    it started from is put back before the re-run (second call of a pair, quirk Q1)."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    monkeypatch.setenv("MP_WAIT_MS", "15")                        # the 0.25 s bound, shortened for the test
+    B, T = 256, 24
+    x = cu(torch_mod, synthetic.make_imu(B, T, seed=77))
+    with MobilePoserNet.from_numpy(weights, smpl) as m:
+        m.set_lstm_mode(mode)
+        first = [t.clone() for t in m.forward_offline(x, [T] * B)]
+        want = [t.clone() for t in m.forward_offline(x, [T] * B)]      # second call: velocity state carried
+        assert m.recovery_count == 0
+        m.reset_all()
+        got1 = [t.clone() for t in m.forward_offline(x, [T] * B)]
+        for a, b in zip(first, got1):
+            assert torch_mod.equal(a, b)
+        _starve(m)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = m.forward_offline(x, [T] * B)
+        assert m.recovery_count == 1 and any("starved" in str(i.message) for i in w), [str(i.message) for i in w]
+        for a, b in zip(want, got):
+            assert bool(torch_mod.isfinite(b).all())
+            assert float((a - b).abs().max()) < 2e-5
+        torch_mod.cuda.synchronize()
+        time.sleep(0.5)                                           # the occupier is gone
+        m.reset_all()
+        again = m.forward_offline(x, [T] * B)                     # back on the fused kernels, undisturbed
+        for a, b in zip(first, again):
+            assert float((a - b).abs().max()) < 2e-5              # (XCD tables are off now: 16-slice / serial schedule may differ)
+        assert m.recovery_count == 1 and m.device_error() == 0
+
+
+def test_starved_call_without_recovery_is_loud(torch_mod, weights, smpl, monkeypatch):
+    """Recovery off: the starved call returns at once (asynchronous); its outputs are NaN, never plausible numbers;
+    finish() raises MP_ERR_DEVICE; afterwards the handle works again."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    monkeypatch.setenv("MP_WAIT_MS", "15")
+    B, T = 256, 24
+    x = cu(torch_mod, synthetic.make_imu(B, T, seed=78))
+    with MobilePoserNet.from_numpy(weights, smpl) as m:
+        m.set_recovery(False)
+        want = [t.clone() for t in m.forward_offline(x, [T] * B)]
+        m.reset_all()
+        _starve(m)
+        got = [t.clone() for t in m.forward_offline(x, [T] * B)]
+        with pytest.raises(RuntimeError, match="gave up a wait"):
+            m.finish()
+        assert any(bool(torch_mod.isnan(t).any()) for t in got), "a starved grid must not leave plausible numbers"
+        joints = got[1]
+        bad = torch_mod.isnan(joints).flatten(1).any(dim=1)          # rows (sequences) whose slab was poisoned
+        ok_rows = (~bad).nonzero().flatten().tolist()
+        # rows that are not NaN are right (a slab either finished undisturbed or is poisoned as a whole)
+        if ok_rows:
+            assert float((joints[ok_rows] - want[1][ok_rows]).abs().max()) < 1e-4
+        time.sleep(0.5)
+        m.reset_all()
+        again = m.forward_offline(x, [T] * B)
+        m.finish()
+        for a, b in zip(want, again):
+            assert float((a - b).abs().max()) < 2e-5
+
+
+def test_close_reports_an_unreported_error(torch_mod, weights, smpl):
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    m = MobilePoserNet.from_numpy(weights, smpl)
+    m.set_recovery(False)
+    m.forward(cu(torch_mod, synthetic.make_imu(2, 8, seed=1)), [8, 8])
+    assert m._lib.mp_debug_poke_error(m._h, 7) == 0
+    with pytest.raises(RuntimeError, match="code 7"):
+        m.close()
+    assert m._h is None
+
+
+def test_state_attributes_can_be_assigned(torch_mod, net):
+    """The reference's per-stream variables are plain attributes (net.py:59-64): reads AND writes work, and repeated
+    reads between two ticks share one device round trip."""
+    from mobileposer_amd import synthetic
+    frames = cu(torch_mod, synthetic.make_imu(1, 3, seed=5)[0])
+    net.reset_all()
+    net.forward_online(frames[0])
+    a = net.last_root_pos
+    assert net.last_root_pos is a                                   # cached until the next tick
+    net.last_root_pos = torch_mod.tensor([1.0, 2.0, 3.0])
+    assert npy(net.last_root_pos).tolist() == [1.0, 2.0, 3.0]
+    net.current_root_y = 0.25
+    assert abs(net.current_root_y - 0.25) < 1e-12
+    net.last_lfoot_pos = torch_mod.tensor([0.1, 0.2, 0.3])
+    assert np.allclose(npy(net.last_lfoot_pos), [0.1, 0.2, 0.3]) and np.allclose(npy(net.last_rfoot_pos), npy(net.feet_pos[1]), atol=1.0)
+    _, _, root, _ = net.forward_online(frames[1])
+    assert abs(float(root[0]) - 1.0) < 0.5                           # the tick continued from the assigned position
+    net.imu = None                                                  # what reset() does to the window
+    assert net.imu is None
+    net.forward_online(frames[2])
+    win = net.imu
+    assert win is not None and float((win - frames[2]).abs().max()) == 0.0    # fresh window = the frame repeated 45 times
+    assert net.device_error() == 0

@@ -368,7 +368,7 @@ def test_hidden_state_transports_agree(torch_mod, net):
 def test_split_bf16_kernel_variants_agree(torch_mod, weights, smpl, monkeypatch):
     """The two split-bf16 layer kernels (mp_lstm_x3: eight 256-register waves per workgroup; mp_lstm_x3w: four
     512-register waves, inline-asm MFMAs with AccVGPR operands) do the same arithmetic in the same order: whichever of them runs the K_in = 256 /
-    K_in = 512 layers (MP_X3W bit mask, default 2), the outputs are bitwise identical -- full-chip batch, ragged
+    K_in = 512 layers (MP_VARIANT x3w bit mask, default 2), the outputs are bitwise identical -- full-chip batch, ragged
     lengths, and a continued velocity state.  (This is also the check on the hand-placed MFMA wait states of mp_lstm_x3w.)"""
     from mobileposer_amd import synthetic
     from mobileposer_amd.net import MobilePoserNet
@@ -379,7 +379,7 @@ def test_split_bf16_kernel_variants_agree(torch_mod, weights, smpl, monkeypatch)
     lengths[0] = T
     outs = {}
     for mask in (0, 1, 2, 3):
-        monkeypatch.setenv("MP_X3W", str(mask))
+        monkeypatch.setenv("MP_VARIANT", "x3w=%d" % mask)
         n = MobilePoserNet.from_numpy(weights, smpl, device="cuda:0")
         n.set_lstm_mode(3)
         o1 = [t.clone() for t in n.forward(x, lengths)]
@@ -389,7 +389,7 @@ def test_split_bf16_kernel_variants_agree(torch_mod, weights, smpl, monkeypatch)
         n.close()
     for mask in (1, 2, 3):
         for a, b in zip(outs[0], outs[mask]):
-            assert torch_mod.equal(a, b), "MP_X3W=%d differs from MP_X3W=0 by %g" % (mask, float((a - b).abs().max()))
+            assert torch_mod.equal(a, b), "x3w=%d differs from x3w=0 by %g" % (mask, float((a - b).abs().max()))
 
 
 @pytest.mark.parametrize("B,T", [(1, 1), (1, 2), (17, 3), (2, 45)])
@@ -464,14 +464,13 @@ def test_soak_bitwise_stable_under_concurrency(torch_mod, net):
 
 def test_small_batch_schedules_agree(torch_mod, weights, smpl, monkeypatch):
     """Batches whose pose + velocity + foot-contact launches fit the chip together run the three blocks side by side
-    (MP_WIDE, default on): bitwise the same outputs as the serial schedule.  Exact-fp32 layers of small batches use 16
-    slices per slab instead of 8 (MP_SLICES16, default on): another summation order, same values to fp32 noise."""
+    (MP_VARIANT wide, default on): bitwise the same outputs as the serial schedule.  Exact-fp32 layers of small batches use 16
+    slices per slab instead of 8 (MP_VARIANT slices16, default on): another summation order, same values to fp32 noise."""
     from mobileposer_amd import synthetic
     from mobileposer_amd.net import MobilePoserNet
     outs = {}
     for wide, s16 in ((1, 1), (0, 1), (1, 0)):
-        monkeypatch.setenv("MP_WIDE", str(wide))
-        monkeypatch.setenv("MP_SLICES16", str(s16))
+        monkeypatch.setenv("MP_VARIANT", "wide=%d,slices16=%d" % (wide, s16))
         with MobilePoserNet.from_numpy(weights, smpl) as n:
             o = []
             for mode in (1, 3):
@@ -494,14 +493,14 @@ def test_small_batch_schedules_agree(torch_mod, weights, smpl, monkeypatch):
 
 def test_half_chip_schedules_agree(torch_mod, weights, smpl, monkeypatch):
     """64 < B <= 128, exact-fp32 operands: the pose layers run on 8 slices per slab (half the chip) beside velocity (and foot
-    contact, B <= 96; after velocity otherwise), every cluster on an XCD chosen by the host (MP_HALF, default on).  Same
+    contact, B <= 96; after velocity otherwise), every cluster on an XCD chosen by the host (MP_VARIANT half, default on).  Same
     values as the serial schedule to fp32 noise (pose on 8 instead of 16 slices: another summation order in the cell
     update); joints / velocity / foot contact use the same kernels in both and must agree bitwise."""
     from mobileposer_amd import synthetic
     from mobileposer_amd.net import MobilePoserNet
     outs = {}
     for half in (1, 0):
-        monkeypatch.setenv("MP_HALF", str(half))
+        monkeypatch.setenv("MP_VARIANT", "half=%d" % half)
         with MobilePoserNet.from_numpy(weights, smpl) as n:
             o = []
             for B, T in ((80, 24), (96, 20), (128, 16), (100, 30)):
@@ -519,33 +518,6 @@ def test_half_chip_schedules_agree(torch_mod, weights, smpl, monkeypatch):
             assert float((a - b).abs().max()) < 5e-6
         else:                                                  # joints, translation, contact: the same kernels
             assert torch_mod.equal(a, b)
-
-
-def test_two_slab_kernel_matches(torch_mod, weights, smpl, monkeypatch):
-    """mp_lstm_pair (two slabs of 16 sequences per workgroup; off by default, MP_PAIR=3 turns it on for the bidirectional
-    fp32 layers): same arithmetic as mp_lstm_fused up to the summation order -- full-chip batch, an odd number of slabs,
-    ragged lengths, several launch groups."""
-    from mobileposer_amd import synthetic
-    from mobileposer_amd.net import MobilePoserNet
-    outs = {}
-    rng = np.random.default_rng(9)
-    shapes = ((256, 40), (300, 12), (40, 30))
-    lens = {s: [int(v) for v in rng.integers(1, s[1] + 1, size=s[0])] for s in shapes}
-    for mask in (0, 3):
-        monkeypatch.setenv("MP_PAIR", str(mask))
-        monkeypatch.setenv("MP_SLICES16", "0")
-        with MobilePoserNet.from_numpy(weights, smpl) as n:
-            n.set_lstm_mode(1)
-            o = []
-            for B, T in shapes:
-                L = list(lens[(B, T)])
-                L[0] = T
-                o += [t.clone() for t in n.forward_offline(cu(torch_mod, synthetic.make_imu(B, T, seed=B + 1)), L)]
-                n.reset_all()
-            assert n.device_error() == 0
-        outs[mask] = o
-    for a, b in zip(outs[0], outs[3]):
-        assert float((a - b).abs().max()) < 5e-6
 
 
 def test_g11_evaluate_pose_table_and_translation_statistics(torch_mod, net):
@@ -582,7 +554,7 @@ def test_g11_evaluate_pose_table_and_translation_statistics(torch_mod, net):
 
 def test_four_wave_fp32_kernel_matches_eight_wave(torch_mod, weights, smpl, monkeypatch):
     """mp_lstm_fused<256,8,KIN,1> (default for the 8-slice fp32 layers: four 512-register waves, weights in AccVGPRs, inline-asm
-    MFMAs with hand-placed wait states) against the eight-wave kernel it replaced (MP_WREG=0): full-chip batch, several
+    MFMAs with hand-placed wait states) against the eight-wave kernel it replaced (MP_VARIANT wreg=0): full-chip batch, several
     launch groups with an odd slab count, ragged lengths, carried velocity state.  Same K split and reduction order; the
     cell update is contracted differently by the compiler, hence fp32-noise-level differences, not bitwise equality."""
     from mobileposer_amd import synthetic
@@ -592,7 +564,7 @@ def test_four_wave_fp32_kernel_matches_eight_wave(torch_mod, weights, smpl, monk
     lens = {sh: [int(v) for v in rng.integers(1, sh[1] + 1, size=sh[0])] for sh in shapes}
     outs = {}
     for mask in (0, 3):
-        monkeypatch.setenv("MP_WREG", str(mask))
+        monkeypatch.setenv("MP_VARIANT", "wreg=%d" % mask)
         with MobilePoserNet.from_numpy(weights, smpl) as n:
             n.set_lstm_mode(1)
             o = []
@@ -621,7 +593,7 @@ def test_32_slice_fp32_kernel_matches_16_slice(torch_mod, weights, smpl, monkeyp
     lens = {sh: [int(v) for v in rng.integers(1, sh[1] + 1, size=sh[0])] for sh in shapes}
     outs = {}
     for s32, remote in ((0, 0), (1, 0), (1, 1)):
-        monkeypatch.setenv("MP_SLICES32", str(s32))
+        monkeypatch.setenv("MP_VARIANT", "slices32=%d" % s32)
         with MobilePoserNet.from_numpy(weights, smpl) as n:
             n.set_lstm_mode(1)
             if remote:
@@ -645,7 +617,7 @@ def test_32_slice_fp32_kernel_matches_16_slice(torch_mod, weights, smpl, monkeyp
 def test_epoch_tagged_exchange_equals_zeroed_exchange(torch_mod, weights, smpl, monkeypatch):
     """The fp32 layer kernels no longer get a zeroed hidden-state exchange area per launch: every launch tags its granules
     with a fresh epoch base (base + step) and the host re-zeroes only before the 32-bit tag would wrap.  Bitwise the same
-    outputs as with a memset before every launch (MP_EPOCH_TAGS=0) -- over many launches on the same areas, different
+    outputs as with a memset before every launch (MP_VARIANT epoch_tags=0) -- over many launches on the same areas, different
     shapes sharing a handle, both operand modes in turn (the split-bf16 kernels leave their own words in the area), and
     with the counter started just below the wrap guard so that the re-zeroing path runs several times."""
     from mobileposer_amd import synthetic
@@ -660,9 +632,7 @@ def test_epoch_tagged_exchange_equals_zeroed_exchange(torch_mod, weights, smpl, 
         lens[sh] = L
     outs = {}
     for tags, start in (("0", None), ("1", None), ("1", "0xEFFFFF00")):
-        monkeypatch.setenv("MP_EPOCH_TAGS", tags)
-        if start:
-            monkeypatch.setenv("MP_EPOCH_START", start)
+        monkeypatch.setenv("MP_VARIANT", "epoch_tags=%s" % tags + (",epoch_start=%s" % start if start else ""))
         with MobilePoserNet.from_numpy(weights, smpl) as n:
             o = []
             for rep in range(3):
