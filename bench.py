@@ -297,6 +297,9 @@ def main():
                     help="MFMA operands of the H=256 LSTM layers for the headline value: fp32 (default = the library default: "
                          "exact v_mfma_f32_16x16x4_f32 operands, the reference's arithmetic) or x3 (opt-in: every fp32 product "
                          "as 3 bf16 products on v_mfma_f32_16x16x32_bf16, fp32 accumulate); the other mode is timed as well")
+    ap.add_argument("--recovery", choices=["on", "off"], default="on",
+                    help="on (library default): every call waits for itself and repairs a starved fused-LSTM launch; off: "
+                         "asynchronous calls (mp_set_recovery(h, 0)) -- an A/B switch, the headline uses the default")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo run of the launcher, rendezvous, broadcast, shard and "
                     "timing path with a stand-in step (no GPU, no kernels); the JSON line says dry_run: true")
     args = ap.parse_args()
@@ -346,6 +349,7 @@ def main():
     else:
         net = MobilePoserNet.from_numpy(synthetic.make_weights(0), synthetic.synthetic_smpl(), device=dev)
     net.set_graph_mode(bool(args.graph))
+    net.set_recovery(args.recovery == "on")
 
     if args.workload == "stream":
         net.set_lstm_mode({"fp32": 1, "x3": 3}[args.lstm_mode])
@@ -538,7 +542,8 @@ def main():
         "config": {"workload": cfg_name + ", seeded synthetic IMU (lw_rp combo), seeded random weights, synthetic SMPL constants",
                    "batch_per_gpu": B, "window": T, "global_batch": global_batch,
                    "parallelism": "independent sequences sharded, dp%d" % world,
-                   "graph": bool(args.graph), "lstm_mode": args.lstm_mode},
+                   "graph": bool(args.graph), "lstm_mode": args.lstm_mode, "recovery": args.recovery,
+                   "recoveries_during_run": net.recovery_count},
         "modes": {
             args.lstm_mode: {"value": round(value, 1), "ms_per_step": round(1e3 * elapsed / args.steps, 4), "headline": True},
             other: {"value": round(value_other, 1), "ms_per_step": round(1e3 * elapsed_other / other_steps, 4),

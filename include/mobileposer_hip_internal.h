@@ -20,9 +20,10 @@ int mp_debug_poke_error(mp_handle* h, int code);
  * persistent-kernel launch: wait, sweep, mfma, reduce, cell+publish, steps. */
 int mp_debug_read_prof(mp_handle* h, long long* out, int n_words);
 
-/* Test hook: occupy `n_wg` compute units for `ms` milliseconds with a spinning kernel on a stream of its own (no
- * ordering against the handle's work) -- starves a persistent layer grid that runs at the same time. */
-int mp_debug_occupy(mp_handle* h, int n_wg, int lds_bytes, double ms);
+/* Test hook: in each of the next `launches` fused-LSTM layer launches, workgroup `block` exits at once -- exactly what its
+ * cluster sees when a workgroup of the grid never becomes resident (a GPU shared with another process): the peers' waits
+ * run into their time bound, poison the slab and raise the error word.  Deterministic stand-in for real starvation. */
+int mp_debug_drop_workgroup(mp_handle* h, int block, int launches);
 
 #ifdef __cplusplus
 }

@@ -90,13 +90,14 @@ class ParametricModel:
             _lib.check(lib.mp_create_body(C.byref(h), idx, parent, self._J.reshape(-1).ctypes.data_as(C.POINTER(C.c_float))), None)
             self._own = h
             self._own_state = {}
-            weakref.finalize(self, _destroy, lib, h)
+            self._finalizer = weakref.finalize(self, _destroy, lib, h)
             upload_mesh(lib, h, self, self._own_state)
         return _lib.load(), self._own, self.device
 
     def close(self):
         h, self._own = self._own, None
         if h is not None:
+            self._finalizer.detach()                          # (the handle is released here, not a second time later)
             _lib.load().mp_destroy(h)
 
     def forward_kinematics(self, pose, shape=None, tran=None, calc_mesh=False):

@@ -209,9 +209,9 @@ struct mp_handle {
     VelState vsnap;                  // recovery: the carried velocity state a call started from
     StreamCtx sc;
     OnlineState st_snap;             // recovery: per-stream solver state a streaming tick started from
+    int dbg_drop_block = 0, dbg_drop_left = 0;   // mp_debug_drop_workgroup
     bool recovery = true;            // mp_set_recovery: calls wait for themselves and repair a starved run in LSTM mode 0
     int recoveries = 0;
-    hipStream_t s_dbg = nullptr;     // mp_debug_occupy
     bool use_graph = false;          // opt-in (mp_set_graph_mode / MP_GRAPH=1): see the note at the top of this file
     bool timing = false;
     std::vector<Seg> segs;
@@ -686,7 +686,8 @@ int fp32_slices(const mp_handle* h, const ModuleW& m, int B) {
     // one or two slabs (B <= 32): 32 slices of 8 units, every (direction, slab) cluster on an XCD of its own (mp_lstm_u8.hip) --
     // at most 4 + 2 clusters of pose and velocity side by side, foot contact on the two XCDs that are left
     // (the joints block always has the chip to itself: 32 slices while its 2 * nslab clusters find an XCD each, B <= 64)
-    const int max32 = &m == &h->mod[MP_MOD_JOINTS] ? 4 : 2;
+    // (without placement tables only blocks that have the chip to themselves use them: joints, and pose in the serial schedule)
+    const int max32 = &m == &h->mod[MP_MOD_JOINTS] ? 4 : ((!h->xcd_rr && &m == &h->mod[MP_MOD_VELOCITY]) ? 0 : 2);
     if (m.H == 256 && m.whhU8[0][0] && h->slices32_ok && h->slices16_ok && nslab <= max32 && cus == 256 && !h->uni2) return 32;
     if (m.H == 256 && m.nslice == 8 && m.whhP16[0][0] && h->slices16_ok && m.dirs * nslab * 16 <= cus) return 16;
     return m.nslice;
@@ -842,6 +843,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             a.err = h->err_dev; a.max_spin = 1u; a.max_ticks = h->wait_ticks;
             a.prof = (prof_layer < 0 || prof_layer == l) ? h->prof_dev : nullptr;
             a.zero_state = j.mode == STATE_ZERO ? 1 : 0; a.force_remote = h->force_remote ? 1 : 0;
+            if (h->dbg_drop_left > 0) { a.debug_drop = h->dbg_drop_block + 1; --h->dbg_drop_left; }
             const bool x3 = use_x3(h, m);
             a.epoch_base = epoch_base;
             a.min_lds = x3 ? 0 : h->excl_lds;
@@ -977,8 +979,11 @@ int side_by_side_plan(mp_handle* h, int B) {
     const int vslices = use_x3(h, vm) ? vm.nsliceX : fp32_slices(h, vm, B);
     XcdJob all[3] = {job(MP_MOD_POSE, pm, pslices), job(MP_MOD_VELOCITY, vm, vslices), job(MP_MOD_FOOT_CONTACT, fm, fm.nslice)};
     int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (any_x3 || !h->xcd_rr || !h->exclusive_ok)   // (no tables: the split-bf16 kernels spread their clusters themselves)
+    if (any_x3)                                     // (no tables: the split-bf16 kernels spread their clusters themselves)
         return layer_workgroups(h, pm, B) + layer_workgroups(h, vm, B) + layer_workgroups(h, fm, B) <= h->n_cu ? 1 : 0;
+    // exact-fp32 kernels side by side need every cluster placed on an XCD with room for ALL its workgroups (two grids that
+    // are each partly resident wait for CUs the other holds until their waits time out): no tables, no side-by-side schedule
+    if (!h->xcd_rr || !h->exclusive_ok) return 0;
     if (place_clusters(h, all, 3, load, h->xcd_plan)) return 1;
     if (!h->half_ok || !pm.whhPW[0][0] || (h->wreg_mask & 3) != 3 || pslices != 16) return 0;
     all[0].wgs = pm.nslice;                   // pose on 8 slices per slab (four-wave kernels)
@@ -1097,10 +1102,9 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         // (B <= 128) each workgroup gets a CU of its own (see the side-by-side schedule above)
         int excl_vf = 0;
         bool vf_tables = false;
-        if (h->exclusive_ok && !use_x3(h, h->mod[MP_MOD_VELOCITY]) && !h->xcd_rr) {
-            if (layer_workgroups(h, h->mod[MP_MOD_VELOCITY], p->B) + layer_workgroups(h, h->mod[MP_MOD_FOOT_CONTACT], p->B) <= h->n_cu)
-                excl_vf = kExclusiveLdsBytes;
-        } else if (h->exclusive_ok && !use_x3(h, h->mod[MP_MOD_VELOCITY])) {
+        // (without placement tables velocity and foot contact share CUs -- 80 + 48 KB of LDS, registers to match: a
+        //  velocity and a foot-contact workgroup fit on one CU together, so both grids are always fully resident)
+        if (h->exclusive_ok && h->xcd_rr && !use_x3(h, h->mod[MP_MOD_VELOCITY])) {
             const int nslab = (p->B + 15) / 16;
             const XcdJob vf[2] = {{MP_MOD_VELOCITY, h->mod[MP_MOD_VELOCITY].dirs * nslab, fp32_slices(h, h->mod[MP_MOD_VELOCITY], p->B)},
                                   {MP_MOD_FOOT_CONTACT, h->mod[MP_MOD_FOOT_CONTACT].dirs * nslab, h->mod[MP_MOD_FOOT_CONTACT].nslice}};
@@ -1323,7 +1327,7 @@ void mp_destroy(mp_handle* h) {
     hipEvent_t evs[5] = {h->ev_in, h->ev_out, h->ev_j, h->ev_v, h->ev_f};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_x) if (e) (void)hipEventDestroy(e);
-    hipStream_t ss[4] = {h->s_main, h->s_vel, h->s_foot, h->s_dbg};   // (s_gp is s_vel)
+    hipStream_t ss[3] = {h->s_main, h->s_vel, h->s_foot};             // (s_gp is s_vel)
     for (hipStream_t s : ss) if (s) (void)hipStreamDestroy(s);
     delete h;
 }
@@ -1803,23 +1807,6 @@ int mp_recovery_count(const mp_handle* h) { return h ? h->recoveries : 0; }
 
 namespace {
 MP_KERNEL void mp_poke_error(int* err, int code) { mp_set_error(err, code); }
-// holds a compute unit (one workgroup with `lds` bytes of LDS) for `ticks` of the 100 MHz clock
-MP_KERNEL void mp_occupy(unsigned long long ticks) {
-    extern __shared__ float occ_lds[];
-    if (threadIdx.x == 0) occ_lds[0] = 0.f;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-}
-}
-
-int mp_debug_occupy(mp_handle* h, int n_wg, int lds_bytes, double ms) {
-    if (!h || n_wg < 1 || lds_bytes < 0 || lds_bytes > 160 * 1024 || ms <= 0.0 || ms > 5000.0) return MP_ERR_INVALID;
-    HIPCHK(h, hipSetDevice(h->device));
-    if (!h->s_dbg) HIPCHK(h, hipStreamCreateWithFlags(&h->s_dbg, hipStreamNonBlocking));
-    HIPCHK(h, hipFuncSetAttribute((const void*)mp_occupy, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(mp_occupy, dim3(n_wg), dim3(64), (size_t)lds_bytes, h->s_dbg, (unsigned long long)(ms * 1e5));
-    HIPCHK(h, hipGetLastError());
-    return MP_OK;
 }
 
 int mp_debug_poke_error(mp_handle* h, int code) {
@@ -1828,6 +1815,13 @@ int mp_debug_poke_error(mp_handle* h, int code) {
     hipLaunchKernelGGL(mp_poke_error, dim3(1), dim3(1), 0, h->s_main, h->err_dev, code);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->s_main));
+    return MP_OK;
+}
+
+int mp_debug_drop_workgroup(mp_handle* h, int block, int launches) {
+    if (!h || block < 0 || launches < 0) return MP_ERR_INVALID;
+    h->dbg_drop_block = block;
+    h->dbg_drop_left = launches;
     return MP_OK;
 }
 

@@ -93,6 +93,8 @@ struct LstmPersistArgs {
     unsigned max_spin;            // 0: never wait (a test hook); otherwise waits are allowed, bounded by max_ticks
     unsigned long long max_ticks; // bound of every wait in ticks of the constant 100 MHz clock (s_memrealtime); mp_api: 0.25 s
     long long* prof;              // optional [grid][6] cycle sums per phase (debug), else nullptr
+    int debug_drop = 0;           // test hook (mp_debug_drop_workgroup): block debug_drop - 1 exits at once, as if it never
+                                  // became resident -- its cluster's waits run into their time bound
     int out_pairs = 0;            // split-bf16 kernel only: write the layer output as pairs (it feeds another layer)
     // mp_lstm_fused only: 0 = the area was zeroed before this launch (tags = step numbers); otherwise the area may hold
     // anything earlier launches of THIS kernel family left there, all with tags < epoch_base: the launch tags its granules

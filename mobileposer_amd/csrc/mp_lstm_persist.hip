@@ -106,6 +106,7 @@ __device__ __forceinline__ void mfma_drain() {
 
 template <int H, int NSLICE, int KIN, int TW, bool PROF>
 MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void mp_lstm_fused(LstmPersistArgs a) {
+    if (a.debug_drop && (int)blockIdx.x == a.debug_drop - 1) return;      // test hook: a workgroup that never shows up
     using C = Cfg<H, NSLICE, KIN, TW>;
     constexpr bool WREG = H == 256 && NSLICE == 8 && TW == 1;
     constexpr int U = C::U, NUB = C::NUB, NWV = C::NWV, NTW = C::NTW, NTG = C::NTG, KW = C::KW, NKS = C::NKS, KQ = C::KQ;
@@ -657,6 +658,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
 // d[0] / d[1] describe layer 0 / layer 1.
 template <int H>
 MP_KERNEL __launch_bounds__(512, 1) void mp_lstm_fused_uni2(LstmPersistArgs a) {
+    if (a.debug_drop && (int)blockIdx.x == a.debug_drop - 1) return;      // test hook: a workgroup that never shows up
     constexpr int NSLICE = 16, U = 16, KW = H / 4, NKS = KW / 4, KQ = H / 4, NXS = KQ / 4, NXJ = KQ / 16, NPW = 4;
     constexpr int KSP = NKS / NPW;
     constexpr int IMG_F4 = 4 * NXS * 64;                                // one W_ih LDS image, in float4

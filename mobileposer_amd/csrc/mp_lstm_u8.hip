@@ -36,6 +36,7 @@ struct U8Cfg {
 
 template <int KIN, bool PROF>
 MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_u8(LstmPersistArgs a) {
+    if (a.debug_drop && (int)blockIdx.x == a.debug_drop - 1) return;      // test hook: a workgroup that never shows up
     using C = U8Cfg<KIN>;
     constexpr int H = C::H, NSLICE = C::NSLICE, U = C::U, KQ = C::KQ, NXS = C::NXS, NXG = C::NXG, NHS = C::NHS, NHG = C::NHG;
     extern __shared__ __attribute__((aligned(16))) float smem[];

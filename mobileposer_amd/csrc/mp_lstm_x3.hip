@@ -97,6 +97,7 @@ constexpr int x3_wg_per_cu(int nslice) { return nslice == 16 ? 2 : 1; }
 
 template <int NSLICE, int KIN, bool PROF>
 MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_lstm_x3(LstmPersistArgs a) {
+    if (a.debug_drop && (int)blockIdx.x == a.debug_drop - 1) return;      // test hook: a workgroup that never shows up
     using C = CfgX<NSLICE, KIN>;
     constexpr int H = 256, U = C::U, NWV = C::NWV, KQ = C::KQ, NXC = C::NXC, NHC = C::NHC, XLC = C::XLC, XRC = C::XRC;
     constexpr int CH_U4 = C::CH_U4, PPW = C::PPW, LPB = C::LPB, WPL = C::WPL, PARTS = C::PARTS, HPITCH = C::HPITCH;

@@ -70,6 +70,7 @@ struct CfgW {
 
 template <int KIN, bool PROF>
 MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
+    if (a.debug_drop && (int)blockIdx.x == a.debug_drop - 1) return;      // test hook: a workgroup that never shows up
     using C = CfgW<KIN>;
     constexpr int H = 256, NSLICE = 8, U = 32, UB = 2, NWV = 4, KQ = C::KQ, NXC = C::NXC, NHC = C::NHC, XLC = C::XLC, XRC = C::XRC;
     constexpr int FR = C::FR, CH_U4 = C::CH_U4;
