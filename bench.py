@@ -147,45 +147,51 @@ def cpu_baseline(seconds=5.0):
 
 def bench_stream(args, net, dev, dist, rank, world):
     """BASELINE configs[4]: S concurrent streams per GPU, one new 60-d frame per stream per tick; every tick runs
-    the reference's forward_online semantics (45-frame window re-evaluated, net.py:173-219) from one captured graph."""
+    the reference's forward_online semantics (45-frame window re-evaluated, net.py:173-219).  Timed twice in the same
+    run: eager launches on the library's three streams (the default) and replay of ONE captured single-branch hipGraph
+    (graph mode 2); the headline is the mode --graph-mode selects (default 0 = eager)."""
     from mobileposer_amd import synthetic
     S = args.streams
-    frames = torch.from_numpy(synthetic.make_imu(S, args.steps + args.warmup + 1, seed=7 + rank)).to(dev)
+    frames = torch.from_numpy(synthetic.make_imu(S, 2 * (args.steps + args.warmup) + 2, seed=7 + rank)).to(dev)
     net.stream_create(S)
     f32 = torch.float32
     io = {"pose": torch.empty(S, 24, 9, device=dev, dtype=f32), "joints": torch.empty(S, 45, 72, device=dev, dtype=f32),
           "root": torch.empty(S, 3, device=dev, dtype=f32), "contact": torch.empty(S, 2, device=dev, dtype=f32)}
+    xin = torch.empty(S, 60, device=dev, dtype=f32)          # one input buffer: a replayed graph is keyed by its addresses
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for k in range(args.warmup):
-        net.stream_step_into(frames[:, k].contiguous(), io["pose"], io["joints"], io["root"], io["contact"])
-    cur = [frames[:, args.warmup + k].contiguous() for k in range(args.steps)]
-    sync()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        net.stream_step_into(cur[k], io["pose"], io["joints"], io["root"], io["contact"])
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    cursor = [0]
+
+    def tick():
+        xin.copy_(frames[:, cursor[0]])
+        cursor[0] += 1
+        net.stream_step_into(xin, io["pose"], io["joints"], io["root"], io["contact"])
+
+    results = {}
+    for name, gmode in (("eager", 0), ("graph_single_branch", 2)):
+        net.set_graph_mode(gmode)
+        elapsed, _ = timed_region(tick, args.steps, args.warmup, sync, dist, dev)
+        results[name] = args.steps / elapsed
+    net.set_graph_mode(0)
     if rank == 0:
-        ticks = args.steps / elapsed
+        head = {0: "eager", 1: "eager", 2: "graph_single_branch"}[args.graph_mode]
+        ticks = results[head]
         print(json.dumps({
             "metric": "streaming output frames/s (forward_online semantics: 45-frame window per output frame)",
-            "value": round(world * S * ticks, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 / ticks, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value": round(world * S * ticks, 1), "unit": "frames/s", "n_gpus": world, "n_ranks_seen": ranks_seen(dist, dev),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 / ticks, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[4]: %d concurrent streams per GPU, one tick = one new frame per stream (%s)"
-                                   % (S, "hipGraph replay" if args.graph else "eager launches"),
+                                   % (S, "single-branch hipGraph replay" if head != "eager" else "eager launches"),
                        "streams_per_gpu": S, "ticks_per_s": round(ticks, 2), "meets_60hz": ticks >= 60.0,
-                       "lstm_mode": args.lstm_mode, "graph": bool(args.graph),
-                       "window_frames_per_s": round(world * S * 45 * ticks, 1)}}))
+                       "lstm_mode": args.lstm_mode, "graph_mode": args.graph_mode,
+                       "window_frames_per_s": round(world * S * 45 * ticks, 1)},
+            "modes": {k: {"ticks_per_s": round(v, 2), "ms_per_tick": round(1e3 / v, 4), "headline": k == head}
+                      for k, v in results.items()}}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -286,8 +292,10 @@ def main():
     ap.add_argument("--steps", type=int, default=300, help="timed steps (default 300: a timed region of > 1 s)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay captured hipGraphs instead of eager launches (opt-in, "
-                    "see profiles/r02_hipgraph_segv.md)")
+    ap.add_argument("--graph", action="store_true", help="same as --graph-mode 1")
+    ap.add_argument("--graph-mode", type=int, choices=[0, 1, 2], default=0,
+                    help="0 (default): eager launches; 1: replay captured multi-branch hipGraphs (profiles/r02_hipgraph_segv.md); "
+                         "2: replay single-branch hipGraphs (every launch captured on one stream)")
     ap.add_argument("--workload", choices=["offline", "stream"], default="offline",
                     help="offline (default, the BASELINE metric) or stream: config 5, S concurrent 45-frame windows per GPU")
     ap.add_argument("--streams", type=int, default=512)
@@ -303,6 +311,8 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo run of the launcher, rendezvous, broadcast, shard and "
                     "timing path with a stand-in step (no GPU, no kernels); the JSON line says dry_run: true")
     args = ap.parse_args()
+    if args.graph and args.graph_mode == 0:
+        args.graph_mode = 1
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
 
@@ -348,7 +358,7 @@ def main():
         net = MobilePoserNet.from_device_blob(blob, smpl, device=dev)
     else:
         net = MobilePoserNet.from_numpy(synthetic.make_weights(0), synthetic.synthetic_smpl(), device=dev)
-    net.set_graph_mode(bool(args.graph))
+    net.set_graph_mode(args.graph_mode)
     net.set_recovery(args.recovery == "on")
 
     if args.workload == "stream":
@@ -542,7 +552,7 @@ def main():
         "config": {"workload": cfg_name + ", seeded synthetic IMU (lw_rp combo), seeded random weights, synthetic SMPL constants",
                    "batch_per_gpu": B, "window": T, "global_batch": global_batch,
                    "parallelism": "independent sequences sharded, dp%d" % world,
-                   "graph": bool(args.graph), "lstm_mode": args.lstm_mode, "recovery": args.recovery,
+                   "graph_mode": args.graph_mode, "lstm_mode": args.lstm_mode, "recovery": args.recovery,
                    "recoveries_during_run": net.recovery_count},
         "modes": {
             args.lstm_mode: {"value": round(value, 1), "ms_per_step": round(1e3 * elapsed / args.steps, 4), "headline": True},

@@ -203,7 +203,8 @@ struct mp_handle {
     int nslice_env = 0;              // 0: pick per module (8 slices / 8 waves for bidirectional layers that fill the
                                      // chip, 16 slices / 4 waves for unidirectional ones); MP_VARIANT slices=8|16 forces one             // LSTM recurrence: persistent kernel (default) or per-step launches
     std::map<std::pair<int, int>, Plan*> plans;
-    std::map<GraphKey, hipGraphExec_t> graphs;
+    struct GraphEntry { hipGraphExec_t exec; unsigned long long last_use; };
+    std::map<GraphKey, GraphEntry> graphs;
     unsigned long long use_clock = 0;
     VelState vstate;
     VelState vsnap;                  // recovery: the carried velocity state a call started from
@@ -213,6 +214,7 @@ struct mp_handle {
     bool recovery = true;            // mp_set_recovery: calls wait for themselves and repair a starved run in LSTM mode 0
     int recoveries = 0;
     bool use_graph = false;          // opt-in (mp_set_graph_mode / MP_GRAPH=1): see the note at the top of this file
+    bool graph_serial = false;       // graph mode 2: every launch captured on s_main -- a single-branch graph
     bool timing = false;
     std::vector<Seg> segs;
     std::vector<hipEvent_t> ev_pool;
@@ -401,7 +403,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     h->has_weights = !body_only;
     auto bail = [&](int rc) { g_create_error = h->err; mp_destroy(h); return rc; };
     if (hipSetDevice(device) != hipSuccess) { h->err = "hipSetDevice failed"; return bail(MP_ERR_HIP); }
-    if (const char* e = getenv("MP_GRAPH")) h->use_graph = e[0] && e[0] != '0';
+    if (const char* e = getenv("MP_GRAPH")) { h->use_graph = e[0] && e[0] != '0'; h->graph_serial = e[0] == '2'; }
     {   // dynamic-LDS limits of the persistent kernels are per-device attributes (and must not be set under capture)
         hipError_t ea = mp_lstm_persist_device_attrs();
         if (ea == hipSuccess) ea = mp_lstm_u8_device_attrs();
@@ -526,7 +528,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
 void free_plan(mp_handle* h, Plan* p) {
     // graphs captured for this shape reference its workspaces
     for (auto it = h->graphs.begin(); it != h->graphs.end();) {
-        if (it->first.B == p->B && it->first.T == p->T) { (void)hipGraphExecDestroy(it->second); it = h->graphs.erase(it); }
+        if (it->first.B == p->B && it->first.T == p->T) { (void)hipGraphExecDestroy(it->second.exec); it = h->graphs.erase(it); }
         else ++it;
     }
     for (void* q : p->allocs) (void)hipFree(q);
@@ -1019,7 +1021,10 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
     RnnJob P{h, p, MP_MOD_POSE, xj, xi, r6d, (long)T * 96, 96, STATE_ZERO, nullptr, nullptr, nullptr, nullptr};
     RnnJob V{h, p, MP_MOD_VELOCITY, xj, xi, vel, (long)T * 72, 72, has_state ? STATE_FROM : STATE_ZERO, vs.h, vs.c, vs.h, vs.c};
     RnnJob F{h, p, MP_MOD_FOOT_CONTACT, xj, xi, contact, (long)T * 2, 2, STATE_ZERO, nullptr, nullptr, nullptr, nullptr};
-    hipStream_t sm = h->s_main, sp = h->s_gp, sv = h->s_vel, sf = h->s_foot;
+    // (graph mode 2: a single-branch graph -- every launch is captured on s_main, in an order that respects all the
+    //  dependencies below; the event record / wait pairs between "streams" become same-stream no-ops)
+    const bool one_branch = h->capturing && h->graph_serial;
+    hipStream_t sm = h->s_main, sp = one_branch ? sm : h->s_gp, sv = one_branch ? sm : h->s_vel, sf = one_branch ? sm : h->s_foot;
 #define RC(x) do { if (int rc_ = (x)) return rc_; } while (0)
     // joints(batch)                                                                       net.py:103
     RC(run_rnn(J, sm));
@@ -1144,15 +1149,21 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
     return MP_OK;
 }
 
+constexpr size_t kMaxGraphs = 64;
+
 template <class Body>
-int run_maybe_graph(mp_handle* h, const GraphKey& key, Body body) {
+int run_maybe_graph(mp_handle* h, GraphKey key, Body body) {
     if (!h->use_graph || h->timing) return body();
+    key.flags |= h->graph_serial ? 16 : 0;
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
-        if (h->graphs.size() >= 64) {                      // callers that keep changing buffers: start over
-            HIPCHK(h, hipDeviceSynchronize());
-            for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
-            h->graphs.clear();
+        if (h->graphs.size() >= kMaxGraphs) {              // a caller that keeps changing buffers: drop the least recently used one
+            auto victim = h->graphs.begin();
+            for (auto jt = h->graphs.begin(); jt != h->graphs.end(); ++jt)
+                if (jt->second.last_use < victim->second.last_use) victim = jt;
+            HIPCHK(h, hipStreamSynchronize(h->s_main));    // (it may still be executing)
+            (void)hipGraphExecDestroy(victim->second.exec);
+            h->graphs.erase(victim);
         }
         hipGraph_t graph = nullptr;
         HIPCHK(h, hipStreamBeginCapture(h->s_main, hipStreamCaptureModeThreadLocal));
@@ -1166,9 +1177,10 @@ int run_maybe_graph(mp_handle* h, const GraphKey& key, Body body) {
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) return fail(h, MP_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
-        it = h->graphs.emplace(key, exec).first;
+        it = h->graphs.emplace(key, mp_handle::GraphEntry{exec, 0}).first;
     }
-    HIPCHK(h, hipGraphLaunch(it->second, h->s_main));
+    it->second.last_use = ++h->use_clock;
+    HIPCHK(h, hipGraphLaunch(it->second.exec, h->s_main));
     return MP_OK;
 }
 
@@ -1291,7 +1303,7 @@ void mp_destroy(mp_handle* h) {
     if (h->err_host && *(volatile int*)h->err_host)     // nobody asked (mp_finish / mp_device_error / a later call): say it
         fprintf(stderr, "libmobileposer_hip: mp_destroy: an unreported device error was pending (code %d): a persistent LSTM "
                         "kernel gave up a wait; the affected outputs of that call were NaN\n", *(volatile int*)h->err_host);
-    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second.exec);
     for (auto& kv : h->plans) {
         for (void* p : kv.second->allocs) (void)hipFree(p);
         if (kv.second->lengths_pin) (void)hipHostFree(kv.second->lengths_pin);
@@ -1845,14 +1857,15 @@ int mp_set_transport(mp_handle* h, int force_remote) {
     if (!h) return MP_ERR_INVALID;
     HIPCHK(h, hipDeviceSynchronize());
     h->force_remote = force_remote != 0;
-    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);     // captured launches carry the old setting
+    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second.exec);   // captured launches carry the old setting
     h->graphs.clear();
     return MP_OK;
 }
 
 int mp_set_graph_mode(mp_handle* h, int on) {
-    if (!h) return MP_ERR_INVALID;
+    if (!h || on < 0 || on > 2) return MP_ERR_INVALID;
     h->use_graph = on != 0;
+    h->graph_serial = on == 2;
     return MP_OK;
 }
 

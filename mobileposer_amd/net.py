@@ -113,6 +113,8 @@ class MobilePoserNet:
         self._h = None
         self._blob = None
         self._stream_S = 0
+        self._graph = int(os.environ.get("MP_GRAPH", "0") or 0)   # graph mode of the handle (set_graph_mode / env MP_GRAPH)
+        self._graph_bufs = {}
         self._tick = 0                  # bumped by everything that changes per-stream state (cache key of stream_state)
         self._state_cache = {}
         self.training = False
@@ -276,16 +278,38 @@ class MobilePoserNet:
             raise RuntimeError("len(input_lengths) = %d but batch = %d" % (len(lens), B))
         return (C.c_int32 * B)(*lens)
 
-    def _input(self, x):
-        """The caller's tensor itself when it already is contiguous fp32 on this device (no copy)."""
+    def _input(self, x, graph_key=None):
+        """The caller's tensor itself when it already is contiguous fp32 on this device (no copy).  Graph mode
+        (``graph_key`` given): a copy in a buffer that stays, so that the captured graph's input address does."""
+        if self._graph and graph_key is not None:
+            held = self._graph_bufs.setdefault(graph_key, {})
+            if "x" not in held:
+                held["x"] = torch.empty(tuple(x.shape), device=self.device, dtype=torch.float32)
+            held["x"].copy_(x)
+            return held["x"]
         if x.device == self.device and x.dtype == torch.float32 and x.is_contiguous():
             return x
         return x.to(device=self.device, dtype=torch.float32).contiguous()
 
     def _outputs(self, B, T, names):
+        """Output tensors the library writes directly.  Eager launches: fresh tensors per call.  Graph mode: one set per
+        (B, T), so that a captured graph (keyed by its buffer addresses) is replayed call after call; the caller gets
+        clones (``_result``)."""
         shapes = {"pose": (B * T, 24, 3, 3), "joints": (B, T, 72), "vel": (B, T, 72), "contact": (B, T, 2),
                   "r6d": (B, T, 96), "tran": (B, T, 3)}
-        return {n: torch.empty(shapes[n], device=self.device, dtype=torch.float32) for n in names}
+        if not self._graph:
+            return {n: torch.empty(shapes[n], device=self.device, dtype=torch.float32) for n in names}
+        key = (B, T)
+        held = self._graph_bufs.setdefault(key, {})
+        for n in names:
+            if n not in held:
+                held[n] = torch.empty(shapes[n], device=self.device, dtype=torch.float32)
+        if len(self._graph_bufs) > 8:                    # shapes keep changing: forget the oldest (the library does the same)
+            self._graph_bufs.pop(next(iter(self._graph_bufs)))
+        return {n: held[n] for n in names}
+
+    def _result(self, t):
+        return t.clone() if self._graph else t
 
     def forward_into(self, imu, lengths_c, pose, joints, vel, contact, r6d=None):
         """mp_forward on caller-owned contiguous fp32 cuda buffers (no allocation, no copies)."""
@@ -304,9 +328,10 @@ class MobilePoserNet:
             raise RuntimeError("expected batch of shape [B, T, 60], got %s" % (tuple(batch.shape),))
         B, T = int(batch.shape[0]), int(batch.shape[1])
         lens = self._lengths(input_lengths, B, T)
-        x = self._input(batch)
+        x = self._input(batch, (B, T))
         o = self._outputs(B, T, ("pose", "joints", "vel", "contact") + (("r6d",) if return_r6d else ()))
         self.forward_into(x, lens, o["pose"], o["joints"], o["vel"], o["contact"], o.get("r6d"))
+        o = {k: self._result(v) for k, v in o.items()}
         out = (o["pose"], o["joints"], o["vel"].squeeze(0), o["contact"])
         return out + (o["r6d"],) if return_r6d else out
 
@@ -323,12 +348,13 @@ class MobilePoserNet:
             raise RuntimeError("expected imu of shape [B, T, 60], got %s" % (tuple(imu.shape),))
         B, T = int(imu.shape[0]), int(imu.shape[1])
         lens = self._lengths(input_lengths, B, T)
-        x = self._input(imu)
+        x = self._input(imu, (B, T))
         o = self._outputs(B, T, ("pose", "joints", "vel", "contact", "tran"))
         rc = self._lib.mp_forward_offline(self._h, _ptr(x), lens, B, T, _ptr(o["pose"]), _ptr(o["joints"]),
                                           _ptr(o["vel"]), _ptr(o["contact"]), _ptr(o["tran"]), None, None, self._stream())
         _lib.check(rc, self._h)
         self._after_call()
+        o = {k: self._result(v) for k, v in o.items()}
         if B == 1:
             return o["pose"], o["joints"], o["tran"][0], o["contact"][0]
         return o["pose"], o["joints"], o["tran"], o["contact"]
@@ -356,6 +382,15 @@ class MobilePoserNet:
         """One tick for all S streams: frames [S,60] -> (pose [S,24,9], joints [S,45,72], root_pos [S,3], contact [S,2])."""
         S, dev, f32 = self._stream_S, self.device, torch.float32
         x = self._input(frames.reshape(S, 60))
+        if self._graph:                                   # replayed graph: fixed buffers in, clones out
+            io = self._graph_bufs.setdefault(("stream", S), {})
+            if not io:
+                io.update(x=torch.empty(S, 60, device=dev, dtype=f32), pose=torch.empty(S, 24, 9, device=dev, dtype=f32),
+                          joints=torch.empty(S, 45, 72, device=dev, dtype=f32), root=torch.empty(S, 3, device=dev, dtype=f32),
+                          contact=torch.empty(S, 2, device=dev, dtype=f32))
+            io["x"].copy_(x)
+            self.stream_step_into(io["x"], io["pose"], io["joints"], io["root"], io["contact"])
+            return io["pose"].clone(), io["joints"].clone(), io["root"].clone(), io["contact"].clone()
         pose = torch.empty(S, 24, 9, device=dev, dtype=f32)
         joints = torch.empty(S, 45, 72, device=dev, dtype=f32)
         root = torch.empty(S, 3, device=dev, dtype=f32)
@@ -515,7 +550,12 @@ class MobilePoserNet:
         return code.value
 
     def set_graph_mode(self, on):
-        _lib.check(self._lib.mp_set_graph_mode(self._h, int(bool(on))), self._h)
+        """0 / False: eager launches (default); 1 / True: replay captured hipGraphs (multi-branch); 2: single-branch graphs
+        (every launch on one stream: nothing for the runtime's graph executor to mis-assign; include/mobileposer_hip.h)."""
+        mode = int(on)
+        _lib.check(self._lib.mp_set_graph_mode(self._h, mode), self._h)
+        self._graph = mode
+        self._graph_bufs = {}
 
 
 assert joint_set.n_reduced == 16 and len(state_dict_manifest()) == 72

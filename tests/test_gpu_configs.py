@@ -209,6 +209,36 @@ print("GRAPH_OK")
     assert r.returncode == 0 and "GRAPH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("mode", [1, 3])
+def test_single_branch_graph_equals_eager_at_baseline_sizes(torch_mod, weights, smpl, mode):
+    """Graph mode 2 (every launch captured on one stream: a single-branch graph, no parallel streams for the runtime's graph
+    executor to assign -- no GPU_MAX_HW_QUEUES workaround, in-process): replay == eager bitwise at the sizes BASELINE.json
+    names -- the 256 x 125 batch (forward + FK-less offline solver, carried velocity state) and the S = 512 streaming tick
+    (configs[4]) -- and a caller that hands in fresh tensors every call (the facade) keeps replaying ONE graph."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    B, T, S, ticks = 256, 125, 512, 5
+    x = cu(torch_mod, synthetic.make_imu(B, T, seed=3))
+    fr = cu(torch_mod, synthetic.make_imu(S, ticks, seed=4))
+    outs = {}
+    for graph in (0, 2):
+        with MobilePoserNet.from_numpy(weights, smpl) as m:
+            m.set_lstm_mode(mode)
+            m.set_graph_mode(graph)
+            o = [t.clone() for t in m.forward_offline(x.clone(), [T] * B)]
+            o += [t.clone() for t in m.forward_offline(x.clone(), [T] * B)]     # replay; velocity state carried (Q1)
+            o += [t.clone() for t in m.forward_offline(x.clone(), [T] * B)]
+            m.velocity.rnn_state = None
+            m.stream_create(S)
+            for k in range(ticks):
+                o += [t.clone() for t in m.stream_step(fr[:, k].contiguous())]
+            assert m.device_error() == 0
+            outs[graph] = o
+    assert len(outs[0]) == len(outs[2])
+    for i, (a, b) in enumerate(zip(outs[0], outs[2])):
+        assert torch_mod.equal(a, b), i
+
+
 def test_live_frame_kernel_golden_and_host_version(torch_mod, weights, smpl):
     """mp_live_form_frames (csrc/mp_live.hip) against golden G10 -- frames computed with the reference's own math functions,
     live_demo.py:213-236 -- and, with a different calibration per stream and every device combo, against the host version."""
