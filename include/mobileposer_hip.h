@@ -113,6 +113,10 @@ int mp_rnn_forward(mp_handle* h, int module, const float* x_dev, const int32_t* 
 /* MobilePoserNet._reduced_global_to_full (models/net.py:93-99): r6d [N,96] -> pose [N,24,3,3]. */
 int mp_reduced_global_to_full(mp_handle* h, const float* r6d_dev, int64_t N, float* pose_dev, void* stream);
 
+/* art.math.r6d_to_rotation_matrix (articulate/math/angular.py:167-182) on n six-vectors [n,6] -> [n,3,3]: the first two
+ * COLUMNS of R, Gram-Schmidt, NaN -> 0.  What evaluate.py:60 applies to the ground-truth pose of a dataset item. */
+int mp_r6d_to_rotation_matrix(mp_handle* h, const float* r6d_dev, int64_t n, float* rot_dev, void* stream);
+
 /* The translation solver of forward_offline (models/net.py:130-154), batched over sequences.
  * joints [B,T,72], vel [B,T,72], contact [B,T,2] (as returned by mp_forward) -> tran [B,T,3].
  * Frames t >= lengths[b] get the last valid translation. */
@@ -145,6 +149,17 @@ int mp_set_shape_space(mp_handle* h, const float* shapedirs_host, const float* j
  * n_shape == N (a body per frame); vert_dev [N,V,3] optional (NULL = calc_mesh False). */
 int mp_fk_shape(mp_handle* h, const float* pose_dev, const float* shape_dev, int n_shape, const float* tran_dev,
                 int64_t N, float* rglobal_dev, float* joint_dev, float* vert_dev, void* stream);
+
+/* FullMotionEvaluator.__call__ (articulate/evaluator.py:292-343, mean shape) as PoseEvaluator.eval calls it
+ * (evaluate.py:20-29): the joints of ignored_mask (bit j = joint j; evaluate.py:25-26) of both poses are set to the
+ * identity, forward kinematics (with linear blend skinning when use_mesh != 0) run on prediction and ground truth, and the
+ * 10 x [mean, std] error table is written to table_dev [10][2]: joint position, vertex position (NaN without mesh), local
+ * angle, global angle (degrees), predicted / true jerk, 1-second root translation error (x 100), and rows 0, 2, 3 restricted
+ * to the joints of joint_mask (0 = no mask: {0, NaN} like torch.zeros(1)).  A matrix without rows (N <= 3, N <= fps) gives
+ * NaN, like the reference.  pose_*_dev [N,24,3,3] local rotations, tran_*_dev [N,3] or NULL. */
+int mp_eval_metrics(mp_handle* h, const float* pose_p_dev, const float* pose_t_dev, const float* tran_p_dev,
+                    const float* tran_t_dev, int64_t N, int fps, int align_joint, unsigned joint_mask,
+                    unsigned ignored_mask, int use_mesh, float* table_dev, void* stream);
 
 /* MobilePoserNet.reset (models/net.py:84-88) clears nothing this library owns for the batch path;
  * clear_velocity != 0 additionally drops the carried velocity LSTM state (what setting

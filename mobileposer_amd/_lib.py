@@ -32,12 +32,14 @@ SIGNATURES = {
     "mp_forward_offline": (_i, [_vp, _vp, _ip, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_rnn_forward": (_i, [_vp, _i, _vp, _ip, _i, _i, _vp, _vp, _vp, _vp]),
     "mp_reduced_global_to_full": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "mp_r6d_to_rotation_matrix": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "mp_translate_offline": (_i, [_vp, _vp, _vp, _vp, _ip, _i, _i, _vp, _vp]),
     "mp_fk": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "mp_set_mesh": (_i, [_vp, _fp, _fp, _i]),
     "mp_fk_mesh": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "mp_set_shape_space": (_i, [_vp, _fp, _fp]),
     "mp_fk_shape": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "mp_eval_metrics": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, C.c_uint, C.c_uint, _i, _vp, _vp]),
     "mp_reset_state": (_i, [_vp, _i]),
     "mp_get_velocity_state": (_i, [_vp, _vp, C.POINTER(_i)]),
     "mp_set_velocity_state": (_i, [_vp, _vp, _i]),

@@ -156,6 +156,8 @@ struct mp_handle {
     float* vtpl_dev = nullptr;       // raw template vertices [V,3] (shape blending starts from these, model.py:86)
     float* shapedirs_dev = nullptr;  // [V,3,10] (mp_set_shape_space)
     float* jreg_dev = nullptr;       // dense J_regressor [24,V]
+    float* eval_ws = nullptr;        // mp_eval_metrics workspace: masked poses, FK outputs of prediction and truth, partials
+    size_t eval_ws_bytes = 0;
     float* shape_ws = nullptr;       // mp_fk_shape workspace: vrest [ns][V][3] | jraw | jrest | bone [ns][72] each
     size_t shape_ws_floats = 0;
     int n_vertex = 0;
@@ -1332,7 +1334,7 @@ void mp_destroy(mp_handle* h) {
                     h->sc.mask_dev, h->sc.st.last_foot, h->sc.st.root_y, h->sc.st.root_pos, h->sc.joints, h->sc.vel,
                     h->sc.contact, h->jrest_dev, h->vrest_dev, h->skinw_dev, h->lin1_pv.Wp, h->lin1_pv.bias, h->prof_dev,
                     h->vtpl_dev, h->shapedirs_dev, h->jreg_dev, h->shape_ws,
-                    h->vsnap.h, h->vsnap.c, h->st_snap.last_foot, h->st_snap.root_y, h->st_snap.root_pos};
+                    h->vsnap.h, h->vsnap.c, h->st_snap.last_foot, h->st_snap.root_y, h->st_snap.root_pos, h->eval_ws};
     for (void* p : misc) if (p) (void)hipFree(p);
     if (h->err_host) (void)hipHostFree(h->err_host);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -1464,6 +1466,14 @@ int mp_reduced_global_to_full(mp_handle* h, const float* r6d_dev, int64_t N, flo
     return leave(h, stream);
 }
 
+int mp_r6d_to_rotation_matrix(mp_handle* h, const float* r6d_dev, int64_t n, float* rot_dev, void* stream) {
+    if (!h || !r6d_dev || !rot_dev || n < 0) return h ? fail(h, MP_ERR_INVALID, "mp_r6d_to_rotation_matrix: bad argument") : MP_ERR_INVALID;
+    if (int rc = enter(h, stream)) return rc;
+    mp_launch_r6d_to_rot(r6d_dev, (long)n, rot_dev, h->s_main);
+    HIPCHK(h, hipGetLastError());
+    return leave(h, stream);
+}
+
 int mp_translate_offline(mp_handle* h, const float* joints_dev, const float* vel_dev, const float* contact_dev,
                          const int32_t* lengths_host, int B, int T, float* tran_dev, void* stream) {
     if (!h || !joints_dev || !vel_dev || !contact_dev || !lengths_host || !tran_dev || B < 1 || T < 1)
@@ -1569,6 +1579,52 @@ int mp_fk_mesh(mp_handle* h, const float* pose_dev, const float* tran_dev, int64
         mp_launch_lbs(rglobal_dev + n0 * 216, joint_dev + n0 * 72, tran_dev ? tran_dev + n0 * 3 : nullptr, cnt, h->jrest_dev,
                       0, h->vrest_dev, 0, h->skinw_dev, h->n_vertex, vert_dev + n0 * h->n_vertex * 3, h->s_main);
     }
+    HIPCHK(h, hipGetLastError());
+    return leave(h, stream);
+}
+
+int mp_eval_metrics(mp_handle* h, const float* pose_p_dev, const float* pose_t_dev, const float* tran_p_dev,
+                    const float* tran_t_dev, int64_t N, int fps, int align_joint, unsigned joint_mask, unsigned ignored_mask,
+                    int use_mesh, float* table_dev, void* stream) {
+    if (!h || !pose_p_dev || !pose_t_dev || !table_dev || N < 1 || fps < 1 || align_joint < 0 || align_joint > 23)
+        return h ? fail(h, MP_ERR_INVALID, "mp_eval_metrics: bad argument") : MP_ERR_INVALID;
+    if (use_mesh && !h->n_vertex) return fail(h, MP_ERR_INVALID, "mp_eval_metrics: use_mesh without mp_set_mesh");
+    const size_t V = use_mesh ? (size_t)h->n_vertex : 0, n = (size_t)N;
+    const size_t f_pose = n * 216, f_j = n * 72, f_v = n * V * 3;
+    const size_t floats = 2 * (2 * f_pose + f_j + f_v);
+    const size_t bytes = floats * sizeof(float) + mp_eval_partial_doubles((int)V) * sizeof(double) + 64;
+    if (bytes > h->eval_ws_bytes) {
+        HIPCHK(h, hipSetDevice(h->device));
+        HIPCHK(h, hipDeviceSynchronize());
+        if (h->eval_ws) (void)hipFree(h->eval_ws);
+        h->eval_ws = nullptr; h->eval_ws_bytes = 0;
+        if (int rc = dev_alloc(h, (void**)&h->eval_ws, bytes)) return rc;
+        h->eval_ws_bytes = bytes;
+    }
+    if (int rc = enter(h, stream)) return rc;
+    float* w = h->eval_ws;
+    float* mp_ = w;            float* mt_ = mp_ + f_pose;        // masked local poses
+    float* rp = mt_ + f_pose;  float* rt = rp + f_pose;          // global rotations
+    float* jp = rt + f_pose;   float* jt = jp + f_j;             // joints
+    float* vp = jt + f_j;      float* vt = vp + f_v;             // vertices
+    double* part = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(vt + f_v) + 63) & ~(uintptr_t)63);
+    hipStream_t s = h->s_main;
+    mp_launch_mask_pose(pose_p_dev, mp_, (long)N, ignored_mask, s);                                  // evaluate.py:25-26
+    mp_launch_mask_pose(pose_t_dev, mt_, (long)N, ignored_mask, s);
+    const float* pose[2] = {mp_, mt_};
+    const float* tran[2] = {tran_p_dev, tran_t_dev};
+    float* rg[2] = {rp, rt}; float* jj[2] = {jp, jt}; float* vv[2] = {vp, vt};
+    for (int k = 0; k < 2; ++k) {                                                                    // evaluator.py:319-320
+        mp_launch_fk(pose[k], tran[k], (long)N, h->bone_dev, h->parent_dev, h->depth_dev, rg[k], jj[k], s);
+        if (V)
+            for (int64_t n0 = 0; n0 < N; n0 += 32768) {
+                const long cnt = (long)(N - n0 < 32768 ? N - n0 : 32768);
+                mp_launch_lbs(rg[k] + n0 * 216, jj[k] + n0 * 72, tran[k] ? tran[k] + n0 * 3 : nullptr, cnt, h->jrest_dev, 0,
+                              h->vrest_dev, 0, h->skinw_dev, h->n_vertex, vv[k] + n0 * V * 3, s);
+            }
+    }
+    mp_launch_eval_metrics(mp_, mt_, rp, rt, jp, jt, V ? vp : nullptr, V ? vt : nullptr, (long)N, (int)V, fps, align_joint,
+                           joint_mask, part, table_dev, s);                                          // evaluator.py:321-343
     HIPCHK(h, hipGetLastError());
     return leave(h, stream);
 }

@@ -150,6 +150,7 @@ hipError_t mp_lstm_x3w_device_attrs();
 
 // ---------------------------------------------------------------- K4/K5: kinematics
 void mp_launch_r6d_ik(const float* r6d, long N, float* pose, const int* parent_dev, hipStream_t s);
+void mp_launch_r6d_to_rot(const float* r6d, long n, float* out, hipStream_t s);   // n six-vectors -> n 3x3 matrices
 // frame n reads its 96 numbers at r6d + n*rowStride + rowOffset
 void mp_launch_r6d_ik_strided(const float* r6d, long N, long rowStride, long rowOffset, float* pose,
                               const int* parent_dev, hipStream_t s);
@@ -167,6 +168,15 @@ void mp_launch_lbs(const float* rglobal, const float* joint, const float* tran, 
 void mp_launch_shape_body(const float* shape, int ns, const float* shapedirs, const float* vtemplate_raw,
                           const float* jreg, const int* parent_dev, int V, float* vrest, float* jraw, float* jrest,
                           float* bone, hipStream_t s);
+
+// ---------------------------------------------------------------- evaluator metrics (mp_eval.hip)
+// FullMotionEvaluator.__call__ (articulate/evaluator.py:292-343) on FK outputs; v_p / v_t may be nullptr (no mesh);
+// part: mp_eval_partial_doubles(V) doubles of scratch; table: [10][2] floats
+size_t mp_eval_partial_doubles(int V);
+void mp_launch_mask_pose(const float* in, float* out, long N, unsigned ignored, hipStream_t s);
+void mp_launch_eval_metrics(const float* pose_p, const float* pose_t, const float* rg_p, const float* rg_t, const float* j_p,
+                            const float* j_t, const float* v_p, const float* v_t, long N, int V, int fps, int align,
+                            unsigned mask, double* part, float* table, hipStream_t s);
 
 // ---------------------------------------------------------------- live front-end (mp_live.hip)
 // raw sensor samples of S streams -> network input frames [S,60] (live_demo.py:213-236)

@@ -85,6 +85,17 @@ MP_KERNEL __launch_bounds__(256) void mp_r6d_ik(const float* __restrict__ r6d, l
     for (int k = 0; k < 9; ++k) o[k] = out[k];
 }
 
+// r6d_to_rotation_matrix (articulate/math/angular.py:167-182) on n six-vectors: the ground-truth side of evaluate.py:60
+MP_KERNEL __launch_bounds__(256) void mp_r6d_to_rot(const float* __restrict__ r6d, long n, float* __restrict__ out) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n) return;
+    float R[9];
+    gram_schmidt(r6d + gid * 6, R);
+    float* o = out + gid * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = R[k];
+}
+
 // lanes = joints, 2 frames per wave; bone[24][3] = j_i - j_parent(i) (bone[0] = j_0 = 0), depth[24]
 // (boneStride: 0 = one body for all frames; 72 = frame n uses bone + n*72, forward_kinematics with per-frame shapes)
 MP_KERNEL __launch_bounds__(256) void mp_fk(const float* __restrict__ pose, const float* __restrict__ tran, long N,
@@ -272,6 +283,11 @@ void mp_launch_r6d_ik_strided(const float* r6d, long N, long rowStride, long row
     const long threads = N * 24;
     hipLaunchKernelGGL(mp_r6d_ik, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, r6d, N, rowStride,
                        rowOffset, pose, parent_dev);
+}
+
+void mp_launch_r6d_to_rot(const float* r6d, long n, float* out, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(mp_r6d_to_rot, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, r6d, n, out);
 }
 
 void mp_launch_r6d_ik(const float* r6d, long N, float* pose, const int* parent_dev, hipStream_t s) {

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from .config import amass, datasets, paths
+from .model_utils import safe_torch_load
 
 
 def rotation_matrix_to_r6d(r):
@@ -33,13 +34,14 @@ def combo_masks(combos=None):
 
 
 class PoseDataset:
-    def __init__(self, fold='train', evaluate=None, finetune=None, data=None, fk=None, combos=None, smpl=None):
+    def __init__(self, fold='train', evaluate=None, finetune=None, data=None, fk=None, combos=None, smpl=None, trusted=False):
         """Reference signature ``PoseDataset(fold, evaluate, finetune)`` (data.py:19).  Extras, all optional: ``data`` -- an
         already-loaded dataset dict or a path instead of the configured file; ``fk`` -- callable pose -> (R_global, joint)
         for the ground-truth joints (e.g. ``MobilePoserNet.forward_kinematics``); default: what the reference does at
         data.py:24,64 -- a ``ParametricModel`` of ``smpl`` / ``paths.smpl_file`` (synthetic body when that file is absent)
         whose forward kinematics run on the GPU (mp_fk); ``combos`` -- a subset of ``amass.combos``."""
         self.fold, self.evaluate, self.finetune = fold, evaluate, finetune
+        self._trusted = trusted                  # model_utils.safe_torch_load: full unpickling only for trusted files
         self.combos = list((combos if combos is not None else amass.combos).items())
         self.bodymodel = None
         self._fk = fk if fk is not None else self._body_fk(smpl)
@@ -50,7 +52,7 @@ class PoseDataset:
     # ---- where the sequences come from (data.py:27-55) ------------------------------------------------------------
     def _sources(self, data):
         if data is not None:
-            yield torch.load(data, map_location="cpu", weights_only=False) if not isinstance(data, dict) else data
+            yield safe_torch_load(data, self._trusted) if not isinstance(data, dict) else data
             return
         if self.fold == 'test':
             if self.evaluate not in datasets.test_datasets:
@@ -63,7 +65,7 @@ class PoseDataset:
         folder = paths.processed_datasets / ('eval' if (self.finetune or self.evaluate) else '')
         for name in names:
             try:                                                       # data.py:50-54: a bad file is reported, not fatal
-                yield torch.load(folder / name, map_location="cpu", weights_only=False)
+                yield safe_torch_load(folder / name, self._trusted)
             except Exception as e:
                 print(f"Error processing {name}: {e}.")
 

@@ -10,7 +10,6 @@ same number); means / stds are torch reductions on the device.  Sequence tables 
 the reference does -- a sequence shorter than one second makes the 1-s distance row NaN there, and here.
 """
 import argparse
-import math
 import os
 
 import numpy as np
@@ -25,62 +24,17 @@ def getenv(key, default=0):
     return type(default)(os.getenv(key, default))
 
 
-def r6d_to_rotation_matrix_torch(r6d):
-    """Ground-truth side only (evaluate.py:60): plain torch restatement of angular.py:167-182."""
-    r6d = r6d.reshape(-1, 6)
-    c0 = r6d[:, 0:3] / r6d[:, 0:3].norm(dim=1, keepdim=True)
-    u = r6d[:, 3:6] - (c0 * r6d[:, 3:6]).sum(dim=1, keepdim=True) * c0
-    c1 = u / u.norm(dim=1, keepdim=True)
-    c2 = torch.cross(c0, c1, dim=1)
-    r = torch.stack((c0, c1, c2), dim=-1)
-    r[torch.isnan(r)] = 0
-    return r
-
-
-def angle_between(Ra, Rb):
-    D = Ra.transpose(-1, -2) @ Rb
-    n = (D - torch.eye(3, device=D.device)).flatten(-2).norm(dim=-1)
-    return 2.0 * torch.asin((n / (2.0 * math.sqrt(2.0))).clamp(0.0, 1.0))
-
-
 class FullMotionEvaluator:
-    """articulate/evaluator.py:269-343: 10 x [mean, std] error table (mean shape, rotation-matrix inputs)."""
+    """articulate/evaluator.py:269-343: 10 x [mean, std] error table (mean shape, rotation-matrix inputs) -- computed by
+    ONE library call (mp_eval_metrics: FK + skinning of prediction and ground truth and all ten metrics on the GPU).
+    ``model``: a MobilePoserNet (or anything with its ``eval_metrics``)."""
 
-    def __init__(self, model, joint_mask=None, fps=60, align_joint=0):
-        self.model, self.joint_mask, self.fps, self.align_joint = model, joint_mask, fps, align_joint
+    def __init__(self, model, joint_mask=None, fps=60, align_joint=0, ignored=()):
+        self.model, self.joint_mask, self.fps, self.align_joint, self.ignored = model, joint_mask, fps, align_joint, ignored
 
     def __call__(self, pose_p, pose_t, tran_p=None, tran_t=None):
-        f, m = self.fps, self.model
-        mesh = m.n_vertex > 0
-        if mesh:
-            Rg_p, j_p, v_p = m.forward_kinematics(pose_p, tran_p, calc_mesh=True)
-            Rg_t, j_t, v_t = m.forward_kinematics(pose_t, tran_t, calc_mesh=True)
-        else:
-            Rg_p, j_p = m.forward_kinematics(pose_p, tran_p)
-            Rg_t, j_t = m.forward_kinematics(pose_t, tran_t)
-        dev = j_p.device
-        pl_p = pose_p.to(dev).reshape(-1, 24, 3, 3)
-        pl_t = pose_t.to(dev).reshape(-1, 24, 3, 3)
-        off = (j_t[:, self.align_joint] - j_p[:, self.align_joint]).unsqueeze(1)
-        je = (j_p + off - j_t).norm(dim=2)
-        ve = (v_p + off - v_t).norm(dim=2) if mesh else torch.full((1, 1), float("nan"), device=dev)
-        lae = torch.rad2deg(angle_between(pl_p, pl_t))
-        gae = torch.rad2deg(angle_between(Rg_p, Rg_t))
-        jkp = ((j_p[3:] - 3 * j_p[2:-1] + 3 * j_p[1:-2] - j_p[:-3]) * (f ** 3)).norm(dim=2)
-        jkt = ((j_t[3:] - 3 * j_t[2:-1] + 3 * j_t[1:-2] - j_t[:-3]) * (f ** 3)).norm(dim=2)
-        te = ((j_p[f:, :1] - j_p[:-f, :1]) - (j_t[f:, :1] - j_t[:-f, :1])).norm(dim=2) * 100
-        jm = self.joint_mask
-        zero = torch.zeros(1, 1, device=dev)
-        rows = [je, ve, lae, gae, jkp, jkt, te,
-                je[:, jm] if jm is not None else zero, lae[:, jm] if jm is not None else zero,
-                gae[:, jm] if jm is not None else zero]
-
-        def ms(x):
-            if x.numel() == 0:
-                return torch.full((2,), float("nan"), device=dev)
-            return torch.stack((x.mean(), x.std(dim=0).mean() if x.shape[0] > 1 else x.new_tensor(float("nan"))))
-
-        return torch.stack([ms(x) for x in rows])
+        return self.model.eval_metrics(pose_p, pose_t, tran_p, tran_t, fps=self.fps, align_joint=self.align_joint,
+                                       joint_mask=self.joint_mask, ignored=self.ignored)
 
 
 # The eight printed metrics (evaluate.py:29,33-35): label, row of the FullMotionEvaluator table it is taken from, unit factor.
@@ -97,16 +51,14 @@ class PoseEvaluator:
 
     def __init__(self, model, joint_mask=(2, 5, 16, 20), fps=datasets.fps):
         self.model = model
-        self._eval_fn = FullMotionEvaluator(model, joint_mask=list(joint_mask), fps=fps)
+        # joints the network does not predict count as identity in both poses (evaluate.py:25-26): done inside the call
+        self._eval_fn = FullMotionEvaluator(model, joint_mask=list(joint_mask), fps=fps, ignored=joint_set.ignored)
+        self._rows = torch.tensor([row for _, row, _ in METRICS])
+        self._scale = torch.tensor([scale for _, _, scale in METRICS], dtype=torch.float32).unsqueeze(1)
 
     def eval(self, pose_p, pose_t, joint_p=None, tran_p=None, tran_t=None):
-        dev = self.model.device
-        pose_p = pose_p.to(dev).reshape(-1, 24, 3, 3).clone()
-        pose_t = pose_t.to(dev).reshape(-1, 24, 3, 3).clone()
-        for pose in (pose_p, pose_t):                       # joints the network does not predict count as identity (:25-26)
-            pose[:, joint_set.ignored] = torch.eye(3, device=dev)
-        table = self._eval_fn(pose_p, pose_t, tran_p=tran_p.to(dev).reshape(-1, 3), tran_t=tran_t.to(dev).reshape(-1, 3))
-        return torch.stack([table[row] * scale for _, row, scale in METRICS])
+        table = self._eval_fn(pose_p, pose_t, tran_p=tran_p, tran_t=tran_t)
+        return table[self._rows.to(table.device)] * self._scale.to(table.device)
 
     @staticmethod
     def print(errors):
@@ -178,7 +130,7 @@ def evaluate_pose(model, dataset, num_past_frame=20, num_future_frame=5, evaluat
         x = imu.to(dev)
         model.reset()
         pose_p, _joints_p, tran_p, _contact = model.forward_offline(x.unsqueeze(0), [x.shape[0]])
-        pose_gt = r6d_to_rotation_matrix_torch(pose_t.to(dev)).view(-1, 24, 3, 3)
+        pose_gt = model.r6d_to_rotation_matrix(pose_t).view(-1, 24, 3, 3)                   # evaluate.py:60
         tables["offline"].append(evaluator.eval(pose_p, pose_gt, tran_p=tran_p, tran_t=tran_t))
         if evaluate_tran:
             for w, v in translation_window_errors(tran_p, tran_t).items():

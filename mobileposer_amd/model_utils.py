@@ -51,18 +51,32 @@ def normalise_state_dict(obj):
     return {k: sd[k] for k in man if k in sd} if all(k in sd for k in man) else sd
 
 
-def load_model(model_path, smpl_file=None, device="cuda:0", smpl=None):
+def safe_torch_load(path, trusted=False):
+    """``torch.load`` restricted to tensors and plain containers (``weights_only=True``).  A file the safe loader refuses
+    -- e.g. a Lightning checkpoint whose hyper-parameters pickle arbitrary classes -- is unpickled in full only when the
+    caller says the file is trusted (``trusted=True`` or env ``MP_TRUSTED_CHECKPOINTS=1``): a silent fallback would make
+    the safe attempt pointless."""
+    import os
+    import pickle
+    import torch
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as e:
+        if not (trusted or os.environ.get("MP_TRUSTED_CHECKPOINTS", "") not in ("", "0")):
+            raise RuntimeError("%s holds pickled objects beyond tensors and plain containers (%s); pass trusted=True (or set "
+                               "MP_TRUSTED_CHECKPOINTS=1) to unpickle it in full -- only for files you trust"
+                               % (path, str(e).splitlines()[0])) from e
+        return torch.load(path, map_location="cpu", weights_only=False)
+
+
+def load_model(model_path, smpl_file=None, device="cuda:0", smpl=None, trusted=False):
     """utils/model_utils.py:6-15: ``load_model(path) -> MobilePoserNet`` with the weights of ``path`` (a ``torch.save``d
     state dict, or a Lightning checkpoint as the reference's fallback branch reads).  ``smpl_file`` defaults to
     ``config.paths.smpl_file`` when that file exists (the reference always reads it, net.py:37), else the synthetic body."""
     import os
-    import torch
     from .config import paths
     from .net import MobilePoserNet
-    try:
-        obj = torch.load(model_path, map_location="cpu", weights_only=True)
-    except Exception:                       # Lightning checkpoints carry non-tensor objects (hyper-parameters)
-        obj = torch.load(model_path, map_location="cpu", weights_only=False)
+    obj = safe_torch_load(model_path, trusted)
     if smpl is None and smpl_file is None and os.path.exists(str(paths.smpl_file)):
         smpl_file = str(paths.smpl_file)
     model = MobilePoserNet(smpl_file=smpl_file, smpl=smpl, device=device)

@@ -506,6 +506,32 @@ class MobilePoserNet:
         self._require_weights()
         return fk_call(self._lib, self._h, self.device, self._mesh_state, pose, shape, tran, calc_mesh)
 
+    def r6d_to_rotation_matrix(self, r6d):
+        """art.math.r6d_to_rotation_matrix (angular.py:167-182): [..., 6] -> [N, 3, 3] (mp_r6d_to_rotation_matrix)."""
+        self._require_weights()
+        r = torch.as_tensor(r6d).to(device=self.device, dtype=torch.float32).reshape(-1, 6).contiguous()
+        out = torch.empty(r.shape[0], 3, 3, device=self.device, dtype=torch.float32)
+        _lib.check(self._lib.mp_r6d_to_rotation_matrix(self._h, _ptr(r), r.shape[0], _ptr(out), self._stream()), self._h)
+        return out
+
+    def eval_metrics(self, pose_p, pose_t, tran_p=None, tran_t=None, fps=60, align_joint=0, joint_mask=None, ignored=()):
+        """mp_eval_metrics: FullMotionEvaluator.__call__ (articulate/evaluator.py:292-343) -> error table [10,2] on the
+        device, in ONE library call (identity on ``ignored`` joints, FK + skinning of both poses, all ten metrics)."""
+        self._require_weights()
+        f = lambda t: None if t is None else torch.as_tensor(t).to(device=self.device, dtype=torch.float32).contiguous()
+        pp, pt = f(pose_p).reshape(-1, 24, 3, 3), f(pose_t).reshape(-1, 24, 3, 3)
+        N = int(pp.shape[0])
+        if int(pt.shape[0]) != N:
+            raise RuntimeError("prediction has %d frames, ground truth %d" % (N, int(pt.shape[0])))
+        tp = None if tran_p is None else f(tran_p).reshape(N, 3)
+        tt = None if tran_t is None else f(tran_t).reshape(N, 3)
+        bits = lambda js: sum(1 << int(j) for j in js) if js is not None else 0
+        table = torch.empty(10, 2, device=self.device, dtype=torch.float32)
+        _lib.check(self._lib.mp_eval_metrics(self._h, _ptr(pp), _ptr(pt), _ptr(tp), _ptr(tt), N, int(fps), int(align_joint),
+                                             bits(joint_mask), bits(ignored), int(self.n_vertex > 0), _ptr(table),
+                                             self._stream()), self._h)
+        return table
+
     def rnn_forward(self, module, x, input_lengths, state=None):
         """RNN.forward of one sub-module (models/rnn.py:20-33): -> (y [B,T,n_out], (h_n, c_n))."""
         self._require_weights()

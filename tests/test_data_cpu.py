@@ -55,3 +55,22 @@ def test_reference_constructor_reads_the_configured_file(smpl, tmp_path, monkeyp
         PoseDataset(fold='test', evaluate='nope', fk=fk)
     with pytest.raises(ValueError):
         PoseDataset(fold='dev', fk=fk)
+
+
+class _Hyper:                         # stands for a Lightning hyper-parameter object: not a tensor, not a plain container
+    def __init__(self):
+        self.lr = 1e-3
+
+
+def test_checkpoints_are_unpickled_in_full_only_when_trusted(tmp_path):
+    """load_model / PoseDataset read files with torch's safe loader; a file that needs arbitrary unpickling is refused
+    unless the caller says it is trusted (no silent fallback)."""
+    import pytest
+    from mobileposer_amd.model_utils import safe_torch_load
+    plain, fancy = tmp_path / "plain.pth", tmp_path / "fancy.ckpt"
+    torch.save({"state_dict": {"w": torch.ones(2)}, "epoch": 3, "hyper_parameters": {"finetune": False}}, plain)
+    torch.save({"state_dict": {"w": torch.ones(2)}, "hyper_parameters": _Hyper()}, fancy)
+    assert safe_torch_load(plain)["epoch"] == 3
+    with pytest.raises(RuntimeError, match="trusted=True"):
+        safe_torch_load(fancy)
+    assert safe_torch_load(fancy, trusted=True)["hyper_parameters"].lr == 1e-3

@@ -345,6 +345,20 @@ def test_g6_fk_mesh_and_g9_evaluator_golden(torch_mod, net):
     ev = FullMotionEvaluator(net, joint_mask=[2, 5, 16, 20], fps=30)
     errs = npy(ev(pp, pt, tran_p=cu(torch_mod, g9["tran_p"]), tran_t=cu(torch_mod, g9["tran_t"])))
     np.testing.assert_allclose(errs, g9["errs"], rtol=2e-4, atol=1e-5)
+    # the same through the `ignored` argument of the kernel (what PoseEvaluator.eval passes) on the unmasked poses
+    ev2 = FullMotionEvaluator(net, joint_mask=[2, 5, 16, 20], fps=30, ignored=ign)
+    errs2 = npy(ev2(cu(torch_mod, g9["pose_p"]), cu(torch_mod, g9["pose_t"]), tran_p=cu(torch_mod, g9["tran_p"]),
+                    tran_t=cu(torch_mod, g9["tran_t"])))
+    assert np.array_equal(errs, errs2)
+    # no mask: {0, NaN} rows like torch.zeros(1); a sequence shorter than the 1-s window / the jerk stencil: NaN rows
+    e3 = npy(FullMotionEvaluator(net, fps=30)(pp[:20], pt[:20]))
+    assert (e3[7:, 0] == 0).all() and np.isnan(e3[7:, 1]).all() and np.isnan(e3[6]).all() and np.isfinite(e3[:6]).all()
+    e4 = npy(FullMotionEvaluator(net, fps=30)(pp[:3], pt[:3]))
+    assert np.isnan(e4[4:7]).all() and np.isfinite(e4[:4]).all()
+    # r6d -> rotation matrix of the ground-truth side (evaluate.py:60) against the reference's function (golden G3 `rot`)
+    g3 = load_golden("g3_r6d_ik.npz")
+    rot = npy(net.r6d_to_rotation_matrix(cu(torch_mod, g3["r6d"])))
+    assert np.abs(rot - g3["rot"].reshape(-1, 3, 3)).max() < 1e-6 and not np.isnan(rot).any()
 
 
 def test_hidden_state_transports_agree(torch_mod, net):
@@ -532,6 +546,8 @@ def test_g11_evaluate_pose_table_and_translation_statistics(torch_mod, net):
     class Canned:                                   # the model under evaluation is not the point here: canned predictions
         device, n_vertex = net.device, net.n_vertex
         forward_kinematics = staticmethod(net.forward_kinematics)
+        eval_metrics = staticmethod(net.eval_metrics)
+        r6d_to_rotation_matrix = staticmethod(net.r6d_to_rotation_matrix)
         k = -1
 
         def eval(self):
