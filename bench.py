@@ -523,7 +523,7 @@ def main():
     # HBM bytes per launch of that kernel from the separate rocprofv3 --pmc passes (profiles/*_pmc_summary.json):
     # (2*FETCH_SIZE + WRITE_SIZE)*1024, corrected as MI355X_MICROARCH.md prescribes; null when no profile is present
     traffic = None
-    for prof in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for prof in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         try:
             pmc = json.load(open(os.path.join(REPO, "profiles", prof)))["kernels"]
             key = {1: "mp_lstm_fused<256, 8, 256, 1, false>", 4: "mp_lstm_fused<256, 8, 512, 1, false>",

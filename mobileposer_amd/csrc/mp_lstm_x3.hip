@@ -5,7 +5,7 @@
 // on v_mfma_f32_16x16x32_bf16 (fp32 accumulate).  One such MFMA covers 8x the K of v_mfma_f32_16x16x4_f32 in
 // about the same issue time, so 3 of them replace 8 fp32 MFMAs: the matrix pipe is no longer what bounds a
 // step.  The dropped a_lo*w_lo term is <= 2^-18 relative per product, hi+lo itself carries 16 significand
-// bits; measured end to end (tools_accuracy.py, tests/test_gpu_parity.py) the outputs stay <= 5e-7 from the same
+// bits; measured end to end (tools/accuracy.py, tests/test_gpu_parity.py) the outputs stay <= 5e-7 from the same
 // arithmetic in float64 -- 200x inside the 1e-4 parity bound, the level of fp32's own rounding noise.
 // A single bf16 term (1e-4 .. 5e-4) does NOT pass; that is why the split exists.
 //

@@ -13,7 +13,7 @@ import sys
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from mobileposer_amd import synthetic                      # noqa: E402
 from mobileposer_amd.net import MobilePoserNet             # noqa: E402
@@ -58,4 +58,4 @@ for name, r in rows.items():
     out["max_abs_error"][name] = e
     print("%-42s %10.2e %10.2e %10.2e %10.2e" % (name, e["r6d"], e["joints"], e["vel"], e["contact"]))
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(REPO, "gpurun_out", "r02_accuracy.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(REPO, "gpurun_out", "r03_accuracy.json"), "w"), indent=1)

@@ -1,7 +1,7 @@
 """Timings of the BASELINE.json configs other than the bench workload (run on the GPU box)."""
 import ctypes as C, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mobileposer_amd import synthetic
 from mobileposer_amd.net import MobilePoserNet
 

@@ -1,7 +1,7 @@
 """Debug helper: phase breakdown of the persistent LSTM kernel (run on the GPU box with MP_PERSIST_PROF=1)."""
 import ctypes as C, os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["MP_PERSIST_PROF"] = "1"
 from mobileposer_amd import synthetic
 from mobileposer_amd.net import MobilePoserNet

@@ -1,4 +1,4 @@
-"""rocprofv3 evidence for bench.py, run ON THE GPU BOX:  python tools_profile.py <tag> [bench args...]
+"""rocprofv3 evidence for bench.py, run ON THE GPU BOX:  python tools/profile.py <tag> [bench args...]
 
   1. rocprofv3 --kernel-trace --stats  of  python bench.py --steps 20 --warmup 5 --no-cpu-baseline <bench args>
   2. four rocprofv3 --pmc passes (one counter group per pass, with --kernel-trace only -- never combined with
@@ -15,7 +15,7 @@ import os
 import subprocess
 import sys
 
-REPO = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(REPO, "gpurun_out")
 PMC_GROUPS = [["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], ["FETCH_SIZE"], ["WRITE_SIZE"],
               ["SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_VALU_MFMA_MOPS_F32"]]
