@@ -845,7 +845,8 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             a.hx_next = (use_x3(h, m) && l == 0) ? w.hx2 + (size_t)dirs * s0 * ((size_t)4 * 16 * H + 16) : nullptr;
             static const int prof_layer = getenv("MP_PERSIST_PROF_LAYER") ? atoi(getenv("MP_PERSIST_PROF_LAYER")) : -1;
             a.err = h->err_dev; a.max_spin = 1u; a.max_ticks = h->wait_ticks;
-            a.prof = (prof_layer < 0 || prof_layer == l) ? h->prof_dev : nullptr;
+            static const int prof_mod = getenv("MP_PERSIST_PROF_MODULE") ? atoi(getenv("MP_PERSIST_PROF_MODULE")) : -1;
+            a.prof = ((prof_layer < 0 || prof_layer == l) && (prof_mod < 0 || prof_mod == j.id)) ? h->prof_dev : nullptr;
             a.zero_state = j.mode == STATE_ZERO ? 1 : 0; a.force_remote = h->force_remote ? 1 : 0;
             if (h->dbg_drop_left > 0) { a.debug_drop = h->dbg_drop_block + 1; --h->dbg_drop_left; }
             const bool x3 = use_x3(h, m);
