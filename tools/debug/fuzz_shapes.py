@@ -10,8 +10,7 @@ from mobileposer_amd.net import MobilePoserNet
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 sd, smpl = synthetic.make_weights(0), synthetic.synthetic_smpl()
 new = MobilePoserNet.from_numpy(sd, smpl)
-for k, v in (("MP_WREG", "0"), ("MP_EPOCH_TAGS", "0"), ("MP_WIDE", "0"), ("MP_SLICES16", "0"), ("MP_EXCLUSIVE", "0"), ("MP_HALF", "0"), ("MP_SLICES32", "0")):
-    os.environ[k] = v
+os.environ["MP_VARIANT"] = "wreg=0,epoch_tags=0,wide=0,slices16=0,exclusive=0,half=0,slices32=0"
 old = MobilePoserNet.from_numpy(sd, smpl)
 rng = np.random.default_rng(2024)
 worst = 0.0
