@@ -50,8 +50,8 @@ KERNEL_CLASSES = {   # timing classes of the C ABI (include/mobileposer_hip.h, m
     0: "mp_gemm_f32 (linear1 / linear2)",
     1: "mp_lstm_fused<256,8,256,1> bidirectional layer 0 (joints, pose)",
     4: "mp_lstm_fused<256,8,512,1> bidirectional layer 1 (joints, pose)",
-    5: "mp_lstm_fused<256,16,256,1> unidirectional layers (velocity)",
-    6: "mp_lstm_fused<64,4,*,1> (foot contact)",
+    5: "mp_lstm_fused<256,16,256,1,FK> unidirectional layers (velocity, the foot-contact layers riding in its workgroups)",
+    6: "mp_lstm_fused<64,4,*,1> (foot contact as launches of its own: B <= 128)",
     7: "mp_lstm_step (per-step fallback)",
     2: "mp_r6d_ik",
 }
@@ -526,13 +526,15 @@ def main():
     for prof in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         try:
             pmc = json.load(open(os.path.join(REPO, "profiles", prof)))["kernels"]
-            key = {1: "mp_lstm_fused<256, 8, 256, 1, false>", 4: "mp_lstm_fused<256, 8, 512, 1, false>",
-                   5: "mp_lstm_fused<256, 16, 256, 1, false>", 0: "mp_gemm_f32<2, 2, 2, 2>"}.get(dominant)
+            # (kernel names as rocprofv3 prints them; matched by prefix: the template list grew a parameter in round 3)
+            key = {1: "mp_lstm_fused<256, 8, 256, 1, false", 4: "mp_lstm_fused<256, 8, 512, 1, false",
+                   5: "mp_lstm_fused<256, 16, 256, 1, false", 0: "mp_gemm_f32<2, 2, 2, 2>"}.get(dominant)
             if args.lstm_mode == "x3":
                 key = {1: "mp_lstm_x3<8, 256, false>", 4: "mp_lstm_x3w<512, false>", 5: "mp_lstm_x3<8, 256, false>",
                        0: "mp_gemm_x3<128, 64>"}.get(dominant)
-            if key in pmc:
-                traffic = pmc[key]["hbm_bytes_per_launch_corrected"]
+            hit = [k for k in pmc if key and k.startswith(key)]
+            if hit:
+                traffic = pmc[hit[0]]["hbm_bytes_per_launch_corrected"]
                 break
         except Exception:
             pass

@@ -99,6 +99,7 @@ struct ModuleW {
     float* whhU8[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // 32 slices of 8 units (mp_lstm_u8): small batches, H = 256 blocks
     float* wihU8[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     float* wihG1 = nullptr;          // unidirectional H=256 block: layer-1 W_ih in granule k-order (wavefront kernel)
+    float* wVF[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};     // H = 64 block: rider fragments of mp_lstm_fused<..., FK> ("VF")
 };
 struct ModuleWS {
     float *xproj = nullptr, *out0 = nullptr, *out1 = nullptr;   // X1 (linear1 output) aliases out1
@@ -212,6 +213,8 @@ struct mp_handle {
     VelState vsnap;                  // recovery: the carried velocity state a call started from
     StreamCtx sc;
     OnlineState st_snap;             // recovery: per-stream solver state a streaming tick started from
+    bool vf_ok = true;               // MP_VARIANT vf=0: the foot-contact layers always run as launches of their own
+    const void* vf_foot = nullptr;   // forward_body -> rnn_rec: the foot-contact job that rides in this call's velocity launches
     int dbg_drop_block = 0, dbg_drop_left = 0;   // mp_debug_drop_workgroup
     bool recovery = true;            // mp_set_recovery: calls wait for themselves and repair a starved run in LSTM mode 0
     int recoveries = 0;
@@ -292,6 +295,8 @@ int pack_weights(mp_handle* h, const float* blob) {
                     if (int rc = dev_alloc(h, (void**)&m.whhP16[l][d], mp_whh_pack_floats(m.H) * sizeof(float))) return rc;
                     if (int rc = dev_alloc(h, (void**)&m.wihP16[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
                 }
+                if (m.H == 64)
+                    if (int rc = dev_alloc(h, (void**)&m.wVF[l][d], mp_foot_vf_floats(kin) * sizeof(float))) return rc;
                 if (m.H == 256) {
                     if (int rc = dev_alloc(h, (void**)&m.whhX[l][d], (size_t)4 * m.H * m.H * sizeof(float))) return rc;
                     if (int rc = dev_alloc(h, (void**)&m.wihX[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
@@ -322,6 +327,7 @@ int pack_weights(mp_handle* h, const float* blob) {
                 mp_launch_pack_whh(find(s.id, K_WHH, l, d), m.whh[l][d], m.H, h->s_main);
                 mp_launch_pack_whh_persist(find(s.id, K_WHH, l, d), m.whhP[l][d], m.H, m.nslice, h->s_main);
                 mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP[l][d], m.H, m.ih[l].K, m.nslice, 0, h->s_main);
+                if (m.wVF[l][d]) mp_launch_pack_foot_vf(find(s.id, K_WIH, l, d), find(s.id, K_WHH, l, d), m.wVF[l][d], m.ih[l].K, h->s_main);
                 if (m.whhU8[l][d]) {
                     mp_launch_pack_w_u8(find(s.id, K_WHH, l, d), m.whhU8[l][d], m.H, h->s_main);
                     mp_launch_pack_w_u8(find(s.id, K_WIH, l, d), m.wihU8[l][d], m.ih[l].K, h->s_main);
@@ -452,6 +458,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     //   exclusive=0    no LDS padding / XCD tables for concurrent persistent launches;  fuse_pv=0: separate linear1 launches
     //   epoch_tags=0   zero the exchange area before every fp32 layer launch;  epoch_start=N: first epoch base (wrap tests)
     //   uni2=1         velocity block as one two-layer wavefront launch (= mp_set_lstm_mode(h, 2))
+    //   vf=0           foot-contact layers as launches of their own beside velocity (B > 128), not as riders in its workgroups
     if (const char* e = getenv("MP_VARIANT")) {
         std::string all(e);
         size_t pos = 0;
@@ -477,6 +484,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
             else if (key == "epoch_start") { if (v >= 1 && v < 0xf0000000ul) h->epoch_start = (unsigned)v; }
             else if (key == "uni2") h->uni2 = v != 0;
             else if (key == "gemm_staged") {}                  // read by mp_launch_gemm
+            else if (key == "vf") h->vf_ok = v != 0;
             else { h->err = "MP_VARIANT: unknown key '" + key + "'"; return bail(MP_ERR_INVALID); }
         }
     }
@@ -766,6 +774,8 @@ bool rnn_g0_pose_velocity(const RnnJob& jp, const RnnJob& jv, hipStream_t s, int
     return true;
 }
 
+inline int fm_kin0(const mp_handle* h) { return h->mod[MP_MOD_FOOT_CONTACT].H; }   // K_in of the rider's layer 0 (= its H)
+
 int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
     mp_handle* h = j.h;
     const ModuleW& m = h->mod[j.id];
@@ -833,7 +843,9 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         const int kin = l == 0 ? H : dirs * H;
         // timing classes: 1 = H256 bidirectional K_in=256, 4 = H256 bidirectional K_in=512, 5 = H256 unidirectional
         const int cls = H != 256 ? 6 : (dirs == 1 ? 5 : (kin == 256 ? 1 : 4));
-        SegScope seg(h, s, cls, (nslab + chunk - 1) / chunk, 2.0 * dirs * (double)B * T * 4.0 * H * (kin + H));
+        // (a velocity launch that carries the foot-contact layer as a rider is credited with that layer's FLOPs as well)
+        const double rider_flop = (j.id == MP_MOD_VELOCITY && h->vf_foot) ? 2.0 * 2 * (double)B * T * 4.0 * 64 * ((l == 0 ? 64 : 128) + 64) : 0.0;
+        SegScope seg(h, s, cls, (nslab + chunk - 1) / chunk, 2.0 * dirs * (double)B * T * 4.0 * H * (kin + H) + rider_flop);
         const float* xin = l == 0 ? w.out1 /* X1 */ : w.out0;
         float* outp = l == 0 ? w.out0 : w.out1;
         // layer 1 overwrites out1, which still holds X1 while layer 0 runs -- layer 0 has finished by then
@@ -865,7 +877,17 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
                 dd.wihpack = x3 ? m.wihX[l][d] : (u8 ? m.wihU8[l][d] : wreg ? m.wihPW[l][d] : (p16 ? m.wihP16[l][d] : m.wihP[l][d])); dd.bias = m.ih[l].bias + (size_t)d * 4 * H; dd.xin = xin;
             }
             if (dirs == 1) a.d[1] = a.d[0];
-            if (x3 && nsl == 8 && (h->x3w_mask & (kin == 256 ? 1 : 2))) mp_launch_lstm_x3w(a, kin, s);
+            // the foot-contact layer l of the same slabs as a rider of this velocity launch (forward_body decides)
+            const RnnJob* fj = (j.id == MP_MOD_VELOCITY && !x3 && nsl == 16 && !p16 && kin == 256) ? static_cast<const RnnJob*>(h->vf_foot) : nullptr;
+            if (fj) {
+                const ModuleW& fm = h->mod[MP_MOD_FOOT_CONTACT];
+                ModuleWS& fws = fj->p->ws[MP_MOD_FOOT_CONTACT];
+                for (int fd = 0; fd < 2; ++fd) { a.f_w[fd] = fm.wVF[l][fd]; a.f_bias[fd] = fm.ih[l].bias + (size_t)fd * 4 * fm.H; }
+                a.f_xin = l == 0 ? fws.out1 /* X1 */ : fws.out0;
+                a.f_out = l == 0 ? fws.out0 : fws.out1;
+            }
+            if (fj) mp_launch_lstm_vf(a, l == 0 ? fm_kin0(h) : 2 * h->mod[MP_MOD_FOOT_CONTACT].H, s);
+            else if (x3 && nsl == 8 && (h->x3w_mask & (kin == 256 ? 1 : 2))) mp_launch_lstm_x3w(a, kin, s);
             else if (x3) mp_launch_lstm_x3(a, kin, nsl, s);
             else if (u8) mp_launch_lstm_u8(a, kin, s);
             else if (wreg) mp_launch_lstm_persist_w(a, kin, s);
@@ -1094,6 +1116,12 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         //  chain joints -> pose linear1 -> pose layers -> velocity layers -> velocity linear2 stays on s_main and the one
         //  edge it needs from a side stream -- velocity's linear1 -- is taken early, in front of the pose layers)
         RC(rnn_g0(F, sf));                                       // linear1 of the three blocks, concurrently
+        // "VF": the foot-contact layers ride in the workgroups of the velocity layer launches (mp_lstm_fused<256,16,256,1,*,FK>)
+        // instead of running as launches of their own beside them -- exact-fp32 16-slice velocity kernel, zero initial state
+        const ModuleW& vmod = h->mod[MP_MOD_VELOCITY];
+        const bool fuse_vf = h->vf_ok && p->B > 128 && h->persist && !h->uni2 && !use_x3(h, vmod) && vmod.nslice == 16 &&
+                             fp32_slices(h, vmod, p->B) == 16 && h->mod[MP_MOD_FOOT_CONTACT].wVF[0][0] != nullptr;
+        if (fuse_vf) RC(rec(4, sf));                             // linear1 of foot contact is done
         int rc_pv = MP_OK;
         const bool fused_pv = rnn_g0_pose_velocity(P, V, sm, &rc_pv);   // pose + velocity: one GEMM on the main stream
         RC(rc_pv);
@@ -1119,13 +1147,16 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
             int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if (place_clusters(h, vf, 2, load, h->xcd_plan)) { excl_vf = kExclusiveLdsBytes; vf_tables = true; }
         }
+        if (fuse_vf) { excl_vf = 0; vf_tables = false; RC(wait(4, sm)); h->vf_foot = &F; }
         h->excl_lds = excl_vf;
         h->xcd_plan_on[MP_MOD_VELOCITY] = vf_tables;
         int rc_v = rnn_rec(V, 0, sm);
         if (!rc_v) rc_v = rnn_rec(V, 1, sm);
         h->excl_lds = 0;
         h->xcd_plan_on[MP_MOD_VELOCITY] = false;
+        h->vf_foot = nullptr;
         RC(rc_v);
+        if (fuse_vf) RC(rec(5, sm));
         RC(rnn_g2(V, sm));                                                                  // net.py:117
         HIPCHK(h, hipEventRecord(h->ev_v, sm));
         RC(wait(2, sp)); RC(rnn_g2(P, sp));
@@ -1133,15 +1164,20 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
           mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sp); }   // net.py:110
         if (fk_rglobal) mp_launch_fk(pose, nullptr, poseRows, h->bone_dev, h->parent_dev, h->depth_dev, fk_rglobal, fk_joint, sp);
         RC(rec(3, sp));
-        RC(wait(2, sf));
-        h->excl_lds = excl_vf;
-        h->xcd_plan_on[MP_MOD_FOOT_CONTACT] = vf_tables;
-        int rc_f = rnn_rec(F, 0, sf);
-        if (!rc_f) rc_f = rnn_rec(F, 1, sf);
-        h->excl_lds = 0;
-        h->xcd_plan_on[MP_MOD_FOOT_CONTACT] = false;
-        RC(rc_f);
-        RC(rnn_g2(F, sf));                                                                  // net.py:113-114
+        if (fuse_vf) {                                   // both foot-contact layers ran inside the velocity launches
+            RC(wait(5, sf));
+            RC(rnn_g2(F, sf));                                                              // net.py:113-114
+        } else {
+            RC(wait(2, sf));
+            h->excl_lds = excl_vf;
+            h->xcd_plan_on[MP_MOD_FOOT_CONTACT] = vf_tables;
+            int rc_f = rnn_rec(F, 0, sf);
+            if (!rc_f) rc_f = rnn_rec(F, 1, sf);
+            h->excl_lds = 0;
+            h->xcd_plan_on[MP_MOD_FOOT_CONTACT] = false;
+            RC(rc_f);
+            RC(rnn_g2(F, sf));                                                              // net.py:113-114
+        }
         HIPCHK(h, hipEventRecord(h->ev_f, sf));
         RC(wait(3, sm));
     }
@@ -1327,6 +1363,7 @@ void mp_destroy(mp_handle* h) {
             if (m.whhP16[l][d]) (void)hipFree(m.whhP16[l][d]);
             if (m.wihP16[l][d]) (void)hipFree(m.wihP16[l][d]);
             if (m.whhX[l][d]) (void)hipFree(m.whhX[l][d]);
+            if (m.wVF[l][d]) (void)hipFree(m.wVF[l][d]);
             if (m.wihX[l][d]) (void)hipFree(m.wihX[l][d]);
         }
         if (m.wihG1) (void)hipFree(m.wihG1);

@@ -93,6 +93,13 @@ struct LstmPersistArgs {
     unsigned max_spin;            // 0: never wait (a test hook); otherwise waits are allowed, bounded by max_ticks
     unsigned long long max_ticks; // bound of every wait in ticks of the constant 100 MHz clock (s_memrealtime); mp_api: 0.25 s
     long long* prof;              // optional [grid][6] cycle sums per phase (debug), else nullptr
+    // mp_lstm_fused<256,16,256,1,*,FK> only ("VF"): a bidirectional H = 64 layer -- the foot-contact block -- rides along in the
+    // workgroups of this unidirectional H = 256 launch: slice j of a slab also carries units 8*(j & 7) .. +7 of direction
+    // j >> 3 of that slab's H = 64 layer (zero initial state, same lengths).  f_w: fragments from mp_launch_pack_foot_vf.
+    const float* f_w[2] = {nullptr, nullptr};
+    const float* f_bias[2] = {nullptr, nullptr};   // per direction: gate-interleaved b_ih + b_hh [4 * 64]
+    const float* f_xin = nullptr;                  // rider's layer input, time-major [T][B][FK]
+    float* f_out = nullptr;                        // rider's layer output, time-major [T][B][128] (direction d at column 64 d)
     int debug_drop = 0;           // test hook (mp_debug_drop_workgroup): block debug_drop - 1 exits at once, as if it never
                                   // became resident -- its cluster's waits run into their time bound
     int out_pairs = 0;            // split-bf16 kernel only: write the layer output as pairs (it feeds another layer)
@@ -121,6 +128,10 @@ struct LstmPersistArgs {
 };
 // nslice: workgroups sharing one slab of an H = 256 layer: 16 (4-wave workgroups, two per CU) or 8 (8-wave, one per CU)
 void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice, hipStream_t s);
+// the unidirectional H = 256, K_in = 256 layer on 16 slices with an H = 64 bidirectional layer riding along (fk = its K_in: 64 | 128)
+void mp_launch_lstm_vf(const LstmPersistArgs& a, int fk, hipStream_t s);
+size_t mp_foot_vf_floats(int fk);     // per direction
+void mp_launch_pack_foot_vf(const float* wih, const float* whh, float* dst, int fk, hipStream_t s);
 void mp_fill_xcd_table(LstmPersistArgs& a, const unsigned char* cnt);   // LstmPersistArgs::xcd_cnt / xcd_base
 void mp_launch_xcc_probe(int* out64, hipStream_t s);                    // 64 workgroups -> their XCC ids
 // 32 slices of 8 units per slab (mp_lstm_u8.hip): small batches; wpack / wihpack from mp_launch_pack_w_u8 (K = 256 / K_in)

@@ -104,8 +104,14 @@ __device__ __forceinline__ void mfma_drain() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int H, int NSLICE, int KIN, int TW, bool PROF>
-MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void mp_lstm_fused(LstmPersistArgs a) {
+// FK != 0 (only <256, 16, 256, 1>, "VF"): a bidirectional H = 64, K_in = FK layer -- the foot-contact block of the same slab --
+// rides along: slice j also computes units 8*(j & 7) .. +7 of direction j >> 3 of it (two extra MFMA tiles: gates i|f and
+// g|o of 8 units), K split over the four waves like everything else, its hidden state exchanged through the same area under
+// the same flags.  Why: run as a kernel of its own beside this one, the H = 64 layer and this layer slow each other on every
+// shared SIMD (profiles/r03_class_times.txt: 335 -> 398 us and 180 -> 450 us per layer); inside these waves it costs its
+// instructions and nothing else.
+template <int H, int NSLICE, int KIN, int TW, bool PROF, int FK = 0>
+MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void mp_lstm_fused(LstmPersistArgs a) {
     if (a.debug_drop && (int)blockIdx.x == a.debug_drop - 1) return;      // test hook: a workgroup that never shows up
     using C = Cfg<H, NSLICE, KIN, TW>;
     constexpr bool WREG = H == 256 && NSLICE == 8 && TW == 1;
@@ -229,6 +235,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
 #pragma unroll
     for (int i = 0; i < NPW; ++i) src_local[i] = true;
     bool all_local = true;
+    unsigned long long same_xcd = ~0ull;   // bit s: producer slice s runs on my XCD
     if (NSLICE > 1) {
         // (epoch_base != 0: the exchange area is NOT zeroed between launches -- every launch uses tags nobody has written
         //  there before: base + step, and base itself for the XCC table; see LstmPersistArgs::epoch_base)
@@ -245,12 +252,14 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
             }
         }
         const unsigned long long same = __ballot(peer == my_xcc);
+        same_xcd = same;
         all_local = (same & ((1ull << NSLICE) - 1)) == ((1ull << NSLICE) - 1);
 #pragma unroll
         for (int i = 0; i < NPW; ++i) src_local[i] = (same >> (NPW * kq + i)) & 1;   // k-steps of part i come from slice NPW*kq+i
         if (__ballot(peer == ~0u)) { spin_budget = 0; poison_cells(cst); }
         if (a.force_remote) {                               // test hook: exercise the any-placement transport
             all_local = false;
+            same_xcd = 0;
 #pragma unroll
             for (int i = 0; i < NPW; ++i) src_local[i] = false;
         }
@@ -279,6 +288,49 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
 #pragma unroll
         for (int i = 0; i < NP; ++i) hr[i] = f32x4{av[(4 * i) % NKS], av[(4 * i + 1) % NKS], av[(4 * i + 2) % NKS], av[(4 * i + 3) % NKS]};
     }
+
+    // ---- FK: the H = 64 rider.  Wave kq takes K quarter kq of both of its products: x k = kq*FK/4 + (i/4)*16 + q*4 + i%4
+    // (x-step i < FNX), h k = kq*16 + 4*ks + q (ks < 4).  Exchange words of the rider: [transport][parity][direction][1024]
+    // behind the flags of this cluster's area; word (row, unit u) at ((u/16*4 + u%4)*16 + row)*4 + (u/4)%4, so that consumer
+    // lane (kq, q, row) finds its four k-steps in one 16-byte piece.  Producers of a piece: slices 8*dir + 2*kq (+1).
+    static_assert(FK == 0 || (H == 256 && NSLICE == 16 && KIN == 256 && TW == 1 && FLAGX), "the rider lives in the 16-slice velocity kernel");
+    constexpr int FNX = FK / 16, FNS = FNX + 4, FNJ = FK / 64;
+    constexpr unsigned F_WORD0 = 4 * 16 * H + 1024;                  // first rider word of the cluster's area
+    constexpr unsigned F_TR = 2 * 2 * 1024;                           // words per transport
+    const int fdir = slice >> 3, fug = slice & 7;
+    float fw[FK ? FNS : 1][2];
+    f32x4 fbias4 = f32x4{0.f, 0.f, 0.f, 0.f}, fxa[FNJ > 0 ? FNJ : 1], fhr = f32x4{0.f, 0.f, 0.f, 0.f};
+    float fcst = 0.f, fhst = 0.f;
+    int flen = 0, frow = 0, funit = 0;
+    unsigned fvoff = 0, fslot = 0;
+    const float *fxp_cur = nullptr, *fxp_nxt = nullptr;
+    size_t fxt = 0;
+    __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(hdL + (FK ? F_WORD0 : 0), 0, 2 * F_TR * 4, 0x00020000);
+    if (FK) {
+        const float* p = a.f_w[fdir] + ((size_t)(fug * 4 + kq) * FNS * 2) * 64 + lane;
+#pragma unroll
+        for (int st = 0; st < FNS; ++st) { fw[st][0] = p[(size_t)(st * 2) * 64]; fw[st][1] = p[(size_t)(st * 2 + 1) * 64]; }
+        // the cell this lane finishes (lanes 0..31 of wave kq): row 4*kq + lane/8 of the slab, unit 8*fug + lane%8
+        frow = brow0 + 4 * kq + ((lane >> 3) & 3);
+        funit = 8 * fug + (lane & 7);
+        flen = (lane < 32 && frow < B) ? a.lengths[frow] : 0;
+        fbias4 = *reinterpret_cast<const f32x4*>(a.f_bias[fdir] + 4 * funit);
+        fslot = (unsigned)((((funit >> 4) * 4 + (funit & 3)) * 16 + 4 * kq + ((lane >> 3) & 3)) * 4 + ((funit >> 2) & 3));
+        const int fs0 = fdir * 8 + 2 * kq;                             // producer slices of this wave's piece
+        const bool floc = ((same_xcd >> fs0) & 1) && ((same_xcd >> (fs0 + 1)) & 1);
+        fvoff = (floc ? 0u : F_TR * 4u) + (unsigned)fdir * 4096u + (unsigned)(((kq * 4 + q) * 16 + r16) * 16);
+        // lanes 16..23 watch the flags of those two slices' four waves (lanes 0..15: this layer's own producers)
+        if (lane >= 16 && lane < 24) {
+            const int fs = fs0 + ((lane - 16) >> 2);
+            hflag = hfL + (((same_xcd >> fs) & 1) ? 0 : HF_R) + 4 * fs + (lane & 3);
+        }
+        fxt = (size_t)B * FK;
+        fxp_cur = a.f_xin + (size_t)(arow_in ? arow : 0) * FK + kq * (FK / 4) + q * 4 + (size_t)(fdir && alen > 0 ? alen - 1 : 0) * fxt;
+        fxp_nxt = fxp_cur;
+#pragma unroll
+        for (int j = 0; j < FNJ; ++j) fxa[j] = *reinterpret_cast<const f32x4*>(fxp_cur + j * 16);
+    }
+    f32x4* fred = reinterpret_cast<f32x4*>(smem) + C::RED_F4 + (size_t)NWV * XL * NTG * 64;   // rider partials [kq][tile][lane]
 
     // ---- x_0: this lane's A values of the input projection, k = kq*KQ + j*16 + q*4 + i  (x-step s = 4j+i)
     f32x4 xa[NXJ];
@@ -333,6 +385,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
     for (int step = 0; step < T; ++step) {
         PROF_T(0);
         if (LEAN) xp_cur = xp_nxt;
+        if (FK) fxp_cur = fxp_nxt;
         if (SPLIT_X && !FLAGX) load_x(step, XJ_PRE, NXJ);
         f32x4 acc[NTW];
         if (!WREG) {                                           // (WREG: the first MFMA of every tile has C = 0)
@@ -388,6 +441,18 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
             }
         }
 
+        // ---- FK: the rider's input projection (independent of h: it lengthens the window that hides the hand-off)
+        f32x4 facc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if (FK) {
+#pragma unroll
+            for (int i = 0; i < FNX; ++i) {
+                const float a_s = fxa[(i >> 2) % (FNJ > 0 ? FNJ : 1)][i & 3];
+                facc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, fw[i % FNS][0], facc[0], 0, 0, 0);
+                facc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, fw[i % FNS][1], facc[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
         // ---- request h_{step-1}: granule (row r16, unit kq*KW + 4*ks + q), 512 contiguous bytes per instruction
         u64 gr[NKS];
         const unsigned epoch = a.epoch_base + (unsigned)step;  // written by the producers at the end of step-1
@@ -424,6 +489,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
 #pragma unroll
                 for (int i = 0; i < NP; ++i)
                     hr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, hvoff[i], par_off, 16 /* sc1 */));
+                if (FK) fhr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(frs, fvoff, ((step + 1) & 1) * 8192, 16 /* sc1 */));
             }
         } else if (EARLY_GATHER && (LEAN || step > 0)) {
 #pragma unroll
@@ -465,6 +531,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
             // of x_{t+1} below is issued (a wait placed after it would also drain those HBM loads)
 #pragma unroll
             for (int i = 0; i < NP; ++i) asm volatile("" : "+v"(hr[i]));
+            if (FK) asm volatile("" : "+v"(fhr));
         } else if (step > 0) {
             if (!EARLY_GATHER) {
 #pragma unroll
@@ -514,6 +581,12 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
             const long dlt = d.reverse ? -(long)xtstride : (long)xtstride;
             xp_nxt = adv ? xp_cur + dlt : xp_cur;
         }
+        if (FK) {      // the rider's x of step + 1 (forward: t = step + 1, reverse: t = len - 2 - step, both clamped)
+            const bool adv = fdir ? (alen - 2 - step >= 0) : (step + 1 < T);
+            fxp_nxt = adv ? (fdir ? fxp_cur - fxt : fxp_cur + fxt) : fxp_cur;
+#pragma unroll
+            for (int j = 0; j < FNJ; ++j) fxa[j] = *reinterpret_cast<const f32x4*>(fxp_nxt + j * 16);
+        }
         load_x((step + 1) | 0x40000000, 0, XJ_PRE);   // next step's x: issued only now so that the granule wait above does not
                                                       // also drain these HBM loads; they land under the MFMAs / cell update below
         PROF_E(1); PROF_T(2);
@@ -528,12 +601,24 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
                 if (WREG) mfma_asm<false, true>(acc[t], a_h, wv[ks][t]);
                 else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_h, wv[ks][t], acc[t], 0, 0, 0);
             }
+        if (FK) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                facc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fhr[ks], fw[(FNX + ks) % FNS][0], facc[0], 0, 0, 0);
+                facc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fhr[ks], fw[(FNX + ks) % FNS][1], facc[1], 0, 0, 0);
+            }
+        }
         if (WREG) mfma_drain();
         PROF_E(2); PROF_T(3);
 
         // ---- K reduction through LDS: the 4 K-quarter waves of a tile group hand each finishing wave the 4 gate
         // values of the accumulator regs it finishes (own share included: register indices stay compile-time)
         __syncthreads();                                       // previous step's reads of `red` are done
+        if (FK) {      // rider partials, transposed for the finishing lanes: [source kq][row 4q+reg][column][tile]
+            float2* ft = reinterpret_cast<float2*>(fred) + (size_t)(kq * 16 + 4 * q) * 16 + r16;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) ft[rg * 16] = float2{facc[0][rg], facc[1][rg]};
+        }
         if (!PER_UB) {
 #pragma unroll
             for (int dw = 0; dw < 4; ++dw) {
@@ -559,6 +644,17 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
 #pragma unroll
             for (int sw = 1; sw < 4; ++sw) v += red[((wave * 4 + sw) * NOWN + o) * 64 + lane];
             gate[o] = v + bias4;
+        }
+        // rider gates of cell (row 4*kq + lane/8, unit u = lane%8): (i, g) = column u, (f, o) = column 8 + u of tiles (0, 1)
+        float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
+        if (FK) {
+            const float2* ft = reinterpret_cast<const float2*>(fred) + (size_t)(4 * kq + ((lane >> 3) & 3)) * 16 + (lane & 7);
+#pragma unroll
+            for (int ksrc = 0; ksrc < 4; ++ksrc) {
+                const float2 ig2 = ft[ksrc * 256], fo2 = ft[ksrc * 256 + 8];
+                gi += ig2.x; gg += ig2.y; gf += fo2.x; go += fo2.y;
+            }
+            gi += fbias4[0]; gf += fbias4[1]; gg += fbias4[2]; go += fbias4[3];
         }
         PROF_E(3); PROF_T(4);
 
@@ -601,6 +697,35 @@ MP_KERNEL __launch_bounds__(256 * TW, (Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void
 #pragma unroll
             for (int o = 0; o < NOWN; ++o)
                 if (bidx[o] < B) *reinterpret_cast<float*>(reinterpret_cast<char*>(outb[o]) + (size_t)(unsigned)tt[o] * out_row_bytes) = oval[o];
+        } else if (FK) {
+            // this layer's cell and the rider's cell (row 4*kq + lane/8, unit lane%8 on lanes 0..31; the other lanes compute the
+            // same numbers and keep nothing) in ONE branch-free block, all stores behind it: the scheduler interleaves the two
+            // dependent exp / rcp chains.  Rider gates: i = tile 0 column u, f = tile 0 column 8 + u, g / o = the same columns of
+            // tile 1; rows 4*kq .. 4*kq+3 are accumulator regs 0 .. 3 of the lanes with q == kq.
+            const bool act = step < blen[0];
+            const int tt = act ? (d.reverse ? blen[0] - 1 - step : step) : step;
+            const bool fact = step < flen;                       // (flen = 0 on lanes 32..63 and for rows past the batch)
+            const int ftt = fact ? (fdir ? flen - 1 - step : step) : step;
+            const float ig = sigmoidf_(gate[0][0]), fig = sigmoidf_(gi);
+            const float fg = sigmoidf_(gate[0][1]), ffg = sigmoidf_(gf);
+            const float gv = tanhf_(gate[0][2]), fgv = tanhf_(gg);
+            const float og = sigmoidf_(gate[0][3]), fog = sigmoidf_(go);
+            const float cnew = fg * cst[0] + ig * gv, fcnew = ffg * fcst + fig * fgv;
+            const float hnew = og * tanhf_(cnew), fhnew = fog * tanhf_(fcnew);
+            cst[0] = act ? cnew : cst[0];
+            hst[0] = act ? hnew : hst[0];
+            fcst = fact ? fcnew : fcst;
+            fhst = fact ? fhnew : fhst;
+            unsigned* hw = hdL + (size_t)(step & 1) * 16 * H + hslot[0];
+            __hip_atomic_store(hw, __float_as_uint(hst[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!all_local) __hip_atomic_store(hw + HD_R / 4, __float_as_uint(hst[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < 32) {
+                unsigned* fwd = hdL + F_WORD0 + (unsigned)(step & 1) * 2048u + (unsigned)fdir * 1024u + fslot;
+                __hip_atomic_store(fwd, __float_as_uint(fhst), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (!all_local) __hip_atomic_store(fwd + F_TR, __float_as_uint(fhst), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (frow < B) a.f_out[((size_t)ftt * B + frow) * 128 + fdir * 64 + funit] = fact ? fhnew : 0.f;
+            }
+            if (bidx[0] < B) *reinterpret_cast<float*>(reinterpret_cast<char*>(outb[0]) + (size_t)(unsigned)tt * out_row_bytes) = act ? hnew : 0.f;
         } else
 #pragma unroll
         for (int o = 0; o < NOWN; ++o) {
@@ -925,6 +1050,50 @@ constexpr size_t fused_lds() {
     using C = Cfg<H, NSLICE, KIN, TW>;
     return (size_t)C::RED_F4 * 16 + (size_t)C::NWV * C::XL * C::NTG * 64 * 16;
 }
+constexpr size_t kVfLds = fused_lds<256, 16, 256, 1>() + 4 * 2 * 64 * 16;      // + the rider's partial sums [kq][tile][lane]
+
+template <int FK>
+void launch_vf(const LstmPersistArgs& a, hipStream_t s) {
+    size_t lds = kVfLds;
+    if ((size_t)a.min_lds > lds) lds = (size_t)a.min_lds;
+    LstmPersistArgs b = a;
+    int most = 0, total = 0;
+    for (int x = 0; x < 8; ++x) { most = b.xcd_cnt[x] > most ? b.xcd_cnt[x] : most; total += b.xcd_cnt[x]; }
+    if (total != a.nslab * a.ndir) {
+        mp_fill_xcd_table(b, nullptr);
+        most = (a.nslab * a.ndir + 7) / 8;
+    }
+    const dim3 grid(8 * most * 16);
+    if (a.prof) hipLaunchKernelGGL((mp_lstm_fused<256, 16, 256, 1, true, FK>), grid, dim3(256), lds, s, b);
+    else hipLaunchKernelGGL((mp_lstm_fused<256, 16, 256, 1, false, FK>), grid, dim3(256), lds, s, b);
+}
+template <int FK>
+hipError_t vf_attrs() {
+    hipError_t e = hipFuncSetAttribute((const void*)mp_lstm_fused<256, 16, 256, 1, true, FK>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVfLds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)mp_lstm_fused<256, 16, 256, 1, false, FK>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVfLds);
+}
+
+// Rider weights of one direction: dst[((((ug*4 + kq)*FNS + st)*2 + tile)*64 + lane] (ug = group of 8 units, FNS = FK/16 + 4)
+//   = W[gate*64 + 8*ug + n%8][k],  gate = 2*tile + n/8,  n = lane % 16,  q = lane / 16
+//   st <  FK/16: W = W_ih, k = kq*FK/4 + (st/4)*16 + q*4 + st%4;   st >= FK/16: W = W_hh, k = kq*16 + 4*(st - FK/16) + q
+MP_KERNEL void mp_pack_foot_vf(const float* __restrict__ wih, const float* __restrict__ whh, float* __restrict__ dst, int FK) {
+    const int FNX = FK / 16, FNS = FNX + 4;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)8 * 4 * FNS * 2 * 64) return;
+    const int lane = idx & 63;
+    size_t rest = idx >> 6;
+    const int tile = rest & 1; rest >>= 1;
+    const int st = rest % FNS; rest /= FNS;
+    const int kq = rest & 3; rest >>= 2;
+    const int ug = (int)rest;
+    const int n = lane & 15, q = lane >> 4;
+    const int row = (2 * tile + (n >> 3)) * 64 + 8 * ug + (n & 7);
+    if (st < FNX) dst[idx] = wih[(size_t)row * FK + kq * (FK / 4) + (st >> 2) * 16 + q * 4 + (st & 3)];
+    else dst[idx] = whh[(size_t)row * 64 + kq * 16 + 4 * (st - FNX) + q];
+}
 
 template <int H, int NSLICE, int KIN, int TW>
 void launch_fused(const LstmPersistArgs& a, hipStream_t s) {
@@ -1009,7 +1178,19 @@ hipError_t mp_lstm_persist_device_attrs() {
     if (!e) e = fused_attrs<64, 4, 128, 1>();
     if (!e) e = hipFuncSetAttribute((const void*)mp_lstm_fused_uni2<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)kUni2Lds);
+    if (!e) e = vf_attrs<64>();
+    if (!e) e = vf_attrs<128>();
     return e;
+}
+
+void mp_launch_lstm_vf(const LstmPersistArgs& a, int fk, hipStream_t s) {
+    if (fk == 64) launch_vf<64>(a, s);
+    else launch_vf<128>(a, s);
+}
+size_t mp_foot_vf_floats(int fk) { return (size_t)8 * 4 * (fk / 16 + 4) * 2 * 64; }
+void mp_launch_pack_foot_vf(const float* wih, const float* whh, float* dst, int fk, hipStream_t s) {
+    const size_t n = mp_foot_vf_floats(fk);
+    hipLaunchKernelGGL(mp_pack_foot_vf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, wih, whh, dst, fk);
 }
 
 void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice, hipStream_t s) {

@@ -65,7 +65,7 @@ def main():
                     % (bench_line["roofline"]["kernel"], bench_line["roofline"]["avg_launch_ms"]))
         trace = glob.glob(os.path.join(d, "**", "bench_kernel_trace.csv"), recursive=True)
         if bench_line and trace:
-            want = bench_line["roofline"]["kernel"].split(" ")[0].replace(",", ", ").replace(">", ", false>")
+            want = bench_line["roofline"]["kernel"].split(" ")[0].replace(",", ", ").replace(">", ", false")
             dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(trace[0]))
                    if want in r["Kernel_Name"]]
             if dur:
