@@ -20,10 +20,10 @@ int mp_debug_poke_error(mp_handle* h, int code);
  * persistent-kernel launch: wait, sweep, mfma, reduce, cell+publish, steps. */
 int mp_debug_read_prof(mp_handle* h, long long* out, int n_words);
 
-/* Test hook: in each of the next `launches` fused-LSTM layer launches, workgroup `block` exits at once -- exactly what its
+/* Test hook: after `skip` further fused-LSTM layer launches, in each of the next `launches` ones, workgroup `block` exits at once -- exactly what its
  * cluster sees when a workgroup of the grid never becomes resident (a GPU shared with another process): the peers' waits
  * run into their time bound, poison the slab and raise the error word.  Deterministic stand-in for real starvation. */
-int mp_debug_drop_workgroup(mp_handle* h, int block, int launches);
+int mp_debug_drop_workgroup(mp_handle* h, int block, int skip, int launches);
 
 #ifdef __cplusplus
 }

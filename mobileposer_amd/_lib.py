@@ -60,7 +60,7 @@ SIGNATURES = {
     "mp_recovery_count": (_i, [_vp]),
     "mp_debug_poke_error": (_i, [_vp, _i]),
     "mp_debug_read_prof": (_i, [_vp, C.POINTER(C.c_longlong), _i]),
-    "mp_debug_drop_workgroup": (_i, [_vp, _i, _i]),
+    "mp_debug_drop_workgroup": (_i, [_vp, _i, _i, _i]),
 }
 
 _lib = None

@@ -215,7 +215,7 @@ struct mp_handle {
     OnlineState st_snap;             // recovery: per-stream solver state a streaming tick started from
     bool vf_ok = true;               // MP_VARIANT vf=0: the foot-contact layers always run as launches of their own
     const void* vf_foot = nullptr;   // forward_body -> rnn_rec: the foot-contact job that rides in this call's velocity launches
-    int dbg_drop_block = 0, dbg_drop_left = 0;   // mp_debug_drop_workgroup
+    int dbg_drop_block = 0, dbg_drop_left = 0, dbg_drop_skip = 0;   // mp_debug_drop_workgroup
     bool recovery = true;            // mp_set_recovery: calls wait for themselves and repair a starved run in LSTM mode 0
     int recoveries = 0;
     bool use_graph = false;          // opt-in (mp_set_graph_mode / MP_GRAPH=1): see the note at the top of this file
@@ -860,7 +860,8 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             static const int prof_mod = getenv("MP_PERSIST_PROF_MODULE") ? atoi(getenv("MP_PERSIST_PROF_MODULE")) : -1;
             a.prof = ((prof_layer < 0 || prof_layer == l) && (prof_mod < 0 || prof_mod == j.id)) ? h->prof_dev : nullptr;
             a.zero_state = j.mode == STATE_ZERO ? 1 : 0; a.force_remote = h->force_remote ? 1 : 0;
-            if (h->dbg_drop_left > 0) { a.debug_drop = h->dbg_drop_block + 1; --h->dbg_drop_left; }
+            if (h->dbg_drop_skip > 0) --h->dbg_drop_skip;
+            else if (h->dbg_drop_left > 0) { a.debug_drop = h->dbg_drop_block + 1; --h->dbg_drop_left; }
             const bool x3 = use_x3(h, m);
             a.epoch_base = epoch_base;
             a.min_lds = x3 ? 0 : h->excl_lds;
@@ -1924,9 +1925,10 @@ int mp_debug_poke_error(mp_handle* h, int code) {
     return MP_OK;
 }
 
-int mp_debug_drop_workgroup(mp_handle* h, int block, int launches) {
-    if (!h || block < 0 || launches < 0) return MP_ERR_INVALID;
+int mp_debug_drop_workgroup(mp_handle* h, int block, int skip, int launches) {
+    if (!h || block < 0 || skip < 0 || launches < 0) return MP_ERR_INVALID;
     h->dbg_drop_block = block;
+    h->dbg_drop_skip = skip;
     h->dbg_drop_left = launches;
     return MP_OK;
 }

@@ -180,6 +180,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
     const int jown = slice * U + ubo * 16 + r16;                           // hidden unit
     const f32x4 bias4 = *reinterpret_cast<const f32x4*>(d.bias + 4 * jown);
     float cst[NOWN], hst[NOWN];
+    float fcst = 0.f, fhst = 0.f;                                        // the rider's cell (FK)
     int blen[NOWN], bidx[NOWN];
     float* outb[NOWN];                                                   // &out[t = 0][sequence][jown]
     const unsigned out_row_bytes = (unsigned)a.B * (unsigned)d.outStride * 4u;   // one time step of the layer output
@@ -256,7 +257,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
         all_local = (same & ((1ull << NSLICE) - 1)) == ((1ull << NSLICE) - 1);
 #pragma unroll
         for (int i = 0; i < NPW; ++i) src_local[i] = (same >> (NPW * kq + i)) & 1;   // k-steps of part i come from slice NPW*kq+i
-        if (__ballot(peer == ~0u)) { spin_budget = 0; poison_cells(cst); }
+        if (__ballot(peer == ~0u)) { spin_budget = 0; poison_cells(cst); fcst = __builtin_nanf(""); }
         if (a.force_remote) {                               // test hook: exercise the any-placement transport
             all_local = false;
             same_xcd = 0;
@@ -300,7 +301,6 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
     const int fdir = slice >> 3, fug = slice & 7;
     float fw[FK ? FNS : 1][2];
     f32x4 fbias4 = f32x4{0.f, 0.f, 0.f, 0.f}, fxa[FNJ > 0 ? FNJ : 1], fhr = f32x4{0.f, 0.f, 0.f, 0.f};
-    float fcst = 0.f, fhst = 0.f;
     int flen = 0, frow = 0, funit = 0;
     unsigned fvoff = 0, fslot = 0;
     const float *fxp_cur = nullptr, *fxp_nxt = nullptr;
@@ -479,7 +479,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
                 while (!__all(ok)) {
                     if (wait_over(spins, spin_budget, wt0, a.max_ticks)) {               // bounded: flag the error and never wait again
                         if (lane == 0) mp_set_error(a.err, 1 + step);
-                        spin_budget = 0; poison_cells(cst);
+                        spin_budget = 0; poison_cells(cst); fcst = __builtin_nanf("");
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
@@ -565,7 +565,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
             }
             if (timed_out) {                                   // bounded: flag the error and never wait again
                 if (lane == 0) mp_set_error(a.err, 1 + step);
-                spin_budget = 0; poison_cells(cst);
+                spin_budget = 0; poison_cells(cst); fcst = __builtin_nanf("");
             }
             if (!DIRECT_GR) {
 #pragma unroll

@@ -35,9 +35,9 @@ def test_poked_error_is_reported_once_by_the_next_entry(torch_mod, weights, smpl
         m.finish()
 
 
-def _starve(m, launches=1):
-    """In the next fused-LSTM layer launch(es) workgroup 8 (slice 1 of a cluster) never shows up."""
-    assert m._lib.mp_debug_drop_workgroup(m._h, 8, launches) == 0
+def _starve(m, skip=0, launches=1):
+    """After `skip` fused-LSTM layer launches, workgroup 8 (slice 1 of a cluster) of the next one(s) never shows up."""
+    assert m._lib.mp_debug_drop_workgroup(m._h, 8, skip, launches) == 0
 
 
 @pytest.mark.parametrize("mode", [1, 3])
@@ -101,6 +101,41 @@ def test_starved_call_without_recovery_is_loud(torch_mod, weights, smpl, monkeyp
         again = m.forward_offline(x, [T] * B)
         m.finish()
         for a, b in zip(want, again):
+            assert float((a - b).abs().max()) < 2e-5
+
+
+def test_starved_velocity_launch_poisons_its_rider_too(torch_mod, weights, smpl, monkeypatch):
+    """B = 256, exact-fp32: the foot-contact layers ride in the velocity launches (the fifth and sixth fused launch of a
+    forward).  A workgroup missing there leaves NaN -- not plausible numbers -- in the slab's velocity AND contact rows, and
+    therefore in its translation; joints and pose (earlier launches) are untouched.  With recovery the call is repaired."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    monkeypatch.setenv("MP_WAIT_MS", "15")
+    B, T = 256, 20
+    x = cu(torch_mod, synthetic.make_imu(B, T, seed=79))
+    with MobilePoserNet.from_numpy(weights, smpl) as m:
+        m.set_recovery(False)
+        want = [t.clone() for t in m.forward_offline(x, [T] * B)]          # pose, joints, tran, contact
+        m.reset_all()
+        _starve(m, skip=4)                                                  # joints L0/L1, pose L0/L1, then velocity L0
+        got = [t.clone() for t in m.forward_offline(x, [T] * B)]
+        with pytest.raises(RuntimeError, match="gave up a wait"):
+            m.finish()
+        assert torch_mod.equal(got[0], want[0]) and torch_mod.equal(got[1], want[1])
+        bad_c = torch_mod.isnan(got[3]).flatten(1).any(dim=1)
+        bad_t = torch_mod.isnan(got[2]).flatten(1).any(dim=1)
+        assert bool(bad_c.any()) and bool(bad_t.any()), "the starved slab's contact and translation rows must be NaN"
+        ok = (~(bad_c | bad_t)).nonzero().flatten().tolist()
+        if ok:
+            assert float((got[3][ok] - want[3][ok]).abs().max()) < 1e-4 and float((got[2][ok] - want[2][ok]).abs().max()) < 1e-3
+        m.reset_all()
+        m.set_recovery(True)
+        _starve(m, skip=4)
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter("always")
+            rep = m.forward_offline(x, [T] * B)
+        assert m.recovery_count == 1
+        for a, b in zip(want, rep):
             assert float((a - b).abs().max()) < 2e-5
 
 
