@@ -358,8 +358,10 @@ int pack_weights(mp_handle* h, const float* blob) {
             pv.N = a.N + b.N; pv.K = a.K; pv.Kpad = a.Kpad; pv.bn = a.bn; pv.Npad = a.Npad + b.Npad;
             if (int rc = dev_alloc(h, (void**)&pv.Wp, (size_t)pv.Npad * pv.Kpad * sizeof(float))) return rc;
             if (int rc = dev_alloc(h, (void**)&pv.bias, (size_t)pv.Npad * sizeof(float))) return rc;
-            pv.W = pv.Wp;                                      // (split-bf16 GEMM only: there is no fp32 image of the stack)
             const size_t na = (size_t)a.Npad * a.Kpad, nb = (size_t)b.Npad * b.Kpad;
+            if (int rc = dev_alloc(h, (void**)&pv.W, (size_t)pv.Npad * pv.Kpad * sizeof(float))) return rc;   // the fp32 image of the stack
+            HIPCHK(h, hipMemcpyAsync(pv.W, a.W, na * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+            HIPCHK(h, hipMemcpyAsync(pv.W + na, b.W, nb * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
             HIPCHK(h, hipMemcpyAsync(pv.Wp, a.Wp, na * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
             HIPCHK(h, hipMemcpyAsync(pv.Wp + na, b.Wp, nb * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
             HIPCHK(h, hipMemcpyAsync(pv.bias, a.bias, (size_t)a.Npad * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
@@ -747,15 +749,16 @@ int rnn_g0(const RnnJob& j, hipStream_t s) {
     return MP_OK;
 }
 
-// linear1 of the pose and the velocity block in ONE split-bf16 GEMM (same rows cat(joints, imu); stacked weights): one launch
+// linear1 of the pose and the velocity block in ONE GEMM (same rows cat(joints, imu); stacked weights; either operand mode): one launch
 // instead of two on two streams, and no cross-stream edge into the velocity layers later.  Only what rnn_g0 does for
-// the persistent split-bf16 path with zero / in-place state; returns false when that does not apply.
+// the persistent path with zero / in-place state; returns false when that does not apply.
 bool rnn_g0_pose_velocity(const RnnJob& jp, const RnnJob& jv, hipStream_t s, int* rc) {
     mp_handle* h = jp.h;
     const ModuleW& mp = h->mod[jp.id];
     const ModuleW& mv = h->mod[jv.id];
     *rc = MP_OK;
-    if (!h->fuse_pv || !h->lin1_pv.Wp || !h->persist || !use_x3(h, mp) || !use_x3(h, mv)) return false;
+    if (!h->fuse_pv || !h->lin1_pv.Wp || !h->persist || use_x3(h, mp) != use_x3(h, mv) || h->uni2) return false;
+    const bool x3 = use_x3(h, mp);
     if (jp.mode != STATE_ZERO || !(jv.mode == STATE_ZERO || (jv.out_h == jv.in_h && jv.out_h))) return false;
     if (jp.a0.base != jv.a0.base || jp.a1.base != jv.a1.base) return false;
     ModuleWS& wp = jp.p->ws[jp.id];
@@ -764,12 +767,16 @@ bool rnn_g0_pose_velocity(const RnnJob& jp, const RnnJob& jv, hipStream_t s, int
     SegScope seg(h, s, 0, 1, 2.0 * M * (double)h->lin1_pv.N * h->lin1_pv.K);
     GemmArgs g;
     const Packed& w = h->lin1_pv;
-    g.a0 = jp.a0; g.a1 = jp.a1; g.W = w.Wp; g.bias = w.bias; g.C = x1_buffer(h, mp, wp); g.C2 = x1_buffer(h, mv, wv);
+    g.a0 = jp.a0; g.a1 = jp.a1; g.W = x3 ? w.Wp : w.W; g.bias = w.bias; g.C = x1_buffer(h, mp, wp); g.C2 = x1_buffer(h, mv, wv);
     g.nsplit = mp.lin1.Npad; g.cStrideB = H; g.cStrideT = (long)B * H;
-    g.M = M; g.N = w.N; g.K = w.K; g.Kpad = w.Kpad; g.B = B; g.relu = 1; g.pairOut = 1; g.aPairs = 0;
-    const int nslab = (B + 15) / 16;
-    g.zero_hx = wp.hx; g.zero_ncl = mp.dirs * nslab; g.zero_hx2 = wv.hx; g.zero_ncl2 = mv.dirs * nslab;
-    mp_launch_gemm_x3(g, w.bn, s);
+    g.M = M; g.N = w.N; g.K = w.K; g.Kpad = w.Kpad; g.B = B; g.relu = 1; g.pairOut = x3 ? 1 : 0; g.aPairs = 0;
+    if (x3) {
+        const int nslab = (B + 15) / 16;
+        g.zero_hx = wp.hx; g.zero_ncl = mp.dirs * nslab; g.zero_hx2 = wv.hx; g.zero_ncl2 = mv.dirs * nslab;
+        mp_launch_gemm_x3(g, w.bn, s);
+    } else {
+        mp_launch_gemm(g, w.bn, s);              // exact-fp32 operands: the same stacked launch (round 3)
+    }
     if (hipGetLastError() != hipSuccess) *rc = fail(h, MP_ERR_HIP, "fused linear1 launch failed");
     return true;
 }
@@ -1371,7 +1378,7 @@ void mp_destroy(mp_handle* h) {
     }
     void* misc[] = {h->parent_dev, h->depth_dev, h->bone_dev, h->vstate.h, h->vstate.c, h->sc.window, h->sc.fresh,
                     h->sc.mask_dev, h->sc.st.last_foot, h->sc.st.root_y, h->sc.st.root_pos, h->sc.joints, h->sc.vel,
-                    h->sc.contact, h->jrest_dev, h->vrest_dev, h->skinw_dev, h->lin1_pv.Wp, h->lin1_pv.bias, h->prof_dev,
+                    h->sc.contact, h->jrest_dev, h->vrest_dev, h->skinw_dev, h->lin1_pv.Wp, h->lin1_pv.W, h->lin1_pv.bias, h->prof_dev,
                     h->vtpl_dev, h->shapedirs_dev, h->jreg_dev, h->shape_ws,
                     h->vsnap.h, h->vsnap.c, h->st_snap.last_foot, h->st_snap.root_y, h->st_snap.root_pos, h->eval_ws};
     for (void* p : misc) if (p) (void)hipFree(p);

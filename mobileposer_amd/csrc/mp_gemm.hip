@@ -132,6 +132,9 @@ MP_KERNEL __launch_bounds__(256) void mp_gemm_f32(GemmArgs g, int nTilesM, int n
     }
 
     // epilogue: D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]; bias (+ReLU), row-mapped store
+    // (two stacked linear layers in one launch: output columns [nsplit, N) go to C2 as its columns [0, N - nsplit))
+    float* const Cb = (g.nsplit > 0 && n0 >= g.nsplit) ? g.C2 : g.C;       // uniform per block: BN divides nsplit
+    const int ncol0 = (g.nsplit > 0 && n0 >= g.nsplit) ? g.nsplit : 0;
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int n = n0 + (wn * TN + b) * 32 + li;
@@ -145,7 +148,7 @@ MP_KERNEL __launch_bounds__(256) void mp_gemm_f32(GemmArgs g, int nTilesM, int n
                 if (m0 + ml < g.M) {
                     float v = acc[a][b][r] + bias;
                     if (g.relu) v = fmaxf(v, 0.f);
-                    g.C[rowOffC[ml] + n] = g.pairOut ? __uint_as_float(pair_of(v)) : v;
+                    Cb[rowOffC[ml] + (n - ncol0)] = g.pairOut ? __uint_as_float(pair_of(v)) : v;
                 }
             }
         }
