@@ -15,6 +15,10 @@
 #include <cstdlib>
 #include <cstring>
 
+#ifndef MP_GEMM_EXP
+#define MP_GEMM_EXP 0      // timing experiments of tools/micro/gemm_bench.hip (1: no output stores, 2: no operand loads after the first k-tile)
+#endif
+
 namespace {
 
 constexpr int BK = 32;
@@ -104,7 +108,9 @@ MP_KERNEL __launch_bounds__(256) void mp_gemm_f32(GemmArgs g, int nTilesM, int n
     store_tile();
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
+#if MP_GEMM_EXP != 2
         if (kt + 1 < nk) load_tile((kt + 1) * BK);
+#endif
         f32x4 fa[TM][4], fb[TN][4];
 #pragma unroll
         for (int a = 0; a < TM; ++a)
@@ -148,6 +154,9 @@ MP_KERNEL __launch_bounds__(256) void mp_gemm_f32(GemmArgs g, int nTilesM, int n
                 if (m0 + ml < g.M) {
                     float v = acc[a][b][r] + bias;
                     if (g.relu) v = fmaxf(v, 0.f);
+#if MP_GEMM_EXP == 1
+                    if (v == 123456.f)
+#endif
                     Cb[rowOffC[ml] + (n - ncol0)] = g.pairOut ? __uint_as_float(pair_of(v)) : v;
                 }
             }
