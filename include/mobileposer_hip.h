@@ -17,7 +17,10 @@
  *   - `stream` is the caller's HIP stream (void* = hipStream_t; NULL = the legacy default
  *     stream).  Work is ordered after everything already enqueued on it and the caller's later
  *     work on that stream is ordered after the call's results (event fork/join onto the
- *     library's own streams); calls are asynchronous with respect to the host.
+ *     library's own streams).  Kinematics / solver / evaluator entry points are asynchronous with
+ *     respect to the host; the network entry points (mp_forward, mp_forward_offline,
+ *     mp_rnn_forward, mp_stream_step) wait for their own completion unless recovery is switched
+ *     off (mp_set_recovery, "error behaviour" below).
  */
 #ifndef MOBILEPOSER_HIP_H
 #define MOBILEPOSER_HIP_H
