@@ -599,7 +599,7 @@ def test_four_wave_fp32_kernel_matches_eight_wave(torch_mod, weights, smpl, monk
 
 def test_32_slice_fp32_kernel_matches_16_slice(torch_mod, weights, smpl, monkeypatch):
     """mp_lstm_u8 (B <= 32, joints block up to B = 64: 32 slices of 8 units per slab, MFMA tiles of 4 gates x 4 units, K reduction
-    and gate transpose in one LDS pass, one XCD per cluster) against the 16-slice kernels (MP_SLICES32=0): one sequence, partly
+    and gate transpose in one LDS pass, one XCD per cluster) against the 16-slice kernels (MP_VARIANT slices32=0): one sequence, partly
     filled and full slabs, ragged lengths, carried velocity state, a long sequence, both transports.  Another order of
     summation: equal to fp32 rounding."""
     from mobileposer_amd import synthetic

@@ -7,7 +7,7 @@ from mobileposer_amd.net import MobilePoserNet
 shapes = ((1, 3000), (1, 125), (16, 125), (64, 125), (128, 125), (256, 125))
 res = {}
 for wide in (0, 1):
-    os.environ["MP_WIDE"] = str(wide)
+    os.environ["MP_VARIANT"] = "wide=%d" % wide
     net = MobilePoserNet.from_numpy(synthetic.make_weights(0), synthetic.synthetic_smpl())
     for mode in (1, 3):
         net.set_lstm_mode(mode)

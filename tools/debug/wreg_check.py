@@ -6,7 +6,7 @@ from mobileposer_amd import synthetic
 from mobileposer_amd.net import MobilePoserNet
 
 def run(mask):
-    os.environ["MP_WREG"] = str(mask)
+    os.environ["MP_VARIANT"] = "wreg=%d" % mask
     net = MobilePoserNet.from_numpy(synthetic.make_weights(0), synthetic.synthetic_smpl())
     outs = {}
     rng = np.random.default_rng(5)
@@ -28,11 +28,11 @@ def run(mask):
     return outs, dt
 
 ref, t_ref = run(0)
-print("MP_WREG=0: %.3f ms per 256x125 forward_offline" % (t_ref * 1e3))
+print("wreg=0: %.3f ms per 256x125 forward_offline" % (t_ref * 1e3))
 for mask in (1, 2, 3, 0):
     got, t = run(mask)
     bad, mx = 0, 0.0
     for k in ref:
         for a, b in zip(ref[k], got[k]):
             if not torch.equal(a, b): bad += 1; mx = max(mx, float((a - b).abs().max()))
-    print("MP_WREG=%d: %.3f ms, %d differing tensors (max abs diff %.2e)" % (mask, t * 1e3, bad, mx))
+    print("wreg=%d: %.3f ms, %d differing tensors (max abs diff %.2e)" % (mask, t * 1e3, bad, mx))
