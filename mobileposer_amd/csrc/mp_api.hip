@@ -963,6 +963,14 @@ int run_rnn(const RnnJob& j, hipStream_t s) {
 
 int ensure_vstate(mp_handle* h, VelState& v, int B) {
     if (v.cap >= B) return MP_OK;
+    // captured graphs hold the old buffers' addresses in their kernel arguments; the new `h` buffer can land on the old one's
+    // address (the two freed blocks coalesce), which made a stale graph match its key again and write through the freed `c`
+    // pointer (found in round 3 by running the whole suite under MP_GRAPH=2): every graph goes when these buffers go
+    if (!h->graphs.empty()) {
+        HIPCHK(h, hipStreamSynchronize(h->s_main));
+        for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second.exec);
+        h->graphs.clear();
+    }
     if (v.h) (void)hipFree(v.h);
     if (v.c) (void)hipFree(v.c);
     v.h = v.c = nullptr; v.cap = 0;
@@ -1200,7 +1208,7 @@ constexpr size_t kMaxGraphs = 64;
 
 template <class Body>
 int run_maybe_graph(mp_handle* h, GraphKey key, Body body) {
-    if (!h->use_graph || h->timing) return body();
+    if (!h->use_graph || h->timing || h->dbg_drop_left > 0) return body();       // (the drop hook edits launch arguments: eager)
     key.flags |= h->graph_serial ? 16 : 0;
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {

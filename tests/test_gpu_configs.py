@@ -202,6 +202,23 @@ for mode in (1, 3):
     assert len(outs[0]) == len(outs[1])
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b), mode
+# a velocity state that has to grow in the middle (its re-allocation drops every captured graph), three passes
+shapes = ((256, 40), (40, 25), (300, 9), (17, 60))
+xs = {sh: torch.from_numpy(synthetic.make_imu(sh[0], sh[1], seed=sum(sh))).cuda() for sh in shapes}
+outs = {}
+for graph in (0, 1):
+    with MobilePoserNet.from_numpy(sd, smpl) as m:
+        m.set_graph_mode(graph)
+        o = []
+        for _ in range(3):
+            for sh in shapes:
+                m.reset_all()
+                for _call in range(2):
+                    o += [t.clone() for t in m.forward_offline(xs[sh], [sh[1]] * sh[0])]
+        assert m.device_error() == 0
+        outs[graph] = o
+for a, b in zip(outs[0], outs[1]):
+    assert torch.equal(a, b)
 print("GRAPH_OK")
 ''' % REPO
     env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
@@ -237,6 +254,32 @@ def test_single_branch_graph_equals_eager_at_baseline_sizes(torch_mod, weights, 
     assert len(outs[0]) == len(outs[2])
     for i, (a, b) in enumerate(zip(outs[0], outs[2])):
         assert torch_mod.equal(a, b), i
+
+
+def test_graphs_survive_a_growing_velocity_state(torch_mod, weights, smpl, gmode=2):
+    """Regression (round 3): the carried velocity state is re-allocated when a larger batch arrives; captured graphs hold the
+    old buffers' addresses, and the new buffer can land on the old address -- a stale graph then matched its key again and
+    wrote through a freed pointer (GPU memory fault).  All graphs go when those buffers go: shapes that force the
+    re-allocation in the middle, replayed over three passes, bitwise equal to eager (single-branch graphs here; the
+    multi-branch mode runs the same shapes in test_graph_replay_equals_eager_in_subprocess)."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    shapes = ((256, 40), (40, 25), (300, 9), (17, 60))
+    xs = {sh: cu(torch_mod, synthetic.make_imu(sh[0], sh[1], seed=sum(sh))) for sh in shapes}
+    outs = {}
+    for graph in (0, gmode):
+        with MobilePoserNet.from_numpy(weights, smpl) as m:
+            m.set_graph_mode(graph)
+            o = []
+            for _ in range(3):
+                for sh in shapes:
+                    m.reset_all()
+                    for _call in range(2):
+                        o += [t.clone() for t in m.forward_offline(xs[sh], [sh[1]] * sh[0])]
+            assert m.device_error() == 0
+            outs[graph] = o
+    for a, b in zip(outs[0], outs[gmode]):
+        assert torch_mod.equal(a, b)
 
 
 def test_live_frame_kernel_golden_and_host_version(torch_mod, weights, smpl):
