@@ -487,6 +487,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
             else if (key == "uni2") h->uni2 = v != 0;
             else if (key == "gemm_staged") {}                  // read by mp_launch_gemm
             else if (key == "vf") h->vf_ok = v != 0;
+            else if (key == "recovery") h->recovery = v != 0;   // (= mp_set_recovery)
             else { h->err = "MP_VARIANT: unknown key '" + key + "'"; return bail(MP_ERR_INVALID); }
         }
     }

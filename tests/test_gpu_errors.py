@@ -52,6 +52,7 @@ def test_starved_call_repairs_itself(torch_mod, weights, smpl, monkeypatch, mode
     x = cu(torch_mod, synthetic.make_imu(B, T, seed=77))
     with MobilePoserNet.from_numpy(weights, smpl) as m:
         m.set_lstm_mode(mode)
+        m.set_recovery(True)
         first = [t.clone() for t in m.forward_offline(x, [T] * B)]
         want = [t.clone() for t in m.forward_offline(x, [T] * B)]      # second call: velocity state carried
         assert m.recovery_count == 0
@@ -83,6 +84,7 @@ def test_starved_call_without_recovery_is_loud(torch_mod, weights, smpl, monkeyp
     B, T = 256, 24
     x = cu(torch_mod, synthetic.make_imu(B, T, seed=78))
     with MobilePoserNet.from_numpy(weights, smpl) as m:
+        m.set_lstm_mode(1)
         m.set_recovery(False)
         want = [t.clone() for t in m.forward_offline(x, [T] * B)]
         m.reset_all()
@@ -114,6 +116,7 @@ def test_starved_velocity_launch_poisons_its_rider_too(torch_mod, weights, smpl,
     B, T = 256, 20
     x = cu(torch_mod, synthetic.make_imu(B, T, seed=79))
     with MobilePoserNet.from_numpy(weights, smpl) as m:
+        m.set_lstm_mode(1)
         m.set_recovery(False)
         want = [t.clone() for t in m.forward_offline(x, [T] * B)]          # pose, joints, tran, contact
         m.reset_all()
