@@ -16,7 +16,8 @@
 #include <cstring>
 
 #ifndef MP_GEMM_EXP
-#define MP_GEMM_EXP 0      // timing experiments of tools/micro/gemm_bench.hip (1: no output stores, 2: no operand loads after the first k-tile)
+#define MP_GEMM_EXP 0      // timing experiments of tools/micro/gemm_bench.hip (1: no output stores, 2: no operand loads after the first k-tile,
+                           // 3: no barriers / LDS refills between k-tiles, 4: no MFMAs)
 #endif
 
 namespace {
@@ -128,13 +129,19 @@ MP_KERNEL __launch_bounds__(256) void mp_gemm_f32(GemmArgs g, int nTilesM, int n
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
+#if MP_GEMM_EXP == 4
+                    acc[a][b][s & 15] += fa[a][s >> 2][s & 3] * fb[b][s >> 2][s & 3];
+#else
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][s >> 2][s & 3], fb[b][s >> 2][s & 3],
                                                                      acc[a][b], 0, 0, 0);
+#endif
+#if MP_GEMM_EXP != 3
         __syncthreads();
         if (kt + 1 < nk) {
             store_tile();
             __syncthreads();
         }
+#endif
     }
 
     // epilogue: D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]; bias (+ReLU), row-mapped store
