@@ -116,7 +116,8 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
     using C = Cfg<H, NSLICE, KIN, TW>;
     constexpr bool WREG = H == 256 && NSLICE == 8 && TW == 1;
     constexpr int U = C::U, NUB = C::NUB, NWV = C::NWV, NTW = C::NTW, NTG = C::NTG, KW = C::KW, NKS = C::NKS, KQ = C::KQ;
-    constexpr int NXS = C::NXS, NXJ = C::NXJ, NOWN = C::NOWN, XL = C::XL, XR = C::XR, NPW = C::NPW;
+    // (FK: one workgroup per CU and 512 registers per lane to spend: the W_ih slice lives in registers, not in LDS)
+    constexpr int NXS = C::NXS, NXJ = C::NXJ, NOWN = C::NOWN, XL = FK ? 0 : C::XL, XR = NXS - XL, NPW = C::NPW;
     constexpr bool PER_UB = C::PER_UB;
     constexpr bool FLAGX = (WREG && (MP_FLAGX & 1)) || (H == 256 && NSLICE == 16 && TW == 1 && (MP_FLAGX & 2));   // flagged hand-off (below)
     constexpr int NP = NKS / 4 > 0 ? NKS / 4 : 1;                     // FLAGX: 16-byte pieces of h per lane (4 k-steps each)
