@@ -310,6 +310,31 @@ def main():
             g11[f"s{k}_{name}"] = v
     np.savez_compressed(os.path.join(HERE, "g11_evaluate.npz"), **g11)
 
+    # ---- G13 evaluate_pose with ONLINE=1 on the real network (evaluate.py:57-65,96-103) ---------------------------
+    # offline and online tables of the reference's own loop: forward_offline per sequence, then forward_online frame by
+    # frame over the sequence padded with num_future_frame copies of its last frame, the first 5 outputs dropped
+    rng = np.random.Generator(np.random.PCG64(13))
+    seqs13 = []
+    for k, n in enumerate((70, 45)):
+        pose_t = synthetic._random_rotations(rng, n * 24).reshape(n, 24, 3, 3).astype(np.float32)
+        tran_t = np.cumsum(rng.standard_normal((n, 3)) * 0.01, axis=0).astype(np.float32)
+        seqs13.append(dict(imu=synthetic.make_imu(1, n, seed=130 + k)[0], pose_t=pose_t, tran_t=tran_t))
+    dataset13 = [(torch.from_numpy(sq["imu"]), art.math.rotation_matrix_to_r6d(torch.from_numpy(sq["pose_t"])).reshape(-1, 144),
+                  torch.zeros(sq["imu"].shape[0], 24, 3), torch.from_numpy(sq["tran_t"])) for sq in seqs13]
+    tables13 = []
+    ref_eval.PoseEvaluator.print = staticmethod(lambda errors: tables13.append(errors.clone()))
+    os.environ["ONLINE"] = "1"
+    try:
+        ref_eval.evaluate_pose(new_model(), dataset13)
+    finally:
+        del os.environ["ONLINE"]
+    assert len(tables13) == 2
+    g13 = {"n_seq": np.int64(len(seqs13)), "offline": tables13[0].numpy(), "online": tables13[1].numpy()}
+    for k, sq in enumerate(seqs13):
+        for name, v in sq.items():
+            g13[f"s{k}_{name}"] = v
+    np.savez_compressed(os.path.join(HERE, "g13_evaluate_online.npz"), **g13)
+
     # ---- G12 forward kinematics with shape blending (articulate/model.py:84-89,208-240) -------------------------
     rng = np.random.Generator(np.random.PCG64(12))
     n12 = 9

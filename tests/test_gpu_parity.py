@@ -665,3 +665,20 @@ def test_epoch_tagged_exchange_equals_zeroed_exchange(torch_mod, weights, smpl, 
         assert len(ref) == len(outs[key])
         for a, b in zip(ref, outs[key]):
             assert torch_mod.equal(a, b), key
+
+
+def test_g13_evaluate_pose_online_branch_golden(torch_mod, net, monkeypatch):
+    """evaluate_pose with ONLINE=1 (evaluate.py:57-65,96-103) on the real network against the reference's own two tables
+    for the same sequences (golden G13): forward_offline per sequence, then forward_online frame by frame over the
+    sequence padded with five copies of its last frame; velocity state and foot positions carry over between sequences.
+    (The fixture's model has run nothing yet, like the reference's when it recorded the tables.)"""
+    from mobileposer_amd.data import rotation_matrix_to_r6d
+    from mobileposer_amd.evaluate import evaluate_pose
+    g = load_golden("g13_evaluate_online.npz")
+    ds = [(torch_mod.from_numpy(g[f"s{k}_imu"]), rotation_matrix_to_r6d(torch_mod.from_numpy(g[f"s{k}_pose_t"])).reshape(-1, 144),
+           None, torch_mod.from_numpy(g[f"s{k}_tran_t"])) for k in range(int(g["n_seq"]))]
+    monkeypatch.setenv("ONLINE", "1")
+    out = evaluate_pose(net, ds, verbose=False)
+    assert net.device_error() == 0
+    np.testing.assert_allclose(npy(out["offline"]), g["offline"], rtol=3e-4, atol=1e-4)
+    np.testing.assert_allclose(npy(out["online"]), g["online"], rtol=3e-4, atol=1e-4)

@@ -172,3 +172,29 @@ def test_g9_full_motion_evaluator(smpl):
     e = O.full_motion_evaluator(pp, pt, smpl, g["tran_p"], g["tran_t"])
     assert np.abs(e - g["errs"]).max() / np.abs(g["errs"]).max() < 1e-6
     np.testing.assert_allclose(e, g["errs"], rtol=2e-5)
+
+
+def test_g13_evaluate_pose_offline_and_online_tables(weights, smpl):
+    """evaluate.py:57-65,96-103 with ONLINE=1, restated with the oracle's network and evaluator, against the tables the
+    reference's own evaluate_pose printed for the same two sequences (golden G13): one model across both sequences (the
+    velocity LSTM state and the last foot positions survive reset()), the online feed padded with 5 copies of the last
+    frame and its first 5 outputs dropped."""
+    g = load_golden("g13_evaluate_online.npz")
+    net = O.OracleNet(weights, smpl["J"])
+    sel = lambda e: np.stack([e[9], e[3], e[9], e[0] * 100, e[7] * 100, e[1] * 100, e[4] / 100, e[6]])   # evaluate.py:29
+    off, on = [], []
+    for k in range(int(g["n_seq"])):
+        x, pose_t, tran_t = g[f"s{k}_imu"], g[f"s{k}_pose_t"].copy(), g[f"s{k}_tran_t"]
+        pose_t[:, O.IGNORED] = np.eye(3)
+        net.reset()
+        pose_p, _, tran_p, _ = net.forward_offline(x[None], [x.shape[0]])
+        pose_p = pose_p.reshape(-1, 24, 3, 3).copy()
+        pose_p[:, O.IGNORED] = np.eye(3)
+        off.append(sel(O.full_motion_evaluator(pose_p, pose_t, smpl, tran_p, tran_t)))
+        frames = [net.forward_online(f) for f in np.concatenate((x, np.repeat(x[-1:], 5, axis=0)))]
+        pose_o = np.stack([f[0] for f in frames])[5:].reshape(-1, 24, 3, 3).copy()
+        tran_o = np.stack([f[2] for f in frames])[5:]
+        pose_o[:, O.IGNORED] = np.eye(3)
+        on.append(sel(O.full_motion_evaluator(pose_o, pose_t, smpl, tran_o, tran_t)))
+    np.testing.assert_allclose(np.mean(off, axis=0), g["offline"], rtol=3e-4, atol=1e-4)
+    np.testing.assert_allclose(np.mean(on, axis=0), g["online"], rtol=3e-4, atol=1e-4)
