@@ -13,7 +13,9 @@
  *   - every function returns MP_OK (0) or a negative mp_status; mp_last_error() gives the text.
  *     No C++ exception crosses the ABI.
  *   - a handle is bound to one device, is NOT thread-safe, and owns its weights, workspaces,
- *     streams and the carried state (velocity LSTM state, streaming windows).
+ *     streams and the carried state (velocity LSTM state, streaming windows).  Every entry point
+ *     selects that device for the duration of the call and puts the calling thread's current
+ *     device back before it returns (mp_create* and mp_destroy included).
  *   - `stream` is the caller's HIP stream (void* = hipStream_t; NULL = the legacy default
  *     stream).  Work is ordered after everything already enqueued on it and the caller's later
  *     work on that stream is ordered after the call's results (event fork/join onto the

@@ -402,6 +402,22 @@ int setup_smpl(mp_handle* h, const int32_t parent[24], const float J[72]) {
     return MP_OK;
 }
 
+// The calling thread's current device is put back when an entry point returns: torch (and any other HIP user in the process)
+// reads hipGetDevice() as ITS current device, so a library call on a handle of another GPU must not move it.
+struct DeviceScope {
+    int prev = -1, dev;
+    bool ok = true;
+    explicit DeviceScope(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceScope() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+#define ON_DEVICE(h) DeviceScope dev_scope_((h)->device); \
+    if (!dev_scope_.ok) return fail((h), MP_ERR_HIP, "hipSetDevice(%d) failed", (h)->device)
+
 int create_common(mp_handle** out, int device, const float* blob, bool blob_on_device, size_t n_floats,
                   const int32_t parent[24], const float J[72]) {
     if (!out || !parent || !J) return fail(nullptr, MP_ERR_INVALID, "mp_create: NULL argument");
@@ -412,7 +428,8 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     h->device = device;
     h->has_weights = !body_only;
     auto bail = [&](int rc) { g_create_error = h->err; mp_destroy(h); return rc; };
-    if (hipSetDevice(device) != hipSuccess) { h->err = "hipSetDevice failed"; return bail(MP_ERR_HIP); }
+    DeviceScope on_device(device);                      // (the caller's current device is restored on every return path)
+    if (!on_device.ok) { h->err = "hipSetDevice failed"; return bail(MP_ERR_HIP); }
     if (const char* e = getenv("MP_GRAPH")) { h->use_graph = e[0] && e[0] != '0'; h->graph_serial = e[0] == '2'; }
     {   // dynamic-LDS limits of the persistent kernels are per-device attributes (and must not be set under capture)
         hipError_t ea = mp_lstm_persist_device_attrs();
@@ -1264,7 +1281,6 @@ int need_weights(mp_handle* h, const char* what) {
 
 int enter(mp_handle* h, void* stream) {
     if (int rc = pending_device_error(h, "mobileposer")) return rc;
-    HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipEventRecord(h->ev_in, (hipStream_t)stream));
     HIPCHK(h, hipStreamWaitEvent(h->s_main, h->ev_in, 0));
     return MP_OK;
@@ -1354,7 +1370,7 @@ int mp_create_body(mp_handle** out, int device, const int32_t parent[24], const 
 
 void mp_destroy(mp_handle* h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceScope on_device(h->device);
     (void)hipDeviceSynchronize();
     if (h->err_host && *(volatile int*)h->err_host)     // nobody asked (mp_finish / mp_device_error / a later call): say it
         fprintf(stderr, "libmobileposer_hip: mp_destroy: an unreported device error was pending (code %d): a persistent LSTM "
@@ -1419,6 +1435,7 @@ int mp_forward(mp_handle* h, const float* imu_dev, const int32_t* lengths_host, 
     if (h->vstate.B != 0 && h->vstate.B != B)
         return fail(h, MP_ERR_STATE_SHAPE, "carried velocity state has batch %d, call has batch %d (reset it first; "
                     "the reference raises here too, velocity.py:45-48)", h->vstate.B, B);
+    ON_DEVICE(h);
     if (int rc = enter(h, stream)) return rc;
     Plan* p = nullptr;
     if (int rc = get_plan(h, B, T, &p)) return rc;
@@ -1458,6 +1475,7 @@ int mp_forward_offline(mp_handle* h, const float* imu_dev, const int32_t* length
         return fail(h, MP_ERR_INVALID, "mp_forward_offline: NULL buffer or non-positive shape");
     if (h->vstate.B != 0 && h->vstate.B != B)
         return fail(h, MP_ERR_STATE_SHAPE, "carried velocity state has batch %d, call has batch %d", h->vstate.B, B);
+    ON_DEVICE(h);
     if (int rc = enter(h, stream)) return rc;
     Plan* p = nullptr;
     if (int rc = get_plan(h, B, T, &p)) return rc;
@@ -1496,6 +1514,7 @@ int mp_rnn_forward(mp_handle* h, int module, const float* x_dev, const int32_t* 
     if (int rc = need_weights(h, "mp_rnn_forward")) return rc;
     if (module < 0 || module > 3 || !x_dev || !y_dev || !lengths_host || B < 1 || T < 1)
         return fail(h, MP_ERR_INVALID, "mp_rnn_forward: bad argument");
+    ON_DEVICE(h);
     if (int rc = enter(h, stream)) return rc;
     Plan* p = nullptr;
     if (int rc = get_plan(h, B, T, &p)) return rc;
@@ -1515,6 +1534,7 @@ int mp_rnn_forward(mp_handle* h, int module, const float* x_dev, const int32_t* 
 
 int mp_reduced_global_to_full(mp_handle* h, const float* r6d_dev, int64_t N, float* pose_dev, void* stream) {
     if (!h || !r6d_dev || !pose_dev || N < 0) return h ? fail(h, MP_ERR_INVALID, "mp_reduced_global_to_full: bad argument") : MP_ERR_INVALID;
+    ON_DEVICE(h);
     if (int rc = enter(h, stream)) return rc;
     mp_launch_r6d_ik(r6d_dev, (long)N, pose_dev, h->parent_dev, h->s_main);
     HIPCHK(h, hipGetLastError());
@@ -1523,6 +1543,7 @@ int mp_reduced_global_to_full(mp_handle* h, const float* r6d_dev, int64_t N, flo
 
 int mp_r6d_to_rotation_matrix(mp_handle* h, const float* r6d_dev, int64_t n, float* rot_dev, void* stream) {
     if (!h || !r6d_dev || !rot_dev || n < 0) return h ? fail(h, MP_ERR_INVALID, "mp_r6d_to_rotation_matrix: bad argument") : MP_ERR_INVALID;
+    ON_DEVICE(h);
     if (int rc = enter(h, stream)) return rc;
     mp_launch_r6d_to_rot(r6d_dev, (long)n, rot_dev, h->s_main);
     HIPCHK(h, hipGetLastError());
@@ -1533,6 +1554,7 @@ int mp_translate_offline(mp_handle* h, const float* joints_dev, const float* vel
                          const int32_t* lengths_host, int B, int T, float* tran_dev, void* stream) {
     if (!h || !joints_dev || !vel_dev || !contact_dev || !lengths_host || !tran_dev || B < 1 || T < 1)
         return h ? fail(h, MP_ERR_INVALID, "mp_translate_offline: bad argument") : MP_ERR_INVALID;
+    ON_DEVICE(h);
     if (int rc = enter(h, stream)) return rc;
     Plan* p = nullptr;
     if (int rc = get_plan(h, B, T, &p)) return rc;
@@ -1545,6 +1567,7 @@ int mp_translate_offline(mp_handle* h, const float* joints_dev, const float* vel
 int mp_fk(mp_handle* h, const float* pose_dev, const float* tran_dev, int64_t N, float* rglobal_dev, float* joint_dev,
           void* stream) {
     if (!h || !pose_dev || !rglobal_dev || !joint_dev || N < 0) return h ? fail(h, MP_ERR_INVALID, "mp_fk: bad argument") : MP_ERR_INVALID;
+    ON_DEVICE(h);
     if (int rc = enter(h, stream)) return rc;
     mp_launch_fk(pose_dev, tran_dev, (long)N, h->bone_dev, h->parent_dev, h->depth_dev, rglobal_dev, joint_dev, h->s_main);
     HIPCHK(h, hipGetLastError());
@@ -1553,7 +1576,7 @@ int mp_fk(mp_handle* h, const float* pose_dev, const float* tran_dev, int64_t N,
 
 int mp_set_mesh(mp_handle* h, const float* v_template_host, const float* weights_host, int n_vertex) {
     if (!h || !v_template_host || !weights_host || n_vertex < 1) return h ? fail(h, MP_ERR_INVALID, "mp_set_mesh: bad argument") : MP_ERR_INVALID;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIPCHK(h, hipDeviceSynchronize());
     for (float** q : {&h->vrest_dev, &h->skinw_dev, &h->vtpl_dev, &h->shapedirs_dev, &h->jreg_dev}) {
         if (*q) (void)hipFree(*q);
@@ -1576,7 +1599,7 @@ int mp_set_mesh(mp_handle* h, const float* v_template_host, const float* weights
 int mp_set_shape_space(mp_handle* h, const float* shapedirs_host, const float* j_regressor_host) {
     if (!h || !shapedirs_host || !j_regressor_host) return h ? fail(h, MP_ERR_INVALID, "mp_set_shape_space: bad argument") : MP_ERR_INVALID;
     if (!h->n_vertex) return fail(h, MP_ERR_INVALID, "mp_set_shape_space before mp_set_mesh");
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIPCHK(h, hipDeviceSynchronize());
     for (float** q : {&h->shapedirs_dev, &h->jreg_dev}) { if (*q) (void)hipFree(*q); *q = nullptr; }
     const size_t V = (size_t)h->n_vertex;
@@ -1593,10 +1616,10 @@ int mp_fk_shape(mp_handle* h, const float* pose_dev, const float* shape_dev, int
         return h ? fail(h, MP_ERR_INVALID, "mp_fk_shape: bad argument (n_shape must be 1 or N)") : MP_ERR_INVALID;
     if (!h->shapedirs_dev) return fail(h, MP_ERR_INVALID, "mp_fk_shape before mp_set_shape_space");
     if (N == 0) return MP_OK;
+    ON_DEVICE(h);
     const size_t V = (size_t)h->n_vertex, ns = (size_t)n_shape;
     const size_t need = ns * (V * 3 + 3 * 72);
     if (need > h->shape_ws_floats) {
-        HIPCHK(h, hipSetDevice(h->device));
         HIPCHK(h, hipDeviceSynchronize());
         if (h->shape_ws) (void)hipFree(h->shape_ws);
         h->shape_ws = nullptr; h->shape_ws_floats = 0;
@@ -1627,6 +1650,7 @@ int mp_fk_mesh(mp_handle* h, const float* pose_dev, const float* tran_dev, int64
                float* vert_dev, void* stream) {
     if (!h || !pose_dev || !rglobal_dev || !joint_dev || !vert_dev || N < 0) return h ? fail(h, MP_ERR_INVALID, "mp_fk_mesh: bad argument") : MP_ERR_INVALID;
     if (!h->n_vertex) return fail(h, MP_ERR_INVALID, "mp_fk_mesh before mp_set_mesh");
+    ON_DEVICE(h);
     if (int rc = enter(h, stream)) return rc;
     mp_launch_fk(pose_dev, tran_dev, (long)N, h->bone_dev, h->parent_dev, h->depth_dev, rglobal_dev, joint_dev, h->s_main);
     for (int64_t n0 = 0; n0 < N; n0 += 32768) {                   // grid.y limit
@@ -1644,12 +1668,12 @@ int mp_eval_metrics(mp_handle* h, const float* pose_p_dev, const float* pose_t_d
     if (!h || !pose_p_dev || !pose_t_dev || !table_dev || N < 1 || fps < 1 || align_joint < 0 || align_joint > 23)
         return h ? fail(h, MP_ERR_INVALID, "mp_eval_metrics: bad argument") : MP_ERR_INVALID;
     if (use_mesh && !h->n_vertex) return fail(h, MP_ERR_INVALID, "mp_eval_metrics: use_mesh without mp_set_mesh");
+    ON_DEVICE(h);
     const size_t V = use_mesh ? (size_t)h->n_vertex : 0, n = (size_t)N;
     const size_t f_pose = n * 216, f_j = n * 72, f_v = n * V * 3;
     const size_t floats = 2 * (2 * f_pose + f_j + f_v);
     const size_t bytes = floats * sizeof(float) + mp_eval_partial_doubles((int)V) * sizeof(double) + 64;
     if (bytes > h->eval_ws_bytes) {
-        HIPCHK(h, hipSetDevice(h->device));
         HIPCHK(h, hipDeviceSynchronize());
         if (h->eval_ws) (void)hipFree(h->eval_ws);
         h->eval_ws = nullptr; h->eval_ws_bytes = 0;
@@ -1692,6 +1716,7 @@ int mp_reset_state(mp_handle* h, int clear_velocity) {
 
 int mp_get_velocity_state(mp_handle* h, float* state_dev, int* batch) {
     if (!h || !batch) return MP_ERR_INVALID;
+    ON_DEVICE(h);
     *batch = h->vstate.B;
     if (h->vstate.B && state_dev) {
         const size_t n = (size_t)2 * h->vstate.B * 256;
@@ -1704,6 +1729,7 @@ int mp_get_velocity_state(mp_handle* h, float* state_dev, int* batch) {
 
 int mp_set_velocity_state(mp_handle* h, const float* state_dev, int batch) {
     if (!h || batch < 0 || (batch > 0 && !state_dev)) return MP_ERR_INVALID;
+    ON_DEVICE(h);
     if (batch == 0) { h->vstate.B = 0; return MP_OK; }
     HIPCHK(h, hipStreamSynchronize(h->s_main));
     if (int rc = ensure_vstate(h, h->vstate, batch)) return rc;
@@ -1718,7 +1744,7 @@ int mp_set_velocity_state(mp_handle* h, const float* state_dev, int batch) {
 int mp_stream_create(mp_handle* h, int S) {
     if (!h || S < 1) return h ? fail(h, MP_ERR_INVALID, "mp_stream_create: S must be positive") : MP_ERR_INVALID;
     if (int rc = need_weights(h, "mp_stream_create")) return rc;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     StreamCtx& c = h->sc;
     if (c.S) return fail(h, MP_ERR_INVALID, "streams already created (S = %d)", c.S);
     const int W = 45;
@@ -1759,6 +1785,7 @@ int mp_stream_step(mp_handle* h, const float* frames_dev, float* pose_dev, float
     // one velocity.rnn_state per model, shared by the batch and the online path (velocity.py:30)
     if (h->vstate.B != 0 && h->vstate.B != S)
         return fail(h, MP_ERR_STATE_SHAPE, "carried velocity state has batch %d, streaming has %d streams", h->vstate.B, S);
+    ON_DEVICE(h);
     if (int rc = enter(h, stream)) return rc;
     if (int rc = ensure_vstate(h, h->vstate, S)) return rc;
     Plan* p = nullptr;
@@ -1815,7 +1842,7 @@ int mp_stream_reset(mp_handle* h, const uint8_t* mask_host, int clear_velocity) 
     if (!h) return MP_ERR_INVALID;
     StreamCtx& c = h->sc;
     if (!c.S) return fail(h, MP_ERR_NO_STREAMS, "mp_stream_reset before mp_stream_create");
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIPCHK(h, hipStreamSynchronize(h->s_main));
     if (mask_host) HIPCHK(h, hipMemcpy(c.mask_dev, mask_host, c.S, hipMemcpyHostToDevice));
     const bool vel = clear_velocity && h->vstate.B == c.S;
@@ -1831,6 +1858,7 @@ int mp_live_form_frames(mp_handle* h, const float* quat_dev, const float* acc_de
                         float* frames_dev, void* stream) {
     if (!h || !quat_dev || !acc_dev || !smpl2imu_dev || !device2bone_dev || !acc_offsets_dev || !frames_dev || S < 1)
         return h ? fail(h, MP_ERR_INVALID, "mp_live_form_frames: bad argument") : MP_ERR_INVALID;
+    ON_DEVICE(h);
     if (int rc = enter(h, stream)) return rc;
     mp_launch_live_frames(quat_dev, acc_dev, smpl2imu_dev, device2bone_dev, acc_offsets_dev, keep_mask, 30.0f /* config.py:74 */,
                           S, frames_dev, h->s_main);
@@ -1844,7 +1872,7 @@ int mp_stream_get_state(mp_handle* h, int s, float* window_dev, float last_foot_
     StreamCtx& c = h->sc;
     if (!c.S) return fail(h, MP_ERR_NO_STREAMS, "mp_stream_get_state before mp_stream_create");
     if (s < 0 || s >= c.S) return fail(h, MP_ERR_INVALID, "mp_stream_get_state: stream %d outside 0..%d", s, c.S - 1);
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIPCHK(h, hipStreamSynchronize(h->s_main));
     if (window_dev)
         HIPCHK(h, hipMemcpy(window_dev, c.window + (size_t)s * 45 * 60, (size_t)45 * 60 * sizeof(float), hipMemcpyDeviceToDevice));
@@ -1865,7 +1893,7 @@ int mp_stream_set_state(mp_handle* h, int s, const float* window_dev, const floa
     StreamCtx& c = h->sc;
     if (!c.S) return fail(h, MP_ERR_NO_STREAMS, "mp_stream_set_state before mp_stream_create");
     if (s < 0 || s >= c.S) return fail(h, MP_ERR_INVALID, "mp_stream_set_state: stream %d outside 0..%d", s, c.S - 1);
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIPCHK(h, hipStreamSynchronize(h->s_main));
     if (window_dev)
         HIPCHK(h, hipMemcpy(c.window + (size_t)s * 45 * 60, window_dev, (size_t)45 * 60 * sizeof(float), hipMemcpyDeviceToDevice));
@@ -1882,6 +1910,7 @@ int mp_stream_set_state(mp_handle* h, int s, const float* window_dev, const floa
 // ------------------------------------------------------------------------------------------ measurement
 int mp_timing_enable(mp_handle* h, int on) {
     if (!h) return MP_ERR_INVALID;
+    ON_DEVICE(h);
     h->timing = on != 0;
     h->segs.clear(); h->ev_used = 0;
     return MP_OK;
@@ -1889,6 +1918,7 @@ int mp_timing_enable(mp_handle* h, int on) {
 
 int mp_timing_read(mp_handle* h, int cls, int* launches, float* ms, double* gflop) {
     if (!h || !launches || !ms) return MP_ERR_INVALID;
+    ON_DEVICE(h);
     HIPCHK(h, hipDeviceSynchronize());
     *launches = 0; *ms = 0.f;
     double fl = 0.0;
@@ -1906,7 +1936,7 @@ int mp_timing_read(mp_handle* h, int cls, int* launches, float* ms, double* gflo
 
 int mp_device_error(mp_handle* h, int* code) {
     if (!h || !code) return MP_ERR_INVALID;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIPCHK(h, hipStreamSynchronize(h->s_main));
     *code = *(volatile int*)h->err_host;
     *(volatile int*)h->err_host = 0;
@@ -1915,7 +1945,7 @@ int mp_device_error(mp_handle* h, int* code) {
 
 int mp_finish(mp_handle* h) {
     if (!h) return MP_ERR_INVALID;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     HIPCHK(h, hipStreamSynchronize(h->s_main));
     return pending_device_error(h, "mp_finish");
 }
@@ -1934,7 +1964,7 @@ MP_KERNEL void mp_poke_error(int* err, int code) { mp_set_error(err, code); }
 
 int mp_debug_poke_error(mp_handle* h, int code) {
     if (!h) return MP_ERR_INVALID;
-    HIPCHK(h, hipSetDevice(h->device));
+    ON_DEVICE(h);
     hipLaunchKernelGGL(mp_poke_error, dim3(1), dim3(1), 0, h->s_main, h->err_dev, code);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->s_main));
@@ -1951,6 +1981,7 @@ int mp_debug_drop_workgroup(mp_handle* h, int block, int skip, int launches) {
 
 int mp_debug_read_prof(mp_handle* h, long long* out, int n_words) {
     if (!h || !out || !h->prof_dev || n_words > (int)kProfWords) return MP_ERR_INVALID;
+    ON_DEVICE(h);
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipMemcpy(out, h->prof_dev, (size_t)n_words * sizeof(long long), hipMemcpyDeviceToHost));
     return MP_OK;
@@ -1958,6 +1989,7 @@ int mp_debug_read_prof(mp_handle* h, long long* out, int n_words) {
 
 int mp_set_lstm_mode(mp_handle* h, int mode) {
     if (!h || mode < 0 || mode > 3) return MP_ERR_INVALID;
+    ON_DEVICE(h);
     HIPCHK(h, hipDeviceSynchronize());
     h->persist = mode != 0;
     h->uni2 = mode == 2;
@@ -1967,6 +1999,7 @@ int mp_set_lstm_mode(mp_handle* h, int mode) {
 
 int mp_set_transport(mp_handle* h, int force_remote) {
     if (!h) return MP_ERR_INVALID;
+    ON_DEVICE(h);
     HIPCHK(h, hipDeviceSynchronize());
     h->force_remote = force_remote != 0;
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second.exec);   // captured launches carry the old setting
@@ -1976,6 +2009,7 @@ int mp_set_transport(mp_handle* h, int force_remote) {
 
 int mp_set_graph_mode(mp_handle* h, int on) {
     if (!h || on < 0 || on > 2) return MP_ERR_INVALID;
+    ON_DEVICE(h);
     h->use_graph = on != 0;
     h->graph_serial = on == 2;
     return MP_OK;

@@ -144,3 +144,30 @@ def test_g12_forward_kinematics_with_shape(torch_mod, net):
     with pytest.raises(RuntimeError):
         net.forward_kinematics(pose, shape=torch_mod.zeros(3, 10))
     assert net.device_error() == 0
+
+
+def test_library_calls_leave_the_current_device_alone(torch_mod, weights, smpl):
+    """Every entry point selects its handle's GPU for the duration of the call and puts the caller's current device back
+    (torch reads hipGetDevice() as its own current device).  With one GPU this pins that calls -- including create /
+    destroy, the state setters and the mode switches, which touch HIP outside enter() -- do not move it; with two or more
+    GPUs the handle lives on the LAST one while device 0 stays current, and the G4 golden must still come out of it."""
+    from mobileposer_amd.net import MobilePoserNet
+    torch = torch_mod
+    n_dev = torch.cuda.device_count()
+    dev = "cuda:%d" % (n_dev - 1)
+    torch.cuda.set_device(0)
+    g = load_golden("g4_offline.npz")
+    with MobilePoserNet.from_numpy(weights, smpl, device=dev) as n:
+        assert torch.cuda.current_device() == 0
+        n.reset()
+        pose, joints, tran, contact = n.forward_offline(torch.from_numpy(g["imu_a"]).to(dev), [g["imu_a"].shape[1]])
+        assert torch.cuda.current_device() == 0 and pose.device == torch.device(dev)
+        assert np.abs(npy(tran) - g["a_tran"]).max() < 1e-3
+        assert np.abs(npy(joints) - g["a_joints"]).max() < 1e-4
+        n.velocity.rnn_state = n.velocity.rnn_state                  # mp_get / mp_set_velocity_state
+        n.set_lstm_mode(0); n.set_lstm_mode(1); n.set_graph_mode(0)
+        Rg, jg = n.forward_kinematics(pose)
+        assert jg.device == torch.device(dev) and n.device_error() == 0
+        n.finish()
+        assert torch.cuda.current_device() == 0
+    assert torch.cuda.current_device() == 0
