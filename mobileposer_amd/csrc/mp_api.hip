@@ -214,6 +214,7 @@ struct mp_handle {
     StreamCtx sc;
     OnlineState st_snap;             // recovery: per-stream solver state a streaming tick started from
     bool vf_ok = true;               // MP_VARIANT vf=0: the foot-contact layers always run as launches of their own
+    bool late_pair_ok = true;        // MP_VARIANT late_pair=0: no schedule 4 (pose layer 0 alone, then pose layer 1 beside velocity + rider) for 64 < B <= 128
     const void* vf_foot = nullptr;   // forward_body -> rnn_rec: the foot-contact job that rides in this call's velocity launches
     int dbg_drop_block = 0, dbg_drop_left = 0, dbg_drop_skip = 0;   // mp_debug_drop_workgroup
     bool recovery = true;            // mp_set_recovery: calls wait for themselves and repair a starved run in LSTM mode 0
@@ -478,6 +479,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     //   epoch_tags=0   zero the exchange area before every fp32 layer launch;  epoch_start=N: first epoch base (wrap tests)
     //   uni2=1         velocity block as one two-layer wavefront launch (= mp_set_lstm_mode(h, 2))
     //   vf=0           foot-contact layers as launches of their own beside velocity (B > 128), not as riders in its workgroups
+    //   late_pair=0    64 < B <= 128: both pose layers on 8 slices beside velocity (schedules 2 / 3) instead of schedule 4
     if (const char* e = getenv("MP_VARIANT")) {
         std::string all(e);
         size_t pos = 0;
@@ -504,6 +506,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
             else if (key == "uni2") h->uni2 = v != 0;
             else if (key == "gemm_staged") {}                  // read by mp_launch_gemm
             else if (key == "vf") h->vf_ok = v != 0;
+            else if (key == "late_pair") h->late_pair_ok = v != 0;
             else if (key == "recovery") h->recovery = v != 0;   // (= mp_set_recovery)
             else { h->err = "MP_VARIANT: unknown key '" + key + "'"; return bail(MP_ERR_INVALID); }
         }
@@ -1026,8 +1029,9 @@ bool place_clusters(const mp_handle* h, const XcdJob* jobs, int njobs, int load[
 }
 
 // Which side-by-side schedule (forward_body) fits batch B: 0 = none, 1 = pose / velocity / foot contact at once, 2 = the same
-// with the pose layers on 8 slices per slab, 3 = pose (8 slices) beside velocity, foot contact after velocity.  Fills the
-// per-XCD cluster tables of the three blocks (h->xcd_plan).
+// with the pose layers on 8 slices per slab, 3 = pose (8 slices) beside velocity, foot contact after velocity, 4 = pose layer 0
+// on 16 slices with the chip to itself, then pose layer 1 on 8 slices beside the velocity layers that carry the foot-contact
+// layers as riders.  Fills the per-XCD cluster tables of the three blocks (h->xcd_plan).
 int side_by_side_plan(mp_handle* h, int B) {
     if (h->uni2 || !h->wide_ok) return 0;
     const ModuleW& pm = h->mod[MP_MOD_POSE];
@@ -1048,6 +1052,11 @@ int side_by_side_plan(mp_handle* h, int B) {
     if (place_clusters(h, all, 3, load, h->xcd_plan)) return 1;
     if (!h->half_ok || !pm.whhPW[0][0] || (h->wreg_mask & 3) != 3 || pslices != 16) return 0;
     all[0].wgs = pm.nslice;                   // pose on 8 slices per slab (four-wave kernels)
+    for (int x = 0; x < 8; ++x) load[x] = 0;
+    // schedule 4 wherever it applies (every B that does not fit schedule 1): its two halves take 797 and 2 x 404 us, after 396 us
+    // of layer 0 -- against a 560 + 797 us pose chain in schedules 2 and 3
+    if (h->late_pair_ok && h->vf_ok && vm.nslice == 16 && vslices == 16 && fm.wVF[0][0] && place_clusters(h, all, 2, load, h->xcd_plan))
+        return 4;
     for (int x = 0; x < 8; ++x) load[x] = 0;
     if (place_clusters(h, all, 3, load, h->xcd_plan)) return 2;
     for (int x = 0; x < 8; ++x) load[x] = 0;
@@ -1110,6 +1119,41 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         //           slab and direction instead of 32): a longer pose chain (1.38 instead of 0.85 ms), but nothing after it;
         //   side 3 (B <= 128, fp32): pose on 8 slices beside velocity; foot contact follows velocity on the CUs it vacates.
         HIPCHK(h, hipStreamWaitEvent(sv, h->ev_j, 0));
+        if (side == 4) {
+            //   side 4 (64 < B <= 128, fp32): pose layer 0 on 16 slices with the chip to itself (as the joints layers), then pose
+            //           layer 1 on 8 slices (the four-wave kernel: half of the CUs) on s_main beside velocity layer 0 -> 1 on s_vel,
+            //           the foot-contact layers riding in the velocity workgroups ("VF"); every cluster placed by the tables
+            auto rec = [&](int i, hipStream_t on) -> int { HIPCHK(h, hipEventRecord(h->ev_x[i], on)); return MP_OK; };
+            auto wait = [&](int i, hipStream_t on) -> int { HIPCHK(h, hipStreamWaitEvent(on, h->ev_x[i], 0)); return MP_OK; };
+            RC(rnn_g0(F, sf)); RC(rec(4, sf));                                            // linear1 of foot contact
+            int rc_pv = MP_OK;
+            if (!rnn_g0_pose_velocity(P, V, sm, &rc_pv)) { RC(rnn_g0(V, sm)); RC(rnn_g0(P, sm)); }
+            RC(rc_pv);
+            RC(rnn_rec(P, 0, sm));                                                        // 16 slices, every CU
+            RC(rec(1, sm));
+            RC(wait(1, sv)); RC(wait(4, sv));                                             // (the velocity grid must not start under it)
+            h->excl_lds = kExclusiveLdsBytes;
+            h->pose_slices8 = true;
+            h->xcd_plan_on[MP_MOD_POSE] = h->xcd_plan_on[MP_MOD_VELOCITY] = true;
+            h->vf_foot = &F;
+            int rc_w = rnn_rec(V, 0, sv);                                                 // net.py:113-117
+            if (!rc_w) rc_w = rnn_rec(P, 1, sm);                                          // net.py:106-107
+            if (!rc_w) rc_w = rnn_rec(V, 1, sv);
+            h->excl_lds = 0;
+            h->pose_slices8 = false;
+            h->xcd_plan_on[MP_MOD_POSE] = h->xcd_plan_on[MP_MOD_VELOCITY] = false;
+            h->vf_foot = nullptr;
+            RC(rc_w);
+            RC(rec(5, sv)); RC(wait(5, sf));
+            RC(rnn_g2(F, sf));                                                            // net.py:113-114
+            HIPCHK(h, hipEventRecord(h->ev_f, sf));
+            RC(rnn_g2(V, sv));                                                            // net.py:117
+            HIPCHK(h, hipEventRecord(h->ev_v, sv));
+            RC(rnn_g2(P, sm));
+            { SegScope seg(h, sm, 2, 1);
+              mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sm); }   // net.py:110
+            if (fk_rglobal) mp_launch_fk(pose, nullptr, poseRows, h->bone_dev, h->parent_dev, h->depth_dev, fk_rglobal, fk_joint, sm);
+        } else {
         h->excl_lds = h->exclusive_ok ? kExclusiveLdsBytes : 0;
         h->pose_slices8 = side >= 2;
         const bool tables = h->exclusive_ok && h->xcd_rr && !use_x3(h, h->mod[MP_MOD_POSE]) && !use_x3(h, h->mod[MP_MOD_VELOCITY]);
@@ -1143,6 +1187,7 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         { SegScope seg(h, sm, 2, 1);
           mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sm); }   // net.py:110
         if (fk_rglobal) mp_launch_fk(pose, nullptr, poseRows, h->bone_dev, h->parent_dev, h->depth_dev, fk_rglobal, fk_joint, sm);
+        }
     } else {
         auto rec = [&](int i, hipStream_t on) -> int { HIPCHK(h, hipEventRecord(h->ev_x[i], on)); return MP_OK; };
         auto wait = [&](int i, hipStream_t on) -> int { HIPCHK(h, hipStreamWaitEvent(on, h->ev_x[i], 0)); return MP_OK; };

@@ -228,3 +228,48 @@ def test_two_handles_two_threads_overlapping_full_chip_calls(torch_mod, weights,
     finally:
         for n in nets:
             n.close()
+
+
+@pytest.mark.parametrize("skip,what", [(3, "velocity layer 0 + rider"), (4, "pose layer 1")])
+def test_starved_launch_in_the_half_chip_schedule(torch_mod, weights, smpl, monkeypatch, skip, what):
+    """B = 128, exact-fp32 (schedule 4 of DESIGN.md section 4): fused launches are issued in the order joints L0, joints L1,
+    pose L0, velocity L0 (with the foot-contact rider), pose L1, velocity L1 -- pose L1 and the velocity layers run side by side
+    on disjoint halves of the chip.  A workgroup missing from one of the two concurrent grids: without recovery NaN in what
+    that grid feeds (and only there), finish() raises; with recovery the call is repaired; the other grid is not disturbed."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    monkeypatch.setenv("MP_WAIT_MS", "15")
+    B, T = 128, 20
+    x = cu(torch_mod, synthetic.make_imu(B, T, seed=81))
+    with MobilePoserNet.from_numpy(weights, smpl) as m:
+        m.set_lstm_mode(1)
+        m.set_recovery(False)
+        want = [t.clone() for t in m.forward_offline(x, [T] * B)]          # pose, joints, tran, contact
+        m.reset_all()
+        _starve(m, skip=skip)
+        got = [t.clone() for t in m.forward_offline(x, [T] * B)]
+        with pytest.raises(RuntimeError, match="gave up a wait"):
+            m.finish()
+        assert torch_mod.equal(got[1], want[1]), "joints ran before the starved launch"
+        nan = [bool(torch_mod.isnan(t).any()) for t in got]
+        if skip == 3:                                                       # velocity + rider: translation and contact
+            assert nan[2] and nan[3] and not nan[0], nan
+            assert torch_mod.equal(got[0], want[0]), "pose layer 1 ran beside the starved grid and must not notice"
+        else:                                                               # pose layer 1: poses (and nothing else)
+            # the poisoned r6d rows reach _reduced_global_to_full, whose own rule turns NaN into 0 (net.py:110, quirk Q8):
+            # the starved slab's poses are all-zero matrices -- no rotation, never a plausible pose
+            assert not nan[2] and not nan[3], nan
+            assert torch_mod.equal(got[3], want[3]) and torch_mod.equal(got[2], want[2])
+            p_got, p_want = got[0].reshape(-1, 24, 3, 3), want[0].reshape(-1, 24, 3, 3)
+            bad = (p_got != p_want).flatten(1).any(dim=1)                    # frames of the starved slab
+            assert bool(bad.any()) and int(bad.sum()) <= 16 * T, int(bad.sum())
+            assert float(p_got[bad][:, 0].abs().max()) == 0.0               # (the root of every such frame: the zero matrix)
+        m.reset_all()
+        m.set_recovery(True)
+        _starve(m, skip=skip)
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter("always")
+            rep = m.forward_offline(x, [T] * B)
+        assert m.recovery_count == 1, what
+        for a, b in zip(want, rep):
+            assert bool(torch_mod.isfinite(b).all()) and float((a - b).abs().max()) < 2e-5

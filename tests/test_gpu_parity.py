@@ -143,6 +143,30 @@ def test_forward_vs_oracle_medium(torch_mod, net, weights, smpl):
     assert geodesic(npy(pose), rpose).max() < TOL
 
 
+@pytest.mark.parametrize("B,T", [(72, 40), (128, 33)])
+def test_half_chip_batches_vs_oracle(torch_mod, net, weights, smpl, B, T):
+    """64 < B <= 128 (on the exact-fp32 path: pose layer 0 on 16 slices, then pose layer 1 on 8 slices beside the velocity
+    layers that carry the foot-contact layers -- DESIGN.md section 4's schedule table), ragged, two calls so that the second one
+    starts from a carried velocity state, against the oracle: network outputs, poses and translation of every sequence."""
+    from mobileposer_amd import synthetic
+    from oracle import mp_oracle as O
+    imu = synthetic.make_imu(B, T, seed=B + T)
+    lengths = [T - (7 * b) % (T - 1) for b in range(B)]
+    lengths[0] = T
+    ref = O.OracleNet(weights, smpl["J"])
+    for call in range(2):
+        pose, joints, vel, contact, r6d = net.forward(cu(torch_mod, imu), lengths, return_r6d=True)
+        rpose, rjoints, rvel, rcontact = ref.forward(imu, lengths)
+        for b in range(B):                                     # (rows past a sequence's length are padding on both sides)
+            n = lengths[b]
+            assert np.abs(npy(joints)[b, :n] - rjoints[b, :n]).max() < TOL, (call, b)
+            assert np.abs(npy(vel)[b, :n] - rvel[b, :n]).max() < TOL, (call, b)
+            assert np.abs(npy(contact)[b, :n] - rcontact[b, :n]).max() < TOL, (call, b)
+            assert np.abs(npy(r6d)[b, :n] - ref._last_r6d[b, :n]).max() < TOL, (call, b)
+        assert geodesic(npy(pose), rpose).max() < TOL, call
+    assert net.device_error() == 0 and net.recovery_count == 0
+
+
 def test_full_size_vs_oracle_and_properties(torch_mod, net, weights, smpl):
     """BASELINE config: 256 x 125.  Oracle comparison on the whole batch (network outputs, all 256 translation rows, FK of
     all 32 000 frames) plus size-independent properties: batch-permutation equivariance (sequences are independent),
@@ -506,18 +530,21 @@ def test_small_batch_schedules_agree(torch_mod, weights, smpl, monkeypatch):
 
 
 def test_half_chip_schedules_agree(torch_mod, weights, smpl, monkeypatch):
-    """64 < B <= 128, exact-fp32 operands: the pose layers run on 8 slices per slab (half the chip) beside velocity (and foot
-    contact, B <= 96; after velocity otherwise), every cluster on an XCD chosen by the host (MP_VARIANT half, default on).  Same
-    values as the serial schedule to fp32 noise (pose on 8 instead of 16 slices: another summation order in the cell
-    update); joints / velocity / foot contact use the same kernels in both and must agree bitwise."""
+    """64 < B <= 128, exact-fp32 operands.  Default (schedule 4, MP_VARIANT late_pair): pose layer 0 on 16 slices with the chip
+    to itself, then pose layer 1 on 8 slices (half the chip) beside the velocity layers, the foot-contact layers riding in the
+    velocity workgroups.  late_pair=0 (schedules 2 / 3, MP_VARIANT half): both pose layers on 8 slices beside velocity (and foot
+    contact, B <= 96; after velocity otherwise).  Every cluster on an XCD chosen by the host.  half=0: the serial schedule.
+    Same values to fp32 noise (8 against 16 slices, rider against stand-alone foot-contact kernel: other summation orders);
+    where two schedules use the same kernels -- joints always; velocity / foot contact of schedules 2 / 3 and the serial one --
+    the outputs must agree bitwise."""
     from mobileposer_amd import synthetic
     from mobileposer_amd.net import MobilePoserNet
     outs = {}
-    for half in (1, 0):
-        monkeypatch.setenv("MP_VARIANT", "half=%d" % half)
+    for variant in ("late_pair=1", "late_pair=0", "half=0"):
+        monkeypatch.setenv("MP_VARIANT", variant)
         with MobilePoserNet.from_numpy(weights, smpl) as n:
             o = []
-            for B, T in ((80, 24), (96, 20), (128, 16), (100, 30)):
+            for B, T in ((80, 24), (96, 20), (128, 16), (100, 30), (65, 40)):
                 x = cu(torch_mod, synthetic.make_imu(B, T, seed=B))
                 L = [T] * B
                 L[B // 2] = max(1, T // 3)
@@ -525,13 +552,17 @@ def test_half_chip_schedules_agree(torch_mod, weights, smpl, monkeypatch):
                 n.reset_all()
                 o += [t.clone() for t in n.forward_offline(x, L)]
                 o += [t.clone() for t in n.forward_offline(x, L)]          # carried velocity state
-            assert n.device_error() == 0
-        outs[half] = o
-    for i, (a, b) in enumerate(zip(outs[1], outs[0])):
+            assert n.device_error() == 0 and n.recovery_count == 0
+        outs[variant] = o
+    for i, (a, b, c) in enumerate(zip(outs["late_pair=1"], outs["late_pair=0"], outs["half=0"])):
         if i % 4 == 0:                                         # pose: 8-slice against 16-slice kernels
-            assert float((a - b).abs().max()) < 5e-6
-        else:                                                  # joints, translation, contact: the same kernels
-            assert torch_mod.equal(a, b)
+            assert float((b - c).abs().max()) < 5e-6 and float((a - c).abs().max()) < 5e-6
+        elif i % 4 == 1:                                       # joints: the same kernels in all three
+            assert torch_mod.equal(b, c) and torch_mod.equal(a, c)
+        else:                                                  # translation, contact: rider in schedule 4, the same kernels otherwise
+            assert torch_mod.equal(b, c)
+            assert float((a - c).abs().max()) < 5e-6
+    assert any(not torch_mod.equal(a, b) for a, b in zip(outs["late_pair=1"], outs["late_pair=0"]))   # (schedule 4 did run)
 
 
 def test_g11_evaluate_pose_table_and_translation_statistics(torch_mod, net):
