@@ -113,6 +113,7 @@ __device__ __forceinline__ void mfma_drain() {
 template <int H, int NSLICE, int KIN, int TW, bool PROF, int FK = 0>
 MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void mp_lstm_fused(LstmPersistArgs a) {
     if (a.debug_drop && (int)blockIdx.x == a.debug_drop - 1) return;      // test hook: a workgroup that never shows up
+    const long long tl_entry = PROF ? (long long)__builtin_amdgcn_s_memrealtime() : 0;   // (PROF: launch timeline, 100 MHz)
     using C = Cfg<H, NSLICE, KIN, TW>;
     constexpr bool WREG = H == 256 && NSLICE == 8 && TW == 1;
     constexpr int U = C::U, NUB = C::NUB, NWV = C::NWV, NTW = C::NTW, NTG = C::NTG, KW = C::KW, NKS = C::NKS, KQ = C::KQ;
@@ -232,6 +233,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
     constexpr unsigned HD_R = 2 * 16 * H * 4;                         // byte offset of the R copy of the values
     constexpr unsigned HF_R = 2 * NSLICE * 4;                         // word offset of the R flags
     unsigned spin_budget = a.max_spin;
+    const long long tl_w = PROF ? (long long)__builtin_amdgcn_s_memrealtime() : 0;      // weight loads issued (not yet waited for)
     const unsigned my_xcc = xcc_id();
     bool src_local[NPW];                   // is the producer slice of each part of this wave's K quarter on my XCD?
 #pragma unroll
@@ -376,6 +378,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
     for (int j = 0; j < XJ_PRE; ++j) asm volatile("" : "+v"(xa[j]));
 
     long long pt[6] = {0, 0, 0, 0, 0, 0};
+    const long long tl_loop = PROF ? (long long)__builtin_amdgcn_s_memrealtime() : 0;   // first step starts
     const bool prof = PROF && a.prof != nullptr && threadIdx.x == 0;
     const long long t_start = PROF ? (long long)__builtin_amdgcn_s_memtime() : 0;
 #define PROF_T(i) do { if (PROF && prof) pt[i] -= (long long)__builtin_amdgcn_s_memtime(); } while (0)
@@ -761,6 +764,8 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
         o[5] = T;
         o[6] = pt[5];
         o[7] = (all_local ? 256 : 0) | my_xcc;                                     // placement: all slices on my XCD?, XCC id
+        long long* tl = a.prof + 4096 + (size_t)blockIdx.x * 4;                    // launch timeline (tools/debug/launch_timeline.py)
+        tl[0] = tl_entry; tl[1] = tl_w; tl[2] = tl_loop; tl[3] = (long long)__builtin_amdgcn_s_memrealtime();
     }
 
     // ---- final state (h_n, c_n of models/rnn.py:33) back to hbuf / cbuf
