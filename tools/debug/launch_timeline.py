@@ -20,10 +20,14 @@ if True:
     buf = (C.c_longlong * (4096 + 512 * 4))()
     net._lib.mp_debug_read_prof(net._h, buf, 4096 + 512 * 4)
     ph = np.array(buf[:4096]).reshape(512, 8)
-    a = np.array(buf[4096:]).reshape(512, 4)[ph[:, 5] == T]
+    sel = ph[:, 5] == T
+    a = np.array(buf[4096:]).reshape(512, 4)[sel]
+    xcc = (ph[sel, 7] & 0xFF).astype(int)
     t0 = a[:, 0].min()
     us = lambda v: v / 100.0
     print("%s L%d T=%d: %d WGs; entry skew max %.1f us; weight loads issued at mean %.1f (max %.1f); loop start mean %.1f (max %.1f); loop end mean %.1f (min %.1f max %.1f); per-step %.3f us"
           % (mod, layer, T, len(a), us(a[:, 0].max() - t0), us((a[:, 1] - t0).mean()), us((a[:, 1] - t0).max()),
              us((a[:, 2] - t0).mean()), us((a[:, 2] - t0).max()), us((a[:, 3] - t0).mean()), us((a[:, 3] - t0).min()), us((a[:, 3] - t0).max()),
              us((a[:, 3] - a[:, 2]).mean()) / T), flush=True)
+    dur = (a[:, 3] - a[:, 2]) / 100.0
+    print("   loop duration by XCC:", {int(x): round(float(dur[xcc == x].mean()), 1) for x in sorted(set(xcc))})
