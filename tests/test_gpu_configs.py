@@ -71,6 +71,36 @@ def test_config3_batch_1024_vs_oracle_rows(torch_mod, net, weights, smpl):
         assert np.abs(tran_h[r, :L] - rt).max() < TOL_TRAN, r
 
 
+def test_config3_share_of_one_gpu_in_eight_vs_oracle(torch_mod, net, weights, smpl):
+    """BASELINE configs[3] split over 8 GPUs (dist.shard_range): each rank gets 128 x 125 -- on the exact-fp32 path the
+    half-chip schedule (pose layer 1 beside the velocity layers with the foot-contact rider).  The whole shard, ragged,
+    forward_offline (network + FK-free translation solver), every row against the oracle."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.dist import shard_range
+    from oracle import mp_oracle as O
+    lo, hi = shard_range(1024, 5, 8)                                   # rank 5's rows of the global batch
+    B, T = hi - lo, 125
+    assert B == 128
+    imu = synthetic.make_imu(1024, T, seed=71)[lo:hi]
+    lengths = [T - (11 * b) % 97 for b in range(B)]
+    lengths[7] = T
+    net.reset_all()
+    pose, joints, tran, contact = net.forward_offline(cu(torch_mod, imu), lengths)
+    assert net.device_error() == 0 and net.recovery_count == 0
+    pose_h = npy(pose).reshape(B, T, 24, 3, 3)
+    joints_h, tran_h, contact_h = npy(joints), npy(tran), npy(contact)
+    ref = O.OracleNet(weights, smpl["J"])
+    rpose, rjoints, rvel, rcontact = ref.forward(imu, lengths)       # the batched oracle forward; solver per row below
+    rpose = np.asarray(rpose).reshape(B, T, 24, 3, 3)
+    for r in range(B):
+        L = lengths[r]
+        assert np.abs(joints_h[r, :L] - rjoints[r, :L]).max() < TOL, r
+        assert np.abs(contact_h[r, :L] - rcontact[r, :L]).max() < TOL, r
+        assert geodesic(pose_h[r, :L], rpose[r, :L]).max() < TOL, r
+        rt = O.translate_offline(rjoints[r, :L].reshape(L, 24, 3), rvel[r, :L], rcontact[r, :L], ref.floor_y)
+        assert np.abs(tran_h[r, :L] - rt).max() < TOL_TRAN, r
+
+
 def test_config4_512_streams_and_masked_reset(torch_mod, net, weights, smpl):
     """BASELINE configs[4] on one GPU: 512 concurrent streams ticked 10 times; streams 0, 17, 255 and 511 are followed
     by the oracle's forward_online.  Then reset() for a subset (mask): those streams restart like fresh ones (window
