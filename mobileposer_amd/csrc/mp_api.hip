@@ -1125,13 +1125,14 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
             //           the foot-contact layers riding in the velocity workgroups ("VF"); every cluster placed by the tables
             auto rec = [&](int i, hipStream_t on) -> int { HIPCHK(h, hipEventRecord(h->ev_x[i], on)); return MP_OK; };
             auto wait = [&](int i, hipStream_t on) -> int { HIPCHK(h, hipStreamWaitEvent(on, h->ev_x[i], 0)); return MP_OK; };
-            RC(rnn_g0(F, sf)); RC(rec(4, sf));                                            // linear1 of foot contact
+            // (two streams only: foot contact's linear layers go where its recurrent layers run, on s_vel)
+            RC(rnn_g0(F, sv));                                                            // linear1 of foot contact
             int rc_pv = MP_OK;
             if (!rnn_g0_pose_velocity(P, V, sm, &rc_pv)) { RC(rnn_g0(V, sm)); RC(rnn_g0(P, sm)); }
             RC(rc_pv);
             RC(rnn_rec(P, 0, sm));                                                        // 16 slices, every CU
             RC(rec(1, sm));
-            RC(wait(1, sv)); RC(wait(4, sv));                                             // (the velocity grid must not start under it)
+            RC(wait(1, sv));                                                              // (the velocity grid must not start under it)
             h->excl_lds = kExclusiveLdsBytes;
             h->pose_slices8 = true;
             h->xcd_plan_on[MP_MOD_POSE] = h->xcd_plan_on[MP_MOD_VELOCITY] = true;
@@ -1144,11 +1145,11 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
             h->xcd_plan_on[MP_MOD_POSE] = h->xcd_plan_on[MP_MOD_VELOCITY] = false;
             h->vf_foot = nullptr;
             RC(rc_w);
-            RC(rec(5, sv)); RC(wait(5, sf));
-            RC(rnn_g2(F, sf));                                                            // net.py:113-114
-            HIPCHK(h, hipEventRecord(h->ev_f, sf));
             RC(rnn_g2(V, sv));                                                            // net.py:117
             HIPCHK(h, hipEventRecord(h->ev_v, sv));
+            RC(rnn_g2(F, sv));                                                            // net.py:113-114
+            HIPCHK(h, hipEventRecord(h->ev_f, sv));
+            RC(rec(4, sf)); RC(wait(4, sm));                // (s_foot was forked into the call above and gets no work here: join it)
             RC(rnn_g2(P, sm));
             { SegScope seg(h, sm, 2, 1);
               mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sm); }   // net.py:110

@@ -113,6 +113,7 @@ def test_starved_velocity_launch_poisons_its_rider_too(torch_mod, weights, smpl,
     from mobileposer_amd import synthetic
     from mobileposer_amd.net import MobilePoserNet
     monkeypatch.setenv("MP_WAIT_MS", "15")
+    monkeypatch.setenv("MP_VARIANT", "")                                   # (this is about the default schedule)
     B, T = 256, 20
     x = cu(torch_mod, synthetic.make_imu(B, T, seed=79))
     with MobilePoserNet.from_numpy(weights, smpl) as m:
@@ -241,6 +242,7 @@ def test_starved_launch_in_the_half_chip_schedule(torch_mod, weights, smpl, monk
     from mobileposer_amd import synthetic
     from mobileposer_amd.net import MobilePoserNet
     monkeypatch.setenv("MP_WAIT_MS", "15")
+    monkeypatch.setenv("MP_VARIANT", "")                                   # (this is about the default schedule)
     B, T = 128, 20
     x = cu(torch_mod, synthetic.make_imu(B, T, seed=81))
     with MobilePoserNet.from_numpy(weights, smpl) as m:
