@@ -565,6 +565,28 @@ def test_half_chip_schedules_agree(torch_mod, weights, smpl, monkeypatch):
     assert any(not torch_mod.equal(a, b) for a, b in zip(outs["late_pair=1"], outs["late_pair=0"]))   # (schedule 4 did run)
 
 
+def test_half_chip_streaming_ticks_vs_oracle(torch_mod, net, weights, smpl):
+    """S = 100 concurrent streams (64 < S <= 128: on the exact-fp32 path every tick runs schedule 4 with the velocity state
+    carried in place from tick to tick), 8 ticks, four of the streams followed by the oracle's forward_online."""
+    from mobileposer_amd import synthetic
+    from oracle import mp_oracle as O
+    S, n = 100, 8
+    watch = [0, 63, 64, 99]
+    frames = synthetic.make_imu(S, n, seed=101)
+    refs = {s: O.OracleNet(weights, smpl["J"]) for s in watch}
+    net.reset_all()
+    net.stream_create(S)
+    for k in range(n):
+        pose, joints, root, contact = net.stream_step(cu(torch_mod, frames[:, k]))
+        for s in watch:
+            rp, rj, rr, rc = refs[s].forward_online(frames[s, k])
+            assert geodesic(npy(pose[s]).reshape(24, 3, 3), rp.reshape(24, 3, 3)).max() < TOL, (s, k)
+            assert np.abs(npy(joints[s]) - rj).max() < TOL, (s, k)
+            assert np.abs(npy(contact[s]) - rc).max() < TOL, (s, k)
+            assert np.abs(npy(root[s]) - rr).max() < TOL_TRAN, (s, k)
+    assert net.device_error() == 0 and net.recovery_count == 0
+
+
 def test_g11_evaluate_pose_table_and_translation_statistics(torch_mod, net):
     """evaluate_pose (evaluate.py:39-107) against the reference's own run on canned predictions (golden G11): the 8 x 2
     table -- aggregated with mean(), so the sequence shorter than one second turns the 1-s distance row into NaN exactly
