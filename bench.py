@@ -348,7 +348,12 @@ def main():
             # device synchronisation, 1.4 ms measured on one rank -- 2 % of a 20-step timed region.  Data still moves over RCCL
             # (the weight broadcast, the MAX over ranks, the gathers behind n_ranks_seen / per_rank)
             global HOST_GROUP
-            HOST_GROUP = dist.new_group(backend="gloo")
+            try:
+                HOST_GROUP = dist.new_group(backend="gloo")
+            except Exception as e:                      # noqa: BLE001 -- same node, same outcome on every rank: RCCL barriers then
+                HOST_GROUP = None
+                if rank == 0:
+                    sys.stderr.write("bench.py: no gloo group for the barriers (%r); using RCCL barriers\n" % (e,))
     if args.dry_run:
         return bench_dry(args, dist, rank, world)
     if dist is None:
