@@ -21,8 +21,14 @@ def _random_rotations(rng, n):
     return q
 
 
-def make_weights(seed=0):
+def make_weights(seed=0, profile="init"):
     """Seeded state dict (key -> float32 ndarray) with PyTorch-like fan-in uniform init.
+
+    ``profile="trained"`` (round 4) rescales the SAME draw into the regime a trained net works in -- what the reference's
+    evaluate.py feeds its 12 sensor combos through (combine_weights.py:42-57): LSTM ``weight_ih`` / ``weight_hh`` x 3
+    (recurrent gain > 1, gates that saturate, hidden activations near +-1), forget-gate biases + 1.0 (bias_ih slice
+    [H:2H]: long memory, rounding differences are carried over many steps instead of being forgotten), ``linear1``
+    weights x 2.  The output conditioning tweaks below are the same for both profiles.
 
     Tweaks that make the random net behave like a trained one where the path is sensitive to it:
       * pose linear2.bias  = 6D of random rotations, so r6d outputs are well conditioned
@@ -42,6 +48,17 @@ def make_weights(seed=0):
             wshape = state_dict_manifest()[key[:-4] + "weight"]
             k = 1.0 / np.sqrt(wshape[1])
         sd[key] = rng.uniform(-k, k, size=shape).astype(np.float32)
+    if profile == "trained":
+        for key in sd:
+            if ".rnn.weight_" in key:
+                sd[key] = (sd[key] * np.float32(3.0)).astype(np.float32)
+            elif ".rnn.bias_ih" in key:
+                hidden = sd[key].shape[0] // 4
+                sd[key][hidden:2 * hidden] += np.float32(1.0)
+            elif key.endswith("linear1.weight"):
+                sd[key] = (sd[key] * np.float32(2.0)).astype(np.float32)
+    elif profile != "init":
+        raise ValueError("profile must be 'init' or 'trained'")
     rot = _random_rotations(rng, 16)
     # 6D = first two columns of R (articulate/math/angular.py:180,192)
     sd["pose.pose.linear2.bias"] = np.ascontiguousarray(
@@ -93,7 +110,8 @@ def make_imu(batch, frames, seed=1, combo="lw_rp", smooth=0.95):
 
     acc block [.., :15]  ~ N(0, 0.3^2) (what a/30 looks like), AR(1)-smoothed in time;
     ori block [.., 15:60] = 5 rotation matrices row-major, a random walk on SO(3);
-    devices not in ``combo`` are zeroed (data.py:72-76).
+    devices not in ``combo`` are zeroed (data.py:72-76).  ``combo`` is one name of config.py:60-73 for the whole batch or a
+    list of ``batch`` names (row k keeps the devices of combo[k]) -- evaluate.py:56 feeds all 12.
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     acc = np.empty((batch, frames, 5, 3), dtype=np.float64)
@@ -115,9 +133,13 @@ def make_imu(batch, frames, seed=1, combo="lw_rp", smooth=0.95):
         th = th[..., None]
         dR = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
         ori[:, t] = ori[:, t - 1] @ dR
-    keep = np.zeros(5, dtype=bool)
-    keep[amass.combos[combo]] = True
-    acc[:, :, ~keep] = 0.0
-    ori[:, :, ~keep] = 0.0
+    names = [combo] * batch if isinstance(combo, str) else list(combo)
+    if len(names) != batch:
+        raise ValueError("need one combo name or %d of them" % batch)
+    for b, name in enumerate(names):
+        keep = np.zeros(5, dtype=bool)
+        keep[amass.combos[name]] = True
+        acc[b][:, ~keep] = 0.0
+        ori[b][:, ~keep] = 0.0
     imu = np.concatenate([acc.reshape(batch, frames, 15), ori.reshape(batch, frames, 45)], axis=-1)
     return np.ascontiguousarray(imu.astype(np.float32))

@@ -220,14 +220,22 @@ def shaped_body(smpl, shape):
     return (j - j[:, :1]).astype(F32), (v - j[:, :1]).astype(F32)
 
 
-def forward_kinematics_shape(pose, smpl, shape, parent=PARENT, tran=None):
+def forward_kinematics_shape(pose, smpl, shape, parent=PARENT, tran=None, pose_blendshape=False):
     """ParametricModel.forward_kinematics with shape != None, calc_mesh=True (articulate/model.py:208-240).
-    shape [10] | [1,10] | [N,10].  Returns R_global [N,24,3,3], joint [N,24,3], vert [N,V,3]."""
+    shape None (mean shape) | [10] | [1,10] | [N,10].  ``pose_blendshape``: v += posedirs . (pose[1:] - I) (model.py:236-238,
+    use_pose_blendshape=True).  Returns R_global [N,24,3,3], joint [N,24,3], vert [N,V,3]."""
     pose = np.asarray(pose, dtype=F32).reshape(-1, 24, 3, 3)
     N = pose.shape[0]
-    j, v = shaped_body(smpl, shape)
+    if shape is None:                                                          # model.py:82
+        J = np.asarray(smpl["J"], dtype=F32)
+        j, v = (J - J[:1])[None], (np.asarray(smpl["v_template"], dtype=F32) - J[:1])[None]
+    else:
+        j, v = shaped_body(smpl, shape)
     j = np.broadcast_to(j, (N, 24, 3))
     v = np.broadcast_to(v, (N,) + v.shape[1:])
+    if pose_blendshape:
+        r = (pose[:, 1:] - np.eye(3, dtype=F32)).reshape(N, 207)
+        v = (v + np.einsum("nk,vck->nvc", r, np.asarray(smpl["posedirs"], dtype=F32))).astype(F32)
     bone = j.copy()
     for i in range(1, 24):
         bone[:, i] = j[:, i] - j[:, parent[i]]
@@ -354,7 +362,8 @@ def translate_offline(joints, vel, contact, floor_y):
         if current_foot_y + float(velocity[i, 1]) <= floor_y:
             velocity[i, 1] = floor_y - current_foot_y
         current_root_y += float(velocity[i, 1])
-    # tran[i] = velocity[:i+1].sum(0) (:154): an fp32 re-summation of the clamped velocities
+    # tran[i] = velocity[:i+1].sum(0) (:154): an fp32 re-summation of the clamped velocities (the O(T^2) form up to T = 512,
+    # a float64 running sum beyond; the long branch is pinned by golden G14's T = 600 sequence: 4e-6 from the reference)
     tran = np.stack([velocity[:i + 1].sum(axis=0, dtype=F32) for i in range(T)]).astype(F32) if T <= 512 \
         else np.cumsum(velocity.astype(np.float64), axis=0).astype(F32)
     return tran

@@ -351,6 +351,93 @@ def main():
             g12[f"{tag}_vert"], g12[f"{tag}_joint_notran"] = vg.numpy(), jg0.numpy()
     np.savez_compressed(os.path.join(HERE, "g12_fk_shape.npz"), **g12)
 
+
+    # ---- G14 "trained-like" weights (round 4): make_weights(0, profile="trained") -- LSTM weights x 3, forget-gate bias + 1,
+    # linear1 x 2: saturated gates, recurrent gain > 1, long memory -- the regime evaluate.py:56 feeds its 12 combos through
+    def model_from(sd):
+        m = MobilePoserNet()
+        m.load_state_dict(to_torch_sd(sd))
+        m.eval()
+        return m
+
+    sd_tr = synthetic.make_weights(0, profile="trained")
+    combos6 = ["lw_rp_h", "rw_lp", "lp_h", "rp", "lw_lp", "rw_rp_h"]
+    imu14 = synthetic.make_imu(6, 60, seed=141, combo=combos6)
+    lens14 = [60, 31, 47, 60, 12, 55]
+    g14 = {"imu": imu14, "lengths": np.array(lens14)}
+    with torch.no_grad():
+        m = model_from(sd_tr)
+        pose, joints, vel, contact = m.forward(torch.from_numpy(imu14), lens14)
+        g14["pose"], g14["joints"], g14["vel"], g14["contact"] = pose.numpy(), joints.numpy(), vel.numpy(), contact.numpy()
+        h, c = m.velocity.rnn_state
+        g14["vel_h"], g14["vel_c"] = h.numpy(), c.numpy()
+        x132 = torch.cat((joints, torch.from_numpy(imu14)), dim=-1)
+        g14["r6d"] = m.pose(x132, lens14).numpy()
+        # forward_offline, T = 600: tran[i] = velocity[:i+1].sum(0) over 600 fp32 terms (net.py:154)
+        imu_long = synthetic.make_imu(1, 600, seed=142, combo="lw_rp_h")
+        m = model_from(sd_tr)
+        m.reset()
+        pose, joints, tran, contact = m.forward_offline(torch.from_numpy(imu_long), [600])
+        g14["off_imu"], g14["off_pose"], g14["off_joints"] = imu_long, pose.numpy(), joints.numpy()
+        g14["off_tran"], g14["off_contact"] = tran.numpy(), contact.numpy()
+        # forward_online x 50 from reset()
+        imu_on14 = synthetic.make_imu(1, 50, seed=143, combo="rw_lp")[0]
+        m = model_from(sd_tr)
+        m.reset()
+        po, jo, to, co = [], [], [], []
+        for f in torch.from_numpy(imu_on14):
+            p_, j_, t_, c_ = m.forward_online(f)
+            po.append(p_.numpy()); jo.append(j_.numpy()[40]); to.append(t_.numpy()); co.append(c_.numpy())
+        h, c = m.velocity.rnn_state
+        g14["on_imu"], g14["on_pose"], g14["on_joints40"] = imu_on14, np.stack(po), np.stack(jo)
+        g14["on_tran"], g14["on_contact"] = np.stack(to), np.stack(co)
+        g14["on_vel_h"], g14["on_vel_c"] = h.numpy(), c.numpy()
+        # one batch whose row k uses combo k of config.py:60-73 (data.py:69-76), trained profile and a second init-scale seed
+        from mobileposer.config import amass as ref_amass
+        names = list(ref_amass.combos)
+        assert names == list(synthetic.amass.combos) and all(ref_amass.combos[k] == synthetic.amass.combos[k] for k in names)
+        imu12 = synthetic.make_imu(12, 40, seed=144, combo=names)
+        g14["c12_imu"] = imu12
+        for tag, sd12 in (("tr", sd_tr), ("s1", synthetic.make_weights(1))):
+            m = model_from(sd12)
+            pose, joints, vel, contact = m.forward(torch.from_numpy(imu12), [40] * 12)
+            x132 = torch.cat((joints, torch.from_numpy(imu12)), dim=-1)
+            g14[f"c12_{tag}_joints"], g14[f"c12_{tag}_vel"] = joints.numpy(), vel.numpy()
+            g14[f"c12_{tag}_contact"], g14[f"c12_{tag}_r6d"] = contact.numpy(), m.pose(x132, [40] * 12).numpy()
+    np.savez_compressed(os.path.join(HERE, "g14_trained.npz"), **g14)
+
+    # ---- G15 the real mesh size: 6890 vertices (articulate/model.py:77-92,208-240, evaluator.py:319-322) -------------
+    # synthetic_smpl(n_vertex=6890): 26 full 256-vertex chunks + a 234-vertex tail; zero-pose body of a shape, FK + skinning
+    # without / with shape, and with pose blend shapes (use_pose_blendshape=True, model.py:236-238)
+    smpl_big = synthetic.synthetic_smpl(n_vertex=6890)
+    pkb = dict(smpl_big)
+    pkb["J_regressor"] = scipy.sparse.csc_matrix(smpl_big["J_regressor"])
+    big_path = os.path.join(work, "smpl", "big_m.pkl")
+    with open(big_path, "wb") as f:
+        pickle.dump(pkb, f)
+    rng = np.random.Generator(np.random.PCG64(15))
+    n15 = 3
+    pose15 = synthetic._random_rotations(rng, n15 * 24).reshape(n15, 24, 3, 3).astype(np.float32)
+    tran15 = rng.standard_normal((n15, 3)).astype(np.float32)
+    shape15 = (rng.standard_normal((n15, 10)) * 1.5).astype(np.float32)
+    g15 = {"pose": pose15, "tran": tran15, "shape": shape15}
+    with torch.no_grad():
+        bm = art.ParametricModel(big_path)
+        _, jg, vg = bm.forward_kinematics(torch.from_numpy(pose15), tran=torch.from_numpy(tran15), calc_mesh=True)
+        g15["joint"], g15["vert"] = jg.numpy(), vg.numpy()
+        _, jg, vg = bm.forward_kinematics(torch.from_numpy(pose15), shape=torch.from_numpy(shape15),
+                                          tran=torch.from_numpy(tran15), calc_mesh=True)
+        g15["shape_joint"], g15["shape_vert"] = jg.numpy(), vg.numpy()
+        j0, v0 = bm.get_zero_pose_joint_and_vertex(torch.from_numpy(shape15[:2]))
+        g15["zero_joint"], g15["zero_vert"] = j0.numpy(), v0.numpy()
+        bmp = art.ParametricModel(big_path, use_pose_blendshape=True)
+        _, jg, vg = bmp.forward_kinematics(torch.from_numpy(pose15), shape=torch.from_numpy(shape15[:1]),
+                                           tran=torch.from_numpy(tran15), calc_mesh=True)
+        g15["blend_joint"], g15["blend_vert"] = jg.numpy(), vg.numpy()
+        _, _, vg = bmp.forward_kinematics(torch.from_numpy(pose15), calc_mesh=True)
+        g15["blend_vert_noshape"] = vg.numpy()
+    np.savez_compressed(os.path.join(HERE, "g15_mesh6890.npz"), **g15)
+
     print("golden vectors written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         print("  %-24s %8d B" % (fn, os.path.getsize(os.path.join(HERE, fn))))

@@ -198,3 +198,99 @@ def test_g13_evaluate_pose_offline_and_online_tables(weights, smpl):
         on.append(sel(O.full_motion_evaluator(pose_o, pose_t, smpl, tran_o, tran_t)))
     np.testing.assert_allclose(np.mean(off, axis=0), g["offline"], rtol=3e-4, atol=1e-4)
     np.testing.assert_allclose(np.mean(on, axis=0), g["online"], rtol=3e-4, atol=1e-4)
+
+
+# ---- round 4: trained-like weights (G14) and the real mesh size (G15) ------------------------------------------------
+@pytest.fixture(scope="module")
+def weights_trained():
+    from mobileposer_amd.synthetic import make_weights
+    return make_weights(0, profile="trained")
+
+
+def test_g14_trained_forward_ragged_mixed_combos(weights_trained, smpl):
+    """forward on a ragged [6,60] batch, six different sensor combos, weights in the trained regime (saturated gates,
+    recurrent gain > 1, forget bias + 1): the oracle stays within 1e-4 of the reference (measured 5e-6)."""
+    g = load_golden("g14_trained.npz")
+    net = O.OracleNet(weights_trained, smpl["J"])
+    pose, joints, vel, contact = net.forward(g["imu"], g["lengths"].tolist())
+    assert np.abs(net._last_r6d - g["r6d"]).max() < TOL
+    assert np.abs(joints - g["joints"]).max() < TOL
+    assert np.abs(vel - g["vel"]).max() < TOL
+    assert np.abs(contact - g["contact"]).max() < TOL
+    assert geodesic(pose, g["pose"]).max() < TOL
+    h, c = net.velocity_rnn_state
+    assert np.abs(h - g["vel_h"]).max() < TOL and np.abs(c - g["vel_c"]).max() < TOL
+    # the regime is what it claims to be: cell states far outside (-1, 1)
+    assert np.abs(g["vel_c"]).max() > 4.0
+
+
+def test_g14_trained_offline_600_frames_pins_the_long_branch(weights_trained, smpl):
+    """forward_offline at T = 600 > 512: the oracle's float64 running sum against net.py:154's fp32 re-summation."""
+    g = load_golden("g14_trained.npz")
+    net = O.OracleNet(weights_trained, smpl["J"])
+    net.reset()
+    pose, joints, tran, contact = net.forward_offline(g["off_imu"], [600])
+    assert np.abs(joints - g["off_joints"]).max() < TOL
+    assert np.abs(contact - g["off_contact"]).max() < TOL
+    assert geodesic(pose, g["off_pose"]).max() < TOL
+    assert np.abs(tran - g["off_tran"]).max() < 5e-5          # 1 mm is the bound; 4e-6 measured
+    # and the short branch's arithmetic on the same data agrees with it (the two forms are interchangeable at 1e-5)
+    j = joints[0].reshape(-1, 24, 3)
+    short = O.translate_offline(j[:512], g_vel_of(net, g)[:512], contact[:512], net.floor_y)
+    assert np.abs(short - g["off_tran"][:512]).max() < 5e-5
+
+
+def g_vel_of(net, g):
+    n2 = O.OracleNet(net.sd, net.J)
+    _, _, vel, _ = n2.forward(g["off_imu"], [600])
+    return vel[0]
+
+
+def test_g14_trained_online_50_frames(weights_trained, smpl):
+    g = load_golden("g14_trained.npz")
+    net = O.OracleNet(weights_trained, smpl["J"])
+    net.reset()
+    for k, f in enumerate(g["on_imu"]):
+        pose, joints, tran, contact = net.forward_online(f)
+        assert geodesic(pose.reshape(24, 3, 3), g["on_pose"][k].reshape(24, 3, 3)).max() < TOL
+        assert np.abs(joints[40] - g["on_joints40"][k]).max() < TOL
+        assert np.abs(contact - g["on_contact"][k]).max() < TOL
+        assert np.abs(tran - g["on_tran"][k]).max() < 1e-3, k
+    h, c = net.velocity_rnn_state
+    assert np.abs(h - g["on_vel_h"]).max() < TOL and np.abs(c - g["on_vel_c"]).max() < TOL
+
+
+@pytest.mark.parametrize("tag", ["tr", "s1"])
+def test_g14_all_twelve_combos(weights_trained, smpl, tag):
+    """Row k of the batch keeps the devices of combo k (config.py:60-73, data.py:69-76); trained profile and a second seed."""
+    from mobileposer_amd.synthetic import make_weights
+    g = load_golden("g14_trained.npz")
+    sd = weights_trained if tag == "tr" else make_weights(1)
+    net = O.OracleNet(sd, smpl["J"])
+    pose, joints, vel, contact = net.forward(g["c12_imu"], [40] * 12)
+    assert np.abs(net._last_r6d - g[f"c12_{tag}_r6d"]).max() < TOL
+    assert np.abs(joints - g[f"c12_{tag}_joints"]).max() < TOL
+    assert np.abs(vel - g[f"c12_{tag}_vel"]).max() < TOL
+    assert np.abs(contact - g[f"c12_{tag}_contact"]).max() < TOL
+
+
+def test_g15_mesh_at_6890_vertices():
+    """forward_kinematics(calc_mesh=True) without / with shape, the zero-pose body of a shape and pose blend shapes
+    (articulate/model.py:77-92,208-240) on a 6890-vertex body: 26 full 256-vertex chunks and a 234-vertex tail."""
+    from mobileposer_amd.synthetic import synthetic_smpl
+    big = synthetic_smpl(n_vertex=6890)
+    g = load_golden("g15_mesh6890.npz")
+    _, jg, vg = O.forward_kinematics_mesh(g["pose"], big, tran=g["tran"])
+    assert vg.shape == (3, 6890, 3)
+    assert np.abs(jg - g["joint"]).max() < TIGHT and np.abs(vg - g["vert"]).max() < TIGHT
+    _, jg, vg = O.forward_kinematics_shape(g["pose"], big, g["shape"], tran=g["tran"])
+    assert np.abs(jg - g["shape_joint"]).max() < TIGHT and np.abs(vg - g["shape_vert"]).max() < TIGHT
+    j0, v0 = O.shaped_body(big, g["shape"][:2])
+    assert np.abs(j0 - g["zero_joint"]).max() < TIGHT and np.abs(v0 - g["zero_vert"]).max() < TIGHT
+    _, jg, vg = O.forward_kinematics_shape(g["pose"], big, g["shape"][:1], tran=g["tran"], pose_blendshape=True)
+    assert np.abs(jg - g["blend_joint"]).max() < TIGHT and np.abs(vg - g["blend_vert"]).max() < TIGHT
+    _, _, vg = O.forward_kinematics_shape(g["pose"], big, None, pose_blendshape=True)
+    assert np.abs(vg - g["blend_vert_noshape"]).max() < TIGHT
+    # pose blend shapes do move vertices (the golden is not vacuous)
+    _, _, plain = O.forward_kinematics_mesh(g["pose"], big)
+    assert np.abs(plain - g["blend_vert_noshape"]).max() > 1e-3
