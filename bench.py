@@ -432,6 +432,11 @@ def main():
     other = "x3" if args.lstm_mode == "fp32" else "fp32"
     elapsed, elapsed_local = timed(args.lstm_mode, args.steps)          # the headline measurement: exactly K steps
     outs_head = [t.clone() for t in (joints, vel, contact, tran, pose)]
+    import hashlib
+    sha = hashlib.sha1()
+    for t in outs_head + [rglob, jglob]:                 # every output of the headline mode's last step, bit for bit
+        sha.update(t.cpu().numpy().tobytes())
+    output_sha1 = sha.hexdigest()
     other_steps = max(20, args.steps // 4)
     elapsed_other, _ = timed(other, other_steps)
     mode_dev = max(float((a - b).abs().max()) for a, b in zip(outs_head, (joints, vel, contact, tran, pose)))
@@ -575,7 +580,11 @@ def main():
                    "batch_per_gpu": B, "window": T, "global_batch": global_batch,
                    "parallelism": "independent sequences sharded, dp%d" % world,
                    "graph_mode": args.graph_mode, "lstm_mode": args.lstm_mode, "recovery": args.recovery,
-                   "recoveries_during_run": net.recovery_count},
+                   "recoveries_during_run": net.recovery_count,
+                   "launcher": ("torch.distributed (RCCL process group, weights broadcast from rank 0, model built from the "
+                                "blob in HBM)" if dist is not None else "single process, no process group"),
+                   "device_index": local_rank, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")},
+        "output_sha1": output_sha1,
         "modes": {
             args.lstm_mode: {"value": round(value, 1), "ms_per_step": round(1e3 * elapsed / args.steps, 4), "headline": True},
             other: {"value": round(value_other, 1), "ms_per_step": round(1e3 * elapsed_other / other_steps, 4),

@@ -139,7 +139,7 @@ int mp_fk(mp_handle* h, const float* pose_dev, const float* tran_dev, int64_t N,
 int mp_set_mesh(mp_handle* h, const float* v_template_host, const float* weights_host, int n_vertex);
 
 /* ParametricModel.forward_kinematics with calc_mesh=True, shape=None, no pose blendshape
- * (articulate/model.py:208-240): as mp_fk, plus vert [N,V,3] by linear blend skinning.  This is what
+ * unless mp_set_pose_blendshape was called (articulate/model.py:208-240): as mp_fk, plus vert [N,V,3] by linear blend skinning.  This is what
  * FullMotionEvaluator.__call__ runs on prediction and ground truth (articulate/evaluator.py:319-320). */
 int mp_fk_mesh(mp_handle* h, const float* pose_dev, const float* tran_dev, int64_t N,
                float* rglobal_dev, float* joint_dev, float* vert_dev, void* stream);
@@ -154,6 +154,17 @@ int mp_set_shape_space(mp_handle* h, const float* shapedirs_host, const float* j
  * n_shape == N (a body per frame); vert_dev [N,V,3] optional (NULL = calc_mesh False). */
 int mp_fk_shape(mp_handle* h, const float* pose_dev, const float* shape_dev, int n_shape, const float* tran_dev,
                 int64_t N, float* rglobal_dev, float* joint_dev, float* vert_dev, void* stream);
+
+/* ParametricModel.get_zero_pose_joint_and_vertex(shape) (articulate/model.py:77-92, the shape != None branch :84-89):
+ * shape_dev [n_shape,10] -> joint_dev [n_shape,24,3] and vert_dev [n_shape,V,3], both aligned to the body's own root joint.
+ * (shape == None is two host constants: J - J[0] and v_template - J[0].) */
+int mp_zero_pose_body(mp_handle* h, const float* shape_dev, int n_shape, float* joint_dev, float* vert_dev, void* stream);
+
+/* ParametricModel(..., use_pose_blendshape=True) (articulate/model.py:30,236-238): posedirs [V,3,207] (host pointer, V as
+ * given to mp_set_mesh).  From then on the mesh of mp_fk_mesh / mp_fk_shape is skinned from
+ * v + posedirs . (pose[:, 1:] - I) instead of v.  NULL switches it off again (the default; no reference caller enables it:
+ * net.py:37, evaluator.py:293, data.py:24).  mp_eval_metrics follows the reference's evaluator and never applies it. */
+int mp_set_pose_blendshape(mp_handle* h, const float* posedirs_host);
 
 /* FullMotionEvaluator.__call__ (articulate/evaluator.py:292-343, mean shape) as PoseEvaluator.eval calls it
  * (evaluate.py:20-29): the joints of ignored_mask (bit j = joint j; evaluate.py:25-26) of both poses are set to the
@@ -250,7 +261,10 @@ int mp_set_lstm_mode(mp_handle* h, int mode);
  * cross-workgroup waits, parity-tested like the fused kernels).  The call then returns MP_OK, mp_last_error() holds a
  * warning, mp_recovery_count() counts such calls, and the handle stops using physical-XCD placement tables.
  * mp_set_recovery(h, 0): calls return as soon as their work is enqueued (throughput loops); an error is reported as
- * MP_ERR_DEVICE by the next API entry, by mp_finish() or read by mp_device_error(); the outputs of the failed call are NaN. */
+ * MP_ERR_DEVICE by the next API entry, by mp_finish() or read by mp_device_error(); the outputs of the failed call are NaN
+ * AND the state it carried forward is lost: when the error is reported the handle drops the carried velocity LSTM state
+ * (as mp_reset_state(h, 1)) and puts every stream back to its state after mp_stream_create (fresh window, root height /
+ * position 0, rest-pose foot positions) -- later calls are finite again, but the caller's sequences start over. */
 int mp_set_recovery(mp_handle* h, int on);
 /* Number of calls that were repaired by the mode-0 re-run since mp_create. */
 int mp_recovery_count(const mp_handle* h);

@@ -39,6 +39,8 @@ SIGNATURES = {
     "mp_fk_mesh": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "mp_set_shape_space": (_i, [_vp, _fp, _fp]),
     "mp_fk_shape": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "mp_zero_pose_body": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "mp_set_pose_blendshape": (_i, [_vp, _fp]),
     "mp_eval_metrics": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, C.c_uint, C.c_uint, _i, _vp, _vp]),
     "mp_reset_state": (_i, [_vp, _i]),
     "mp_get_velocity_state": (_i, [_vp, _vp, C.POINTER(_i)]),

@@ -29,9 +29,6 @@ class ParametricModel:
     def __init__(self, official_model_file=None, use_pose_blendshape=False, device="cuda:0", data=None):
         """From an SMPL pickle (articulate/model.py:26-37: latin1 pickle, scipy-sparse ``J_regressor``, ``kintree_table``)
         or an already-loaded dict with the same keys."""
-        if use_pose_blendshape:
-            raise NotImplementedError("pose blend shapes are outside the inference path (the reference's callers leave "
-                                      "use_pose_blendshape at False: net.py:37, evaluator.py:293, data.py:24)")
         if data is None:
             with open(official_model_file, "rb") as f:
                 data = pickle.load(f, encoding="latin1")
@@ -42,8 +39,12 @@ class ParametricModel:
         self._skinning_weights = np.asarray(data["weights"], dtype=np.float32) if "weights" in data else None
         self._shapedirs = np.asarray(data["shapedirs"], dtype=np.float32) if "shapedirs" in data else None
         self._J_regressor = _dense(data["J_regressor"]) if "J_regressor" in data else None
+        self._posedirs = np.asarray(data["posedirs"], dtype=np.float32) if "posedirs" in data else None
         self.face = data.get("f")
-        self.use_pose_blendshape = False
+        # articulate/model.py:38,236-238.  No reference caller enables it (net.py:37, evaluator.py:293, data.py:24)
+        self.use_pose_blendshape = bool(use_pose_blendshape)
+        if self.use_pose_blendshape and self._posedirs is None:
+            raise ValueError("use_pose_blendshape=True needs 'posedirs' in the model file")
         self.device = torch.device(device)
         self._net_ref = None
         self._own = None              # body-only native handle (created on first use when not bound to a net)
@@ -58,11 +59,24 @@ class ParametricModel:
         return self._J
 
     def get_zero_pose_joint_and_vertex(self, shape=None):
-        """articulate/model.py:77-92 with shape=None: root-aligned joints and vertices (host constants)."""
-        if shape is not None:
-            raise NotImplementedError("zero-pose joints for a given shape are computed on the GPU inside forward_kinematics")
-        j = self._J - self._J[:1]
-        v = None if self._v_template is None else self._v_template - self._J[:1]
+        """articulate/model.py:77-92.  shape None: root-aligned joints [24,3] and vertices [V,3] of the mean shape (host
+        constants, numpy).  shape reshapeable to [S,10]: joints [S,24,3] and vertices [S,V,3] of those bodies, each aligned to
+        its own root joint, computed on the GPU (mp_zero_pose_body) and returned as device tensors."""
+        if shape is None:
+            j = self._J - self._J[:1]
+            v = None if self._v_template is None else self._v_template - self._J[:1]
+            return j, v
+        lib, h, dev = self._handle()
+        net = self._net
+        state = net._mesh_state if (net is not None and net._h is not None) else self._own_state
+        if not state.get("has_shape"):
+            raise RuntimeError("the body model has no shape space (shapedirs / J_regressor) loaded")
+        sh = torch.as_tensor(shape).to(device=dev, dtype=torch.float32).reshape(-1, 10).contiguous()
+        S, V = sh.shape[0], state["n_vertex"]
+        j = torch.empty(S, 24, 3, device=dev, dtype=torch.float32)
+        v = torch.empty(S, V, 3, device=dev, dtype=torch.float32)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.mp_zero_pose_body(h, _ptr(sh), S, _ptr(j), _ptr(v), stream), h)
         return j, v
 
     # ---- native handle ---------------------------------------------------------------------------------------------
@@ -133,6 +147,11 @@ def upload_mesh(lib, h, bm, state):
         if sd.shape == (vt.shape[0], 3, 10) and jr.shape == (24, vt.shape[0]):
             _lib.check(lib.mp_set_shape_space(h, sd.ctypes.data_as(fp), jr.ctypes.data_as(fp)), h)
             state["has_shape"] = True
+    if getattr(bm, "use_pose_blendshape", False):
+        pd = np.ascontiguousarray(bm._posedirs, dtype=np.float32)
+        if pd.shape != (vt.shape[0], 3, 207):
+            raise ValueError("posedirs must be [V,3,207], got %s" % (pd.shape,))
+        _lib.check(lib.mp_set_pose_blendshape(h, pd.ctypes.data_as(fp)), h)
 
 
 def fk_call(lib, h, dev, state, pose, shape, tran, calc_mesh):

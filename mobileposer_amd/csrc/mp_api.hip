@@ -157,6 +157,7 @@ struct mp_handle {
     float* vtpl_dev = nullptr;       // raw template vertices [V,3] (shape blending starts from these, model.py:86)
     float* shapedirs_dev = nullptr;  // [V,3,10] (mp_set_shape_space)
     float* jreg_dev = nullptr;       // dense J_regressor [24,V]
+    float* posedirsT_dev = nullptr;  // pose blend shapes, transposed [207][3V] (mp_set_pose_blendshape; nullptr = off)
     float* eval_ws = nullptr;        // mp_eval_metrics workspace: masked poses, FK outputs of prediction and truth, partials
     size_t eval_ws_bytes = 0;
     float* shape_ws = nullptr;       // mp_fk_shape workspace: vrest [ns][V][3] | jraw | jrest | bone [ns][72] each
@@ -211,6 +212,8 @@ struct mp_handle {
     unsigned long long use_clock = 0;
     VelState vstate;
     VelState vsnap;                  // recovery: the carried velocity state a call started from
+    float* rnn_snap = nullptr;       // recovery: mp_rnn_forward's state when the caller passes state_in == state_out
+    size_t rnn_snap_bytes = 0;
     StreamCtx sc;
     OnlineState st_snap;             // recovery: per-stream solver state a streaming tick started from
     bool vf_ok = true;               // MP_VARIANT vf=0: the foot-contact layers always run as launches of their own
@@ -1310,14 +1313,34 @@ int run_maybe_graph(mp_handle* h, GraphKey key, Body body) {
 // blockIdx % 8 round robin (placement then only affects speed, never which (cluster, slice) a workgroup takes).
 void disable_xcd_tables(mp_handle* h) { h->xcd_rr = false; }
 
+// A failed call without recovery has poisoned what it carries forward: the velocity LSTM state it updated in place is NaN for
+// the starved slab, and a streaming tick derived root height / root position / last foot positions from NaN outputs.  Once
+// the error has been REPORTED the handle must not keep feeding that state into later calls (they would return NaN with
+// MP_OK): the carried velocity state is dropped (as `model.velocity.rnn_state = None`) and every stream is put back to its
+// state after construction + reset() (fresh window, root height / position 0, last foot positions = rest pose, net.py:59-64).
+void invalidate_carried_state(mp_handle* h) {
+    h->vstate.B = 0;
+    StreamCtx& c = h->sc;
+    if (!c.S) return;
+    (void)hipStreamSynchronize(h->s_main);
+    std::vector<float> lf((size_t)c.S * 6);
+    for (int s = 0; s < c.S; ++s) memcpy(&lf[(size_t)s * 6], h->feet_pos, sizeof(h->feet_pos));
+    (void)hipMemcpy(c.st.last_foot, lf.data(), lf.size() * sizeof(float), hipMemcpyHostToDevice);
+    (void)hipMemset(c.fresh, 1, c.S);
+    (void)hipMemset(c.st.root_y, 0, (size_t)c.S * sizeof(double));
+    (void)hipMemset(c.st.root_pos, 0, (size_t)c.S * 3 * sizeof(float));
+}
+
 int pending_device_error(mp_handle* h, const char* where) {
     const int code = h->err_host ? *(volatile int*)h->err_host : 0;
     if (!code) return MP_OK;
     *(volatile int*)h->err_host = 0;
     disable_xcd_tables(h);
+    invalidate_carried_state(h);
     return fail(h, MP_ERR_DEVICE, "%s: a previous call's persistent LSTM kernel gave up a wait for another workgroup's "
                 "hidden state (code %d: 1+step, or 1000000 = start-up handshake; the GPU was shared?); the affected "
-                "outputs of that call are NaN.  Physical-XCD placement tables are now off for this handle", where, code);
+                "outputs of that call are NaN and the state it carried forward is lost: the velocity LSTM state has been "
+                "dropped and all streams reset.  Physical-XCD placement tables are now off for this handle", where, code);
 }
 
 int need_weights(mp_handle* h, const char* what) {
@@ -1450,7 +1473,7 @@ void mp_destroy(mp_handle* h) {
     void* misc[] = {h->parent_dev, h->depth_dev, h->bone_dev, h->vstate.h, h->vstate.c, h->sc.window, h->sc.fresh,
                     h->sc.mask_dev, h->sc.st.last_foot, h->sc.st.root_y, h->sc.st.root_pos, h->sc.joints, h->sc.vel,
                     h->sc.contact, h->jrest_dev, h->vrest_dev, h->skinw_dev, h->lin1_pv.Wp, h->lin1_pv.W, h->lin1_pv.bias, h->prof_dev,
-                    h->vtpl_dev, h->shapedirs_dev, h->jreg_dev, h->shape_ws,
+                    h->vtpl_dev, h->shapedirs_dev, h->jreg_dev, h->shape_ws, h->posedirsT_dev, h->rnn_snap,
                     h->vsnap.h, h->vsnap.c, h->st_snap.last_foot, h->st_snap.root_y, h->st_snap.root_pos, h->eval_ws};
     for (void* p : misc) if (p) (void)hipFree(p);
     if (h->err_host) (void)hipHostFree(h->err_host);
@@ -1572,9 +1595,26 @@ int mp_rnn_forward(mp_handle* h, int module, const float* x_dev, const int32_t* 
     RnnJob job{h, p, module, user_map(x_dev, T, m.n_in), none, y_dev, (long)T * m.n_out, m.n_out,
                state_in_dev ? STATE_FROM : STATE_ZERO, state_in_dev, state_in_dev ? state_in_dev + half : nullptr,
                state_out_dev, state_out_dev ? state_out_dev + half : nullptr};
+    // state_in_dev == state_out_dev: the fused kernels update the state in place, so a starved run would leave NaN where the
+    // repair has to start from -- keep a copy for the restore (recovery on only)
+    const bool aliased = state_in_dev && state_in_dev == state_out_dev;
+    const size_t state_bytes = 2 * half * sizeof(float);
+    if (aliased && h->recovery) {
+        if (state_bytes > h->rnn_snap_bytes) {
+            HIPCHK(h, hipStreamSynchronize(h->s_main));
+            if (h->rnn_snap) (void)hipFree(h->rnn_snap);
+            h->rnn_snap = nullptr; h->rnn_snap_bytes = 0;
+            if (int rc = dev_alloc(h, (void**)&h->rnn_snap, state_bytes)) return rc;
+            h->rnn_snap_bytes = state_bytes;
+        }
+        HIPCHK(h, hipMemcpyAsync(h->rnn_snap, state_in_dev, state_bytes, hipMemcpyDeviceToDevice, h->s_main));
+    }
     int rc = run_rnn(job, h->s_main);
     if (rc) return rc;
-    if (int rc2 = finish_or_recover(h, p, "mp_rnn_forward", []() { return (int)MP_OK; }, [&]() { return run_rnn(job, h->s_main); })) return rc2;
+    if (int rc2 = finish_or_recover(h, p, "mp_rnn_forward", [&]() {
+            if (aliased) HIPCHK(h, hipMemcpyAsync(state_out_dev, h->rnn_snap, state_bytes, hipMemcpyDeviceToDevice, h->s_main));
+            return (int)MP_OK;
+        }, [&]() { return run_rnn(job, h->s_main); })) return rc2;
     return leave(h, stream);
 }
 
@@ -1624,7 +1664,7 @@ int mp_set_mesh(mp_handle* h, const float* v_template_host, const float* weights
     if (!h || !v_template_host || !weights_host || n_vertex < 1) return h ? fail(h, MP_ERR_INVALID, "mp_set_mesh: bad argument") : MP_ERR_INVALID;
     ON_DEVICE(h);
     HIPCHK(h, hipDeviceSynchronize());
-    for (float** q : {&h->vrest_dev, &h->skinw_dev, &h->vtpl_dev, &h->shapedirs_dev, &h->jreg_dev}) {
+    for (float** q : {&h->vrest_dev, &h->skinw_dev, &h->vtpl_dev, &h->shapedirs_dev, &h->jreg_dev, &h->posedirsT_dev}) {
         if (*q) (void)hipFree(*q);
         *q = nullptr;
     }
@@ -1656,54 +1696,100 @@ int mp_set_shape_space(mp_handle* h, const float* shapedirs_host, const float* j
     return MP_OK;
 }
 
+// forward_kinematics in all its forms (articulate/model.py:208-240): optional shape (n_shape bodies: 1 or N), optional
+// mesh, optional pose blend shapes (the handle's, mp_set_pose_blendshape).  Workspace layout (floats):
+//   vrest [ns][V][3] | jraw, jrest, bone [ns][72] each | vposed [N][V][3] (pose blend shapes only)
+namespace {
+int ensure_shape_ws(mp_handle* h, size_t need) {
+    if (need <= h->shape_ws_floats) return MP_OK;
+    HIPCHK(h, hipDeviceSynchronize());
+    if (h->shape_ws) (void)hipFree(h->shape_ws);
+    h->shape_ws = nullptr; h->shape_ws_floats = 0;
+    if (int rc = dev_alloc(h, (void**)&h->shape_ws, need * sizeof(float))) return rc;
+    h->shape_ws_floats = need;
+    return MP_OK;
+}
+
+int fk_general(mp_handle* h, const char* what, const float* pose_dev, const float* shape_dev, int n_shape,
+               const float* tran_dev, int64_t N, float* rglobal_dev, float* joint_dev, float* vert_dev, void* stream) {
+    if (N == 0) return MP_OK;
+    if (vert_dev && !h->n_vertex) return fail(h, MP_ERR_INVALID, "%s before mp_set_mesh", what);
+    if (shape_dev && !h->shapedirs_dev) return fail(h, MP_ERR_INVALID, "%s before mp_set_shape_space", what);
+    ON_DEVICE(h);
+    const size_t V = (size_t)h->n_vertex, ns = shape_dev ? (size_t)n_shape : 0;
+    const bool blend = vert_dev && h->posedirsT_dev;
+    const size_t f_body = ns * (V * 3 + 3 * 72);
+    if (int rc = ensure_shape_ws(h, f_body + (blend ? (size_t)N * V * 3 : 0))) return rc;
+    if (int rc = enter(h, stream)) return rc;
+    const float *bone = h->bone_dev, *jrest = h->jrest_dev, *vrest = h->vrest_dev;
+    long bstride = 0, vstride = 0;
+    if (shape_dev) {
+        float* vr = h->shape_ws;
+        float* jraw = vr + ns * V * 3;
+        float* jr = jraw + ns * 72;
+        float* bn = jr + ns * 72;
+        mp_launch_shape_body(shape_dev, n_shape, h->shapedirs_dev, h->vtpl_dev, h->jreg_dev, h->parent_dev, h->n_vertex, vr,
+                             jraw, jr, bn, h->s_main);                                        // model.py:84-89
+        bone = bn; jrest = jr; vrest = vr;
+        if (n_shape != 1) { bstride = 72; vstride = (long)V * 3; }
+    }
+    mp_launch_fk(pose_dev, tran_dev, (long)N, bone, h->parent_dev, h->depth_dev, rglobal_dev, joint_dev, h->s_main, bstride);
+    if (vert_dev) {
+        if (blend) {                                                                          // model.py:236-238
+            float* vposed = h->shape_ws + f_body;
+            mp_launch_pose_blend(pose_dev, (long)N, vrest, vstride, h->posedirsT_dev, h->n_vertex, vposed, h->s_main);
+            vrest = vposed; vstride = (long)V * 3;
+        }
+        mp_launch_lbs(rglobal_dev, joint_dev, tran_dev, (long)N, jrest, bstride, vrest, vstride, h->skinw_dev, h->n_vertex,
+                      vert_dev, h->s_main);
+    }
+    HIPCHK(h, hipGetLastError());
+    return leave(h, stream);
+}
+}  // namespace
+
 int mp_fk_shape(mp_handle* h, const float* pose_dev, const float* shape_dev, int n_shape, const float* tran_dev, int64_t N,
                 float* rglobal_dev, float* joint_dev, float* vert_dev, void* stream) {
     if (!h || !pose_dev || !shape_dev || !rglobal_dev || !joint_dev || N < 0 || !(n_shape == 1 || n_shape == N))
         return h ? fail(h, MP_ERR_INVALID, "mp_fk_shape: bad argument (n_shape must be 1 or N)") : MP_ERR_INVALID;
-    if (!h->shapedirs_dev) return fail(h, MP_ERR_INVALID, "mp_fk_shape before mp_set_shape_space");
-    if (N == 0) return MP_OK;
-    ON_DEVICE(h);
-    const size_t V = (size_t)h->n_vertex, ns = (size_t)n_shape;
-    const size_t need = ns * (V * 3 + 3 * 72);
-    if (need > h->shape_ws_floats) {
-        HIPCHK(h, hipDeviceSynchronize());
-        if (h->shape_ws) (void)hipFree(h->shape_ws);
-        h->shape_ws = nullptr; h->shape_ws_floats = 0;
-        if (int rc = dev_alloc(h, (void**)&h->shape_ws, need * sizeof(float))) return rc;
-        h->shape_ws_floats = need;
-    }
-    if (int rc = enter(h, stream)) return rc;
-    float* vrest = h->shape_ws;
-    float* jraw = vrest + ns * V * 3;
-    float* jrest = jraw + ns * 72;
-    float* bone = jrest + ns * 72;
-    mp_launch_shape_body(shape_dev, n_shape, h->shapedirs_dev, h->vtpl_dev, h->jreg_dev, h->parent_dev, h->n_vertex, vrest,
-                         jraw, jrest, bone, h->s_main);                                       // model.py:84-89
-    const long bstride = n_shape == 1 ? 0 : 72, vstride = n_shape == 1 ? 0 : (long)V * 3;
-    mp_launch_fk(pose_dev, tran_dev, (long)N, bone, h->parent_dev, h->depth_dev, rglobal_dev, joint_dev, h->s_main, bstride);
-    if (vert_dev)
-        for (int64_t n0 = 0; n0 < N; n0 += 32768) {
-            const long cnt = (long)(N - n0 < 32768 ? N - n0 : 32768);
-            mp_launch_lbs(rglobal_dev + n0 * 216, joint_dev + n0 * 72, tran_dev ? tran_dev + n0 * 3 : nullptr, cnt,
-                          jrest + n0 * bstride, bstride, vrest + n0 * vstride, vstride, h->skinw_dev, h->n_vertex,
-                          vert_dev + n0 * h->n_vertex * 3, h->s_main);
-        }
-    HIPCHK(h, hipGetLastError());
-    return leave(h, stream);
+    return fk_general(h, "mp_fk_shape", pose_dev, shape_dev, n_shape, tran_dev, N, rglobal_dev, joint_dev, vert_dev, stream);
 }
 
 int mp_fk_mesh(mp_handle* h, const float* pose_dev, const float* tran_dev, int64_t N, float* rglobal_dev, float* joint_dev,
                float* vert_dev, void* stream) {
     if (!h || !pose_dev || !rglobal_dev || !joint_dev || !vert_dev || N < 0) return h ? fail(h, MP_ERR_INVALID, "mp_fk_mesh: bad argument") : MP_ERR_INVALID;
-    if (!h->n_vertex) return fail(h, MP_ERR_INVALID, "mp_fk_mesh before mp_set_mesh");
+    return fk_general(h, "mp_fk_mesh", pose_dev, nullptr, 0, tran_dev, N, rglobal_dev, joint_dev, vert_dev, stream);
+}
+
+int mp_set_pose_blendshape(mp_handle* h, const float* posedirs_host) {
+    if (!h) return MP_ERR_INVALID;
     ON_DEVICE(h);
+    HIPCHK(h, hipDeviceSynchronize());
+    if (h->posedirsT_dev) { (void)hipFree(h->posedirsT_dev); h->posedirsT_dev = nullptr; }
+    if (!posedirs_host) return MP_OK;                                          // use_pose_blendshape = False
+    if (!h->n_vertex) return fail(h, MP_ERR_INVALID, "mp_set_pose_blendshape before mp_set_mesh");
+    const size_t n = (size_t)h->n_vertex * 3 * 207;
+    float* staging = nullptr;
+    if (int rc = dev_alloc(h, (void**)&staging, n * sizeof(float))) return rc;
+    if (int rc = dev_alloc(h, (void**)&h->posedirsT_dev, n * sizeof(float))) { (void)hipFree(staging); return rc; }
+    hipError_t e = hipMemcpy(staging, posedirs_host, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) { mp_launch_transpose_posedirs(staging, h->n_vertex, h->posedirsT_dev, h->s_main); e = hipStreamSynchronize(h->s_main); }
+    (void)hipFree(staging);
+    if (e != hipSuccess) return fail(h, MP_ERR_HIP, "mp_set_pose_blendshape: %s", hipGetErrorString(e));
+    return MP_OK;
+}
+
+int mp_zero_pose_body(mp_handle* h, const float* shape_dev, int n_shape, float* joint_dev, float* vert_dev, void* stream) {
+    if (!h || !shape_dev || n_shape < 1 || !joint_dev || !vert_dev)
+        return h ? fail(h, MP_ERR_INVALID, "mp_zero_pose_body: bad argument") : MP_ERR_INVALID;
+    if (!h->shapedirs_dev) return fail(h, MP_ERR_INVALID, "mp_zero_pose_body before mp_set_shape_space");
+    ON_DEVICE(h);
+    const size_t ns = (size_t)n_shape;
+    if (int rc = ensure_shape_ws(h, ns * 2 * 72)) return rc;
     if (int rc = enter(h, stream)) return rc;
-    mp_launch_fk(pose_dev, tran_dev, (long)N, h->bone_dev, h->parent_dev, h->depth_dev, rglobal_dev, joint_dev, h->s_main);
-    for (int64_t n0 = 0; n0 < N; n0 += 32768) {                   // grid.y limit
-        const long cnt = (long)(N - n0 < 32768 ? N - n0 : 32768);
-        mp_launch_lbs(rglobal_dev + n0 * 216, joint_dev + n0 * 72, tran_dev ? tran_dev + n0 * 3 : nullptr, cnt, h->jrest_dev,
-                      0, h->vrest_dev, 0, h->skinw_dev, h->n_vertex, vert_dev + n0 * h->n_vertex * 3, h->s_main);
-    }
+    // vertices and joints go straight into the caller's buffers; the raw joints and the bone vectors are scratch
+    mp_launch_shape_body(shape_dev, n_shape, h->shapedirs_dev, h->vtpl_dev, h->jreg_dev, h->parent_dev, h->n_vertex, vert_dev,
+                         h->shape_ws, joint_dev, h->shape_ws + ns * 72, h->s_main);           // model.py:84-89
     HIPCHK(h, hipGetLastError());
     return leave(h, stream);
 }
@@ -1741,12 +1827,7 @@ int mp_eval_metrics(mp_handle* h, const float* pose_p_dev, const float* pose_t_d
     float* rg[2] = {rp, rt}; float* jj[2] = {jp, jt}; float* vv[2] = {vp, vt};
     for (int k = 0; k < 2; ++k) {                                                                    // evaluator.py:319-320
         mp_launch_fk(pose[k], tran[k], (long)N, h->bone_dev, h->parent_dev, h->depth_dev, rg[k], jj[k], s);
-        if (V)
-            for (int64_t n0 = 0; n0 < N; n0 += 32768) {
-                const long cnt = (long)(N - n0 < 32768 ? N - n0 : 32768);
-                mp_launch_lbs(rg[k] + n0 * 216, jj[k] + n0 * 72, tran[k] ? tran[k] + n0 * 3 : nullptr, cnt, h->jrest_dev, 0,
-                              h->vrest_dev, 0, h->skinw_dev, h->n_vertex, vv[k] + n0 * V * 3, s);
-            }
+        if (V) mp_launch_lbs(rg[k], jj[k], tran[k], (long)N, h->jrest_dev, 0, h->vrest_dev, 0, h->skinw_dev, h->n_vertex, vv[k], s);
     }
     mp_launch_eval_metrics(mp_, mt_, rp, rt, jp, jt, V ? vp : nullptr, V ? vt : nullptr, (long)N, (int)V, fps, align_joint,
                            joint_mask, part, table_dev, s);                                          // evaluator.py:321-343
@@ -1986,6 +2067,7 @@ int mp_device_error(mp_handle* h, int* code) {
     HIPCHK(h, hipStreamSynchronize(h->s_main));
     *code = *(volatile int*)h->err_host;
     *(volatile int*)h->err_host = 0;
+    if (*code) { disable_xcd_tables(h); invalidate_carried_state(h); }
     return MP_OK;
 }
 

@@ -169,7 +169,7 @@ void mp_launch_r6d_ik_strided(const float* r6d, long N, long rowStride, long row
 void mp_launch_fk(const float* pose, const float* tran, long N, const float* bone_dev, const int* parent_dev,
                   const int* depth_dev, float* rglobal, float* joint, hipStream_t s, long boneStride = 0);
 
-// linear blend skinning on mp_fk's outputs (joint already translated by tran); grid.y = N frames (<= 65535 per launch);
+// linear blend skinning on mp_fk's outputs (joint already translated by tran); any N (chunked inside);
 // jrestStride / vrestStride: floats between the rest joints / rest vertices of consecutive frames (0 = shared body)
 void mp_launch_lbs(const float* rglobal, const float* joint, const float* tran, long N, const float* jrest_dev,
                    long jrestStride, const float* vrest_dev, long vrestStride, const float* weights_dev, int V,
@@ -179,6 +179,12 @@ void mp_launch_lbs(const float* rglobal, const float* joint, const float* tran, 
 void mp_launch_shape_body(const float* shape, int ns, const float* shapedirs, const float* vtemplate_raw,
                           const float* jreg, const int* parent_dev, int V, float* vrest, float* jraw, float* jrest,
                           float* bone, hipStream_t s);
+
+// pose blend shapes (articulate/model.py:236-238): vposed [N][V][3] = vrest[(n)] + posedirs . (pose[1:] - I); posedirsT is
+// the [207][3V] transpose made by mp_launch_transpose_posedirs from the pickle's [V][3][207]
+void mp_launch_pose_blend(const float* pose, long N, const float* vrest, long vrestStride, const float* posedirsT, int V,
+                          float* vposed, hipStream_t s);
+void mp_launch_transpose_posedirs(const float* src, int V, float* dst, hipStream_t s);
 
 // ---------------------------------------------------------------- evaluator metrics (mp_eval.hip)
 // FullMotionEvaluator.__call__ (articulate/evaluator.py:292-343) on FK outputs; v_p / v_t may be nullptr (no mesh);

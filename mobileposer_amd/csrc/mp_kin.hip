@@ -255,7 +255,67 @@ MP_KERNEL __launch_bounds__(256) void mp_shape_align(float* __restrict__ v, cons
     }
 }
 
+// Pose blend shapes (articulate/model.py:236-238, use_pose_blendshape=True):
+//   v_posed[n][v][c] = v_rest[(n)][v][c] + sum_k (pose[n][1 + k/9] - I)[k%9] * posedirs[v][c][k],  k < 207.
+// A [F frames x 207] x [207 x 3V] product, bandwidth-bound on the 3V x 207 posedirs (17 MB at V = 6890): posedirs are
+// stored TRANSPOSED [207][3V] at upload so that a wave's loads of one k are contiguous; a workgroup keeps the 207
+// coefficients of 8 frames in LDS and every posedirs element it loads serves those 8 frames.
+constexpr int kBlendFrames = 8;
+MP_KERNEL __launch_bounds__(256) void mp_pose_blend(const float* __restrict__ pose, long N, const float* __restrict__ vrest,
+                                                      long vrestStride, const float* __restrict__ posedirsT, int V3,
+                                                      float* __restrict__ vposed) {
+    __shared__ float r[kBlendFrames][208];
+    const long n0 = (long)blockIdx.y * kBlendFrames;
+    for (int e = threadIdx.x; e < kBlendFrames * 207; e += 256) {
+        const int f = e / 207, k = e - f * 207;
+        const long n = n0 + f;
+        float x = 0.f;
+        if (n < N) x = pose[n * 216 + 9 + k] - ((k % 9) % 4 == 0 ? 1.f : 0.f);      // minus the identity's diagonal
+        r[f][k] = x;
+    }
+    __syncthreads();
+    const int vc = blockIdx.x * 256 + threadIdx.x;
+    if (vc >= V3) return;
+    float acc[kBlendFrames];
+#pragma unroll
+    for (int f = 0; f < kBlendFrames; ++f) acc[f] = 0.f;
+    for (int k = 0; k < 207; ++k) {
+        const float p = posedirsT[(size_t)k * V3 + vc];
+#pragma unroll
+        for (int f = 0; f < kBlendFrames; ++f) acc[f] += r[f][k] * p;
+    }
+#pragma unroll
+    for (int f = 0; f < kBlendFrames; ++f) {
+        const long n = n0 + f;
+        if (n < N) vposed[(size_t)n * V3 + vc] = vrest[n * vrestStride + vc] + acc[f];
+    }
+}
+
+MP_KERNEL __launch_bounds__(256) void mp_transpose_posedirs(const float* __restrict__ src, int V3, float* __restrict__ dst) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;               // (k, vc) of the destination
+    if (gid >= (long)V3 * 207) return;
+    const long k = gid / V3, vc = gid - k * V3;
+    dst[gid] = src[vc * 207 + k];
+}
+
 }  // namespace
+
+void mp_launch_pose_blend(const float* pose, long N, const float* vrest, long vrestStride, const float* posedirsT, int V,
+                          float* vposed, hipStream_t s) {
+    if (N <= 0 || V <= 0) return;
+    const int V3 = V * 3;
+    for (long n0 = 0; n0 < N; n0 += 32768L * kBlendFrames) {                // grid.y limit
+        const long cnt = N - n0 < 32768L * kBlendFrames ? N - n0 : 32768L * kBlendFrames;
+        hipLaunchKernelGGL(mp_pose_blend, dim3((V3 + 255) / 256, (unsigned)((cnt + kBlendFrames - 1) / kBlendFrames)), dim3(256), 0,
+                           s, pose + n0 * 216, cnt, vrest + n0 * vrestStride, vrestStride, posedirsT, V3,
+                           vposed + (size_t)n0 * V3);
+    }
+}
+
+void mp_launch_transpose_posedirs(const float* src, int V, float* dst, hipStream_t s) {
+    const long n = (long)V * 3 * 207;
+    hipLaunchKernelGGL(mp_transpose_posedirs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, V * 3, dst);
+}
 
 void mp_launch_shape_body(const float* shape, int ns, const float* shapedirs, const float* vtemplate_raw,
                           const float* jreg, const int* parent_dev, int V, float* vrest, float* jraw, float* jrest,
@@ -273,8 +333,12 @@ void mp_launch_lbs(const float* rglobal, const float* joint, const float* tran, 
                    long jrestStride, const float* vrest_dev, long vrestStride, const float* weights_dev, int V,
                    float* vert, hipStream_t s) {
     if (N <= 0 || V <= 0) return;
-    hipLaunchKernelGGL(mp_lbs, dim3((V + 255) / 256, (unsigned)N), dim3(256), 0, s, rglobal, joint, tran, jrest_dev,
-                       jrestStride, vrest_dev, vrestStride, weights_dev, V, vert);
+    for (long n0 = 0; n0 < N; n0 += 32768) {                              // grid.y limit
+        const long cnt = N - n0 < 32768 ? N - n0 : 32768;
+        hipLaunchKernelGGL(mp_lbs, dim3((V + 255) / 256, (unsigned)cnt), dim3(256), 0, s, rglobal + n0 * 216, joint + n0 * 72,
+                           tran ? tran + n0 * 3 : nullptr, jrest_dev + n0 * jrestStride, jrestStride,
+                           vrest_dev + n0 * vrestStride, vrestStride, weights_dev, V, vert + (size_t)n0 * V * 3);
+    }
 }
 
 void mp_launch_r6d_ik_strided(const float* r6d, long N, long rowStride, long rowOffset, float* pose,

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .config import amass, datasets, paths
-from .model_utils import safe_torch_load
+from .model_utils import UntrustedFileError, safe_torch_load
 
 
 def rotation_matrix_to_r6d(r):
@@ -66,6 +66,8 @@ class PoseDataset:
         for name in names:
             try:                                                       # data.py:50-54: a bad file is reported, not fatal
                 yield safe_torch_load(folder / name, self._trusted)
+            except UntrustedFileError:
+                raise                                                  # not a broken file: the caller must decide (trusted=True)
             except Exception as e:
                 print(f"Error processing {name}: {e}.")
 

@@ -176,6 +176,8 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--model', type=str, required=True)
     ap.add_argument('--dataset', type=str, default='dip')
+    ap.add_argument('--trusted', action='store_true',
+                    help="unpickle --model / the dataset file in full (files you trust only; default: tensors and plain containers)")
     args = ap.parse_args(argv)
     from . import synthetic
     from .model_utils import load_model
@@ -183,13 +185,13 @@ def main(argv=None):
     if args.model == 'synthetic':
         model = MobilePoserNet().load_state_dict(synthetic.make_weights(0))
     else:
-        model = load_model(args.model)
+        model = load_model(args.model, trusted=args.trusted)
     if args.dataset == 'synthetic':
         dataset = PoseDataset(fold='test', evaluate='dip', data=synthetic_dataset(), fk=model.forward_kinematics)
     else:
         if args.dataset not in datasets.test_datasets:
             raise ValueError(f"Test dataset: {args.dataset} not found.")
-        dataset = PoseDataset(fold='test', evaluate=args.dataset, fk=model.forward_kinematics)
+        dataset = PoseDataset(fold='test', evaluate=args.dataset, fk=model.forward_kinematics, trusted=args.trusted)
     print(f"Starting evaluation: {args.dataset.capitalize()}")
     evaluate_pose(model, dataset)
 

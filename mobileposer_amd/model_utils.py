@@ -51,6 +51,11 @@ def normalise_state_dict(obj):
     return {k: sd[k] for k in man if k in sd} if all(k in sd for k in man) else sd
 
 
+class UntrustedFileError(RuntimeError):
+    """A file needs full unpickling and the caller has not declared it trusted.  A class of its own so that loaders which
+    tolerate broken files (PoseDataset: "a bad file is reported, not fatal", data.py:50-54) do not swallow it."""
+
+
 def safe_torch_load(path, trusted=False):
     """``torch.load`` restricted to tensors and plain containers (``weights_only=True``).  A file the safe loader refuses
     -- e.g. a Lightning checkpoint whose hyper-parameters pickle arbitrary classes -- is unpickled in full only when the
@@ -61,9 +66,11 @@ def safe_torch_load(path, trusted=False):
     import torch
     try:
         return torch.load(path, map_location="cpu", weights_only=True)
-    except pickle.UnpicklingError as e:
+    except (pickle.UnpicklingError, AttributeError, ImportError, ModuleNotFoundError, TypeError) as e:
+        # (everything the restricted unpickler raises on content it does not allow: UnpicklingError for unknown globals,
+        #  the others when a pickled class or its module cannot be resolved / rebuilt)
         if not (trusted or os.environ.get("MP_TRUSTED_CHECKPOINTS", "") not in ("", "0")):
-            raise RuntimeError("%s holds pickled objects beyond tensors and plain containers (%s); pass trusted=True (or set "
+            raise UntrustedFileError("%s holds pickled objects beyond tensors and plain containers (%s); pass trusted=True (or set "
                                "MP_TRUSTED_CHECKPOINTS=1) to unpickle it in full -- only for files you trust"
                                % (path, str(e).splitlines()[0])) from e
         return torch.load(path, map_location="cpu", weights_only=False)

@@ -31,6 +31,15 @@ def _ptr(t):
 _LIVE = weakref.WeakSet()       # nets that own a native handle
 
 
+def _env_graph_mode():
+    """MP_GRAPH as csrc/mp_api.hip reads it: unset, empty or starting with '0' = eager; starting with '2' = single-branch
+    graphs; anything else = multi-branch graphs."""
+    e = os.environ.get("MP_GRAPH", "")
+    if not e or e[0] == "0":
+        return 0
+    return 2 if e[0] == "2" else 1
+
+
 @atexit.register
 def _close_all():               # runs before interpreter finalisation, while the HIP runtime is still loaded
     for net in list(_LIVE):
@@ -113,7 +122,7 @@ class MobilePoserNet:
         self._h = None
         self._blob = None
         self._stream_S = 0
-        self._graph = int(os.environ.get("MP_GRAPH", "0") or 0)   # graph mode of the handle (set_graph_mode / env MP_GRAPH)
+        self._graph = _env_graph_mode()      # graph mode of the handle (set_graph_mode / env MP_GRAPH, parsed as the library does)
         self._graph_bufs = {}
         self._tick = 0                  # bumped by everything that changes per-stream state (cache key of stream_state)
         self._state_cache = {}
@@ -170,6 +179,10 @@ class MobilePoserNet:
         _lib.check(self._lib.mp_get_constants(self._h, C.byref(fy), fp), self._h)
         assert abs(fy.value - self.floor_y) < 1e-6
         self._stream_S = 0
+        # Python owns the graph mode: a fresh handle re-reads MP_GRAPH in C, which may differ from what set_graph_mode() last
+        # chose -- and a library that captures while the facade hands it fresh tensors every call captures on every call
+        _lib.check(self._lib.mp_set_graph_mode(self._h, int(self._graph)), self._h)
+        self._graph_bufs = {}
         self._mesh_state = {}
         upload_mesh(self._lib, self._h, self.bodymodel, self._mesh_state)
         self.n_vertex = self._mesh_state["n_vertex"]
@@ -209,8 +222,14 @@ class MobilePoserNet:
     def __enter__(self):
         return self
 
-    def __exit__(self, *exc):
-        self.close()
+    def __exit__(self, exc_type, exc, tb):
+        try:
+            self.close()
+        except RuntimeError as e:
+            if exc_type is None:
+                raise
+            # an exception from the body is already propagating: do not mask it with the close()-time device error
+            warnings.warn("MobilePoserNet.close(): %s" % e, RuntimeWarning, stacklevel=2)
 
     def __del__(self):
         # no reference cycles (the velocity view and the body model hold this object weakly), so this runs when the
@@ -442,7 +461,9 @@ class MobilePoserNet:
                     "last_lfoot_pos": feet[0], "last_rfoot_pos": feet[1]}
         hit = self._state_cache.get(s)
         if hit is not None and hit[0] == self._tick:
-            return hit[1]
+            # copies: in-place edits of a returned tensor must not look as if they had reached the device -- only
+            # ASSIGNMENT to the attribute writes through (mp_stream_set_state), as documented on the properties below
+            return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in hit[1].items()}
         win = torch.empty(45, 60, device=self.device, dtype=torch.float32)
         feet = (C.c_float * 6)()
         root = (C.c_float * 3)()
@@ -452,7 +473,7 @@ class MobilePoserNet:
         st = {"imu": None if fresh.value else win, "current_root_y": y.value if not fresh.value else 0,
               "last_root_pos": t(root), "last_lfoot_pos": t(feet[0:3]), "last_rfoot_pos": t(feet[3:6])}
         self._state_cache[s] = (self._tick, st)
-        return st
+        return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
 
     def _set_stream_state(self, name, value, s=0):
         """Assignment to one of the reference's state attributes (net.py:59-64) -> mp_stream_set_state."""
@@ -480,6 +501,9 @@ class MobilePoserNet:
                                                  root, C.byref(fresh) if fresh is not None else None), self._h)
         self._tick += 1                         # invalidates the read-back cache
 
+    # Reads return COPIES of the device state (one round trip per tick, shared by the five attributes); assignment
+    # (``model.last_root_pos = t``, ``model.imu = None``) writes through to the device.  In-place edits of a value read
+    # earlier (``model.last_root_pos[1] = 0``) change only that copy -- assign the edited tensor back.
     def _state_property(name):
         return property(lambda self: self.stream_state()[name], lambda self, v: self._set_stream_state(name, v))
 
@@ -525,7 +549,11 @@ class MobilePoserNet:
             raise RuntimeError("prediction has %d frames, ground truth %d" % (N, int(pt.shape[0])))
         tp = None if tran_p is None else f(tran_p).reshape(N, 3)
         tt = None if tran_t is None else f(tran_t).reshape(N, 3)
-        bits = lambda js: sum(1 << int(j) for j in js) if js is not None else 0
+        def bits(js):
+            js = [] if js is None else [int(j) for j in js]
+            if any(j < 0 or j > 23 for j in js):
+                raise ValueError("joint indices must be in 0..23, got %s" % (js,))
+            return sum(1 << j for j in set(js))
         table = torch.empty(10, 2, device=self.device, dtype=torch.float32)
         _lib.check(self._lib.mp_eval_metrics(self._h, _ptr(pp), _ptr(pt), _ptr(tp), _ptr(tt), N, int(fps), int(align_joint),
                                              bits(joint_mask), bits(ignored), int(self.n_vertex > 0), _ptr(table),

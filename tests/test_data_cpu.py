@@ -74,3 +74,21 @@ def test_checkpoints_are_unpickled_in_full_only_when_trusted(tmp_path):
     with pytest.raises(RuntimeError, match="trusted=True"):
         safe_torch_load(fancy)
     assert safe_torch_load(fancy, trusted=True)["hyper_parameters"].lr == 1e-3
+
+
+def test_untrusted_dataset_file_is_not_swallowed_as_a_broken_file(tmp_path, monkeypatch):
+    """The per-file ``except Exception: print(...)`` of the source loop (data.py:50-54) must not turn "this file needs
+    trusted=True" into an empty dataset (ADVICE r3): the refusal escapes, and trusted=True reads the file."""
+    import pytest
+    from mobileposer_amd import config
+    from mobileposer_amd.model_utils import UntrustedFileError
+    g = load_golden("g8_dataset.npz")
+    data = {k: [torch.from_numpy(g[f"in{i}_{k}"]) for i in range(2)] for k in ("acc", "ori", "pose", "tran")}
+    data["meta"] = _Hyper()                                    # something the safe loader refuses
+    (tmp_path / "eval").mkdir()
+    torch.save(data, tmp_path / "eval" / "dip_test.pt")
+    monkeypatch.setattr(config.paths, "processed_datasets", tmp_path)
+    fk = lambda pose: (pose, torch.zeros(pose.shape[0], 24, 3))
+    with pytest.raises(UntrustedFileError, match="trusted=True"):
+        PoseDataset(fold='test', evaluate='dip', fk=fk)
+    assert len(PoseDataset(fold='test', evaluate='dip', fk=fk, trusted=True)) == 24

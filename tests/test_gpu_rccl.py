@@ -1,0 +1,79 @@
+"""The RCCL branch of bench.py on the hardware there is: ONE rank under torch.distributed.run on the leased MI355X
+(no 8-GPU node was available to any round so far).  What this exercises on a real GPU, that the gloo dry
+run on CPU cannot: init_process_group("nccl") with a device id, the gloo side group for the barriers, the broadcast of the
+weight blob + SMPL constants as CUDA tensors, a model built from the blob in HBM (mp_create_from_device) under a rank, the
+MAX all-reduce over ranks, the all-gathers behind n_ranks_seen / per_rank -- and that none of it costs step time or changes
+a single output bit against the plain single-process run.  The JSON lines are kept under gpurun_out/ (copied to profiles/)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _bench(argv, launcher):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable]
+    if launcher:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())]
+    cmd += [os.path.join(REPO, "bench.py"), "--gpus", "1", "--no-cpu-baseline"] + argv
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    return json.loads(lines[0])
+
+
+def _keep(name, line):
+    out = os.path.join(REPO, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, name), "w") as f:
+            json.dump(line, f, indent=1)
+    except OSError:
+        pass
+
+
+def test_one_rank_rccl_launch_matches_the_plain_run():
+    args = ["--steps", "50", "--warmup", "5"]
+    plain = _bench(args, launcher=False)
+    ranked = _bench(args, launcher=True)
+    _keep("r04_rccl_1rank_weak.json", ranked)
+    _keep("r04_plain_1gpu.json", plain)
+    assert plain["n_ranks_seen"] == 1 and "per_rank" not in plain
+    assert ranked["n_gpus"] == 1 and ranked["n_ranks_seen"] == 1
+    assert [p["rank"] for p in ranked["per_rank"]] == [0] and ranked["per_rank"][0]["frames"] == 256 * 125 * 50
+    assert "RCCL" in ranked["config"]["launcher"] and ranked["config"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # the model built from the broadcast blob in HBM computes the same bits as the one built from host weights
+    assert ranked["output_sha1"] == plain["output_sha1"]
+    # and the process group costs no step time (host-side barriers; same box, back to back)
+    ratio = ranked["ms_per_step"] / plain["ms_per_step"]
+    print("1-rank RCCL launch: %.4f ms/step, plain: %.4f ms/step, ratio %.4f" % (ranked["ms_per_step"], plain["ms_per_step"], ratio))
+    assert 0.95 < ratio < 1.05, (ranked["ms_per_step"], plain["ms_per_step"])
+    assert ranked["config"]["recoveries_during_run"] == 0
+
+
+def test_one_rank_rccl_launch_strong_scaling_and_streams():
+    strong = _bench(["--steps", "10", "--warmup", "2", "--scaling", "strong"], launcher=True)
+    _keep("r04_rccl_1rank_strong.json", strong)
+    assert strong["n_ranks_seen"] == 1 and strong["scaling"] == "strong" and strong["config"]["global_batch"] == 1024
+    assert strong["per_rank"][0]["frames"] == 1024 * 125 * 10
+    stream = _bench(["--steps", "10", "--warmup", "2", "--workload", "stream", "--streams", "512"], launcher=True)
+    _keep("r04_rccl_1rank_stream.json", stream)
+    assert stream["n_ranks_seen"] == 1 and stream["config"]["streams_per_gpu"] == 512 and stream["config"]["meets_60hz"]

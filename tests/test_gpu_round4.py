@@ -1,0 +1,315 @@
+"""Round-4 GPU parity tests: the inputs the round-3 verdict found missing.
+
+  * weights in the TRAINED regime (synthetic.make_weights(0, profile="trained"): LSTM weights x 3, forget bias + 1, linear1 x 2)
+    against golden G14 recorded from the reference -- ragged mixed-combo forward, forward_offline at T = 600, 50 online
+    frames -- and against the oracle at the BASELINE size 256 x 125; a second init-scale seed; all 12 sensor combos
+    (config.py:60-73, data.py:69-76) in one batch.  Exact-fp32 operands (mode 1, the library default) must meet 1e-4 / 1 mm
+    everywhere.  The opt-in split-bf16 mode (mode 3) is measured on the same inputs: X3_TOL is what it is held to, and
+    where that is wider than 1e-4 the header / INTEGRATION.md say so.
+  * the mesh kernels at the real SMPL size (6890 vertices = 26 x 256 + 234) and at chunk edges (V = 257, 512), golden G15:
+    forward_kinematics(calc_mesh), with shape, zero-pose body of a shape, pose blend shapes, the evaluator table.
+  * the state a failed call carries forward: after a reported device error with recovery off the next call is finite.
+  * the RCCL branch of bench.py on the one GPU there is: a 1-rank torch.distributed.run launch (tests/test_gpu_rccl.py).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import cu, geodesic, load_golden, npy
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+TOL_TRAN = 1e-3
+# what each operand mode is held to on trained-regime weights (max abs error on raw network outputs / rad on rotations)
+MODE_TOL = {"fp32": 1e-4, "x3": 1e-4}
+
+
+@pytest.fixture(scope="module")
+def weights_trained():
+    from mobileposer_amd.synthetic import make_weights
+    return make_weights(0, profile="trained")
+
+
+@pytest.fixture(params=["fp32", "x3"])
+def tnet(request, torch_mod, weights_trained, smpl):
+    """A net with trained-regime weights, once per operand mode."""
+    from mobileposer_amd.net import MobilePoserNet
+    n = MobilePoserNet.from_numpy(weights_trained, smpl, device="cuda:0")
+    n.mode_name = request.param
+    n.set_lstm_mode(3 if request.param == "x3" else 1)
+    yield n
+    n.close()
+
+
+def test_g14_trained_forward_ragged_mixed_combos(torch_mod, tnet):
+    g = load_golden("g14_trained.npz")
+    tol = MODE_TOL[tnet.mode_name]
+    lengths = g["lengths"].tolist()
+    pose, joints, vel, contact, r6d = tnet.forward(cu(torch_mod, g["imu"]), lengths, return_r6d=True)
+    errs = {}
+    for b, n in enumerate(lengths):                       # rows past a sequence's length are padding on both sides
+        for name, got, want in (("joints", joints, g["joints"]), ("vel", vel, g["vel"]), ("contact", contact, g["contact"]),
+                                ("r6d", r6d, g["r6d"])):
+            errs[name] = max(errs.get(name, 0.0), float(np.abs(npy(got)[b, :n] - want[b, :n]).max()))
+    errs["pose"] = float(geodesic(npy(pose), g["pose"]).max())
+    h, c = tnet.velocity.rnn_state
+    errs["vel_h"], errs["vel_c"] = float(np.abs(npy(h) - g["vel_h"]).max()), float(np.abs(npy(c) - g["vel_c"]).max())
+    print("G14 ragged forward, mode %s: %s" % (tnet.mode_name, {k: "%.2e" % v for k, v in errs.items()}))
+    assert max(errs.values()) < tol, errs
+
+
+def test_g14_trained_offline_600_frames(torch_mod, tnet):
+    g = load_golden("g14_trained.npz")
+    tol = MODE_TOL[tnet.mode_name]
+    tnet.reset_all()
+    pose, joints, tran, contact = tnet.forward_offline(cu(torch_mod, g["off_imu"]), [600])
+    e = {"pose": float(geodesic(npy(pose), g["off_pose"]).max()), "joints": float(np.abs(npy(joints) - g["off_joints"]).max()),
+         "contact": float(np.abs(npy(contact) - g["off_contact"]).max()), "tran": float(np.abs(npy(tran) - g["off_tran"]).max())}
+    print("G14 offline T=600, mode %s: %s" % (tnet.mode_name, {k: "%.2e" % v for k, v in e.items()}))
+    assert e["pose"] < tol and e["joints"] < tol and e["contact"] < tol, e
+    assert e["tran"] < TOL_TRAN, e                      # 1 mm after 600 accumulated frames (net.py:154)
+
+
+def test_g14_trained_online_50_frames(torch_mod, tnet):
+    g = load_golden("g14_trained.npz")
+    tol = MODE_TOL[tnet.mode_name]
+    tnet.reset_all()
+    worst = {"pose": 0.0, "joints": 0.0, "contact": 0.0, "tran": 0.0}
+    for k, f in enumerate(g["on_imu"]):
+        pose, joints, tran, contact = tnet.forward_online(cu(torch_mod, f))
+        worst["pose"] = max(worst["pose"], float(geodesic(npy(pose).reshape(24, 3, 3), g["on_pose"][k].reshape(24, 3, 3)).max()))
+        worst["joints"] = max(worst["joints"], float(np.abs(npy(joints)[40] - g["on_joints40"][k]).max()))
+        worst["contact"] = max(worst["contact"], float(np.abs(npy(contact) - g["on_contact"][k]).max()))
+        worst["tran"] = max(worst["tran"], float(np.abs(npy(tran) - g["on_tran"][k]).max()))
+    h, c = tnet.velocity.rnn_state
+    worst["vel_c"] = float(np.abs(npy(c) - g["on_vel_c"]).max())
+    print("G14 online x50, mode %s: %s" % (tnet.mode_name, {k: "%.2e" % v for k, v in worst.items()}))
+    assert worst["pose"] < tol and worst["joints"] < tol and worst["contact"] < tol and worst["vel_c"] < tol, worst
+    assert worst["tran"] < TOL_TRAN, worst
+
+
+@pytest.mark.parametrize("tag", ["tr", "s1"])
+@pytest.mark.parametrize("mode", ["fp32", "x3"])
+def test_g14_all_twelve_combos(torch_mod, weights_trained, smpl, tag, mode):
+    """Row k of the batch keeps the devices of combo k: all 12 of config.py:60-73 through one forward; trained profile and
+    a second init-scale seed (make_weights(1))."""
+    from mobileposer_amd.net import MobilePoserNet
+    from mobileposer_amd.synthetic import make_weights
+    g = load_golden("g14_trained.npz")
+    sd = weights_trained if tag == "tr" else make_weights(1)
+    with MobilePoserNet.from_numpy(sd, smpl) as n:
+        n.set_lstm_mode(3 if mode == "x3" else 1)
+        pose, joints, vel, contact, r6d = n.forward(cu(torch_mod, g["c12_imu"]), [40] * 12, return_r6d=True)
+        e = {"joints": float(np.abs(npy(joints) - g[f"c12_{tag}_joints"]).max()), "vel": float(np.abs(npy(vel) - g[f"c12_{tag}_vel"]).max()),
+             "contact": float(np.abs(npy(contact) - g[f"c12_{tag}_contact"]).max()), "r6d": float(np.abs(npy(r6d) - g[f"c12_{tag}_r6d"]).max())}
+        print("G14 12 combos (%s), mode %s: %s" % (tag, mode, {k: "%.2e" % v for k, v in e.items()}))
+        assert max(e.values()) < MODE_TOL[mode], e
+        assert n.device_error() == 0
+
+
+@pytest.mark.parametrize("profile,seed", [("trained", 0), ("init", 1)])
+@pytest.mark.parametrize("mode", ["fp32", "x3"])
+def test_baseline_size_vs_oracle_other_weights(torch_mod, smpl, profile, seed, mode):
+    """256 x 125 (the BASELINE shape, every schedule decision of the headline) against the oracle with weights other than
+    the one draw rounds 1-3 tested: the trained profile, and a second init-scale seed.  All 12 combos appear in the batch
+    (row b uses combo b % 12)."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.config import amass
+    from mobileposer_amd.net import MobilePoserNet
+    from oracle import mp_oracle as O
+    B, T = 256, 125
+    names = list(amass.combos)
+    sd = synthetic.make_weights(seed, profile=profile)
+    imu = synthetic.make_imu(B, T, seed=40 + seed, combo=[names[b % 12] for b in range(B)])
+    ref = O.OracleNet(sd, smpl["J"])
+    rpose, rjoints, rvel, rcontact = ref.forward(imu, [T] * B)
+    with MobilePoserNet.from_numpy(sd, smpl) as n:
+        n.set_lstm_mode(3 if mode == "x3" else 1)
+        pose, joints, vel, contact, r6d = n.forward(cu(torch_mod, imu), [T] * B, return_r6d=True)
+        e = {"joints": float(np.abs(npy(joints) - rjoints).max()), "vel": float(np.abs(npy(vel) - rvel).max()),
+             "contact": float(np.abs(npy(contact) - rcontact).max()), "r6d": float(np.abs(npy(r6d) - ref._last_r6d).max()),
+             "pose": float(geodesic(npy(pose), rpose).max())}
+        print("256x125 vs oracle, %s seed %d, mode %s: %s" % (profile, seed, mode, {k: "%.2e" % v for k, v in e.items()}))
+        assert max(e.values()) < MODE_TOL[mode], e
+        # translation of every 16th row through the batched solver, 1 mm
+        tran = torch_mod.empty(B, T, 3, device="cuda")
+        n.translate_offline_into(joints, vel.reshape(B, T, 72), contact, (C.c_int32 * B)(*([T] * B)), tran)
+        tran_h = npy(tran)
+        for b in range(0, B, 16):
+            rt = O.translate_offline(rjoints[b].reshape(T, 24, 3), rvel[b], rcontact[b], ref.floor_y)
+            assert np.abs(tran_h[b] - rt).max() < TOL_TRAN, b
+        assert n.device_error() == 0 and n.recovery_count == 0
+
+
+# ---- the mesh kernels at the real size -------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def big_body(torch_mod):
+    from mobileposer_amd.body_model import ParametricModel
+    from mobileposer_amd.synthetic import synthetic_smpl
+    data = synthetic_smpl(n_vertex=6890)
+    bm = ParametricModel(data=data)
+    yield bm, data
+    bm.close()
+
+
+def test_g15_mesh_6890_golden(torch_mod, big_body):
+    """forward_kinematics(calc_mesh=True) at V = 6890 (27 vertex chunks, the last one 234 wide), with and without shape,
+    against the reference's own outputs; and get_zero_pose_joint_and_vertex(shape) (articulate/model.py:84-89)."""
+    bm, _ = big_body
+    g = load_golden("g15_mesh6890.npz")
+    pose, tran, shape = cu(torch_mod, g["pose"]), cu(torch_mod, g["tran"]), cu(torch_mod, g["shape"])
+    _, jg, vg = bm.forward_kinematics(pose, tran=tran, calc_mesh=True)
+    assert tuple(vg.shape) == (3, 6890, 3)
+    assert np.abs(npy(jg) - g["joint"]).max() < 1e-5 and np.abs(npy(vg) - g["vert"]).max() < 1e-5
+    _, jg, vg = bm.forward_kinematics(pose, shape=shape, tran=tran, calc_mesh=True)
+    assert np.abs(npy(jg) - g["shape_joint"]).max() < 1e-5 and np.abs(npy(vg) - g["shape_vert"]).max() < 2e-5
+    j0, v0 = bm.get_zero_pose_joint_and_vertex(shape[:2])
+    assert tuple(j0.shape) == (2, 24, 3) and tuple(v0.shape) == (2, 6890, 3)
+    assert np.abs(npy(j0) - g["zero_joint"]).max() < 1e-5 and np.abs(npy(v0) - g["zero_vert"]).max() < 1e-5
+    jn, vn = bm.get_zero_pose_joint_and_vertex()                       # shape None: host constants, as before
+    assert jn.shape == (24, 3) and vn.shape == (6890, 3) and np.abs(jn[0]).max() == 0
+
+
+def test_g15_pose_blend_shapes(torch_mod):
+    """ParametricModel(use_pose_blendshape=True) (articulate/model.py:236-238): vertices skinned from
+    v + posedirs . (pose[1:] - I), with and without a shape, against the reference."""
+    from mobileposer_amd.body_model import ParametricModel
+    from mobileposer_amd.synthetic import synthetic_smpl
+    g = load_golden("g15_mesh6890.npz")
+    bm = ParametricModel(data=synthetic_smpl(n_vertex=6890), use_pose_blendshape=True)
+    try:
+        pose, tran, shape = cu(torch_mod, g["pose"]), cu(torch_mod, g["tran"]), cu(torch_mod, g["shape"])
+        _, jg, vg = bm.forward_kinematics(pose, shape=shape[:1], tran=tran, calc_mesh=True)
+        assert np.abs(npy(jg) - g["blend_joint"]).max() < 1e-5
+        assert np.abs(npy(vg) - g["blend_vert"]).max() < 2e-5
+        _, _, vg = bm.forward_kinematics(pose, calc_mesh=True)
+        assert np.abs(npy(vg) - g["blend_vert_noshape"]).max() < 2e-5
+    finally:
+        bm.close()
+
+
+@pytest.mark.parametrize("V", [96, 257, 512, 6890])
+def test_mesh_and_evaluator_vs_oracle_at_chunk_edges(torch_mod, weights, V):
+    """mp_lbs / mp_shape_* / mp_eval_metrics for N = 40 frames at V = 96 (one partial chunk), 257 (a 1-vertex tail), 512 (two
+    full chunks) and 6890 (the real mesh) against the numpy oracle (size-agnostic; pinned at V = 96 by G6 / G9 / G12 and at
+    V = 6890 by G15)."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    from oracle import mp_oracle as O
+    data = synthetic.synthetic_smpl(n_vertex=V)
+    rng = np.random.Generator(np.random.PCG64(500 + V))
+    N = 40
+    pose_t = synthetic._random_rotations(rng, N * 24).reshape(N, 24, 3, 3).astype(np.float32)
+    from scipy.spatial.transform import Rotation
+    noise = Rotation.from_rotvec((rng.standard_normal((N * 24, 3)) * 0.1)).as_matrix().reshape(N, 24, 3, 3)
+    pose_p = np.einsum("njab,njbc->njac", pose_t, noise).astype(np.float32)
+    tran_t = np.cumsum(rng.standard_normal((N, 3)) * 0.02, axis=0).astype(np.float32)
+    tran_p = (tran_t + np.cumsum(rng.standard_normal((N, 3)) * 0.005, axis=0)).astype(np.float32)
+    shape = (rng.standard_normal((N, 10)) * 1.2).astype(np.float32)
+    with MobilePoserNet.from_numpy(weights, data) as n:
+        Rg, jg, vg = n.forward_kinematics(cu(torch_mod, pose_p), tran=cu(torch_mod, tran_p), calc_mesh=True)
+        rRg, rjg, rvg = O.forward_kinematics_mesh(pose_p, data, tran=tran_p)
+        assert np.abs(npy(vg) - rvg).max() < 2e-5 and np.abs(npy(jg) - rjg).max() < 1e-5
+        Rg, jg, vg = n.forward_kinematics(cu(torch_mod, pose_p), tran=cu(torch_mod, tran_p), calc_mesh=True, shape=cu(torch_mod, shape))
+        rRg, rjg, rvg = O.forward_kinematics_shape(pose_p, data, shape, tran=tran_p)
+        assert np.abs(npy(vg) - rvg).max() < 3e-5 and np.abs(npy(jg) - rjg).max() < 2e-5
+        ign = O.IGNORED
+        table = npy(n.eval_metrics(pose_p, pose_t, tran_p, tran_t, fps=30, joint_mask=[2, 5, 16, 20], ignored=ign))
+        pp, pt = pose_p.copy(), pose_t.copy()
+        pp[:, ign] = np.eye(3)
+        pt[:, ign] = np.eye(3)
+        want = O.full_motion_evaluator(pp, pt, data, tran_p, tran_t, fps=30)
+        np.testing.assert_allclose(table, want, rtol=2e-4, atol=2e-5)
+        with pytest.raises(ValueError):
+            n.eval_metrics(pose_p, pose_t, joint_mask=[32])
+        assert n.device_error() == 0
+
+
+# ---- carried state after a reported device error ---------------------------------------------------------
+def _starve(m, skip=0, launches=1):
+    assert m._lib.mp_debug_drop_workgroup(m._h, 8, skip, launches) == 0
+
+
+def test_call_after_a_reported_error_is_finite_without_reset(torch_mod, weights, smpl, monkeypatch):
+    """Recovery off: a starved call leaves NaN in the velocity state it updates in place.  Once the error has been reported
+    (finish() raises) the handle drops that state, so the NEXT call -- with no reset by the caller -- is finite and equals
+    a call from zero state."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    monkeypatch.setenv("MP_WAIT_MS", "15")
+    B, T = 256, 20
+    x = cu(torch_mod, synthetic.make_imu(B, T, seed=80))
+    with MobilePoserNet.from_numpy(weights, smpl) as m:
+        m.set_lstm_mode(1)
+        m.set_recovery(False)
+        want = [t.clone() for t in m.forward_offline(x, [T] * B)]          # from zero state
+        m.finish()
+        m.reset_all()
+        _starve(m, skip=4)                                                  # velocity layer 0 of the next forward
+        m.forward_offline(x, [T] * B)
+        with pytest.raises(RuntimeError, match="state it carried forward is lost"):
+            m.finish()
+        assert m.velocity.rnn_state is None                                # dropped, like `model.velocity.rnn_state = None`
+        got = m.forward_offline(x, [T] * B)                                 # NO reset in between
+        m.finish()
+        for a, b in zip(want, got):
+            assert bool(torch_mod.isfinite(b).all())
+            assert float((a - b).abs().max()) < 2e-5
+
+
+def test_stream_tick_after_a_reported_error_is_finite(torch_mod, weights, smpl, monkeypatch):
+    """The same for streaming: a starved tick with recovery off derives root height / position and last foot positions from
+    NaN outputs.  After the error is reported every stream is back to its state after construction; later ticks are finite
+    and equal those of a fresh model fed the same frames."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    monkeypatch.setenv("MP_WAIT_MS", "15")
+    S = 256
+    frames = cu(torch_mod, synthetic.make_imu(S, 6, seed=81))
+    with MobilePoserNet.from_numpy(weights, smpl) as m, MobilePoserNet.from_numpy(weights, smpl) as fresh:
+        for n in (m, fresh):
+            n.set_lstm_mode(1)
+            n.stream_create(S)
+        m.set_recovery(False)
+        m.stream_step(frames[:, 0])
+        m.finish()
+        _starve(m, skip=4)
+        m.stream_step(frames[:, 1])                                         # poisoned tick
+        with pytest.raises(RuntimeError, match="all streams reset"):
+            m.finish()
+        for k in (2, 3, 4):
+            got = m.stream_step(frames[:, k])
+            want = fresh.stream_step(frames[:, k])
+            m.finish()
+            for a, b in zip(want, got):
+                assert bool(torch_mod.isfinite(b).all()), k
+                assert float((a - b).abs().max()) < 2e-5, k
+
+
+def test_rnn_forward_repairs_an_aliased_state(torch_mod, weights, smpl, monkeypatch):
+    """mp_rnn_forward with state_in_dev == state_out_dev (in-place state): a starved fused run overwrites the initial state
+    with NaN; recovery restores it from its snapshot before the per-step re-run."""
+    import warnings
+    from mobileposer_amd.net import MobilePoserNet, _ptr
+    monkeypatch.setenv("MP_WAIT_MS", "15")
+    B, T = 256, 12
+    rng = np.random.Generator(np.random.PCG64(82))
+    x = cu(torch_mod, (rng.standard_normal((B, T, 132)) * 0.5).astype(np.float32))
+    st0 = cu(torch_mod, (rng.standard_normal((2, 2, B, 256)) * 0.3).astype(np.float32))
+    lens = (C.c_int32 * B)(*([T] * B))
+    with MobilePoserNet.from_numpy(weights, smpl) as m:
+        m.set_lstm_mode(1)
+        y_ref = torch_mod.empty(B, T, 72, device="cuda")
+        st_ref = st0.clone()
+        assert m._lib.mp_rnn_forward(m._h, 3, _ptr(x), lens, B, T, _ptr(y_ref), _ptr(st_ref), _ptr(st_ref), m._stream()) == 0
+        y = torch_mod.empty(B, T, 72, device="cuda")
+        st = st0.clone()
+        _starve(m)
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter("always")
+            assert m._lib.mp_rnn_forward(m._h, 3, _ptr(x), lens, B, T, _ptr(y), _ptr(st), _ptr(st), m._stream()) == 0
+        assert m.recovery_count == 1
+        assert bool(torch_mod.isfinite(y).all()) and bool(torch_mod.isfinite(st).all())
+        assert float((y - y_ref).abs().max()) < 2e-5 and float((st - st_ref).abs().max()) < 2e-5
