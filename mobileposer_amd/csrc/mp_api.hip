@@ -234,7 +234,7 @@ struct mp_handle {
 namespace {
 
 int fail(mp_handle* h, int code, const char* fmt, ...) {
-    char buf[512];
+    char buf[1024];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);

@@ -163,7 +163,11 @@ def test_state_attributes_can_be_assigned(torch_mod, net):
     net.reset_all()
     net.forward_online(frames[0])
     a = net.last_root_pos
-    assert net.last_root_pos is a                                   # cached until the next tick
+    assert net._state_cache[0][0] == net._tick                      # one round trip per tick: the second read is served from it
+    b = net.last_root_pos
+    assert b is not a and torch_mod.equal(a, b)                     # ... as a COPY: an in-place edit of a value read earlier
+    a[1] = 123.0                                                    # does not masquerade as device state (only assignment
+    assert float(net.last_root_pos[1]) != 123.0                     # writes through)
     net.last_root_pos = torch_mod.tensor([1.0, 2.0, 3.0])
     assert npy(net.last_root_pos).tolist() == [1.0, 2.0, 3.0]
     net.current_root_y = 0.25
