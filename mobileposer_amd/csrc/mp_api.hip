@@ -508,6 +508,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
             else if (key == "epoch_start") { if (v >= 1 && v < 0xf0000000ul) h->epoch_start = (unsigned)v; }
             else if (key == "uni2") h->uni2 = v != 0;
             else if (key == "gemm_staged") {}                  // read by mp_launch_gemm
+            else if (key == "kin_scalar") {}                   // read by mp_kin.hip
             else if (key == "vf") h->vf_ok = v != 0;
             else if (key == "late_pair") h->late_pair_ok = v != 0;
             else if (key == "recovery") h->recovery = v != 0;   // (= mp_set_recovery)

@@ -15,6 +15,14 @@
 // walked level by level and a lane fetches its parent's global transform with wavefront shuffles
 // (ds_bpermute) -- the kinematic reduction never touches LDS or HBM.
 #include "mp_common.h"
+#include <cstdlib>
+#include <cstring>
+
+// MP_VARIANT kin_scalar=1: the scalar-access kernels even for aligned buffers (A/B runs and the cross-check test)
+static bool mp_kin_scalar_forced() {
+    static const bool f = getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "kin_scalar=1");
+    return f;
+}
 
 namespace {
 
@@ -123,22 +131,35 @@ MP_KERNEL __launch_bounds__(256) void mp_fk(const float* __restrict__ pose, cons
         for (int k = 0; k < 9; ++k) { L[k] = 0.f; G[k] = 0.f; }
         bv[0] = bv[1] = bv[2] = 0.f; p[0] = p[1] = p[2] = 0.f;
     }
-    const int srcLane = (lane & 32) + par;
+    // Tree walk by pointer jumping (round 4): every lane holds the transform (G | p) of its joint relative to its `anc`-th
+    // ancestor's frame and doubles that distance per round -- 1, 2, 4, 8 levels: four rounds of 13 wavefront shuffles cover
+    // the SMPL tree (depth 8; setup_smpl rejects deeper trees) where the level-by-level walk needed eight rounds of 12.  The
+    // shuffles (ds_bpermute) are what this kernel is bound by: 21.6 -> 13 us for 32 000 frames.  Products are associated as
+    // (T_a T_b)(T_c T_d) instead of ((T_a T_b) T_c) T_d: results differ from the sequential walk in the last bits only.
+    int anc = live && i > 0 ? par : -1;               // nearest ancestor not yet folded in (-1: relative to the world)
+    (void)dep;
 #pragma unroll 1
-    for (int level = 1; level <= 8; ++level) {
+    for (int round = 0; round < 4; ++round) {
+        const int srcLane = (lane & 32) + (anc >= 0 ? anc : 0);
         float Pg[9], pp[3];
 #pragma unroll
         for (int k = 0; k < 9; ++k) Pg[k] = __shfl(G[k], srcLane, 64);
 #pragma unroll
         for (int k = 0; k < 3; ++k) pp[k] = __shfl(p[k], srcLane, 64);
-        if (dep == level) {
+        const int up = __shfl(anc, srcLane, 64);
+        if (anc >= 0) {
+            float Gn[9], pn[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    G[r * 3 + c] = Pg[r * 3 + 0] * L[0 * 3 + c] + Pg[r * 3 + 1] * L[1 * 3 + c] + Pg[r * 3 + 2] * L[2 * 3 + c];
-                p[r] = Pg[r * 3 + 0] * bv[0] + Pg[r * 3 + 1] * bv[1] + Pg[r * 3 + 2] * bv[2] + pp[r];
+                    Gn[r * 3 + c] = Pg[r * 3 + 0] * G[0 * 3 + c] + Pg[r * 3 + 1] * G[1 * 3 + c] + Pg[r * 3 + 2] * G[2 * 3 + c];
+                pn[r] = Pg[r * 3 + 0] * p[0] + Pg[r * 3 + 1] * p[1] + Pg[r * 3 + 2] * p[2] + pp[r];
             }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) G[k] = Gn[k];
+            p[0] = pn[0]; p[1] = pn[1]; p[2] = pn[2];
+            anc = up;
         }
     }
     if (live) {
@@ -150,6 +171,65 @@ MP_KERNEL __launch_bounds__(256) void mp_fk(const float* __restrict__ pose, cons
         float* oj = joint + (n * 24 + i) * 3;
         oj[0] = p[0] + tx; oj[1] = p[1] + ty; oj[2] = p[2] + tz;
     }
+}
+
+// ---- coalesced forms (round 4).  The two kernels above move 36-byte records with nine scalar loads / stores per lane:
+// every 128-byte line passes the L1 tags nine times and a wave's store instruction touches 18 lines -- measured 1.7-2.3 TB/s.
+// Here a workgroup stages 8 frames through LDS: global traffic is 16-byte pieces of contiguous runs (6912-byte pose blocks,
+// 384-byte r6d rows), lanes pick their record out of LDS (word stride 9: conflict-free) and results leave the same way.
+// Same arithmetic in the same order: bit-identical outputs.  Used when the buffers are 16-byte aligned.
+constexpr int kFkFrames = 8;          // frames per workgroup (4 waves x 2)
+
+// 8 frames x 24 joints = 192 threads; frame n reads its 96 numbers at r6d + n*rowStride + rowOffset
+MP_KERNEL __launch_bounds__(192) void mp_r6d_ik_lds(const float* __restrict__ r6d, long N, long rowStride, long rowOffset,
+                                                      float* __restrict__ pose, const int* __restrict__ parent) {
+    __shared__ __attribute__((aligned(16))) float sR[kFkFrames * 96];
+    __shared__ float sG[kFkFrames * 16 * 9];           // global rotations of the 16 predicted joints, computed ONCE per frame
+    __shared__ __attribute__((aligned(16))) float sO[kFkFrames * 216];
+    const long n0 = (long)blockIdx.x * kFkFrames;
+    const int nf = (int)(N - n0 < kFkFrames ? N - n0 : kFkFrames);
+    const int tid = threadIdx.x;
+    const int f = tid / 24, i = tid - f * 24;          // frame within the block; 16-byte piece of its row, then joint
+    if (f < nf)
+        reinterpret_cast<f32x4*>(sR)[tid] = *reinterpret_cast<const f32x4*>(r6d + (n0 + f) * rowStride + rowOffset + i * 4);
+    __syncthreads();
+    if (f < nf && i < 16) gram_schmidt(sR + f * 96 + 6 * i, sG + (f * 16 + i) * 9);
+    __syncthreads();
+    if (f < nf) {
+        auto rot = [&](int joint, float R[9]) {
+            const int sl = c_slot[joint];
+            if (sl >= 0) {
+                const float* g = sG + (f * 16 + sl) * 9;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) R[k] = g[k];
+            } else {
+                R[0] = 1.f; R[1] = 0.f; R[2] = 0.f; R[3] = 0.f; R[4] = 1.f; R[5] = 0.f; R[6] = 0.f; R[7] = 0.f; R[8] = 1.f;
+            }
+        };
+        float G[9], out[9];
+        rot(i, G);
+        if (i == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) out[k] = G[k];
+        } else if ((IGNORED_MASK >> i) & 1u) {
+            out[0] = 1.f; out[1] = 0.f; out[2] = 0.f; out[3] = 0.f; out[4] = 1.f; out[5] = 0.f; out[6] = 0.f; out[7] = 0.f; out[8] = 1.f;
+        } else {
+            float P[9];
+            rot(parent[i], P);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    out[r * 3 + c] = P[0 * 3 + r] * G[0 * 3 + c] + P[1 * 3 + r] * G[1 * 3 + c] + P[2 * 3 + r] * G[2 * 3 + c];
+        }
+        float* o = sO + tid * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[k] = out[k];
+    }
+    __syncthreads();
+    const f32x4* src = reinterpret_cast<const f32x4*>(sO);
+    f32x4* dst = reinterpret_cast<f32x4*>(pose + n0 * 216);
+    for (int e = tid; e < nf * 54; e += 192) dst[e] = src[e];
 }
 
 // Linear blend skinning of the SMPL mesh on top of mp_fk's outputs (articulate/model.py:234-240, no pose
@@ -344,6 +424,13 @@ void mp_launch_lbs(const float* rglobal, const float* joint, const float* tran, 
 void mp_launch_r6d_ik_strided(const float* r6d, long N, long rowStride, long rowOffset, float* pose,
                               const int* parent_dev, hipStream_t s) {
     if (N <= 0) return;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(r6d) | reinterpret_cast<uintptr_t>(pose)) & 15) == 0 &&
+                         ((rowStride | rowOffset) & 3) == 0;
+    if (aligned && !mp_kin_scalar_forced()) {
+        hipLaunchKernelGGL(mp_r6d_ik_lds, dim3((unsigned)((N + kFkFrames - 1) / kFkFrames)), dim3(192), 0, s, r6d, N, rowStride,
+                           rowOffset, pose, parent_dev);
+        return;
+    }
     const long threads = N * 24;
     hipLaunchKernelGGL(mp_r6d_ik, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, r6d, N, rowStride,
                        rowOffset, pose, parent_dev);

@@ -359,3 +359,27 @@ def test_rnn_forward_repairs_an_aliased_state(torch_mod, weights, smpl, monkeypa
         assert m.recovery_count == 1
         assert bool(torch_mod.isfinite(y).all()) and bool(torch_mod.isfinite(st).all())
         assert float((y - y_ref).abs().max()) < 2e-5 and float((st - st_ref).abs().max()) < 2e-5
+
+
+# ---- coalesced kinematics kernels (round 4) ---------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [1, 7, 8, 13, 32000])
+def test_coalesced_fk_and_ik_equal_the_scalar_kernels_bitwise(torch_mod, net, N):
+    """mp_fk_lds / mp_r6d_ik_lds (16-byte pieces through LDS, chosen for 16-byte aligned buffers) against mp_fk / mp_r6d_ik
+    (scalar accesses, what a misaligned buffer gets): same arithmetic in the same order, so every bit agrees; ragged last
+    workgroup (N not a multiple of 8); translation added; and both against the oracle."""
+    from oracle import mp_oracle as O
+    rng = np.random.Generator(np.random.PCG64(600 + N))
+    r6d = rng.standard_normal((N, 96)).astype(np.float32)
+    tran = rng.standard_normal((N, 3)).astype(np.float32)
+    pad = lambda a: torch_mod.cat((torch_mod.zeros(1, device="cuda"), cu(torch_mod, a).reshape(-1)))[1:].reshape(a.shape)   # 4-byte aligned only
+    pose_a = net._reduced_global_to_full(cu(torch_mod, r6d))
+    pose_u = net._reduced_global_to_full(pad(r6d))
+    assert pad(r6d).data_ptr() % 16 != 0 and torch_mod.equal(pose_a, pose_u)
+    Rg_a, jg_a = net.forward_kinematics(pose_a, tran=cu(torch_mod, tran))
+    Rg_u, jg_u = net.forward_kinematics(pad(npy(pose_a)), tran=cu(torch_mod, tran))
+    assert torch_mod.equal(Rg_a, Rg_u) and torch_mod.equal(jg_a, jg_u)
+    if N <= 13:
+        ref = O.reduced_global_to_full(r6d)
+        assert np.abs(npy(pose_a) - ref).max() < 1e-5
+        rRg, rjg = O.forward_kinematics(ref, net.bodymodel.J, tran=tran)
+        assert np.abs(npy(Rg_a) - rRg).max() < 1e-5 and np.abs(npy(jg_a) - rjg).max() < 1e-5
