@@ -83,7 +83,8 @@ size_t manifest_floats() {
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 struct Packed { float* W = nullptr; float* bias = nullptr; int N = 0, K = 0, Kpad = 0, Npad = 0, bn = 0;
-                float* Wp = nullptr; };   // Wp: the same padded matrix as split-bf16 pair words (linear layers only)
+                float* Wp = nullptr;      // Wp: the same padded matrix as split-bf16 pair words (linear layers only)
+                float* Wf = nullptr; };   // Wf: the same padded matrix in MFMA B-fragment order (mp_gemm_f32_frag; linear layers only)
 struct ModuleW {
     int n_in = 0, n_out = 0, H = 0, dirs = 0, nslice = 0, nsliceX = 0;   // slices per slab: fp32 kernels | split-bf16 kernels
     Packed lin1, ih[2], lin2;
@@ -323,6 +324,8 @@ int pack_weights(mp_handle* h, const float* blob) {
             const size_t n = (size_t)pk->Npad * pk->Kpad;
             if (int rc = dev_alloc(h, (void**)&pk->Wp, n * sizeof(float))) return rc;
             mp_launch_pairs(pk->W, pk->Wp, n, h->s_main);
+            if (int rc = dev_alloc(h, (void**)&pk->Wf, n * sizeof(float))) return rc;
+            mp_launch_pack_wfrag(pk->W, pk->Wf, pk->Npad, pk->Kpad, h->s_main);
         }
         for (int l = 0; l < 2; ++l)
             for (int d = 0; d < m.dirs; ++d) {
@@ -370,6 +373,8 @@ int pack_weights(mp_handle* h, const float* blob) {
             HIPCHK(h, hipMemcpyAsync(pv.Wp + na, b.Wp, nb * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
             HIPCHK(h, hipMemcpyAsync(pv.bias, a.bias, (size_t)a.Npad * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
             HIPCHK(h, hipMemcpyAsync(pv.bias + a.Npad, b.bias, (size_t)b.Npad * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+            if (int rc = dev_alloc(h, (void**)&pv.Wf, (size_t)pv.Npad * pv.Kpad * sizeof(float))) return rc;
+            mp_launch_pack_wfrag(pv.W, pv.Wf, pv.Npad, pv.Kpad, h->s_main);
         }
     }
     HIPCHK(h, hipGetLastError());
@@ -509,6 +514,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
             else if (key == "uni2") h->uni2 = v != 0;
             else if (key == "gemm_staged") {}                  // read by mp_launch_gemm
             else if (key == "kin_scalar") {}                   // read by mp_kin.hip
+            else if (key == "gemm_frag") {}                    // read by mp_launch_gemm
             else if (key == "vf") h->vf_ok = v != 0;
             else if (key == "late_pair") h->late_pair_ok = v != 0;
             else if (key == "recovery") h->recovery = v != 0;   // (= mp_set_recovery)
@@ -685,6 +691,7 @@ int run_gemm(mp_handle* h, hipStream_t s, RowMap a0, RowMap a1, const Packed& w,
     GemmArgs g;
     g.a0 = a0; g.a1 = a1; g.W = w.W; g.bias = w.bias; g.C = C; g.cStrideB = cStrideB; g.cStrideT = cStrideT;
     g.M = M; g.N = w.N; g.K = w.K; g.Kpad = w.Kpad; g.B = B; g.relu = relu; g.pairOut = pair_out ? 1 : 0;
+    g.Wf = w.Wf; g.NB = w.Wf ? w.Npad / 32 : 0;
     if (x3_gemm && w.Wp) {                                    // split-bf16 mode: the H = 256 blocks' linear layers run on bf16 MFMAs as well
         g.W = w.Wp; g.aPairs = a_pairs ? 1 : 0; g.zero_hx = zero_hx; g.zero_ncl = zero_hx ? zero_ncl : 0;
         mp_launch_gemm_x3(g, w.bn, s);
@@ -795,6 +802,7 @@ bool rnn_g0_pose_velocity(const RnnJob& jp, const RnnJob& jv, hipStream_t s, int
     g.a0 = jp.a0; g.a1 = jp.a1; g.W = x3 ? w.Wp : w.W; g.bias = w.bias; g.C = x1_buffer(h, mp, wp); g.C2 = x1_buffer(h, mv, wv);
     g.nsplit = mp.lin1.Npad; g.cStrideB = H; g.cStrideT = (long)B * H;
     g.M = M; g.N = w.N; g.K = w.K; g.Kpad = w.Kpad; g.B = B; g.relu = 1; g.pairOut = x3 ? 1 : 0; g.aPairs = 0;
+    g.Wf = w.Wf; g.NB = w.Wf ? w.Npad / 32 : 0;
     if (x3) {
         const int nslab = (B + 15) / 16;
         g.zero_hx = wp.hx; g.zero_ncl = mp.dirs * nslab; g.zero_hx2 = wv.hx; g.zero_ncl2 = mv.dirs * nslab;
@@ -1454,7 +1462,7 @@ void mp_destroy(mp_handle* h) {
     h->plans.clear();
     for (ModuleW& m : h->mod) {
         Packed* ps[4] = {&m.lin1, &m.ih[0], &m.ih[1], &m.lin2};
-        for (Packed* p : ps) { if (p->W) (void)hipFree(p->W); if (p->bias) (void)hipFree(p->bias); if (p->Wp) (void)hipFree(p->Wp); }
+        for (Packed* p : ps) { if (p->W) (void)hipFree(p->W); if (p->bias) (void)hipFree(p->bias); if (p->Wp) (void)hipFree(p->Wp); if (p->Wf) (void)hipFree(p->Wf); }
         for (int l = 0; l < 2; ++l) for (int d = 0; d < 2; ++d) {
             if (m.whh[l][d]) (void)hipFree(m.whh[l][d]);
             if (m.whhP[l][d]) (void)hipFree(m.whhP[l][d]);
@@ -1473,7 +1481,7 @@ void mp_destroy(mp_handle* h) {
     }
     void* misc[] = {h->parent_dev, h->depth_dev, h->bone_dev, h->vstate.h, h->vstate.c, h->sc.window, h->sc.fresh,
                     h->sc.mask_dev, h->sc.st.last_foot, h->sc.st.root_y, h->sc.st.root_pos, h->sc.joints, h->sc.vel,
-                    h->sc.contact, h->jrest_dev, h->vrest_dev, h->skinw_dev, h->lin1_pv.Wp, h->lin1_pv.W, h->lin1_pv.bias, h->prof_dev,
+                    h->sc.contact, h->jrest_dev, h->vrest_dev, h->skinw_dev, h->lin1_pv.Wp, h->lin1_pv.W, h->lin1_pv.Wf, h->lin1_pv.bias, h->prof_dev,
                     h->vtpl_dev, h->shapedirs_dev, h->jreg_dev, h->shape_ws, h->posedirsT_dev, h->rnn_snap,
                     h->vsnap.h, h->vsnap.c, h->st_snap.last_foot, h->st_snap.root_y, h->st_snap.root_pos, h->eval_ws};
     for (void* p : misc) if (p) (void)hipFree(p);

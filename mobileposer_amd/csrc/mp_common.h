@@ -45,7 +45,14 @@ struct GemmArgs {
     int nsplit = 0;
     unsigned long long* zero_hx2 = nullptr;
     int zero_ncl2 = 0;
+    // mp_gemm_f32 only: the same padded W in MFMA B-fragment order (mp_launch_pack_wfrag) -- piece (k-tile kt, quarter q,
+    // 32-column tile b) is 64 lanes x 16 bytes contiguous -- and its number of 32-column tiles; nullptr: row-major W only
+    const float* Wf = nullptr;
+    int NB = 0;
 };
+// W [Npad][Kpad] row-major -> fragment order [Kpad/32][4][Npad/32][64 lanes][4]: lane (li = lane & 31, lh = lane >> 5) of piece
+// (kt, q, b) holds W[b*32 + li][kt*32 + lh*16 + q*4 .. +3] -- what a lane of mp_gemm_f32_rows feeds its MFMAs of quarter q
+void mp_launch_pack_wfrag(const float* W, float* Wf, int Npad, int Kpad, hipStream_t s);
 // bn: 128, 96 or 32 (chosen by the caller from N)
 void mp_launch_gemm(const GemmArgs& g, int bn, hipStream_t s);
 int mp_gemm_pick_bn(int N);

@@ -274,6 +274,126 @@ MP_KERNEL __launch_bounds__(256, 2) void mp_gemm_f32_rows(GemmArgs g, int nTiles
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// mp_gemm_f32_frag<TN, NK> (round 4) -- mp_gemm_f32_rows with W read in MFMA B-fragment order (GemmArgs::Wf).
+// What bounded the rows kernel: a lane's 16-byte piece of "its" W row sits 4 * Kpad bytes from its neighbour's, so one wave-wide
+// W load touches 64 different 128-byte lines, and with four waves per CU re-reading the same W the L1 does 4 096 tag look-ups
+// per k-tile and CU against 3 072 cycles of MFMAs.  In fragment order the 64 pieces of a load are one contiguous KB (8 lines):
+// ~600 look-ups per k-tile and CU, A included.  Same k pairing, same MFMA order: bit-identical to both older kernels.
+// Also serves the wide linear1 shapes (N = 256 / 512: TN = 4, n-tiles of an m-tile on one XCD so that A comes from L2).
+template <int TN, int NK>
+MP_KERNEL __launch_bounds__(256, 2) void mp_gemm_f32_frag(GemmArgs g, int nTilesM, int nTilesN) {
+    __shared__ long rowOffC[4][32];
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int mt = (idx / nTilesN) * 8 + xcd;               // all n-tiles of an m-tile on one XCD (A panel from HBM once)
+    const int nt = idx % nTilesN;
+    if (mt >= nTilesM) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int m0 = mt * 128 + wave * 32, n0 = nt * (TN * 32);
+    if (m0 >= g.M) return;
+
+    const int m = m0 + li < g.M ? m0 + li : g.M - 1;
+    const int rb = m % g.B, rt = m / g.B;
+    const float* pa0 = g.a0.base + (long)rb * g.a0.strideB + (long)rt * g.a0.strideT;
+    const float* pa1 = g.a1.base ? g.a1.base + (long)rb * g.a1.strideB + (long)rt * g.a1.strideT - g.a0.width : pa0;
+    if (lane < 32) rowOffC[wave][lane] = (long)rb * g.cStrideB + (long)rt * g.cStrideT;
+    const int w0 = g.a0.width, klast = g.K - 4;
+    // piece (kt, q, b) of this lane: Wf + (((kt*4 + q) * NB + nt*TN + b) * 64 + lane) * 4
+    const float* pw = g.Wf + ((long)(nt * TN) * 64 + lane) * 4;
+    const long wq = (long)g.NB * 256;                        // floats between consecutive (kt, q) slabs
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+    f32x4 fa[2][4], fw[TN][4];
+    auto request_a = [&](f32x4& dst, int q, int k0) {            // A piece q of the k-tile at k0 (past K: the row's last piece)
+        const int k = k0 + lh * 16 + q * 4;
+        const int kk = k < klast ? k : klast;
+        dst = *reinterpret_cast<const f32x4*>((kk < w0 ? pa0 : pa1) + kk);
+    };
+    auto request_w = [&](int q, int kt) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b) fw[b][q] = *reinterpret_cast<const f32x4*>(pw + (long)(kt * 4 + q) * wq + b * 256);
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) request_a(fa[0][q], q, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { request_w(q, 0); if (NK > 1) request_a(fa[1][q], q, BK); }
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kt & 1][q][s4], fw[b][q][s4], acc[b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 2 < NK) request_a(fa[kt & 1][q], q, (kt + 2) * BK);
+            if (kt + 1 < NK) request_w(q, kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // rowOffC of this wave (written by its own lanes)
+    float* const Cb = (g.nsplit > 0 && n0 >= g.nsplit) ? g.C2 : g.C;       // uniform per block: TN*32 divides nsplit
+    const int ncol0 = (g.nsplit > 0 && n0 >= g.nsplit) ? g.nsplit : 0;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + b * 32 + li;
+        if (n >= g.N) continue;
+        const float bias = g.bias[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m0 + ml < g.M) {
+                float v = acc[b][r] + bias;
+                if (g.relu) v = fmaxf(v, 0.f);
+                Cb[rowOffC[wave][ml] + (n - ncol0)] = g.pairOut ? __uint_as_float(pair_of(v)) : v;
+            }
+        }
+    }
+}
+
+MP_KERNEL __launch_bounds__(256) void mp_pack_wfrag(const float* __restrict__ W, float* __restrict__ Wf, int Npad, int Kpad) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;       // destination float
+    const long total = (long)Npad * Kpad;
+    if (gid >= total) return;
+    const int NB = Npad / 32;
+    const int j = (int)(gid & 3), lane = (int)((gid >> 2) & 63);
+    const long piece = gid >> 8;                                  // (kt*4 + q) * NB + b
+    const int b = (int)(piece % NB);
+    const int kq = (int)(piece / NB);
+    const int kt = kq >> 2, q = kq & 3;
+    const int li = lane & 31, lh = lane >> 5;
+    Wf[gid] = W[(long)(b * 32 + li) * Kpad + kt * 32 + lh * 16 + q * 4 + j];
+}
+
+template <int TN, int NK>
+void launch_frag(const GemmArgs& g, hipStream_t s) {
+    const int nTilesM = (g.M + 127) / 128;
+    const int nTilesN = (g.N + TN * 32 - 1) / (TN * 32);
+    const int grid = ((nTilesM + 7) / 8) * 8 * nTilesN;
+    hipLaunchKernelGGL((mp_gemm_f32_frag<TN, NK>), dim3(grid), dim3(256), 0, s, g, nTilesM, nTilesN);
+}
+
+template <int TN>
+bool launch_frag_k(const GemmArgs& g, hipStream_t s) {
+    switch (g.Kpad / BK) {
+        case 2: launch_frag<TN, 2>(g, s); return true;
+        case 4: launch_frag<TN, 4>(g, s); return true;
+        case 5: launch_frag<TN, 5>(g, s); return true;
+        case 8: launch_frag<TN, 8>(g, s); return true;
+        case 16: launch_frag<TN, 16>(g, s); return true;
+        default: return false;
+    }
+}
+
 template <int TN, int NK>
 void launch_rows(const GemmArgs& g, hipStream_t s) {
     const int nTilesM = (g.M + 127) / 128;
@@ -307,8 +427,27 @@ void launch(const GemmArgs& g, hipStream_t s) {
 
 int mp_gemm_pick_bn(int N) { return N > 96 ? 128 : (N > 32 ? 96 : 32); }
 
+void mp_launch_pack_wfrag(const float* W, float* Wf, int Npad, int Kpad, hipStream_t s) {
+    const long n = (long)Npad * Kpad;
+    hipLaunchKernelGGL(mp_pack_wfrag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, Wf, Npad, Kpad);
+}
+
 void mp_launch_gemm(const GemmArgs& g, int bn, hipStream_t s) {
     static const bool staged = getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "gemm_staged=1");   // A/B runs: the LDS-staged kernel
+    static const int frag_tn = getenv("MP_GEMM_FRAG_TN") ? atoi(getenv("MP_GEMM_FRAG_TN")) : 0;          // micro-benchmark only
+    static const bool no_frag = getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "gemm_frag=0");     // A/B runs: the round-3 kernels
+    if (g.Wf && !staged && !no_frag && g.NB > 0 && (g.K & 3) == 0 && (g.a0.width & 3) == 0) {
+        const int npad32 = g.NB;                                      // 32-column tiles of the padded W
+        // columns per wave: all of a narrow output (linear2: N <= 96); 64 of a wide one (linear1: four waves per SIMD keep the
+        // MFMA pipe busier than two waves with 128 columns each -- 78.6 vs 85.0 us for the stacked pose + velocity linear1)
+        int tn = g.N <= 32 ? 1 : g.N <= 64 ? 2 : g.N <= 96 ? 3 : 2;
+        if (frag_tn) tn = frag_tn;
+        if (npad32 % tn == 0 && (g.nsplit == 0 || g.nsplit % (tn * 32) == 0)) {
+            const bool done = tn == 1 ? launch_frag_k<1>(g, s) : tn == 2 ? launch_frag_k<2>(g, s) : tn == 3 ? launch_frag_k<3>(g, s)
+                                                                                                             : launch_frag_k<4>(g, s);
+            if (done) return;
+        }
+    }
     // (row-streaming kernel for the linear2 shapes -- few columns, K >= 128)
     if (!staged && g.N <= 96 && g.Kpad >= 128) {
         // (W is padded to a multiple of bn rows: bn = 32 -> 1 tile, 96 -> up to 3)

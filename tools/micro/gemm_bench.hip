@@ -23,6 +23,9 @@ int main() {
     float* out2 = dalloc((size_t)M * 256, 0.f);
     float* W = dalloc((size_t)640 * 512, 0.1f);
     float* bias = dalloc(640, 0.1f);
+    float* Wf = dalloc((size_t)640 * 512, 0.f);
+    float* chk1 = dalloc((size_t)M * 256, 0.f);
+    float* chk2 = dalloc((size_t)M * 256, 0.f);
     hipStream_t s; hipStreamCreate(&s);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     struct Shape { const char* name; int K, N, relu, two, user_in; };
@@ -41,17 +44,35 @@ int main() {
         if (sh.relu) { g.cStrideB = ncols; g.cStrideT = (long)B * ncols; }          // internal time-major output
         else { g.cStrideB = (long)T * ncols; g.cStrideT = ncols; }                 // linear2 writes the caller's layout
         g.M = M; g.N = sh.N; g.K = sh.K; g.Kpad = (sh.K + 31) / 32 * 32; g.B = B; g.relu = sh.relu;
-        for (int i = 0; i < 5; ++i) mp_launch_gemm(g, bn, s);
-        hipStreamSynchronize(s);
-        const int reps = 50;
-        hipEventRecord(e0, s);
-        for (int i = 0; i < reps; ++i) mp_launch_gemm(g, bn, s);
-        hipEventRecord(e1, s);
-        hipStreamSynchronize(s);
-        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-        const double us = 1e3 * ms / reps, gf = 2.0 * M * (double)sh.N * sh.K * 1e-9;
-        printf("%-42s %7.1f us  %6.1f TFLOP/s (%.0f %% of 157.3)   err=%s\n", sh.name, us, gf / us * 1e-3 * 1e3, 100.0 * gf / us / 157.3,
-               hipGetErrorString(hipGetLastError()));
+        const int npad = (sh.N + bn - 1) / bn * bn;
+        for (int variant = 0; variant < 2; ++variant) {
+            g.Wf = nullptr; g.NB = 0;
+            if (variant == 1) {
+                mp_launch_pack_wfrag(W, Wf, npad, g.Kpad, s);
+                g.Wf = Wf; g.NB = npad / 32;
+                g.C = chk1; if (sh.two) g.C2 = chk2;
+            }
+            for (int i = 0; i < 5; ++i) mp_launch_gemm(g, bn, s);
+            hipStreamSynchronize(s);
+            const int reps = 50;
+            hipEventRecord(e0, s);
+            for (int i = 0; i < reps; ++i) mp_launch_gemm(g, bn, s);
+            hipEventRecord(e1, s);
+            hipStreamSynchronize(s);
+            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+            const double us = 1e3 * ms / reps, gf = 2.0 * M * (double)sh.N * sh.K * 1e-9;
+            printf("%-42s %-9s %7.1f us  %6.1f TFLOP/s (%.0f %% of 157.3)   err=%s\n", sh.name, variant ? "frag-W" : "current", us, gf / us * 1e-3 * 1e3, 100.0 * gf / us / 157.3,
+                   hipGetErrorString(hipGetLastError()));
+        }
+        {   // bitwise comparison of the two variants' outputs
+            const size_t nout = (size_t)M * (sh.two ? 256 : (sh.relu ? ncols : ncols));
+            std::vector<float> a(nout), b(nout);
+            hipMemcpy(a.data(), out1, nout * sizeof(float), hipMemcpyDeviceToHost);
+            hipMemcpy(b.data(), chk1, nout * sizeof(float), hipMemcpyDeviceToHost);
+            size_t bad = 0;
+            for (size_t i = 0; i < nout; ++i) bad += memcmp(&a[i], &b[i], 4) != 0;
+            printf("    outputs differ in %zu of %zu values\n", bad, nout);
+        }
     }
     return 0;
 }
