@@ -546,20 +546,28 @@ def main():
                      "SURVEY.md 8(d): 2*4H*(K_in+H) per frame and direction) / HIP-event duration of the launch on the "
                      "library stream, against the dense v_mfma_f32_16x16x4_f32 peak")
     # HBM bytes per launch of that kernel from the separate rocprofv3 --pmc passes (profiles/*_pmc_summary.json):
-    # (2*FETCH_SIZE + WRITE_SIZE)*1024, corrected as MI355X_MICROARCH.md prescribes; null when no profile is present
-    traffic = None
-    for prof in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+    # (2*FETCH_SIZE + WRITE_SIZE)*1024, corrected as MI355X_MICROARCH.md prescribes.  A PMC pass cannot run inside this timed
+    # process, so the figure is quoted from the committed profile -- and ONLY while the library that just ran is the binary
+    # that was profiled (the summary records its md5): a changed kernel must not inherit a stale counter.  null otherwise.
+    traffic, traffic_src = None, "no PMC summary of this library binary (profiles/*_pmc_summary.json lib_md5 differs or is absent)"
+    import hashlib
+    lib_md5 = hashlib.md5(open(__graft_entry__.LIB, "rb").read()).hexdigest()
+    for prof in ("r04_pmc_summary.json",):
         try:
-            pmc = json.load(open(os.path.join(REPO, "profiles", prof)))["kernels"]
-            # (kernel names as rocprofv3 prints them; matched by prefix: the template list grew a parameter in round 3)
+            summ = json.load(open(os.path.join(REPO, "profiles", prof)))
+            if summ.get("lib_md5") != lib_md5:
+                continue
+            pmc = summ["kernels"]
+            # (kernel names as rocprofv3 prints them; matched by prefix)
             key = {1: "mp_lstm_fused<256, 8, 256, 1, false", 4: "mp_lstm_fused<256, 8, 512, 1, false",
-                   5: "mp_lstm_fused<256, 16, 256, 1, false", 0: "mp_gemm_f32<2, 2, 2, 2>"}.get(dominant)
+                   5: "mp_lstm_fused<256, 16, 256, 1, false", 0: "mp_gemm_f32_frag<2, 5>"}.get(dominant)
             if args.lstm_mode == "x3":
                 key = {1: "mp_lstm_x3<8, 256, false>", 4: "mp_lstm_x3w<512, false>", 5: "mp_lstm_x3<8, 256, false>",
                        0: "mp_gemm_x3<128, 64>"}.get(dominant)
             hit = [k for k in pmc if key and k.startswith(key)]
             if hit:
                 traffic = pmc[hit[0]]["hbm_bytes_per_launch_corrected"]
+                traffic_src = "profiles/%s (rocprofv3 --pmc passes of this library binary, md5 %s)" % (prof, lib_md5[:12])
                 break
         except Exception:
             pass
@@ -598,7 +606,7 @@ def main():
                        "hbm_gbps_compulsory": round(value / world * BYTES_PER_FRAME / 1e9, 2)},
         "roofline": {"kernel": names[dominant], "bound": "mfma",
                      "achieved": round(roof_achieved, 2), "peak": roof_peak, "unit": "TFLOP/s",
-                     "frac": round(roof_achieved / roof_peak, 4), "traffic": traffic,
+                     "frac": round(roof_achieved / roof_peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "flop_per_launch": round(dgf / dn * 1e9), "algorithmic_tflops": round(achieved, 2),
                      "avg_launch_ms": round(dms / dn, 4), "note": roof_note},
         "kernels": kern,

@@ -1,7 +1,7 @@
 """Pull the gfx950 code objects out of the built shared library and disassemble them (build / test tooling only).
 
-Used by tests/test_cabi_cpu.py to check that no kernel contains packed-fp32 VALU instructions (the gfx950
-co-execution erratum described in csrc/mp_common.h and DESIGN.md) and by tools that want per-kernel ISA."""
+Used by tests/test_cabi_cpu.py to check that no kernel contains packed-fp32 VALU instructions (insurance kept from
+round 2, not a claimed hardware erratum: csrc/mp_common.h, profiles/r02_coexec_glitch.md) and by tools that want per-kernel ISA."""
 import os
 import struct
 import subprocess

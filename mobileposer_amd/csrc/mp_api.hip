@@ -200,6 +200,7 @@ struct mp_handle {
     bool half_ok = true;             // MP_VARIANT half=0: no pose-on-half-the-chip schedule for 64 < B <= 128
     bool fuse_pv = true;             // MP_VARIANT fuse_pv=0: separate linear1 launches for pose and velocity
     Packed lin1_pv;                  // pose.linear1 and velocity.linear1 stacked (split-bf16 mode: one GEMM over the shared rows)
+    Packed lin1_pvf;                 // ... with foot_contact.linear1 on top (exact-fp32 mode, B > 128: one GEMM, three outputs)
     int wreg_mask = 3;               // fp32 mode, 8-slice bidirectional layers on the four-wave / AccVGPR-weight configuration
                                      // (mp_lstm_fused<256,8,KIN,1>): bit 0 K_in = 512, bit 1 K_in = 256 (MP_VARIANT wreg; 0 = the
                                      // eight-wave kernels).  Measured on one box: 4.47 -> 4.35 ms per 256 x 125 forward.
@@ -375,6 +376,21 @@ int pack_weights(mp_handle* h, const float* blob) {
             HIPCHK(h, hipMemcpyAsync(pv.bias + a.Npad, b.bias, (size_t)b.Npad * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
             if (int rc = dev_alloc(h, (void**)&pv.Wf, (size_t)pv.Npad * pv.Kpad * sizeof(float))) return rc;
             mp_launch_pack_wfrag(pv.W, pv.Wf, pv.Npad, pv.Kpad, h->s_main);
+            // the foot-contact block reads the same rows too (net.py:113): its 64 linear1 rows under the other 512
+            const Packed& f = h->mod[MP_MOD_FOOT_CONTACT].lin1;
+            Packed& pvf = h->lin1_pvf;
+            if (f.K == a.K && f.Kpad == a.Kpad && f.N % 64 == 0 && f.N <= f.Npad) {
+                pvf.N = pv.N + f.N; pvf.K = a.K; pvf.Kpad = a.Kpad; pvf.bn = a.bn; pvf.Npad = pv.Npad + f.N;
+                const size_t nf = (size_t)f.N * f.Kpad;
+                if (int rc = dev_alloc(h, (void**)&pvf.W, (size_t)pvf.Npad * pvf.Kpad * sizeof(float))) return rc;
+                if (int rc = dev_alloc(h, (void**)&pvf.Wf, (size_t)pvf.Npad * pvf.Kpad * sizeof(float))) return rc;
+                if (int rc = dev_alloc(h, (void**)&pvf.bias, (size_t)pvf.Npad * sizeof(float))) return rc;
+                HIPCHK(h, hipMemcpyAsync(pvf.W, pv.W, (na + nb) * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+                HIPCHK(h, hipMemcpyAsync(pvf.W + na + nb, f.W, nf * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+                HIPCHK(h, hipMemcpyAsync(pvf.bias, pv.bias, (size_t)pv.Npad * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+                HIPCHK(h, hipMemcpyAsync(pvf.bias + pv.Npad, f.bias, (size_t)f.N * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+                mp_launch_pack_wfrag(pvf.W, pvf.Wf, pvf.Npad, pvf.Kpad, h->s_main);
+            }
         }
     }
     HIPCHK(h, hipGetLastError());
@@ -515,6 +531,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
             else if (key == "gemm_staged") {}                  // read by mp_launch_gemm
             else if (key == "kin_scalar") {}                   // read by mp_kin.hip
             else if (key == "gemm_frag") {}                    // read by mp_launch_gemm
+            else if (key == "one_stream") {}                   // read by forward_body: 0 = the round-3 three-stream serial schedule
             else if (key == "vf") h->vf_ok = v != 0;
             else if (key == "late_pair") h->late_pair_ok = v != 0;
             else if (key == "recovery") h->recovery = v != 0;   // (= mp_set_recovery)
@@ -678,6 +695,27 @@ struct SegScope {
 
 constexpr int kExclusiveLdsBytes = 84 * 1024;   // LstmPersistArgs::min_lds: more than half of a CU's 160 KB
 
+// The per-call schedule fields forward_body hands to rnn_rec through the handle (excl_lds, pose_slices8, xcd_plan_on[],
+// vf_foot).  A ScheduleScope sets them and its destructor puts ALL of them back to the defaults -- whichever way the
+// enclosing block is left, early error returns included -- so a handle can never carry one call's schedule into the next
+// (round 3 reset them by hand after collecting return codes).
+struct ScheduleScope {
+    mp_handle* h;
+    explicit ScheduleScope(mp_handle* h_) : h(h_) {}
+    ScheduleScope& exclusive_lds(int bytes) { h->excl_lds = bytes; return *this; }
+    ScheduleScope& pose_on_8_slices(bool on) { h->pose_slices8 = on; return *this; }
+    ScheduleScope& tables(int module, bool on) { h->xcd_plan_on[module] = on; return *this; }
+    ScheduleScope& rider(const void* foot_job) { h->vf_foot = foot_job; return *this; }
+    ~ScheduleScope() {
+        h->excl_lds = 0;
+        h->pose_slices8 = false;
+        for (bool& b : h->xcd_plan_on) b = false;
+        h->vf_foot = nullptr;
+    }
+    ScheduleScope(const ScheduleScope&) = delete;
+    ScheduleScope& operator=(const ScheduleScope&) = delete;
+};
+
 // ------------------------------------------------------------------------------------------ one RNN block
 enum StateMode { STATE_ZERO, STATE_FROM };
 
@@ -784,7 +822,7 @@ int rnn_g0(const RnnJob& j, hipStream_t s) {
 // linear1 of the pose and the velocity block in ONE GEMM (same rows cat(joints, imu); stacked weights; either operand mode): one launch
 // instead of two on two streams, and no cross-stream edge into the velocity layers later.  Only what rnn_g0 does for
 // the persistent path with zero / in-place state; returns false when that does not apply.
-bool rnn_g0_pose_velocity(const RnnJob& jp, const RnnJob& jv, hipStream_t s, int* rc) {
+bool rnn_g0_pose_velocity(const RnnJob& jp, const RnnJob& jv, hipStream_t s, int* rc, const RnnJob* jf = nullptr) {
     mp_handle* h = jp.h;
     const ModuleW& mp = h->mod[jp.id];
     const ModuleW& mv = h->mod[jv.id];
@@ -796,9 +834,17 @@ bool rnn_g0_pose_velocity(const RnnJob& jp, const RnnJob& jv, hipStream_t s, int
     ModuleWS& wp = jp.p->ws[jp.id];
     ModuleWS& wv = jv.p->ws[jv.id];
     const int B = jp.p->B, T = jp.p->T, M = B * T, H = mp.H;
-    SegScope seg(h, s, 0, 1, 2.0 * M * (double)h->lin1_pv.N * h->lin1_pv.K);
+    // (jf: the foot-contact block's linear1 as a third output of the same launch -- exact-fp32 operands, fragment-ordered W)
+    const bool three = jf != nullptr && !x3 && h->lin1_pvf.Wf != nullptr && mp_gemm_frag_enabled() && jf->mode == STATE_ZERO && jf->a0.base == jp.a0.base &&
+                       jf->a1.base == jp.a1.base;
+    if (jf != nullptr && !three) return false;
+    const Packed& w = three ? h->lin1_pvf : h->lin1_pv;
+    SegScope seg(h, s, 0, 1, 2.0 * M * (double)w.N * w.K);
     GemmArgs g;
-    const Packed& w = h->lin1_pv;
+    if (three) {
+        const ModuleW& mf = h->mod[jf->id];
+        g.C3 = x1_buffer(h, mf, jf->p->ws[jf->id]); g.nsplit3 = h->lin1_pv.Npad; g.c3StrideB = mf.H; g.c3StrideT = (long)B * mf.H;
+    }
     g.a0 = jp.a0; g.a1 = jp.a1; g.W = x3 ? w.Wp : w.W; g.bias = w.bias; g.C = x1_buffer(h, mp, wp); g.C2 = x1_buffer(h, mv, wv);
     g.nsplit = mp.lin1.Npad; g.cStrideB = H; g.cStrideT = (long)B * H;
     g.M = M; g.N = w.N; g.K = w.K; g.Kpad = w.Kpad; g.B = B; g.relu = 1; g.pairOut = x3 ? 1 : 0; g.aPairs = 0;
@@ -986,6 +1032,30 @@ int rnn_g2(const RnnJob& j, hipStream_t s) {
     return MP_OK;
 }
 
+// linear2 of two blocks in ONE launch (mp_launch_gemm_pair: velocity + foot contact at the end of a forward); neither job
+// copies state out (in-place / no carried state).  Falls back to two launches when the pair form does not cover the shapes.
+int rnn_g2_pair(const RnnJob& j1, const RnnJob& j2, hipStream_t s) {
+    mp_handle* h = j1.h;
+    auto copies_state = [&](const RnnJob& j) { return j.out_h && !(h->persist && j.out_h == j.in_h); };
+    if (!copies_state(j1) && !copies_state(j2) && !use_x3(h, h->mod[j1.id]) && !use_x3(h, h->mod[j2.id])) {
+        const int B = j1.p->B, T = j1.p->T, M = B * T;
+        auto args = [&](const RnnJob& j) {
+            const ModuleW& m = h->mod[j.id];
+            GemmArgs g;
+            g.a0 = internal_map(j.p->ws[j.id].out1, B, m.dirs * m.H); g.a1 = RowMap{nullptr, 0, 0, 0};
+            g.W = m.lin2.W; g.bias = m.lin2.bias; g.C = j.y; g.cStrideB = j.yStrideB; g.cStrideT = j.yStrideT;
+            g.M = M; g.N = m.lin2.N; g.K = m.lin2.K; g.Kpad = m.lin2.Kpad; g.B = B; g.relu = 0;
+            g.Wf = m.lin2.Wf; g.NB = m.lin2.Wf ? m.lin2.Npad / 32 : 0;
+            return g;
+        };
+        const GemmArgs g1 = args(j1), g2 = args(j2);
+        SegScope seg(h, s, 0, 1, 2.0 * M * ((double)g1.N * g1.K + (double)g2.N * g2.K));
+        if (mp_launch_gemm_pair(g1, g2, s)) { HIPCHK(h, hipGetLastError()); return MP_OK; }
+    }
+    if (int rc = rnn_g2(j1, s)) return rc;
+    return rnn_g2(j2, s);
+}
+
 int run_rnn(const RnnJob& j, hipStream_t s) {
     if (int rc = rnn_g0(j, s)) return rc;
     if (int rc = rnn_rec(j, 0, s)) return rc;
@@ -1093,8 +1163,9 @@ int side_by_side_plan(mp_handle* h, int B) {
 //    free) run on s_foot beside the velocity layers, the linear2 / IK / FK tail of pose on s_gp (= s_vel, idle by then).
 int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long poseRows, long poseRowStride,
                  long poseRowOffset, float* joints, float* vel, float* contact, float* r6d, VelState& vs,
-                 bool has_state, float* fk_rglobal = nullptr, float* fk_joint = nullptr) {
+                 bool has_state, float* fk_rglobal = nullptr, float* fk_joint = nullptr, bool* tail_pending = nullptr) {
     const int T = p->T;
+    if (tail_pending) *tail_pending = false;
     const RowMap none{nullptr, 0, 0, 0};
     const RowMap xj = user_map(joints, T, 72), xi = user_map(imu, T, 60);
     RnnJob J{h, p, MP_MOD_JOINTS, xi, none, joints, (long)T * 72, 72, STATE_ZERO, nullptr, nullptr, nullptr, nullptr};
@@ -1106,6 +1177,45 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
     const bool one_branch = h->capturing && h->graph_serial;
     hipStream_t sm = h->s_main, sp = one_branch ? sm : h->s_gp, sv = one_branch ? sm : h->s_vel, sf = one_branch ? sm : h->s_foot;
 #define RC(x) do { if (int rc_ = (x)) return rc_; } while (0)
+    // ---- the default schedule of full batches (B > 128, exact-fp32 operands), round 4: ONE stream for everything but pose's
+    // linear2 / IK / FK tail.  joints block -> linear1 of pose | velocity | foot contact as ONE GEMM with three outputs -> pose
+    // layers -> velocity layers with the foot-contact layers riding in their workgroups -> linear2 of velocity and foot contact
+    // as ONE launch.  Round 3 ran foot contact's two linear layers on a stream of their own: four cross-stream edges on the
+    // critical chain (9-16 us of barrier packets each in the rocprof timeline: 45 us per forward) and a linear1 that ran beside
+    // the stacked one and slowed it down (90 vs 79 us).  The tail's join is left to the caller when it asks for that
+    // (tail_pending): the translation solver does not read the pose.
+    {
+        const ModuleW& vmod = h->mod[MP_MOD_VELOCITY];
+        const bool vf = h->vf_ok && p->B > 128 && h->persist && !h->uni2 && !use_x3(h, vmod) && vmod.nslice == 16 &&
+                        fp32_slices(h, vmod, p->B) == 16 && h->mod[MP_MOD_FOOT_CONTACT].wVF[0][0] != nullptr;
+        static const bool one_stream_ok = !(getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "one_stream=0"));
+        if (vf && one_stream_ok && h->lin1_pvf.Wf && mp_gemm_frag_enabled() && h->fuse_pv && !use_x3(h, h->mod[MP_MOD_POSE]) &&
+            side_by_side_plan(h, p->B) == 0) {
+            RC(run_rnn(J, sm));                                                             // net.py:103
+            int rc_pv = MP_OK;
+            if (!rnn_g0_pose_velocity(P, V, sm, &rc_pv, &F)) return fail(h, MP_ERR_INVALID, "internal: stacked linear1 refused");
+            RC(rc_pv);
+            RC(rnn_rec(P, 0, sm)); RC(rnn_rec(P, 1, sm));                                   // net.py:106-107
+            HIPCHK(h, hipEventRecord(h->ev_x[2], sm));
+            {
+                ScheduleScope sched(h);
+                sched.rider(&F);
+                RC(rnn_rec(V, 0, sm));                                                      // net.py:113-117
+                RC(rnn_rec(V, 1, sm));
+            }
+            RC(rnn_g2_pair(V, F, sm));
+            HIPCHK(h, hipStreamWaitEvent(sp, h->ev_x[2], 0));
+            RC(rnn_g2(P, sp));
+            { SegScope seg(h, sp, 2, 1);
+              mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sp); }   // net.py:110
+            if (fk_rglobal) mp_launch_fk(pose, nullptr, poseRows, h->bone_dev, h->parent_dev, h->depth_dev, fk_rglobal, fk_joint, sp);
+            HIPCHK(h, hipEventRecord(h->ev_x[3], sp));
+            if (tail_pending) *tail_pending = true;
+            else HIPCHK(h, hipStreamWaitEvent(sm, h->ev_x[3], 0));
+            HIPCHK(h, hipGetLastError());
+            return MP_OK;
+        }
+    }
     // joints(batch)                                                                       net.py:103
     RC(run_rnn(J, sm));
     HIPCHK(h, hipEventRecord(h->ev_j, sm));
@@ -1145,18 +1255,13 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
             RC(rnn_rec(P, 0, sm));                                                        // 16 slices, every CU
             RC(rec(1, sm));
             RC(wait(1, sv));                                                              // (the velocity grid must not start under it)
-            h->excl_lds = kExclusiveLdsBytes;
-            h->pose_slices8 = true;
-            h->xcd_plan_on[MP_MOD_POSE] = h->xcd_plan_on[MP_MOD_VELOCITY] = true;
-            h->vf_foot = &F;
-            int rc_w = rnn_rec(V, 0, sv);                                                 // net.py:113-117
-            if (!rc_w) rc_w = rnn_rec(P, 1, sm);                                          // net.py:106-107
-            if (!rc_w) rc_w = rnn_rec(V, 1, sv);
-            h->excl_lds = 0;
-            h->pose_slices8 = false;
-            h->xcd_plan_on[MP_MOD_POSE] = h->xcd_plan_on[MP_MOD_VELOCITY] = false;
-            h->vf_foot = nullptr;
-            RC(rc_w);
+            {
+                ScheduleScope sched(h);
+                sched.exclusive_lds(kExclusiveLdsBytes).pose_on_8_slices(true).tables(MP_MOD_POSE, true).tables(MP_MOD_VELOCITY, true).rider(&F);
+                RC(rnn_rec(V, 0, sv));                                                    // net.py:113-117
+                RC(rnn_rec(P, 1, sm));                                                    // net.py:106-107
+                RC(rnn_rec(V, 1, sv));
+            }
             RC(rnn_g2(V, sv));                                                            // net.py:117
             HIPCHK(h, hipEventRecord(h->ev_v, sv));
             RC(rnn_g2(F, sv));                                                            // net.py:113-114
@@ -1167,36 +1272,29 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
               mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sm); }   // net.py:110
             if (fk_rglobal) mp_launch_fk(pose, nullptr, poseRows, h->bone_dev, h->parent_dev, h->depth_dev, fk_rglobal, fk_joint, sm);
         } else {
-        h->excl_lds = h->exclusive_ok ? kExclusiveLdsBytes : 0;
-        h->pose_slices8 = side >= 2;
+        {
+        ScheduleScope sched(h);
         const bool tables = h->exclusive_ok && h->xcd_rr && !use_x3(h, h->mod[MP_MOD_POSE]) && !use_x3(h, h->mod[MP_MOD_VELOCITY]);
-        h->xcd_plan_on[MP_MOD_POSE] = h->xcd_plan_on[MP_MOD_VELOCITY] = h->xcd_plan_on[MP_MOD_FOOT_CONTACT] = tables;
-        auto ev = [&](hipEvent_t e, hipStream_t on) -> int {
-            hipError_t r = hipEventRecord(e, on);
-            return r == hipSuccess ? MP_OK : fail(h, MP_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(r));
-        };
-        int rc_w = MP_OK;
+        sched.exclusive_lds(h->exclusive_ok ? kExclusiveLdsBytes : 0).pose_on_8_slices(side >= 2)
+             .tables(MP_MOD_POSE, tables).tables(MP_MOD_VELOCITY, tables).tables(MP_MOD_FOOT_CONTACT, tables);
         if (side == 3) {
-            rc_w = rnn_g0(F, sf);                                                         // linear1 right away
-            if (!rc_w) rc_w = run_rnn(V, sv);                                             // net.py:117
-            if (!rc_w) rc_w = ev(h->ev_v, sv);
-            if (!rc_w) { hipError_t r = hipStreamWaitEvent(sf, h->ev_v, 0); if (r != hipSuccess) rc_w = fail(h, MP_ERR_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(r)); }
-            if (!rc_w) rc_w = rnn_rec(F, 0, sf);                                          // net.py:113-114
-            if (!rc_w) rc_w = rnn_g1(F, sf);
-            if (!rc_w) rc_w = rnn_rec(F, 1, sf);
-            if (!rc_w) rc_w = rnn_g2(F, sf);
-            if (!rc_w) rc_w = ev(h->ev_f, sf);
+            RC(rnn_g0(F, sf));                                                            // linear1 right away
+            RC(run_rnn(V, sv));                                                           // net.py:117
+            HIPCHK(h, hipEventRecord(h->ev_v, sv));
+            HIPCHK(h, hipStreamWaitEvent(sf, h->ev_v, 0));
+            RC(rnn_rec(F, 0, sf));                                                        // net.py:113-114
+            RC(rnn_g1(F, sf));
+            RC(rnn_rec(F, 1, sf));
+            RC(rnn_g2(F, sf));
+            HIPCHK(h, hipEventRecord(h->ev_f, sf));
         } else {
-            rc_w = run_rnn(F, sf);                                                        // net.py:113-114
-            if (!rc_w) rc_w = ev(h->ev_f, sf);
-            if (!rc_w) rc_w = run_rnn(V, sv);                                             // net.py:117
-            if (!rc_w) rc_w = ev(h->ev_v, sv);
+            RC(run_rnn(F, sf));                                                           // net.py:113-114
+            HIPCHK(h, hipEventRecord(h->ev_f, sf));
+            RC(run_rnn(V, sv));                                                           // net.py:117
+            HIPCHK(h, hipEventRecord(h->ev_v, sv));
         }
-        if (!rc_w) rc_w = run_rnn(P, sm);                                                 // net.py:106-107
-        h->excl_lds = 0;
-        h->pose_slices8 = false;
-        h->xcd_plan_on[MP_MOD_POSE] = h->xcd_plan_on[MP_MOD_VELOCITY] = h->xcd_plan_on[MP_MOD_FOOT_CONTACT] = false;
-        RC(rc_w);
+        RC(run_rnn(P, sm));                                                               // net.py:106-107
+        }
         { SegScope seg(h, sm, 2, 1);
           mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sm); }   // net.py:110
         if (fk_rglobal) mp_launch_fk(pose, nullptr, poseRows, h->bone_dev, h->parent_dev, h->depth_dev, fk_rglobal, fk_joint, sm);
@@ -1239,15 +1337,13 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
             int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if (place_clusters(h, vf, 2, load, h->xcd_plan)) { excl_vf = kExclusiveLdsBytes; vf_tables = true; }
         }
-        if (fuse_vf) { excl_vf = 0; vf_tables = false; RC(wait(4, sm)); h->vf_foot = &F; }
-        h->excl_lds = excl_vf;
-        h->xcd_plan_on[MP_MOD_VELOCITY] = vf_tables;
-        int rc_v = rnn_rec(V, 0, sm);
-        if (!rc_v) rc_v = rnn_rec(V, 1, sm);
-        h->excl_lds = 0;
-        h->xcd_plan_on[MP_MOD_VELOCITY] = false;
-        h->vf_foot = nullptr;
-        RC(rc_v);
+        if (fuse_vf) { excl_vf = 0; vf_tables = false; RC(wait(4, sm)); }
+        {
+            ScheduleScope sched(h);
+            sched.exclusive_lds(excl_vf).tables(MP_MOD_VELOCITY, vf_tables).rider(fuse_vf ? &F : nullptr);
+            RC(rnn_rec(V, 0, sm));
+            RC(rnn_rec(V, 1, sm));
+        }
         if (fuse_vf) RC(rec(5, sm));
         RC(rnn_g2(V, sm));                                                                  // net.py:117
         HIPCHK(h, hipEventRecord(h->ev_v, sm));
@@ -1261,13 +1357,12 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
             RC(rnn_g2(F, sf));                                                              // net.py:113-114
         } else {
             RC(wait(2, sf));
-            h->excl_lds = excl_vf;
-            h->xcd_plan_on[MP_MOD_FOOT_CONTACT] = vf_tables;
-            int rc_f = rnn_rec(F, 0, sf);
-            if (!rc_f) rc_f = rnn_rec(F, 1, sf);
-            h->excl_lds = 0;
-            h->xcd_plan_on[MP_MOD_FOOT_CONTACT] = false;
-            RC(rc_f);
+            {
+                ScheduleScope sched(h);
+                sched.exclusive_lds(excl_vf).tables(MP_MOD_FOOT_CONTACT, vf_tables);
+                RC(rnn_rec(F, 0, sf));
+                RC(rnn_rec(F, 1, sf));
+            }
             RC(rnn_g2(F, sf));                                                              // net.py:113-114
         }
         HIPCHK(h, hipEventRecord(h->ev_f, sf));
@@ -1481,7 +1576,7 @@ void mp_destroy(mp_handle* h) {
     }
     void* misc[] = {h->parent_dev, h->depth_dev, h->bone_dev, h->vstate.h, h->vstate.c, h->sc.window, h->sc.fresh,
                     h->sc.mask_dev, h->sc.st.last_foot, h->sc.st.root_y, h->sc.st.root_pos, h->sc.joints, h->sc.vel,
-                    h->sc.contact, h->jrest_dev, h->vrest_dev, h->skinw_dev, h->lin1_pv.Wp, h->lin1_pv.W, h->lin1_pv.Wf, h->lin1_pv.bias, h->prof_dev,
+                    h->sc.contact, h->jrest_dev, h->vrest_dev, h->skinw_dev, h->lin1_pv.Wp, h->lin1_pv.W, h->lin1_pv.Wf, h->lin1_pv.bias, h->lin1_pvf.W, h->lin1_pvf.Wf, h->lin1_pvf.bias, h->prof_dev,
                     h->vtpl_dev, h->shapedirs_dev, h->jreg_dev, h->shape_ws, h->posedirsT_dev, h->rnn_snap,
                     h->vsnap.h, h->vsnap.c, h->st_snap.last_foot, h->st_snap.root_y, h->st_snap.root_pos, h->eval_ws};
     for (void* p : misc) if (p) (void)hipFree(p);
@@ -1568,10 +1663,12 @@ int mp_forward_offline(mp_handle* h, const float* imu_dev, const int32_t* length
     key.p[0] = imu_dev; key.p[1] = pose_dev; key.p[2] = joints_dev; key.p[3] = vel_dev; key.p[4] = contact_dev;
     key.p[5] = tran_dev; key.p[6] = h->vstate.h; key.p[7] = rglobal_dev;
     auto body = [&]() {
+        bool tail = false;                 // pose's linear2 / IK / FK still running on the side stream (the solver does not read them)
         if (int r = forward_body(h, p, imu_dev, pose_dev, (long)B * T, 96, 0, joints_dev, vel_dev, contact_dev, p->r6d,
-                                 h->vstate, has_state, rglobal_dev, joint_dev)) return r;
+                                 h->vstate, has_state, rglobal_dev, joint_dev, &tail)) return r;
         mp_launch_translate_offline(joints_dev, vel_dev, contact_dev, p->lengths_dev, B, T, h->floor_y, tran_dev,
                                     h->s_main);                                       // net.py:130-154
+        if (tail) HIPCHK(h, hipStreamWaitEvent(h->s_main, h->ev_x[3], 0));
         HIPCHK(h, hipGetLastError());
         return (int)MP_OK;
     };
@@ -1946,10 +2043,12 @@ int mp_stream_step(mp_handle* h, const float* frames_dev, float* pose_dev, float
     key.p[6] = h->vstate.h;
     auto net_and_solver = [&]() {
         // forward on the 45-frame window (net.py:178); pose only for index 40 (net.py:181)
+        bool tail = false;
         if (int r = forward_body(h, p, c.window, pose_dev, S, (long)W * 96, (long)PAST * 96, joints, c.vel, c.contact,
-                                 p->r6d, h->vstate, has_state)) return r;
+                                 p->r6d, h->vstate, has_state, nullptr, nullptr, &tail)) return r;
         mp_launch_translate_online(joints, c.vel, c.contact, S, W, PAST, h->floor_y, c.st, root_pos_dev, contact_dev,
                                    h->s_main);                                                // net.py:186-208
+        if (tail) HIPCHK(h, hipStreamWaitEvent(h->s_main, h->ev_x[3], 0));
         HIPCHK(h, hipGetLastError());
         return (int)MP_OK;
     };

@@ -49,7 +49,17 @@ struct GemmArgs {
     // 32-column tile b) is 64 lanes x 16 bytes contiguous -- and its number of 32-column tiles; nullptr: row-major W only
     const float* Wf = nullptr;
     int NB = 0;
+    // mp_gemm_f32_frag only: a third stacked output -- columns [nsplit3, N) go to C3 (as its columns [0, N - nsplit3)) with
+    // row strides of its own (the foot-contact block's linear1 is 64 wide, pose's and velocity's 256)
+    float* C3 = nullptr;
+    int nsplit3 = 0;
+    long c3StrideB = 0, c3StrideT = 0;
 };
+// two independent GEMMs in ONE launch (workgroups [0, n1) run g1, the rest g2): linear2 of the velocity block and of the
+// foot-contact block at the end of a forward -- the second one is 10 us of work that would otherwise cost a launch of its own on
+// the critical chain or a cross-stream join in front of the solver.  Both need W in fragment order; false = shapes not covered
+bool mp_launch_gemm_pair(const GemmArgs& g1, const GemmArgs& g2, hipStream_t s);
+bool mp_gemm_frag_enabled();          // false under MP_VARIANT gemm_frag=0 / gemm_staged=1 (A/B runs with the round-3 kernels)
 // W [Npad][Kpad] row-major -> fragment order [Kpad/32][4][Npad/32][64 lanes][4]: lane (li = lane & 31, lh = lane >> 5) of piece
 // (kt, q, b) holds W[b*32 + li][kt*32 + lh*16 + q*4 .. +3] -- what a lane of mp_gemm_f32_rows feeds its MFMAs of quarter q
 void mp_launch_pack_wfrag(const float* W, float* Wf, int Npad, int Kpad, hipStream_t s);

@@ -282,9 +282,7 @@ MP_KERNEL __launch_bounds__(256, 2) void mp_gemm_f32_rows(GemmArgs g, int nTiles
 // ~600 look-ups per k-tile and CU, A included.  Same k pairing, same MFMA order: bit-identical to both older kernels.
 // Also serves the wide linear1 shapes (N = 256 / 512: TN = 4, n-tiles of an m-tile on one XCD so that A comes from L2).
 template <int TN, int NK>
-MP_KERNEL __launch_bounds__(256, 2) void mp_gemm_f32_frag(GemmArgs g, int nTilesM, int nTilesN) {
-    __shared__ long rowOffC[4][32];
-    const int bid = blockIdx.x;
+__device__ __forceinline__ void gemm_frag_body(const GemmArgs& g, int bid, int nTilesM, int nTilesN, long (*rowOffC)[32]) {
     const int xcd = bid & 7, idx = bid >> 3;
     const int mt = (idx / nTilesN) * 8 + xcd;               // all n-tiles of an m-tile on one XCD (A panel from HBM once)
     const int nt = idx % nTilesN;
@@ -294,11 +292,19 @@ MP_KERNEL __launch_bounds__(256, 2) void mp_gemm_f32_frag(GemmArgs g, int nTiles
     const int m0 = mt * 128 + wave * 32, n0 = nt * (TN * 32);
     if (m0 >= g.M) return;
 
+    // which of the stacked outputs this block's columns belong to (uniform per block: TN*32 divides the split points)
+    float* Cb = g.C;
+    int ncol0 = 0;
+    long sB = g.cStrideB, sT = g.cStrideT;
+    if (g.nsplit3 > 0 && n0 >= g.nsplit3) { Cb = g.C3; ncol0 = g.nsplit3; sB = g.c3StrideB; sT = g.c3StrideT; }
+    else if (g.nsplit > 0 && n0 >= g.nsplit) { Cb = g.C2; ncol0 = g.nsplit; }
+    const int ncols_end = (g.nsplit3 > 0 && n0 < g.nsplit3) ? g.nsplit3 : g.N;   // (columns of this output only)
+
     const int m = m0 + li < g.M ? m0 + li : g.M - 1;
     const int rb = m % g.B, rt = m / g.B;
     const float* pa0 = g.a0.base + (long)rb * g.a0.strideB + (long)rt * g.a0.strideT;
     const float* pa1 = g.a1.base ? g.a1.base + (long)rb * g.a1.strideB + (long)rt * g.a1.strideT - g.a0.width : pa0;
-    if (lane < 32) rowOffC[wave][lane] = (long)rb * g.cStrideB + (long)rt * g.cStrideT;
+    if (lane < 32) rowOffC[wave][lane] = (long)rb * sB + (long)rt * sT;
     const int w0 = g.a0.width, klast = g.K - 4;
     // piece (kt, q, b) of this lane: Wf + (((kt*4 + q) * NB + nt*TN + b) * 64 + lane) * 4
     const float* pw = g.Wf + ((long)(nt * TN) * 64 + lane) * 4;
@@ -341,12 +347,10 @@ MP_KERNEL __launch_bounds__(256, 2) void mp_gemm_f32_frag(GemmArgs g, int nTiles
     }
 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // rowOffC of this wave (written by its own lanes)
-    float* const Cb = (g.nsplit > 0 && n0 >= g.nsplit) ? g.C2 : g.C;       // uniform per block: TN*32 divides nsplit
-    const int ncol0 = (g.nsplit > 0 && n0 >= g.nsplit) ? g.nsplit : 0;
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int n = n0 + b * 32 + li;
-        if (n >= g.N) continue;
+        if (n >= ncols_end) continue;
         const float bias = g.bias[n];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -358,6 +362,21 @@ MP_KERNEL __launch_bounds__(256, 2) void mp_gemm_f32_frag(GemmArgs g, int nTiles
             }
         }
     }
+}
+
+template <int TN, int NK>
+MP_KERNEL __launch_bounds__(256, 2) void mp_gemm_f32_frag(GemmArgs g, int nTilesM, int nTilesN) {
+    __shared__ long rowOffC[4][32];
+    gemm_frag_body<TN, NK>(g, (int)blockIdx.x, nTilesM, nTilesN, rowOffC);
+}
+
+// two independent GEMMs in one launch: workgroups [0, grid1) run g1, the others g2 (mp_launch_gemm_pair)
+template <int TN1, int NK1, int TN2, int NK2>
+MP_KERNEL __launch_bounds__(256, 2) void mp_gemm_f32_frag2(GemmArgs g1, int nTilesM1, int nTilesN1, int grid1,
+                                                             GemmArgs g2, int nTilesM2, int nTilesN2) {
+    __shared__ long rowOffC[4][32];
+    if ((int)blockIdx.x < grid1) gemm_frag_body<TN1, NK1>(g1, (int)blockIdx.x, nTilesM1, nTilesN1, rowOffC);
+    else gemm_frag_body<TN2, NK2>(g2, (int)blockIdx.x - grid1, nTilesM2, nTilesN2, rowOffC);
 }
 
 MP_KERNEL __launch_bounds__(256) void mp_pack_wfrag(const float* __restrict__ W, float* __restrict__ Wf, int Npad, int Kpad) {
@@ -432,17 +451,39 @@ void mp_launch_pack_wfrag(const float* W, float* Wf, int Npad, int Kpad, hipStre
     hipLaunchKernelGGL(mp_pack_wfrag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, Wf, Npad, Kpad);
 }
 
+static bool frag_usable(const GemmArgs& g) {
+    static const bool staged = getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "gemm_staged=1");
+    static const bool no_frag = getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "gemm_frag=0");
+    return g.Wf && !staged && !no_frag && g.NB > 0 && (g.K & 3) == 0 && (g.a0.width & 3) == 0;
+}
+
+bool mp_gemm_frag_enabled() {
+    GemmArgs probe;
+    static const float one = 0.f;
+    probe.Wf = &one; probe.NB = 1; probe.K = 4; probe.a0.width = 4;
+    return frag_usable(probe);
+}
+
+bool mp_launch_gemm_pair(const GemmArgs& g1, const GemmArgs& g2, hipStream_t s) {
+    // velocity.linear2 (K = 256, N = 72: three 32-column tiles, 8 k-tiles) + foot_contact.linear2 (K = 128, N = 2: one tile, 4 k-tiles)
+    if (!frag_usable(g1) || !frag_usable(g2) || g1.nsplit || g2.nsplit || g1.nsplit3 || g2.nsplit3) return false;
+    if (!(g1.NB == 3 && g1.Kpad == 256 && g1.N > 64 && g1.N <= 96 && g2.NB == 1 && g2.Kpad == 128 && g2.N <= 32)) return false;
+    const int tm1 = (g1.M + 127) / 128, tm2 = (g2.M + 127) / 128;
+    const int grid1 = ((tm1 + 7) / 8) * 8, grid2 = ((tm2 + 7) / 8) * 8;
+    hipLaunchKernelGGL((mp_gemm_f32_frag2<3, 8, 1, 4>), dim3(grid1 + grid2), dim3(256), 0, s, g1, tm1, 1, grid1, g2, tm2, 1);
+    return true;
+}
+
 void mp_launch_gemm(const GemmArgs& g, int bn, hipStream_t s) {
     static const bool staged = getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "gemm_staged=1");   // A/B runs: the LDS-staged kernel
     static const int frag_tn = getenv("MP_GEMM_FRAG_TN") ? atoi(getenv("MP_GEMM_FRAG_TN")) : 0;          // micro-benchmark only
-    static const bool no_frag = getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "gemm_frag=0");     // A/B runs: the round-3 kernels
-    if (g.Wf && !staged && !no_frag && g.NB > 0 && (g.K & 3) == 0 && (g.a0.width & 3) == 0) {
+    if (frag_usable(g)) {      // (MP_VARIANT gemm_frag=0: the round-3 kernels, A/B runs)
         const int npad32 = g.NB;                                      // 32-column tiles of the padded W
         // columns per wave: all of a narrow output (linear2: N <= 96); 64 of a wide one (linear1: four waves per SIMD keep the
         // MFMA pipe busier than two waves with 128 columns each -- 78.6 vs 85.0 us for the stacked pose + velocity linear1)
         int tn = g.N <= 32 ? 1 : g.N <= 64 ? 2 : g.N <= 96 ? 3 : 2;
         if (frag_tn) tn = frag_tn;
-        if (npad32 % tn == 0 && (g.nsplit == 0 || g.nsplit % (tn * 32) == 0)) {
+        if (npad32 % tn == 0 && (g.nsplit == 0 || g.nsplit % (tn * 32) == 0) && (g.nsplit3 == 0 || g.nsplit3 % (tn * 32) == 0)) {
             const bool done = tn == 1 ? launch_frag_k<1>(g, s) : tn == 2 ? launch_frag_k<2>(g, s) : tn == 3 ? launch_frag_k<3>(g, s)
                                                                                                              : launch_frag_k<4>(g, s);
             if (done) return;

@@ -93,7 +93,11 @@ def main():
             e = acc.setdefault(k, {}).setdefault(r["Counter_Name"], [0.0, 0])
             e[0] += float(r["Counter_Value"])
             e[1] += 1
-    summary = {"note": __doc__.split("Counter arithmetic")[1].strip(), "kernels": {}}
+    import hashlib
+    lib = os.path.join(REPO, "mobileposer_amd", "libmobileposer_hip.so")
+    summary = {"note": __doc__.split("Counter arithmetic")[1].strip(),
+               # bench.py quotes roofline.traffic from this file only while the library it runs is this very binary
+               "lib_md5": hashlib.md5(open(lib, "rb").read()).hexdigest(), "kernels": {}}
     for k, c in acc.items():
         e = {n: v[0] / v[1] for n, v in c.items()}
         e["launches_sampled"] = max(v[1] for v in c.values())
