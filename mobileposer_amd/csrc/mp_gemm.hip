@@ -338,10 +338,18 @@ __device__ __forceinline__ void gemm_frag_body(const GemmArgs& g, int bid, int n
             for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
+#if MP_GEMM_EXP == 4
+                    acc[b][s4] += fa[kt & 1][q][s4] * fw[b][q][s4];
+#else
                     acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kt & 1][q][s4], fw[b][q][s4], acc[b], 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
+#if MP_GEMM_EXP != 2 && MP_GEMM_EXP != 5
             if (kt + 2 < NK) request_a(fa[kt & 1][q], q, (kt + 2) * BK);
+#endif
+#if MP_GEMM_EXP != 2 && MP_GEMM_EXP != 6
             if (kt + 1 < NK) request_w(q, kt + 1);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -358,6 +366,9 @@ __device__ __forceinline__ void gemm_frag_body(const GemmArgs& g, int bid, int n
             if (m0 + ml < g.M) {
                 float v = acc[b][r] + bias;
                 if (g.relu) v = fmaxf(v, 0.f);
+#if MP_GEMM_EXP == 1
+                if (v == 123456.f)
+#endif
                 Cb[rowOffC[wave][ml] + (n - ncol0)] = g.pairOut ? __uint_as_float(pair_of(v)) : v;
             }
         }

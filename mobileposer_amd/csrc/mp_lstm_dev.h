@@ -67,7 +67,7 @@ constexpr unsigned XCC_TAG = 0x7fffffffu;
 // half and lo = bf16_rne(v - hi) in the lower half.  hi + lo carries 16 significand bits of v (relative error
 // <= 2^-17); the products hi*hi + hi*lo + lo*hi of two such pairs, accumulated in fp32 by the MFMA, reproduce the
 // fp32 product to ~2^-16 relative -- measured end to end: 4e-7 on the network outputs, the same as the
-// exact-fp32 path's own distance from the reference (DESIGN.md "split-bf16").
+// exact-fp32 path's own distance from the reference (profiles/NOTES_r01-r03.md 4.2).
 static __device__ __forceinline__ unsigned bf16_rne_bits(float x) {
     const unsigned u = __float_as_uint(x);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;             // finite inputs only (activations and weights)

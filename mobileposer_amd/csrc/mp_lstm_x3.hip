@@ -626,7 +626,7 @@ void mp_launch_pack_w_x3(const float* w, float* dst, int K, int nslice, hipStrea
 }
 
 void mp_launch_lstm_x3(const LstmPersistArgs& a, int KIN, int nslice, hipStream_t s) {
-    // (8 slices only: the 16-slice / two-workgroups-per-CU packing was measured slower on every layer -- DESIGN.md -- and is
+    // (8 slices only: the 16-slice / two-workgroups-per-CU packing was measured slower on every layer -- profiles/NOTES_r01-r03.md 4.2 -- and is
     //  no longer instantiated; `nslice` stays in the signature for the packing helper's sake)
     (void)nslice;
     if (KIN == 256) launch_x3<8, 256>(a, s);

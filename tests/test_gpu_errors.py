@@ -239,7 +239,7 @@ def test_two_handles_two_threads_overlapping_full_chip_calls(torch_mod, weights,
 
 @pytest.mark.parametrize("skip,what", [(3, "velocity layer 0 + rider"), (4, "pose layer 1")])
 def test_starved_launch_in_the_half_chip_schedule(torch_mod, weights, smpl, monkeypatch, skip, what):
-    """B = 128, exact-fp32 (schedule 4 of DESIGN.md section 4): fused launches are issued in the order joints L0, joints L1,
+    """B = 128, exact-fp32 (schedule 4 of profiles/NOTES_r01-r03.md section 4): fused launches are issued in the order joints L0, joints L1,
     pose L0, velocity L0 (with the foot-contact rider), pose L1, velocity L1 -- pose L1 and the velocity layers run side by side
     on disjoint halves of the chip.  A workgroup missing from one of the two concurrent grids: without recovery NaN in what
     that grid feeds (and only there), finish() raises; with recovery the call is repaired; the other grid is not disturbed."""

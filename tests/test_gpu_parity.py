@@ -146,7 +146,7 @@ def test_forward_vs_oracle_medium(torch_mod, net, weights, smpl):
 @pytest.mark.parametrize("B,T", [(72, 40), (128, 33)])
 def test_half_chip_batches_vs_oracle(torch_mod, net, weights, smpl, B, T):
     """64 < B <= 128 (on the exact-fp32 path: pose layer 0 on 16 slices, then pose layer 1 on 8 slices beside the velocity
-    layers that carry the foot-contact layers -- DESIGN.md section 4's schedule table), ragged, two calls so that the second one
+    layers that carry the foot-contact layers -- DESIGN.md section 4 and profiles/NOTES_r01-r03.md section 4), ragged, two calls so that the second one
     starts from a carried velocity state, against the oracle: network outputs, poses and translation of every sequence."""
     from mobileposer_amd import synthetic
     from oracle import mp_oracle as O
