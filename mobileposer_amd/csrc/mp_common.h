@@ -7,7 +7,7 @@
 // `-Xclang -target-feature -Xclang -packed-fp32-ops` for all device code (__graft_entry__.build) and tests/test_cabi_cpu.py
 // disassembles the library to check that none slipped in.  Insurance, not a claimed hardware erratum: some historical
 // revisions of the split-bf16 LSTM kernels disturbed such results (lanes 48..63) of a kernel running beside them, the
-// current ones do not, and no trigger could be named (profiles/r02_coexec_glitch.md).
+// current ones do not, and no trigger could be named (profiles/NOTES_r01-r03.md 4.3, profiles/r02_coexec_glitch.md).
 #define MP_KERNEL __global__
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

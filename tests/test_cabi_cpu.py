@@ -83,7 +83,7 @@ def test_facade_requires_gpu_and_library():
 
 
 def test_no_packed_fp32_instructions_in_device_code():
-    """Insurance kept from round 2 (csrc/mp_common.h): some historical revisions of the split-bf16 kernels
+    """Insurance kept from round 2 (csrc/mp_common.h, profiles/NOTES_r01-r03.md 4.3): some historical revisions of the split-bf16 kernels
     disturbed packed-fp32 VALU results of kernels running beside them; the library is therefore built without a single
     v_pk_{mul,add,fma}_f32."""
     import os

@@ -482,7 +482,7 @@ def test_live_session_feeds_stream_step(torch_mod, weights, smpl):
 
 
 def test_soak_bitwise_stable_under_concurrency(torch_mod, net):
-    """Glitch detector: the whole captured forward + FK + solver -- LSTM layers, GEMMs, IK, FK and the
+    """Glitch detector (profiles/NOTES_r01-r03.md 4.3): the whole captured forward + FK + solver -- LSTM layers, GEMMs, IK, FK and the
     solver running beside each other on four streams -- must give bit-identical outputs every time."""
     from mobileposer_amd import synthetic
     B, T = 256, 125

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Reproducer for DESIGN.md 4.3 (gfx950: packed-fp32 VALU results of one kernel wrong in lanes 48..63 while certain
+# Reproducer for profiles/NOTES_r01-r03.md 4.3 (gfx950: packed-fp32 VALU results of one kernel wrong in lanes 48..63 while certain
 # revisions of the split-bf16 LSTM kernel run on the same CUs).  Step 1 (any machine with hipcc): rebuild historical
 # revisions of this repository WITH packed-fp32 instructions enabled:   tools/debug/erratum_history.sh build
 # Step 2 (MI355X):                                                       tools/debug/erratum_history.sh run

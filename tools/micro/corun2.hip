@@ -1,4 +1,4 @@
-// Standalone probe for the gfx950 co-execution glitch: the library's own r6d -> rotation kernel, compiled
+// Standalone probe for the gfx950 co-execution glitch (profiles/NOTES_r01-r03.md 4.3): the library's own r6d -> rotation kernel, compiled
 // WITH packed-fp32 instructions, beside synthetic MFMA hogs of varying register footprint.  No library involved.
 //   hipcc --offload-arch=gfx950 -O3 -o corun2 corun2.hip && ./corun2
 #include <hip/hip_runtime.h>
