@@ -4,7 +4,7 @@
 One "step" = one pass of the hot path over one synthetic batch of IMU windows x 125 frames that is already resident in
 HBM:  mp_forward_offline = forward (4 stacked-LSTM modules + 6D->SO(3) + global->local) + SMPL forward kinematics of the
 predicted pose + foot-contact/velocity translation solver.  The headline `value` is measured in the library's default
-arithmetic -- exact-fp32 MFMA operands, the reference's arithmetic (`dtype` "f32"); the opt-in split-bf16 mode is timed
+arithmetic -- exact-fp32 MFMA operands, the reference's arithmetic (`dtype` "f32"); the opt-in split-fp16 mode is timed
 in the same run and reported under `modes`.
 
   --scaling weak   (default)  256 sequences per GPU (BASELINE metric: batch 256 x window 125 per GPU)
@@ -314,7 +314,7 @@ def main():
     ap.add_argument("--lstm-mode", choices=["fp32", "x3"], default="fp32",
                     help="MFMA operands of the H=256 LSTM layers for the headline value: fp32 (default = the library default: "
                          "exact v_mfma_f32_16x16x4_f32 operands, the reference's arithmetic) or x3 (opt-in: every fp32 product "
-                         "as 3 bf16 products on v_mfma_f32_16x16x32_bf16, fp32 accumulate); the other mode is timed as well")
+                         "as 3 products of fp16 halves on v_mfma_f32_16x16x32_f16, fp32 accumulate); the other mode is timed as well")
     ap.add_argument("--recovery", choices=["on", "off"], default="on",
                     help="on (library default): every call waits for itself and repairs a starved fused-LSTM launch; off: "
                          "asynchronous calls (mp_set_recovery(h, 0)) -- an A/B switch, the headline uses the default")
@@ -539,7 +539,7 @@ def main():
         # flops against the dense bf16 peak (the algorithmic rate is reported beside it)
         roof_peak, roof_achieved = PEAK_BF16_MFMA_TFLOPS, 3.0 * achieved
         roof_note = ("3 x algorithmic FLOPs of the launch (each fp32 product = hi*hi + hi*lo + lo*hi on "
-                     "v_mfma_f32_16x16x32_bf16) / HIP-event duration, dense bf16 MFMA peak")
+                     "v_mfma_f32_16x16x32_f16) / HIP-event duration, dense fp16 MFMA peak (= the bf16 peak)")
     else:
         roof_peak, roof_achieved = PEAK_FP32_MFMA_TFLOPS, achieved
         roof_note = ("algorithmic FLOPs of one launch (input projection + recurrence of one bidirectional layer, "
@@ -582,7 +582,7 @@ def main():
         "n_gpus": world, "n_ranks_seen": seen, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4),
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": "f32" if args.lstm_mode == "fp32" else "f32 state/accumulate, matrix products as 3-term split-bf16 MFMA (opt-in mode)",
+        "dtype": "f32" if args.lstm_mode == "fp32" else "f32 state/accumulate, matrix products as 3-term split-fp16 MFMA (opt-in mode)",
         "data": "synthetic",
         "config": {"workload": cfg_name + ", seeded synthetic IMU (lw_rp combo), seeded random weights, synthetic SMPL constants",
                    "batch_per_gpu": B, "window": T, "global_batch": global_batch,
@@ -599,8 +599,9 @@ def main():
                     "steps": other_steps, "headline": False},
             "max_abs_output_difference_between_modes": mode_dev,
             "note": "fp32 (library default) = exact v_mfma_f32_16x16x4_f32 operands; x3 (opt-in, mp_set_lstm_mode(h, 3)) = each "
-                    "fp32 product as hi*hi+hi*lo+lo*hi of bf16 parts on v_mfma_f32_16x16x32_bf16 with fp32 accumulate and fp32 "
-                    "state; both pass the same parity tests at 1e-4 / 1 mm"},
+                    "fp32 product as hi*hi+hi*lo+lo*hi of fp16 halves (24-bit operands, weights pre-scaled by 16) on "
+                    "v_mfma_f32_16x16x32_f16 with fp32 accumulate and fp32 state; both pass the same parity tests at 1e-4 / 1 mm on "
+                    "init-scale and trained-regime weights (profiles/r04_accuracy.json)"},
         "end_to_end": {"tflops": round(value * FLOP_PER_FRAME / 1e12, 3),      # algorithmic fp32 FLOPs of the 4 modules
                        "frac_of_fp32_mfma_peak": round(value / world * FLOP_PER_FRAME / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                        "hbm_gbps_compulsory": round(value / world * BYTES_PER_FRAME / 1e9, 2)},

@@ -239,14 +239,14 @@ int mp_set_graph_mode(mp_handle* h, int on);
 /* LSTM implementation of the H = 256 layers (the H = 64 foot-contact block always uses the fp32 kernels):
  *   1 (default; env MP_LSTM_MODE=fp32): fused persistent layer kernels, one launch per layer, exact-fp32 MFMA operands
  *       (v_mfma_f32_16x16x4_f32, mp_lstm_persist.hip) -- the reference's arithmetic;
- *   3 (opt-in; env MP_LSTM_MODE=x3): the same layers with the two matrix products per step on split-bf16 MFMA operands
- *       -- every fp32 product as hi*hi + hi*lo + lo*hi of bf16 parts on v_mfma_f32_16x16x32_bf16, fp32 accumulate,
- *       fp32 state (mp_lstm_x3.hip), 2.2x faster.  16 significand bits per operand, i.e. 2^-17 relative error per product
- *       (fp32: 2^-24).  ACCURACY LIMIT (measured in round 4, profiles/r04_accuracy.json): on init-scale weights that is
- *       5e-7 from float64 on the network outputs (mode 1: 1.2e-7) and well inside the 1e-4 parity bound; on weights in the
- *       TRAINED regime (saturated gates, recurrent gain > 1, long memory) the recurrence amplifies it and mode 3 does NOT
- *       meet 1e-4: 2e-3 on the 6D pose output, 5e-3 on the contact logits at 64 x 125 (mode 1 and PyTorch's CPU path:
- *       3e-5 / 1e-4 there).  Use it where ~1e-2 is acceptable; the default (mode 1) is the one that matches the reference;
+ *   3 (opt-in; env MP_LSTM_MODE=x3): the same layers (and the linear layers of the H = 256 blocks) with every fp32 product
+ *       as hi*hi + hi*lo + lo*hi of two 16-bit halves per operand on v_mfma_f32_16x16x32_f16, fp32 accumulate, fp32 state
+ *       (mp_lstm_x3.hip), 2.1x faster.  Since round 4 the halves are IEEE fp16 (hi + lo = 24 significand bits; weights are
+ *       split as 16 w so that their low half stays a normal fp16 number): measured on init-scale AND on trained-regime weights
+ *       (saturated gates, recurrent gain > 1) the outputs are as close to float64 as mode 1's and PyTorch's CPU path's are
+ *       (profiles/r04_accuracy.json; 1.8-3.3 x the fp32 oracle's own noise at the worst element of a 256 x 125 batch, mode 1:
+ *       0.9-1.5 x).  Not bit-identical to mode 1; operands above 65504 (weights: 4094) in magnitude turn into inf / NaN.
+ *       (Rounds 1-3 used bf16 halves -- 17 bits: fine on init-scale weights, 2e-3 .. 2e-2 off on trained-regime ones.)
  *   2: mode 1 plus the unidirectional velocity block as ONE two-layer wavefront launch;
  *   0 (env MP_LSTM_MODE=step): input-projection GEMM + one launch per time step. */
 int mp_set_lstm_mode(mp_handle* h, int mode);

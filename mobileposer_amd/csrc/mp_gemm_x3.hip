@@ -1,3 +1,6 @@
+// NOTE (round 4): the 16-bit halves of a split operand are IEEE fp16 now (mp_lstm_dev.h pair_of: 24-bit operands, weights split
+// as 16 w, MFMA v_mfma_f32_16x16x32_f16), not bf16 as in rounds 1-3 when this file was written; "bf16" in the comments below
+// describes the same data path with the other half format.  The hidden-state tag sits in bit 30 of the word (hpair_of).
 // K1x/K3x -- the linear layers (models/rnn.py:22,32; the fused torch.cat of net.py:106,113) with SPLIT-bf16 MFMA
 // operands, for the default LSTM mode: same arithmetic contract as mp_lstm_x3.hip (every fp32 product a*w as
 // a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on v_mfma_f32_16x16x32_bf16, fp32 accumulate, fp32 bias / ReLU / output).
@@ -143,7 +146,7 @@ MP_KERNEL __launch_bounds__(256) void mp_gemm_x3(GemmArgs g, int nTilesM, int nT
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ml = wave * (BM / 4) + a * 16 + 4 * q + r;
-                float v = acc[a][b][r] + bias;
+                float v = acc[a][b][r] * kPairWInv + bias;      // (W was split as 16 W: mp_lstm_dev.h pair_of)
                 if (g.relu) v = fmaxf(v, 0.f);
                 Os[ml * OPITCH + b * 16 + r16] = g.pairOut ? pair_of(v) : __float_as_uint(v);
             }
@@ -173,7 +176,7 @@ MP_KERNEL __launch_bounds__(256) void mp_gemm_x3(GemmArgs g, int nTilesM, int nT
 
 MP_KERNEL void mp_pairs(const float* __restrict__ src, unsigned* __restrict__ dst, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = pair_of(src[i]);
+    if (i < n) dst[i] = wpair_of(src[i]);                      // weights only (mp_api.hip pack_weights)
 }
 
 template <int BN, int BM>

@@ -63,33 +63,34 @@ static __device__ __forceinline__ unsigned xcc_id() {
 }
 constexpr unsigned XCC_TAG = 0x7fffffffu;
 
-// ---- split-bf16 pair: one fp32 value v as two bf16 numbers in one 32-bit word, hi = bf16_rne(v) in the upper
-// half and lo = bf16_rne(v - hi) in the lower half.  hi + lo carries 16 significand bits of v (relative error
-// <= 2^-17); the products hi*hi + hi*lo + lo*hi of two such pairs, accumulated in fp32 by the MFMA, reproduce the
-// fp32 product to ~2^-16 relative -- measured end to end: 4e-7 on the network outputs, the same as the
-// exact-fp32 path's own distance from the reference (profiles/NOTES_r01-r03.md 4.2).
-static __device__ __forceinline__ unsigned bf16_rne_bits(float x) {
-    const unsigned u = __float_as_uint(x);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;             // finite inputs only (activations and weights)
-}
+// ---- split pair: one fp32 value v as two 16-bit floats in one 32-bit word, hi = rne16(v) in the upper half and
+// lo = rne16(v - hi) in the lower half; the products hi*hi + hi*lo + lo*hi of two such pairs, accumulated in fp32 by the MFMA,
+// stand in for the fp32 product.
+// Round 4: the 16-bit format is IEEE fp16 (11 significand bits), not bf16 (8).  Rounds 1-3 used bf16 pairs: hi + lo carried
+// 17 bits (2^-18 relative), ~100 x fp32's rounding, and on weights in the trained regime (saturated gates, recurrent gain > 1)
+// the recurrence amplified that to 2e-3 .. 2e-2 on the network outputs -- outside the 1e-4 parity bound
+// (profiles/r04_accuracy.json).  An fp16 pair carries 11 + 1 + 11 = 23 bits plus the hidden one: |v - hi - lo| <= 2^-24 |v|,
+// fp32's own half ulp, as long as lo is a NORMAL fp16 number; lo is about 2^-12 |v| and fp16's normal range ends at 2^-14, so
+// for |v| < 0.25 lo is subnormal (v_mfma_f32_16x16x32_f16 honours subnormal inputs: tools/micro/mfma_f16_denorm.hip) and the
+// representation error becomes ABSOLUTE, 2^-25 = 3e-8 -- that of an fp32 value near 0.5.  Hidden states and layer inputs
+// live with that (it is what fp32 gives the large terms of a dot product); WEIGHTS (|w| ~ 0.05 .. 0.5) do not -- they are
+// multiplied by kPairWScale = 16 before they are split (exact) and the accumulated sum is multiplied by 1/16 (exact) where the
+// bias is added.  CPU emulation (tools/experiments/x3h_emulation.py): at or below plain fp32's distance from float64 on both
+// weight profiles; without the weight scale 4 x above it.  Range: |value| <= 65504 (weights: 4094); beyond that an operand
+// becomes inf and the output NaN -- loud, and far outside anything an LSTM pose network produces.
+constexpr float kPairWScale = 16.0f;
+constexpr float kPairWInv = 0.0625f;
 static __device__ __forceinline__ unsigned pair_of(float x) {
 #pragma clang fp contract(off)
-#ifdef MP_PAIR_SWCVT
-    const unsigned hi = bf16_rne_bits(x);                        // integer form, kept as the cross-check
-    const float rest = x - __uint_as_float(hi << 16);           // exact in fp32
-    return (hi << 16) | bf16_rne_bits(rest);
-#else
-    // gfx950 converts in hardware (v_cvt_pk_bf16_f32, round to nearest even): 5 instructions instead of 14.  The whole
-    // forward is bit-identical to the integer form above (checked on the 256 x 125 batch, 30 repetitions).
-    const __bf16 h = (__bf16)x;
+    const _Float16 h = (_Float16)x;                              // v_cvt_f16_f32, round to nearest even
     const unsigned hi = __builtin_bit_cast(unsigned short, h);
     // (the difference is exact in fp32.  `fp contract(off)` above: with x = a * b the compiler would otherwise fuse the
     //  subtraction into fma(a, b, -hi), i.e. take the residual of the UNROUNDED product -- a lo part that differs in its
     //  last bit from the pair of the fp32 value, and only in those instantiations where the scheduler happens to see it)
-    const __bf16 l = (__bf16)(x - __uint_as_float(hi << 16));
+    const _Float16 l = (_Float16)(x - (float)h);
     return (hi << 16) | (unsigned)__builtin_bit_cast(unsigned short, l);
-#endif
 }
+static __device__ __forceinline__ unsigned wpair_of(float w) { return pair_of(w * kPairWScale); }   // weights (see above)
 
 // Workgroup barrier that only waits for this wave's LDS traffic (lgkmcnt), not for its outstanding global loads
 // and stores: __syncthreads() also drains vmcnt, which would put the latency of a prefetch that is in flight on
@@ -111,12 +112,13 @@ static __device__ __forceinline__ void rearm_exchange(unsigned long long* hx, in
 }
 
 // ---- shared by the split-bf16 LSTM kernels (mp_lstm_x3.hip, mp_lstm_x3w.hip)
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// (the name is from rounds 1-3, when the halves were bf16; they are fp16 now -- pair_of above)
 static __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
-// 8 pair words (k = e) -> hi fragment (8 bf16, element e in the low/high half of dword e/2) and lo fragment
+// 8 pair words (k = e) -> hi fragment (8 halves, element e in the low/high half of dword e/2) and lo fragment
 static __device__ __forceinline__ void split_pairs(u32x4 w0, u32x4 w1, u32x4& hi, u32x4& lo) {
     hi[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x07060302u);
     hi[1] = __builtin_amdgcn_perm(w0[3], w0[2], 0x07060302u);
@@ -127,13 +129,15 @@ static __device__ __forceinline__ void split_pairs(u32x4 w0, u32x4 w1, u32x4& hi
     lo[2] = __builtin_amdgcn_perm(w1[1], w1[0], 0x05040100u);
     lo[3] = __builtin_amdgcn_perm(w1[3], w1[2], 0x05040100u);
 }
-// ---- the exchanged hidden-state word: a pair whose lo part is rounded (to nearest even) to 7 mantissa bits, so that bit 0
-// is free for the epoch tag of the exchange; tag of the h written at `step` = ((step / 2) + 1) & 1 (see the kernel header)
-static __device__ __forceinline__ unsigned hpair_of(float x) {
-    const unsigned w = pair_of(x);
-    return (w + ((w >> 1) & 1u)) & ~1u;
-}
-static __device__ __forceinline__ unsigned tag_of_step(int step) { return (((unsigned)step >> 1) + 1u) & 1u; }
+// ---- the exchanged hidden-state word: the pair of h with the epoch tag of the exchange in bit 30 -- the top exponent bit of
+// the fp16 hi half, which is 0 for every |h| < 2 and h = o * tanh(c) never leaves [-1, 1]; tag of the h written at `step`
+// = ((step / 2) + 1) & 1 (see the kernel header).  (Rounds 1-3 took the last mantissa bit of lo for the tag; with fp16 halves
+// that would cost the pair its 23rd bit -- 4 x fp32's rounding on every recurrent operand, measured 3 x on the trained-regime
+// outputs.)  A NaN h -- a poisoned slab, mp_lstm_dev.h poison_cells -- would carry a set bit 30 of its own and lose its NaN-ness
+// when the consumer clears the tag: it travels as hi = 0, lo = NaN instead, and the consumer's MFMAs turn it back into NaN gates.
+constexpr unsigned kHTagBit = 1u << 30;
+static __device__ __forceinline__ unsigned hpair_of(float x) { return x != x ? 0x00007e00u : pair_of(x); }
+static __device__ __forceinline__ unsigned tag_of_step(int step) { return ((((unsigned)step >> 1) + 1u) & 1u) << 30; }
 // stores of the exchange as inline asm: the compiler's s_waitcnt bookkeeping must not see a store in the loop (with loads
 // AND stores pending it waits with vmcnt(0) everywhere); nothing ever waits for these stores -- the data is its own flag
 static __device__ __forceinline__ void store_word_xcd(unsigned* p, unsigned v) {          // stays in this XCD's L2

@@ -1,3 +1,6 @@
+// NOTE (round 4): the 16-bit halves of a split operand are IEEE fp16 now (mp_lstm_dev.h pair_of: 24-bit operands, weights split
+// as 16 w, MFMA v_mfma_f32_16x16x32_f16), not bf16 as in rounds 1-3 when this file was written; "bf16" in the comments below
+// describes the same data path with the other half format.  The hidden-state tag sits in bit 30 of the word (hpair_of).
 // K2x -- the persistent fused nn.LSTM layer of mp_lstm_persist.hip (models/rnn.py:27) with SPLIT-bf16 MFMA
 // operands: same decomposition, same fp32 state / gates / accumulation, but every fp32
 // product a*w inside the two matrix products of a step is evaluated as
@@ -172,7 +175,7 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         for (int c = 0; c < NHC; ++c)
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                hw[c][e >> 2][e & 3] = (arow_in && !a.zero_state) ? hpair_of(p[c * 32 + e]) : 0u;
+                hw[c][e >> 2][e & 3] = (arow_in && !a.zero_state) ? pair_of(p[c * 32 + e]) : 0u;
     }
 
     // exchange area of this cluster (32-bit words): hx[cluster] = { dataL[2 parities][16*H], dataR[2][16*H],
@@ -420,7 +423,7 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
                 unsigned m = 0;
 #pragma unroll
                 for (int i = 0; i < WPL / 4; ++i) m |= (blk[i][0] ^ want) | (blk[i][1] ^ want) | (blk[i][2] ^ want) | (blk[i][3] ^ want);
-                return (m & 1u) != 0;
+                return (m & kHTagBit) != 0;
             };
             bool late = stale();
             if (!__all(!late)) {
@@ -442,7 +445,7 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
             if (C::HT_ALIAS) __syncthreads();
 #pragma unroll
             for (int i = 0; i < WPL / 4; ++i)
-                *reinterpret_cast<u32x4*>(hT + cdst_off[i]) = blk[i] & u32x4{~1u, ~1u, ~1u, ~1u};
+                *reinterpret_cast<u32x4*>(hT + cdst_off[i]) = blk[i] & u32x4{~kHTagBit, ~kHTagBit, ~kHTagBit, ~kHTagBit};
             __syncthreads();
 #pragma unroll
             for (int c = 0; c < NHC; ++c) {
@@ -498,7 +501,7 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         f32x4 gate = redb[(wave * 4 + 0) * 64 + lane];
 #pragma unroll
         for (int sw = 1; sw < 4; ++sw) gate += redb[(wave * 4 + sw) * 64 + lane];
-        gate += bias4;
+        gate = gate * kPairWInv + bias4;                       // (weights were split as 16 w: mp_lstm_dev.h pair_of)
         TR(4);
         PROF_E(3); PROF_T(4);
 
@@ -592,8 +595,8 @@ MP_KERNEL void mp_pack_w_x3(const float* __restrict__ w, unsigned* __restrict__ 
     const int kq = wv & 3, tw = wv >> 2;
     const int row = t * H + slice * U + tw * 16 + (lane & 15);
     const int col = kq * KQ + c * 32 + (lane >> 4) * 8 + 2 * dd;
-    const unsigned p0 = pair_of(w[(size_t)row * K + col]);
-    const unsigned p1 = pair_of(w[(size_t)row * K + col + 1]);
+    const unsigned p0 = wpair_of(w[(size_t)row * K + col]);
+    const unsigned p1 = wpair_of(w[(size_t)row * K + col + 1]);
     dst[idx] = part == 0 ? ((p1 & 0xffff0000u) | (p0 >> 16)) : ((p1 << 16) | (p0 & 0xffffu));
 }
 

@@ -1,3 +1,6 @@
+// NOTE (round 4): the 16-bit halves of a split operand are IEEE fp16 now (mp_lstm_dev.h pair_of: 24-bit operands, weights split
+// as 16 w, MFMA v_mfma_f32_16x16x32_f16), not bf16 as in rounds 1-3 when this file was written; "bf16" in the comments below
+// describes the same data path with the other half format.  The hidden-state tag sits in bit 30 of the word (hpair_of).
 // K2w -- the split-bf16 persistent LSTM layer of mp_lstm_x3.hip with FOUR 512-register waves per workgroup instead
 // of eight 256-register ones.  Same arithmetic, same packed weights (mp_pack_w_x3<8>), same exchange protocol and
 // exchange area, same decomposition of a layer into (direction, slab of 16 sequences, slice of 32 hidden units)
@@ -30,15 +33,15 @@ namespace {
 // states the ISA asks for between the last MFMA and a VALU / LDS read of its result.
 template <bool B_IN_AGPR>
 static __device__ __forceinline__ void mfma_x(f32x4& c, u32x4 a, u32x4 b) {
-    if constexpr (B_IN_AGPR) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "a"(b));
-    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    if constexpr (B_IN_AGPR) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "a"(b));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 // first MFMA of an accumulation: C = 0 as an inline constant (no VALU write of the AccVGPRs in front of an MFMA that
 // the hazard recogniser cannot see)
 template <bool B_IN_AGPR>
 static __device__ __forceinline__ void mfma_x0(f32x4& c, u32x4 a, u32x4 b) {
-    if constexpr (B_IN_AGPR) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "a"(b));
-    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+    if constexpr (B_IN_AGPR) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "a"(b));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
 }
 // gfx950 wants two wait states between a VALU write of a VGPR and an MFMA that reads it as SrcA / SrcB (the compiler
 // puts `s_nop` there for its own MFMAs; measured without: the MFMA multiplies the previous chunk's fragment)
@@ -150,7 +153,7 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
         for (int c = 0; c < NHC; ++c)
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                hw[c][e >> 2][e & 3] = (arow_in && !a.zero_state) ? hpair_of(p[c * 32 + e]) : 0u;
+                hw[c][e >> 2][e & 3] = (arow_in && !a.zero_state) ? pair_of(p[c * 32 + e]) : 0u;
     }
 
     // ---- exchange area of this cluster (layout of mp_lstm_x3)
@@ -307,7 +310,7 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
                 unsigned m = 0;
 #pragma unroll
                 for (int i = 0; i < 2 * NHC; ++i) m |= (blk[i][0] ^ want) | (blk[i][1] ^ want) | (blk[i][2] ^ want) | (blk[i][3] ^ want);
-                return (m & 1u) != 0;
+                return (m & kHTagBit) != 0;
             };
             bool late = stale();
             if (!__all(!late)) {
@@ -328,8 +331,8 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
             // the fetched words ARE the A fragments (tags cleared)
 #pragma unroll
             for (int c = 0; c < NHC; ++c) {
-                hw[c][0] = blk[2 * c] & u32x4{~1u, ~1u, ~1u, ~1u};
-                hw[c][1] = blk[2 * c + 1] & u32x4{~1u, ~1u, ~1u, ~1u};
+                hw[c][0] = blk[2 * c] & u32x4{~kHTagBit, ~kHTagBit, ~kHTagBit, ~kHTagBit};
+                hw[c][1] = blk[2 * c + 1] & u32x4{~kHTagBit, ~kHTagBit, ~kHTagBit, ~kHTagBit};
             }
         }
         // ---- next x (after the wait for the blocks, so that this wait does not drain these loads as well)
@@ -357,7 +360,7 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
             gate[ub] = redb[((wave * 4 + 0) * UB + ub) * 64 + lane];
 #pragma unroll
             for (int sw = 1; sw < 4; ++sw) gate[ub] += redb[((wave * 4 + sw) * UB + ub) * 64 + lane];
-            gate[ub] += bias4[ub];
+            gate[ub] = gate[ub] * kPairWInv + bias4[ub];       // (weights were split as 16 w: mp_lstm_dev.h pair_of)
         }
         PROF_E(3); PROF_T(4);
 

@@ -92,5 +92,5 @@ def test_no_packed_fp32_instructions_in_device_code():
     if not os.path.exists(os.path.join(_devcode.LLVM_BIN, "llvm-objdump")):
         pytest.skip("llvm-objdump not available")
     text = _devcode.disassemble(_lib.LIB_PATH)
-    assert len(re.findall(r"v_mfma_f32_16x16x32[_a-z0-9]*bf16", text)) > 0, "split-bf16 kernels missing from the library"
+    assert len(re.findall(r"v_mfma_f32_16x16x32[_a-z0-9]*f16", text)) > 0, "split-fp16 kernels (mode 3) missing from the library"
     assert re.findall(r"v_pk_(?:mul|add|fma)_f32", text) == []

@@ -4,8 +4,7 @@
     against golden G14 recorded from the reference -- ragged mixed-combo forward, forward_offline at T = 600, 50 online
     frames -- and against the oracle at the BASELINE size 256 x 125; a second init-scale seed; all 12 sensor combos
     (config.py:60-73, data.py:69-76) in one batch.  Exact-fp32 operands (mode 1, the library default) must meet 1e-4 / 1 mm
-    everywhere.  The opt-in split-bf16 mode (mode 3) is measured on the same inputs: X3_TOL is what it is held to, and
-    where that is wider than 1e-4 the header / INTEGRATION.md say so.
+    everywhere, and so must the opt-in split-fp16 mode (mode 3) since it was rebuilt on fp16 halves this round.
   * the mesh kernels at the real SMPL size (6890 vertices = 26 x 256 + 234) and at chunk edges (V = 257, 512), golden G15:
     forward_kinematics(calc_mesh), with shape, zero-pose body of a shape, pose blend shapes, the evaluator table.
   * the state a failed call carries forward: after a reported device error with recovery off the next call is finite.
@@ -22,24 +21,23 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
 TOL_TRAN = 1e-3
-# What each operand mode is held to (max abs error on raw network outputs / rad on rotations).
-#   exact-fp32 operands (mode 1, the default): the north-star bound, 1e-4 / 1 mm, on every weight profile.
-#   split-bf16 operands (mode 3, opt-in): 1e-4 on init-scale weights (rounds 1-3 and the second seed here); on trained-regime
-#   weights it does NOT meet 1e-4 -- its 16-bit operands put 2^-17 relative error into every product, ~100 x fp32's, and the
-#   trained regime amplifies it through the recurrence: measured 2e-3 on r6d, 5e-3 on contact logits at 64 x 125
-#   (profiles/r04_accuracy.json).  The tests hold it to X3_TRAINED_TOL so that a regression is caught, and
-#   include/mobileposer_hip.h / INTEGRATION.md state the limitation.
+# What each operand mode is held to (max abs error on raw network outputs / rad on rotations): the north-star bound, 1e-4 / 1 mm,
+# on every weight profile, in BOTH modes.  History: until this round mode 3 split its operands into bf16 halves (17 bits) and
+# missed the bound on trained-regime weights by 20-200 x (2e-3 on r6d at 64 x 125, 1.6e-2 in 256 x 125: the first run of these
+# tests, profiles/r04_parity_errors.txt); it now splits into fp16 halves with weights pre-scaled by 16 (24 bits, mp_lstm_dev.h
+# pair_of) and sits at fp32's own noise level (profiles/r04_accuracy.json).  At 256 x 125 on the trained-regime net, where fp32
+# implementations differ from each other by more than 1e-4, a mode is held to NOISE_FACTOR x the fp32 oracle's own distance
+# from float64 (measured: mode 1 0.9-1.5 x, mode 3 1.8-3.3 x).
 MODE_TOL = {"fp32": 1e-4, "x3": 1e-4}
-X3_TRAINED_TOL = 3e-2
-X3_TRAINED_TOL_TRAN = 3e-2
+NOISE_FACTOR = {"fp32": 3.0, "x3": 5.0}
 
 
 def trained_tol(mode):
-    return 1e-4 if mode == "fp32" else X3_TRAINED_TOL
+    return MODE_TOL[mode]
 
 
 def trained_tol_tran(mode):
-    return TOL_TRAN if mode == "fp32" else X3_TRAINED_TOL_TRAN
+    return TOL_TRAN
 
 
 @pytest.fixture(scope="module")
@@ -178,7 +176,7 @@ def test_baseline_size_vs_oracle_other_weights(torch_mod, smpl, profile, seed, m
             n64 = {k: err(ref[k], truth[k], k) for k in got}                  # fp32 oracle vs exact arithmetic
             print("   vs float64: library %s | fp32 oracle %s" % ({k: "%.2e" % v for k, v in e64.items()}, {k: "%.2e" % v for k, v in n64.items()}))
             for k in got:
-                assert e[k] < tol or e64[k] < 3.0 * n64[k], (k, e[k], e64[k], n64[k])
+                assert e[k] < tol or e64[k] < NOISE_FACTOR[mode] * n64[k], (k, e[k], e64[k], n64[k])
         # translation of every 16th row through the batched solver, 1 mm
         tran = torch_mod.empty(B, T, 3, device="cuda")
         n.translate_offline_into(joints, vel.reshape(B, T, 72), contact, (C.c_int32 * B)(*([T] * B)), tran)

@@ -4,7 +4,7 @@ carried out in float64 (the oracle with its dtype switched), on one seeded batch
   python tools/accuracy.py [B] [T]      (GPU box; writes gpurun_out/r04_accuracy.json -> profiles/)
 
 Rows: numpy fp32 oracle, torch CPU fp32 (nn.LSTM, what the reference runs), HIP path with exact-fp32 MFMA operands,
-HIP path with split-bf16 operands -- for BOTH weight profiles of mobileposer_amd.synthetic.make_weights: "init" (uniform
+HIP path with split-fp16 operands (mode 3; bf16 halves until round 3) -- for BOTH weight profiles of mobileposer_amd.synthetic.make_weights: "init" (uniform
 +-1/sqrt(H), gates near 0.5) and "trained" (LSTM weights x 3, forget bias + 1, linear1 x 2: saturated gates, recurrent
 gain > 1, long memory -- rounding differences are amplified through the recurrence instead of being forgotten).
 """
@@ -27,7 +27,7 @@ T = int(sys.argv[2]) if len(sys.argv) > 2 else 125
 smpl = synthetic.synthetic_smpl()
 imu = synthetic.make_imu(B, T, seed=1)
 lengths = [T] * B
-MODES = [("HIP, exact fp32 MFMA operands (mode 1)", 1), ("HIP, split-bf16 MFMA operands (mode 3)", 3)]
+MODES = [("HIP, exact fp32 MFMA operands (mode 1)", 1), ("HIP, split-fp16 MFMA operands (mode 3)", 3)]
 if os.environ.get("MP_ACCURACY_MODES"):                       # e.g. "1,3,4": further operand modes under test
     MODES = [("HIP, LSTM mode %s" % m, int(m)) for m in os.environ["MP_ACCURACY_MODES"].split(",")]
 
