@@ -15,6 +15,7 @@ def child(B, T):
     from mobileposer_amd import synthetic
     from mobileposer_amd.net import MobilePoserNet
     net = MobilePoserNet.from_numpy(synthetic.make_weights(0), synthetic.synthetic_smpl())
+    net.set_lstm_mode(int(os.environ.get("MP_TL_MODE", "1")))        # 1 = exact fp32 (default), 3 = split-fp16
     x = torch.from_numpy(synthetic.make_imu(B, T, seed=1)).cuda()
     L = [T] * B
     for _ in range(6):
