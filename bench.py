@@ -39,7 +39,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x
 PEAK_BF16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
 
-X3_NAMES = {         # the same timing classes when the H = 256 blocks run on split-bf16 operands (--lstm-mode x3)
+X3_NAMES = {         # the same timing classes when the H = 256 blocks run on split-fp16 operands (--lstm-mode x3)
     0: "mp_gemm_x3 (linear1 / linear2 of the H=256 blocks) + mp_gemm_f32 (foot-contact block)",
     1: "mp_lstm_x3<8,256> bidirectional layer 0 (joints, pose)",
     4: "mp_lstm_x3w<512> bidirectional layer 1 (joints, pose)",
@@ -47,7 +47,7 @@ X3_NAMES = {         # the same timing classes when the H = 256 blocks run on sp
 }
 
 KERNEL_CLASSES = {   # timing classes of the C ABI (include/mobileposer_hip.h, mp_timing_read)
-    0: "mp_gemm_f32 (linear1 / linear2)",
+    0: "mp_gemm_f32_frag (linear1 / linear2; pose|velocity|foot-contact linear1 and velocity+foot-contact linear2 as one launch each)",
     1: "mp_lstm_fused<256,8,256,1> bidirectional layer 0 (joints, pose)",
     4: "mp_lstm_fused<256,8,512,1> bidirectional layer 1 (joints, pose)",
     5: "mp_lstm_fused<256,16,256,1,FK> unidirectional layers (velocity, the foot-contact layers riding in its workgroups)",
@@ -549,13 +549,14 @@ def main():
     # (2*FETCH_SIZE + WRITE_SIZE)*1024, corrected as MI355X_MICROARCH.md prescribes.  A PMC pass cannot run inside this timed
     # process, so the figure is quoted from the committed profile -- and ONLY while the library that just ran is the binary
     # that was profiled (the summary records its md5): a changed kernel must not inherit a stale counter.  null otherwise.
-    traffic, traffic_src = None, "no PMC summary of this library binary (profiles/*_pmc_summary.json lib_md5 differs or is absent)"
+    traffic, traffic_src = None, "no PMC summary of this library (profiles/r04_pmc_summary.json absent, or profiled from other sources / another binary)"
     import hashlib
     lib_md5 = hashlib.md5(open(__graft_entry__.LIB, "rb").read()).hexdigest()
+    src_md5 = __graft_entry__.source_md5()       # (a rebuild of the same sources gives the same device code, another .so md5)
     for prof in ("r04_pmc_summary.json",):
         try:
             summ = json.load(open(os.path.join(REPO, "profiles", prof)))
-            if summ.get("lib_md5") != lib_md5:
+            if summ.get("lib_md5") != lib_md5 and summ.get("src_md5") != src_md5:
                 continue
             pmc = summ["kernels"]
             # (kernel names as rocprofv3 prints them; matched by prefix)
@@ -567,7 +568,8 @@ def main():
             hit = [k for k in pmc if key and k.startswith(key)]
             if hit:
                 traffic = pmc[hit[0]]["hbm_bytes_per_launch_corrected"]
-                traffic_src = "profiles/%s (rocprofv3 --pmc passes of this library binary, md5 %s)" % (prof, lib_md5[:12])
+                traffic_src = ("profiles/%s (rocprofv3 --pmc passes of %s)" % (prof, "this library binary, md5 " + lib_md5[:12]
+                               if summ.get("lib_md5") == lib_md5 else "a build of these very sources, source md5 " + src_md5[:12]))
                 break
         except Exception:
             pass

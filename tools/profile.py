@@ -17,6 +17,7 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(REPO, "gpurun_out")
+sys.path.insert(0, REPO)
 PMC_GROUPS = [["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], ["FETCH_SIZE"], ["WRITE_SIZE"],
               ["SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_VALU_MFMA_MOPS_F32"]]
 
@@ -97,7 +98,8 @@ def main():
     lib = os.path.join(REPO, "mobileposer_amd", "libmobileposer_hip.so")
     summary = {"note": __doc__.split("Counter arithmetic")[1].strip(),
                # bench.py quotes roofline.traffic from this file only while the library it runs is this very binary
-               "lib_md5": hashlib.md5(open(lib, "rb").read()).hexdigest(), "kernels": {}}
+               "lib_md5": hashlib.md5(open(lib, "rb").read()).hexdigest(), "src_md5": __import__("__graft_entry__").source_md5(),
+               "kernels": {}}
     for k, c in acc.items():
         e = {n: v[0] / v[1] for n, v in c.items()}
         e["launches_sampled"] = max(v[1] for v in c.values())
