@@ -531,6 +531,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
             else if (key == "gemm_staged") {}                  // read by mp_launch_gemm
             else if (key == "kin_scalar") {}                   // read by mp_kin.hip
             else if (key == "gemm_frag") {}                    // read by mp_launch_gemm
+            else if (key == "l2l1") {}                         // read by mp_launch_gemm_l2l1: 0 = joints.linear2 and the stacked linear1 as two launches
             else if (key == "one_stream") {}                   // read by forward_body: 0 = the round-3 three-stream serial schedule
             else if (key == "vf") h->vf_ok = v != 0;
             else if (key == "late_pair") h->late_pair_ok = v != 0;
@@ -857,6 +858,38 @@ bool rnn_g0_pose_velocity(const RnnJob& jp, const RnnJob& jv, hipStream_t s, int
         mp_launch_gemm(g, w.bn, s);              // exact-fp32 operands: the same stacked launch (round 3)
     }
     if (hipGetLastError() != hipSuccess) *rc = fail(h, MP_ERR_HIP, "fused linear1 launch failed");
+    return true;
+}
+
+// joints.linear2 and the stacked linear1 of pose | velocity | foot contact as ONE launch (mp_gemm_l2l1): what rnn_g2(J) and
+// rnn_g0_pose_velocity(P, V, F) do for the full-batch exact-fp32 schedule.  false = not applicable (nothing launched).
+bool rnn_g2_g0_fused(const RnnJob& jj, const RnnJob& jp, const RnnJob& jv, const RnnJob& jf, hipStream_t s, int* rc) {
+    mp_handle* h = jj.h;
+    *rc = MP_OK;
+    const ModuleW& mj = h->mod[jj.id];
+    const ModuleW& mp = h->mod[jp.id];
+    const ModuleW& mv = h->mod[jv.id];
+    const ModuleW& mf = h->mod[jf.id];
+    if (!h->persist || h->uni2 || !h->fuse_pv || use_x3(h, mj) || use_x3(h, mp) || use_x3(h, mv) || !h->lin1_pvf.Wf || !mj.lin2.Wf) return false;
+    if (jj.out_h || jp.mode != STATE_ZERO || jf.mode != STATE_ZERO || !(jv.mode == STATE_ZERO || (jv.out_h == jv.in_h && jv.out_h))) return false;
+    // the stacked GEMM must read exactly what linear2 writes: cat(pred_joints, imu) with pred_joints = this call's output
+    if (jp.a0.base != jj.y || jv.a0.base != jj.y || jf.a0.base != jj.y || jp.a1.base != jv.a1.base || jp.a1.base != jf.a1.base) return false;
+    if (jp.a0.strideB != jj.yStrideB || jp.a0.strideT != jj.yStrideT) return false;
+    const int B = jj.p->B, T = jj.p->T, M = B * T, H = mp.H;
+    const Packed& w2 = mj.lin2;
+    const Packed& w1 = h->lin1_pvf;
+    GemmArgs g2, g1;
+    g2.a0 = internal_map(jj.p->ws[jj.id].out1, B, mj.dirs * mj.H); g2.a1 = RowMap{nullptr, 0, 0, 0};
+    g2.W = w2.W; g2.Wf = w2.Wf; g2.NB = w2.Npad / 32; g2.bias = w2.bias; g2.C = jj.y; g2.cStrideB = jj.yStrideB; g2.cStrideT = jj.yStrideT;
+    g2.M = M; g2.N = w2.N; g2.K = w2.K; g2.Kpad = w2.Kpad; g2.B = B; g2.relu = 0;
+    g1.a0 = jp.a0; g1.a1 = jp.a1; g1.W = w1.W; g1.Wf = w1.Wf; g1.NB = w1.Npad / 32; g1.bias = w1.bias;
+    g1.C = x1_buffer(h, mp, jp.p->ws[jp.id]); g1.C2 = x1_buffer(h, mv, jv.p->ws[jv.id]); g1.C3 = x1_buffer(h, mf, jf.p->ws[jf.id]);
+    g1.nsplit = mp.lin1.Npad; g1.nsplit3 = h->lin1_pv.Npad; g1.cStrideB = H; g1.cStrideT = (long)B * H; g1.c3StrideB = mf.H; g1.c3StrideT = (long)B * mf.H;
+    g1.M = M; g1.N = w1.N; g1.K = w1.K; g1.Kpad = w1.Kpad; g1.B = B; g1.relu = 1;
+    if (!mp_gemm_l2l1_applicable(g2, g1)) return false;
+    SegScope seg(h, s, 0, 1, 2.0 * M * ((double)w2.N * w2.K + (double)w1.N * w1.K));
+    (void)mp_launch_gemm_l2l1(g2, g1, s);
+    if (hipGetLastError() != hipSuccess) *rc = fail(h, MP_ERR_HIP, "fused linear2 / linear1 launch failed");
     return true;
 }
 
@@ -1191,9 +1224,12 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         static const bool one_stream_ok = !(getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "one_stream=0"));
         if (vf && one_stream_ok && h->lin1_pvf.Wf && mp_gemm_frag_enabled() && h->fuse_pv && !use_x3(h, h->mod[MP_MOD_POSE]) &&
             side_by_side_plan(h, p->B) == 0) {
-            RC(run_rnn(J, sm));                                                             // net.py:103
+            RC(rnn_g0(J, sm)); RC(rnn_rec(J, 0, sm)); RC(rnn_g1(J, sm)); RC(rnn_rec(J, 1, sm));   // net.py:103
             int rc_pv = MP_OK;
-            if (!rnn_g0_pose_velocity(P, V, sm, &rc_pv, &F)) return fail(h, MP_ERR_INVALID, "internal: stacked linear1 refused");
+            if (!rnn_g2_g0_fused(J, P, V, F, sm, &rc_pv)) {         // (linear2 of joints + the stacked linear1: one launch, else two)
+                RC(rnn_g2(J, sm));
+                if (!rnn_g0_pose_velocity(P, V, sm, &rc_pv, &F)) return fail(h, MP_ERR_INVALID, "internal: stacked linear1 refused");
+            }
             RC(rc_pv);
             RC(rnn_rec(P, 0, sm)); RC(rnn_rec(P, 1, sm));                                   // net.py:106-107
             HIPCHK(h, hipEventRecord(h->ev_x[2], sm));

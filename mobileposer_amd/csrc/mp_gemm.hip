@@ -315,6 +315,10 @@ __device__ __forceinline__ void gemm_frag_body(const GemmArgs& g, int bid, int n
     for (int b = 0; b < TN; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    // (the biases are requested FIRST: loaded in the epilogue their latency -- an L2 round trip -- is paid at the end of every tile)
+    float biasv[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) { const int n = n0 + b * 32 + li; biasv[b] = g.bias[n < ncols_end ? n : ncols_end - 1]; }
 
     f32x4 fa[2][4], fw[TN][4];
     auto request_a = [&](f32x4& dst, int q, int k0) {            // A piece q of the k-tile at k0 (past K: the row's last piece)
@@ -359,7 +363,7 @@ __device__ __forceinline__ void gemm_frag_body(const GemmArgs& g, int bid, int n
     for (int b = 0; b < TN; ++b) {
         const int n = n0 + b * 32 + li;
         if (n >= ncols_end) continue;
-        const float bias = g.bias[n];
+        const float bias = biasv[b];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -379,6 +383,168 @@ template <int TN, int NK>
 MP_KERNEL __launch_bounds__(256, 2) void mp_gemm_f32_frag(GemmArgs g, int nTilesM, int nTilesN) {
     __shared__ long rowOffC[4][32];
     gemm_frag_body<TN, NK>(g, (int)blockIdx.x, nTilesM, nTilesN, rowOffC);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// mp_gemm_l2l1<NK2, NT1> (round 4) -- the seam between the joints block and the three blocks that read its output
+// (models/net.py:103-117): joints.linear2 (y = out1 W2^T + b2, N2 <= 96 columns) and the stacked linear1 of pose | velocity |
+// foot contact over cat(y, imu) (net.py:106,113) in ONE launch.  A wave owns 32 rows: it computes their y tile exactly as
+// mp_gemm_f32_frag<3, NK2> does, stores it (the caller wants pred_joints) and keeps it in LDS -- the rows of y are the first
+// K segment of the second GEMM's A operand, so they never come back from HBM and there is no kernel boundary, no launch
+// ramp and no tail between the two; the second GEMM then runs all NT1 64-column groups of the stacked output for those rows
+// from A fragments held in registers (80 VGPRs for K = 132) with W streamed in fragment order, one long MFMA stream per wave.
+// Same k pairing and MFMA order per output element as the separate launches: bit-identical results.
+constexpr int L2L1_YP = 76;     // LDS row pitch of the y tile in floats (16-byte aligned; 32 rows x b128 reads conflict-free)
+
+// FULL: M is a multiple of 32 -- no row of any wave's tile lies past M, and the per-group epilogues of phase 2 carry no branch:
+// behind a branch the compiler merges the wait counts of both paths into vmcnt(0), i.e. the first MFMAs of the next group
+// would wait for the 32 stores of this one to be acknowledged (measured: 128 -> ... us per launch).
+template <int NK2, int NT1, bool FULL>
+MP_KERNEL __launch_bounds__(256, 1) void mp_gemm_l2l1(GemmArgs g2, GemmArgs g1) {
+    constexpr int TN2 = 3, NK1 = 5, TN1 = 2;
+    __shared__ long rowOff2[4][32], rowOffA[4][32], rowOffF[4][32];
+    __shared__ __attribute__((aligned(16))) float ytile[4][32 * L2L1_YP];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int m0 = ((int)blockIdx.x * 4 + wave) * 32;
+    if (m0 >= g2.M) return;
+    const int m = m0 + li < g2.M ? m0 + li : g2.M - 1;
+    const int rb = m % g2.B, rt = m / g2.B;
+    if (lane < 32) {
+        rowOff2[wave][lane] = (long)rb * g2.cStrideB + (long)rt * g2.cStrideT;
+        rowOffA[wave][lane] = (long)rb * g1.cStrideB + (long)rt * g1.cStrideT;
+        rowOffF[wave][lane] = (long)rb * g1.c3StrideB + (long)rt * g1.c3StrideT;
+    }
+    float* Y = ytile[wave];
+
+    // ---- phase 1: y = A2 W2^T + b2 (one K segment: the layer-1 output, time-major)
+    {
+        const float* pa = g2.a0.base + (long)rb * g2.a0.strideB + (long)rt * g2.a0.strideT;
+        const float* pw = g2.Wf + (long)lane * 4;
+        const long wq = (long)g2.NB * 256;
+        f32x16 acc[TN2];
+#pragma unroll
+        for (int b = 0; b < TN2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        float bias2[TN2];
+#pragma unroll
+        for (int b = 0; b < TN2; ++b) { const int n = b * 32 + li; bias2[b] = g2.bias[n < g2.N ? n : g2.N - 1]; }
+        f32x4 fa[2][4], fw[TN2][4];
+        auto request_a = [&](f32x4& dst, int q, int k0) { dst = *reinterpret_cast<const f32x4*>(pa + k0 + lh * 16 + q * 4); };
+        auto request_w = [&](int q, int kt) {
+#pragma unroll
+            for (int b = 0; b < TN2; ++b) fw[b][q] = *reinterpret_cast<const f32x4*>(pw + (long)(kt * 4 + q) * wq + b * 256);
+        };
+#pragma unroll
+        for (int q = 0; q < 4; ++q) request_a(fa[0][q], q, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { request_w(q, 0); request_a(fa[1][q], q, BK); }
+#pragma unroll
+        for (int kt = 0; kt < NK2; ++kt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int b = 0; b < TN2; ++b)
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kt & 1][q][s4], fw[b][q][s4], acc[b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + 2 < NK2) request_a(fa[kt & 1][q], q, (kt + 2) * BK);
+                if (kt + 1 < NK2) request_w(q, kt + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the row offsets of this wave (written by its own lanes)
+#pragma unroll
+        for (int b = 0; b < TN2; ++b) {
+            const int n = b * 32 + li;
+            if (n >= g2.N) continue;
+            const float bias = bias2[b];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float v = acc[b][r] + bias;
+                Y[ml * L2L1_YP + n] = v;                          // (rows past M: computed from the clamped row, never stored)
+                if (m0 + ml < g2.M) g2.C[rowOff2[wave][ml] + n] = v;
+            }
+        }
+    }
+    // the y tile is written and read by this wave only: a wave-level fence orders its LDS writes before its reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- phase 2: X1 = relu(cat(y, imu) W1^T + b1) for all NT1 64-column groups; A fragments of the 32 rows in registers
+    const int w0 = g1.a0.width, klast = g1.K - 4;               // w0 = columns of y (72); k >= K: the row's last piece (W is 0 there)
+    const float* pa1 = g1.a1.base + (long)rb * g1.a1.strideB + (long)rt * g1.a1.strideT - w0;
+    f32x4 fa[NK1][4];
+#pragma unroll
+    for (int kt = 0; kt < NK1; ++kt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = kt * BK + lh * 16 + q * 4;
+            const int kk = k < klast ? k : klast;
+            fa[kt][q] = kk < w0 ? *reinterpret_cast<const f32x4*>(Y + li * L2L1_YP + kk) : *reinterpret_cast<const f32x4*>(pa1 + kk);
+        }
+    // (all biases up front: a bias load inside an epilogue is a load whose first use waits with vmcnt(0) -- for the output
+    //  stores in front of it too, one store round trip per group)
+    float bias1[NT1][TN1];
+#pragma unroll
+    for (int ng = 0; ng < NT1; ++ng)
+#pragma unroll
+        for (int b = 0; b < TN1; ++b) bias1[ng][b] = g1.bias[(ng * TN1 + b) * 32 + li];
+    const float* pw = g1.Wf + (long)lane * 4;
+    const long wq = (long)g1.NB * 256;
+    f32x4 fw[TN1][4];
+    auto request_w = [&](int q, int flat) {                      // flat = group * NK1 + kt
+        const int ng = flat / NK1, kt = flat - ng * NK1;
+#pragma unroll
+        for (int b = 0; b < TN1; ++b) fw[b][q] = *reinterpret_cast<const f32x4*>(pw + (long)(kt * 4 + q) * wq + (ng * TN1 + b) * 256);
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) request_w(q, 0);
+    // (unrolled completely: with a real loop the compiler merges the wait counts at its header into one vmcnt(0), i.e. every
+    //  group would wait for the previous group's 32 output stores to be acknowledged before its first MFMA)
+#pragma unroll
+    for (int ng = 0; ng < NT1; ++ng) {
+        f32x16 acc[TN1];
+#pragma unroll
+        for (int b = 0; b < TN1; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NK1; ++kt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int b = 0; b < TN1; ++b)
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kt][q][s4], fw[b][q][s4], acc[b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const int nxt = ng * NK1 + kt + 1;
+                if (nxt < NT1 * NK1) request_w(q, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const int n0 = ng * TN1 * 32;
+        float* Cb = g1.C;
+        int ncol0 = 0;
+        const long* roff = rowOffA[wave];
+        if (g1.nsplit3 > 0 && n0 >= g1.nsplit3) { Cb = g1.C3; ncol0 = g1.nsplit3; roff = rowOffF[wave]; }
+        else if (g1.nsplit > 0 && n0 >= g1.nsplit) { Cb = g1.C2; ncol0 = g1.nsplit; }
+#pragma unroll
+        for (int b = 0; b < TN1; ++b) {
+            const int n = n0 + b * 32 + li;
+            const float bias = bias1[ng][b];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (FULL || m0 + ml < g1.M) Cb[roff[ml] + (n - ncol0)] = fmaxf(acc[b][r] + bias, 0.f);
+            }
+        }
+    }
 }
 
 // two independent GEMMs in one launch: workgroups [0, grid1) run g1, the others g2 (mp_launch_gemm_pair)
@@ -473,6 +639,23 @@ bool mp_gemm_frag_enabled() {
     static const float one = 0.f;
     probe.Wf = &one; probe.NB = 1; probe.K = 4; probe.a0.width = 4;
     return frag_usable(probe);
+}
+
+bool mp_gemm_l2l1_applicable(const GemmArgs& g2, const GemmArgs& g1) {
+    // joints.linear2 (K = 512, N = 72) -> stacked linear1 over cat(y, imu) (K = 72 + 60, N = 576 = nine 64-column groups)
+    static const bool off = getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "l2l1=0");
+    if (off || !frag_usable(g2) || !frag_usable(g1) || g2.a1.base || !g1.a1.base) return false;
+    if (!(g2.NB == 3 && g2.Kpad == 512 && g2.K == 512 && g2.N > 64 && g2.N <= L2L1_YP && (g2.N & 3) == 0 && !g2.relu && !g2.pairOut)) return false;
+    return g1.Kpad == 160 && g1.a0.width == g2.N && g1.NB == 18 && g1.N == 576 && g1.relu && !g1.pairOut && g1.M == g2.M && g1.B == g2.B &&
+           g1.nsplit > 0 && g1.nsplit % 64 == 0 && g1.nsplit3 > g1.nsplit && g1.nsplit3 % 64 == 0 && g1.C && g1.C2 && g1.C3;
+}
+
+bool mp_launch_gemm_l2l1(const GemmArgs& g2, const GemmArgs& g1, hipStream_t s) {
+    if (!mp_gemm_l2l1_applicable(g2, g1)) return false;
+    const int blocks = (g2.M + 127) / 128;
+    if (g2.M % 32 == 0) hipLaunchKernelGGL((mp_gemm_l2l1<16, 9, true>), dim3(blocks), dim3(256), 0, s, g2, g1);
+    else hipLaunchKernelGGL((mp_gemm_l2l1<16, 9, false>), dim3(blocks), dim3(256), 0, s, g2, g1);
+    return true;
 }
 
 bool mp_launch_gemm_pair(const GemmArgs& g1, const GemmArgs& g2, hipStream_t s) {

@@ -56,7 +56,7 @@ def main():
         f.write("Command (MI355X, via gpurun): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
                 "--no-cpu-baseline %s --steps 20 --warmup 5`\n" % " ".join(extra))
         f.write("(bench.py in one process: 25 forwards of the headline mode (exact-fp32 operands, eager launches on the library's "
-                "streams), 23 of the opt-in split-bf16 mode, the configs[3] leg (B = 1024), 5 event-timed forwards of the "
+                "streams), 23 of the opt-in split-fp16 mode, the configs[3] leg (B = 1024), 5 event-timed forwards of the "
                 "headline mode; B=256 x T=125; raw CSV next to this file)\n\n")
         if bench_line:
             f.write("bench line of this (profiled) run: %.4f ms/step = %.0f frames/s headline (%s); modes: %s\n\n"
