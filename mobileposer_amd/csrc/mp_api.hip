@@ -532,6 +532,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
             else if (key == "kin_scalar") {}                   // read by mp_kin.hip
             else if (key == "gemm_frag") {}                    // read by mp_launch_gemm
             else if (key == "l2l1") {}                         // read by mp_launch_gemm_l2l1: 0 = joints.linear2 and the stacked linear1 as two launches
+            else if (key == "gemm_wide") {}                    // read by mp_launch_gemm: 0 = wide linear1 layers on mp_gemm_f32_frag's small tiles
             else if (key == "one_stream") {}                   // read by forward_body: 0 = the round-3 three-stream serial schedule
             else if (key == "vf") h->vf_ok = v != 0;
             else if (key == "late_pair") h->late_pair_ok = v != 0;

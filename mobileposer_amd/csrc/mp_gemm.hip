@@ -547,6 +547,104 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_gemm_l2l1(GemmArgs g2, GemmArgs g1) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// mp_gemm_f32_wide<NK, NT, FULL> (round 4) -- phase 2 of mp_gemm_l2l1 on its own: a wide linear1 (N = NT * 64 columns, K <= 160)
+// whose A rows come from global memory.  A wave owns 32 rows and ALL columns: its A fragments (16 * NK registers) are loaded once,
+// W streams through in fragment order, one uninterrupted MFMA stream of NT * NK * 32 instructions per wave, branch-free
+// epilogues (FULL: M % 32 == 0).  For full batches (>= one wave per SIMD); smaller ones keep mp_gemm_f32_frag's many small tiles.
+template <int NK, int NT, bool FULL>
+MP_KERNEL __launch_bounds__(256, 1) void mp_gemm_f32_wide(GemmArgs g) {
+    constexpr int TN1 = 2;
+    __shared__ long rowOffA[4][32], rowOffF[4][32];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int m0 = ((int)blockIdx.x * 4 + wave) * 32;
+    if (m0 >= g.M) return;
+    const int m = m0 + li < g.M ? m0 + li : g.M - 1;
+    const int rb = m % g.B, rt = m / g.B;
+    if (lane < 32) {
+        rowOffA[wave][lane] = (long)rb * g.cStrideB + (long)rt * g.cStrideT;
+        rowOffF[wave][lane] = (long)rb * g.c3StrideB + (long)rt * g.c3StrideT;
+    }
+    const int w0 = g.a0.width, klast = g.K - 4;
+    const float* pa0 = g.a0.base + (long)rb * g.a0.strideB + (long)rt * g.a0.strideT;
+    const float* pa1 = g.a1.base ? g.a1.base + (long)rb * g.a1.strideB + (long)rt * g.a1.strideT - w0 : pa0;
+    float bias1[NT][TN1];
+#pragma unroll
+    for (int ng = 0; ng < NT; ++ng)
+#pragma unroll
+        for (int b = 0; b < TN1; ++b) bias1[ng][b] = g.bias[(ng * TN1 + b) * 32 + li];
+    f32x4 fa[NK][4];
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = kt * BK + lh * 16 + q * 4;
+            const int kk = k < klast ? k : klast;
+            fa[kt][q] = *reinterpret_cast<const f32x4*>((kk < w0 ? pa0 : pa1) + kk);
+        }
+    const float* pw = g.Wf + (long)lane * 4;
+    const long wq = (long)g.NB * 256;
+    f32x4 fw[TN1][4];
+    auto request_w = [&](int q, int flat) {                      // flat = group * NK + kt
+        const int ng = flat / NK, kt = flat - ng * NK;
+#pragma unroll
+        for (int b = 0; b < TN1; ++b) fw[b][q] = *reinterpret_cast<const f32x4*>(pw + (long)(kt * 4 + q) * wq + (ng * TN1 + b) * 256);
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) request_w(q, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the row offsets of this wave (written by its own lanes)
+#pragma unroll
+    for (int ng = 0; ng < NT; ++ng) {
+        f32x16 acc[TN1];
+#pragma unroll
+        for (int b = 0; b < TN1; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int b = 0; b < TN1; ++b)
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kt][q][s4], fw[b][q][s4], acc[b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const int nxt = ng * NK + kt + 1;
+                if (nxt < NT * NK) request_w(q, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const int n0 = ng * TN1 * 32;
+        float* Cb = g.C;
+        int ncol0 = 0;
+        const long* roff = rowOffA[wave];
+        if (g.nsplit3 > 0 && n0 >= g.nsplit3) { Cb = g.C3; ncol0 = g.nsplit3; roff = rowOffF[wave]; }
+        else if (g.nsplit > 0 && n0 >= g.nsplit) { Cb = g.C2; ncol0 = g.nsplit; }
+#pragma unroll
+        for (int b = 0; b < TN1; ++b) {
+            const int n = n0 + b * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (FULL || m0 + ml < g.M) {
+                    float v = acc[b][r] + bias1[ng][b];
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    Cb[roff[ml] + (n - ncol0)] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int NK, int NT>
+void launch_wide(const GemmArgs& g, hipStream_t s) {
+    const int blocks = (g.M + 127) / 128;
+    if (g.M % 32 == 0) hipLaunchKernelGGL((mp_gemm_f32_wide<NK, NT, true>), dim3(blocks), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((mp_gemm_f32_wide<NK, NT, false>), dim3(blocks), dim3(256), 0, s, g);
+}
+
 // two independent GEMMs in one launch: workgroups [0, grid1) run g1, the others g2 (mp_launch_gemm_pair)
 template <int TN1, int NK1, int TN2, int NK2>
 MP_KERNEL __launch_bounds__(256, 2) void mp_gemm_f32_frag2(GemmArgs g1, int nTilesM1, int nTilesN1, int grid1,
@@ -672,6 +770,16 @@ void mp_launch_gemm(const GemmArgs& g, int bn, hipStream_t s) {
     static const bool staged = getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "gemm_staged=1");   // A/B runs: the LDS-staged kernel
     static const int frag_tn = getenv("MP_GEMM_FRAG_TN") ? atoi(getenv("MP_GEMM_FRAG_TN")) : 0;          // micro-benchmark only
     if (frag_usable(g)) {      // (MP_VARIANT gemm_frag=0: the round-3 kernels, A/B runs)
+        // full batches (at least three quarters of a wave per SIMD), wide outputs without padding columns: one wave = 32 rows x ALL columns
+        static const bool wide_ok = !(getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "gemm_wide=0"));
+        if (wide_ok && !frag_tn && !g.pairOut && g.M >= 24576 && g.N == g.NB * 32 && g.N % 64 == 0 && (g.nsplit % 64) == 0 && (g.nsplit3 % 64) == 0 &&
+            (g.nsplit3 == 0 || g.C3) && (g.nsplit == 0 || g.C2)) {
+            const int nk = g.Kpad / BK, nt = g.N / 64;
+            if (nk == 2 && nt == 4) { launch_wide<2, 4>(g, s); return; }          // joints.linear1
+            if (nk == 5 && nt == 4) { launch_wide<5, 4>(g, s); return; }          // a single H = 256 block's linear1
+            if (nk == 5 && nt == 8) { launch_wide<5, 8>(g, s); return; }          // pose | velocity
+            if (nk == 5 && nt == 9) { launch_wide<5, 9>(g, s); return; }          // pose | velocity | foot contact
+        }
         const int npad32 = g.NB;                                      // 32-column tiles of the padded W
         // columns per wave: all of a narrow output (linear2: N <= 96); 64 of a wide one (linear1: four waves per SIMD keep the
         // MFMA pipe busier than two waves with 128 columns each -- 78.6 vs 85.0 us for the stacked pose + velocity linear1)
