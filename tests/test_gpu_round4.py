@@ -381,3 +381,26 @@ def test_coalesced_fk_and_ik_equal_the_scalar_kernels_bitwise(torch_mod, net, N)
         assert np.abs(npy(pose_a) - ref).max() < 1e-5
         rRg, rjg = O.forward_kinematics(ref, net.bodymodel.J, tran=tran)
         assert np.abs(npy(Rg_a) - rRg).max() < 1e-5 and np.abs(npy(jg_a) - rjg).max() < 1e-5
+
+
+@pytest.mark.parametrize("B,T", [(257, 100), (200, 30)])
+def test_linear_layer_kernels_on_ragged_row_counts(torch_mod, net, weights, smpl, B, T):
+    """The full-batch linear-layer kernels of round 4 (mp_gemm_l2l1, mp_gemm_f32_wide: one wave = 32 rows x all columns) when
+    B * T is NOT a multiple of 32 -- the instantiations with per-row bounds checks, whose last wave owns a partial tile:
+    257 x 100 = 25 700 rows (wide + l2l1), 200 x 30 = 6 000 (l2l1 only).  Against the oracle on a subset of the sequences
+    (sequences never interact), the last ones included, and on every row for NaN / garbage past the valid rows."""
+    from mobileposer_amd import synthetic
+    from oracle import mp_oracle as O
+    imu = synthetic.make_imu(B, T, seed=B + T)
+    net.reset_all()
+    pose, joints, vel, contact = net.forward(cu(torch_mod, imu), [T] * B)
+    for t in (pose, joints, vel, contact):
+        assert bool(torch_mod.isfinite(t).all())
+    rows = [0, 1, B // 2, B - 2, B - 1]
+    ref = O.OracleNet(weights, smpl["J"])
+    rpose, rjoints, rvel, rcontact = ref.forward(imu[rows], [T] * len(rows))
+    assert np.abs(npy(joints)[rows] - rjoints).max() < TOL
+    assert np.abs(npy(vel).reshape(B, T, 72)[rows] - rvel).max() < TOL
+    assert np.abs(npy(contact)[rows] - rcontact).max() < TOL
+    assert geodesic(npy(pose).reshape(B, T, 24, 3, 3)[rows].reshape(-1, 24, 3, 3), rpose).max() < TOL
+    assert net.device_error() == 0
