@@ -138,8 +138,8 @@ struct LstmPersistArgs {
     // workgroup b to XCD b % 8 -- strictly: a workgroup whose XCD has no CU left for it WAITS, even while other XCDs stand
     // empty (tools/micro/xcd_dispatch.hip) -- and a cluster's workgroups share an XCD (their hand-off lives in its L2).  XCD x
     // runs clusters xcd_base[x] .. xcd_base[x] + xcd_cnt[x] - 1; all zero = spread round robin (mp_fill_xcd_table).
-    unsigned char xcd_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned short xcd_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    alignas(8) unsigned char xcd_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    alignas(8) unsigned short xcd_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // 1: the table is indexed by the XCD a workgroup really runs on (its XCC id), not by blockIdx % 8 -- the round robin
     // does not start at XCD 0 for every launch (another stream's launch of the same micro-benchmark started at XCD 7), and
     // tables of launches that run side by side must mean the same XCDs.  Only when the device was probed (mp_create) to
@@ -148,6 +148,19 @@ struct LstmPersistArgs {
     unsigned long long* hx_next = nullptr;   // split-bf16 kernel only: exchange area of the NEXT layer's launch (same cluster
                                               // indexing), re-armed by this launch at its start
 };
+// Entry x of the two tables by shifts on whole words (round 4).  `a.xcd_cnt[xcd]` with a run-time index is a LOAD from the kernel
+// argument segment -- two dependent memory round trips (count, then base) in front of the first weight load of every layer
+// launch; the words themselves arrive with the other arguments through the scalar cache.
+static __device__ __forceinline__ int mp_xcd_count(const LstmPersistArgs& a, int xcd) {
+    unsigned long long w;
+    __builtin_memcpy(&w, a.xcd_cnt, 8);
+    return (int)((w >> (8 * xcd)) & 0xffu);
+}
+static __device__ __forceinline__ int mp_xcd_first(const LstmPersistArgs& a, int xcd) {
+    unsigned long long w[2];
+    __builtin_memcpy(w, a.xcd_base, 16);
+    return (int)(((xcd & 4 ? w[1] : w[0]) >> (16 * (xcd & 3))) & 0xffffu);
+}
 // nslice: workgroups sharing one slab of an H = 256 layer: 16 (4-wave workgroups, two per CU) or 8 (8-wave, one per CU)
 void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice, hipStream_t s);
 // the unidirectional H = 256, K_in = 256 layer on 16 slices with an H = 64 bidirectional layer riding along (fk = its K_in: 64 | 128)

@@ -141,8 +141,8 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
     const int xcd = a.xcd_physical ? (int)(xcc_id() & 7) : (int)(blockIdx.x & 7);
     const int kth = (int)(blockIdx.x >> 3) / NSLICE;                                     // the XCD's kth cluster
     const int slice = (int)(blockIdx.x >> 3) % NSLICE;
-    if (kth >= (int)a.xcd_cnt[xcd]) return;
-    const int cl = (int)a.xcd_base[xcd] + kth;
+    if (kth >= mp_xcd_count(a, xcd)) return;
+    const int cl = mp_xcd_first(a, xcd) + kth;
     if (cl >= ncl) return;
     const int dir = cl / a.nslab, slab = cl % a.nslab;
     const LstmDir d = a.d[dir];
