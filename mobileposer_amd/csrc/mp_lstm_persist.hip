@@ -153,12 +153,6 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
     const int brow0 = (a.slab0 + slab) * 16;
 
     // ---- W_ih slice: k-steps [0, XL) -> LDS, [XL, NXS) -> registers; W_hh slice -> registers
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(d.wihpack) + (size_t)slice * NWV * NXS * NTG * 64;
-        for (int w = 0; w < NWV; ++w)
-            for (int i = threadIdx.x; i < XL * NTG * 64; i += NTHREADS)
-                wxl[(size_t)w * XL * NTG * 64 + i] = src[(size_t)w * NXS * NTG * 64 + i];
-    }
     f32x4 wxr[XR > 0 ? XR : 1][NTG];
     if (XR > 0) {
         const f32x4* src = reinterpret_cast<const f32x4*>(d.wihpack) + ((size_t)(slice * NWV + wave) * NXS + XL) * NTG * 64 + lane;
@@ -174,6 +168,35 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
             for (int t = 0; t < NTW; ++t) wv[ks][t] = wp[(size_t)(ks * NTW + t) * 64];
+    }
+    // the LDS image of W_ih, AFTER the register-resident weights have been requested (round 4): in batches of 16 pieces per
+    // thread, all requested before the first is written.  The plain copy loop compiled into load -> wait -> write per piece for
+    // most of its trips -- 16 dependent memory round trips -- and the register loads were only issued behind it: first step of a
+    // K_in = 512 launch 10.3 -> 7.7 us after kernel entry (tools/debug/launch_timeline.py; profiles/r03_launch_timeline.txt).
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(d.wihpack) + (size_t)slice * NWV * NXS * NTG * 64;
+        constexpr int PER_W = XL * NTG * 64;                     // pieces per wave image
+        if constexpr (PER_W > 0 && PER_W % NTHREADS == 0 && (NWV * (PER_W / NTHREADS)) % 16 == 0) {
+            constexpr int TRIPS = PER_W / NTHREADS, TOTAL = NWV * TRIPS;
+#pragma unroll 1
+            for (int b0 = 0; b0 < TOTAL; b0 += 16) {
+                f32x4 tmp[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int w = (b0 + k) / TRIPS, i = threadIdx.x + ((b0 + k) % TRIPS) * NTHREADS;
+                    tmp[k] = src[(size_t)w * NXS * NTG * 64 + i];
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int w = (b0 + k) / TRIPS, i = threadIdx.x + ((b0 + k) % TRIPS) * NTHREADS;
+                    wxl[(size_t)w * PER_W + i] = tmp[k];
+                }
+            }
+        } else {
+            for (int w = 0; w < NWV; ++w)
+                for (int i = threadIdx.x; i < PER_W; i += NTHREADS)
+                    wxl[(size_t)w * PER_W + i] = src[(size_t)w * NXS * NTG * 64 + i];
+        }
     }
 
     // ---- the (sequence, unit) pairs this lane finishes: accumulator regs of tile column r16
