@@ -100,7 +100,9 @@ constexpr int x3_wg_per_cu(int nslice) { return nslice == 16 ? 2 : 1; }
 
 template <int NSLICE, int KIN, bool PROF>
 MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_lstm_x3(LstmPersistArgs a) {
-    if (a.debug_drop && (int)blockIdx.x == a.debug_drop - 1) return;      // test hook: a workgroup that never shows up
+    // test hook (mp_debug_drop_workgroup): a workgroup that never shows up.  Only in the PROF instantiation, which the launcher
+    // picks when the hook is armed -- the product kernels carry no test code (round 4)
+    if (PROF && a.debug_drop && (int)blockIdx.x == a.debug_drop - 1) return;
     using C = CfgX<NSLICE, KIN>;
     constexpr int H = 256, U = C::U, NWV = C::NWV, KQ = C::KQ, NXC = C::NXC, NHC = C::NHC, XLC = C::XLC, XRC = C::XRC;
     constexpr int CH_U4 = C::CH_U4, PPW = C::PPW, LPB = C::LPB, WPL = C::WPL, PARTS = C::PARTS, HPITCH = C::HPITCH;
@@ -605,7 +607,7 @@ void launch_x3(const LstmPersistArgs& a, hipStream_t s) {
     using C = CfgX<NSLICE, KIN>;
     const size_t lds = (size_t)C::LDS_BYTES;
     const dim3 grid(((a.nslab * a.ndir + 7) / 8) * 8 * NSLICE);
-    if (a.prof) hipLaunchKernelGGL((mp_lstm_x3<NSLICE, KIN, true>), grid, dim3(64 * C::NWV), lds, s, a);
+    if (a.prof || a.debug_drop) hipLaunchKernelGGL((mp_lstm_x3<NSLICE, KIN, true>), grid, dim3(64 * C::NWV), lds, s, a);
     else hipLaunchKernelGGL((mp_lstm_x3<NSLICE, KIN, false>), grid, dim3(64 * C::NWV), lds, s, a);
 }
 

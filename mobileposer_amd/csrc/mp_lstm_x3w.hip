@@ -73,7 +73,9 @@ struct CfgW {
 
 template <int KIN, bool PROF>
 MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
-    if (a.debug_drop && (int)blockIdx.x == a.debug_drop - 1) return;      // test hook: a workgroup that never shows up
+    // test hook (mp_debug_drop_workgroup): a workgroup that never shows up.  Only in the PROF instantiation, which the launcher
+    // picks when the hook is armed -- the product kernels carry no test code (round 4)
+    if (PROF && a.debug_drop && (int)blockIdx.x == a.debug_drop - 1) return;
     using C = CfgW<KIN>;
     constexpr int H = 256, NSLICE = 8, U = 32, UB = 2, NWV = 4, KQ = C::KQ, NXC = C::NXC, NHC = C::NHC, XLC = C::XLC, XRC = C::XRC;
     constexpr int FR = C::FR, CH_U4 = C::CH_U4;
@@ -438,7 +440,7 @@ void launch_x3w(const LstmPersistArgs& a, hipStream_t s) {
     using C = CfgW<KIN>;
     const size_t lds = (size_t)C::LDS_BYTES;
     const dim3 grid(((a.nslab * a.ndir + 7) / 8) * 8 * 8);
-    if (a.prof) hipLaunchKernelGGL((mp_lstm_x3w<KIN, true>), grid, dim3(256), lds, s, a);
+    if (a.prof || a.debug_drop) hipLaunchKernelGGL((mp_lstm_x3w<KIN, true>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((mp_lstm_x3w<KIN, false>), grid, dim3(256), lds, s, a);
 }
 
