@@ -1,6 +1,7 @@
 import numpy as np, sys
-sys.path.insert(0,'/root/repo')
-exec(open('/root/repo/tools/experiments/x6_emulation.py').read().split("smpl=synthetic")[0])
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
+import os
+exec(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'x6_emulation.py')).read().split("smpl=synthetic")[0])
 def f16(x): return np.asarray(x,np.float32).astype(np.float16).astype(np.float32)
 def split16(x, n):
     ps=[]; r=np.asarray(x,np.float32)

@@ -1,5 +1,5 @@
 import numpy as np, sys
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from mobileposer_amd import synthetic
 from oracle import mp_oracle as O
 def bf16(x):
