@@ -589,7 +589,7 @@ class MobilePoserNet:
         return n.value, ms.value, gf.value
 
     def set_lstm_mode(self, mode):
-        """1 (default): fused persistent layers on exact-fp32 MFMA operands; 3: the same on split-bf16 operands (opt-in
+        """1 (default): fused persistent layers on exact-fp32 MFMA operands; 3: the same on split-fp16 operands (opt-in
         fast mode); 2: mode 1 + two-layer wavefront velocity kernel; 0: per-step kernels.  (include/mobileposer_hip.h)"""
         _lib.check(self._lib.mp_set_lstm_mode(self._h, int(mode)), self._h)
 
