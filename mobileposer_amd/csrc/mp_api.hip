@@ -110,6 +110,8 @@ struct ModuleWS {
     unsigned long long* hx2 = nullptr;  // split-bf16 mode: exchange buffer of layer 1 (re-armed by the layer-0 launch)
     size_t hx_bytes = 0;
     unsigned hx_epoch = 0;              // next epoch base of `hx` (mp_lstm_fused launches); 0 = must be zeroed first
+    unsigned hx_flip = 3;               // tagged-word launches (LstmPersistArgs::tag_flip): first tags of the next launch
+    bool hx_tagged = false;             // the area holds tagged words (else: granules / flagged words of the epoch family)
 };
 struct VelState { float* h = nullptr; float* c = nullptr; int B = 0; int cap = 0; };   // [2][B][256] each
 
@@ -941,21 +943,26 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         //  at 128 x 125; the memset between the launches is the boundary that prevents it.  The 8-slice kernels own their CU.)
         const bool crowded16 = !use_x3(h, m) && dirs == 2 && fp32_slices(h, m, B) == 16 && dirs * nslab * 16 > 128;
         const bool epoch_ok = !use_x3(h, m) && !h->capturing && h->epoch_tags && !crowded16;
+        const int nsl = use_x3(h, m) ? m.nsliceX : fp32_slices(h, m, B);
+        const bool p16 = !use_x3(h, m) && nsl == 16 && m.nslice != 16;      // 16-slice packing of a bidirectional block
+        const bool wreg = !use_x3(h, m) && H == 256 && nsl == 8 && m.whhPW[0][0] &&
+                          (h->wreg_mask & (kin_l == 512 ? 1 : 2));
+        // (tagged-word kernels: one tag bit per word, so the area is also zeroed when the other kernel family -- granules with
+        //  32-bit epochs -- wrote to it last; the tags a launch starts with follow from what the previous one left: hx_flip)
+        const bool tagged = !use_x3(h, m) && mp_persist_tagged(H, nsl, wreg || nsl == 16);
         unsigned epoch_base = 0;
         if (!use_x3(h, m)) {
-            if (!epoch_ok || w.hx_epoch == 0 || w.hx_epoch > 0xf0000000u) {
+            if (!epoch_ok || w.hx_epoch == 0 || w.hx_epoch > 0xf0000000u || w.hx_tagged != tagged) {
                 HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
                 w.hx_epoch = epoch_ok ? h->epoch_start : 0u;
+                w.hx_flip = 3u;
             }
+            w.hx_tagged = tagged;
             epoch_base = epoch_ok ? w.hx_epoch : 0u;
         } else {
             w.hx_epoch = 0;                                   // split-bf16 words in there now
         }
         unsigned long long* hx_l = (use_x3(h, m) && l == 1) ? w.hx2 : w.hx;
-        const int nsl = use_x3(h, m) ? m.nsliceX : fp32_slices(h, m, B);
-        const bool p16 = !use_x3(h, m) && nsl == 16 && m.nslice != 16;      // 16-slice packing of a bidirectional block
-        const bool wreg = !use_x3(h, m) && H == 256 && nsl == 8 && m.whhPW[0][0] &&
-                          (h->wreg_mask & (kin_l == 512 ? 1 : 2));
         const bool u8 = !use_x3(h, m) && H == 256 && nsl == 32;
         const int cus = h->n_cu < 256 ? h->n_cu : 256;
         // slabs per launch: grid <= #CUs, one workgroup per CU
@@ -984,6 +991,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             else if (h->dbg_drop_left > 0) { a.debug_drop = h->dbg_drop_block + 1; --h->dbg_drop_left; }
             const bool x3 = use_x3(h, m);
             a.epoch_base = epoch_base;
+            a.tag_flip = w.hx_flip;
             a.min_lds = x3 ? 0 : h->excl_lds;
             if (!x3 && h->xcd_plan_on[j.id] && a.nslab == nslab) { mp_fill_xcd_table(a, h->xcd_plan[j.id]); a.xcd_physical = 1; }
             a.out_pairs = x3 ? 1 : 0;                          // both layers feed split-bf16 consumers (layer 1 / linear2)
@@ -1015,6 +1023,9 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             else mp_launch_lstm_persist(a, H, kin, nsl, s);
         }
         if (epoch_base) w.hx_epoch += (unsigned)T + 1u;       // tags base .. base + T are used up
+        // parity slot 0 was written (T + 1) / 2 times (steps 0, 2, ...), slot 1 1 + T / 2 times (the initial state as "step -1",
+        // then steps 1, 3, ...), tags alternating: an odd count turns the slot's next first tag around
+        if (tagged && epoch_ok) w.hx_flip ^= (unsigned)(((T + 1) / 2) & 1) | ((unsigned)((1 + T / 2) & 1) << 1);
     } else {
         SegScope seg(h, s, 7, T, 2.0 * dirs * (double)B * T * 4.0 * H * H);
         LstmStepArgs a;
@@ -1452,7 +1463,13 @@ int run_maybe_graph(mp_handle* h, GraphKey key, Body body) {
 // The side-by-side schedules address clusters by the XCD a workgroup really lands on, which rests on a probed but
 // undocumented dispatcher order.  After any device error the handle stops relying on it: launches fall back to the
 // blockIdx % 8 round robin (placement then only affects speed, never which (cluster, slice) a workgroup takes).
-void disable_xcd_tables(mp_handle* h) { h->xcd_rr = false; }
+// ... and the exchange areas of every plan are zeroed before their next use: a launch that lost a workgroup leaves tagged
+// words behind that no later launch's bookkeeping (ModuleWS::hx_flip) describes.
+void disable_xcd_tables(mp_handle* h) {
+    h->xcd_rr = false;
+    for (auto& kv : h->plans)
+        for (ModuleWS& w : kv.second->ws) w.hx_epoch = 0;
+}
 
 // A failed call without recovery has poisoned what it carries forward: the velocity LSTM state it updated in place is NaN for
 // the starved slab, and a streaming tick derived root height / root position / last foot positions from NaN outputs.  Once

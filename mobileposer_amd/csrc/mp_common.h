@@ -10,6 +10,10 @@
 // current ones do not, and no trigger could be named (profiles/NOTES_r01-r03.md 4.3, profiles/r02_coexec_glitch.md).
 #define MP_KERNEL __global__
 
+// ReLU as torch computes it (rnn.py:22, F.relu): a NaN stays a NaN.  fmaxf(x, 0) returns 0 for a NaN (IEEE maxNum), which
+// turned a NaN input sample -- or a poisoned slab's NaN joints -- into plausible numbers behind every linear1 (round 4).
+static __device__ __forceinline__ float relu_(float x) { return x < 0.f ? 0.f : x; }
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -130,6 +134,13 @@ struct LstmPersistArgs {
     // epoch_base + step (and its XCC table entries epoch_base), so nothing stale can match and no memset sits between two
     // layers on the critical path.  The host advances the base by T + 1 per launch and re-zeroes before a wrap-around.
     unsigned epoch_base = 0;
+    // mp_lstm_fused, the kernels that exchange tagged words ("TAGX": H = 256 on 16 slices or on 8 slices with four waves; see
+    // mp_persist_tagged): bit p = the tag of the FIRST write of this launch to parity slot p (slot 0: steps 0, 2, ...; slot 1:
+    // the initial state as "step -1", then steps 1, 3, ...), the opposite of what the slot's words were left with -- 3 after
+    // the area was zeroed; the host keeps the two bits per area (every launch rewrites every word of a slot, with alternating
+    // tags) and zeroes the area when another kernel family wrote to it, after a device error, and where launches are
+    // replayed (graphs).
+    unsigned tag_flip = 3;
     // mp_lstm_fused, host side only: ask for at least this much dynamic LDS (bytes) although the kernel uses less.  With
     // more than half a CU's LDS per workgroup no CU takes two persistent workgroups -- of this launch or of a launch
     // running beside it -- as long as CUs are free: a workgroup that shares its SIMDs slows its whole lock-stepped cluster.
@@ -163,6 +174,8 @@ static __device__ __forceinline__ int mp_xcd_first(const LstmPersistArgs& a, int
 }
 // nslice: workgroups sharing one slab of an H = 256 layer: 16 (4-wave workgroups, two per CU) or 8 (8-wave, one per CU)
 void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice, hipStream_t s);
+// does the mp_lstm_fused launch of this shape exchange tagged words (LstmPersistArgs::tag_flip)?  four_wave: mp_launch_lstm_persist_w / _vf
+bool mp_persist_tagged(int H, int nslice, bool four_wave);
 // the unidirectional H = 256, K_in = 256 layer on 16 slices with an H = 64 bidirectional layer riding along (fk = its K_in: 64 | 128)
 void mp_launch_lstm_vf(const LstmPersistArgs& a, int fk, hipStream_t s);
 size_t mp_foot_vf_floats(int fk);     // per direction

@@ -160,7 +160,7 @@ MP_KERNEL __launch_bounds__(256) void mp_gemm_f32(GemmArgs g, int nTilesM, int n
                 const int ml = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m0 + ml < g.M) {
                     float v = acc[a][b][r] + bias;
-                    if (g.relu) v = fmaxf(v, 0.f);
+                    if (g.relu) v = relu_(v);
 #if MP_GEMM_EXP == 1
                     if (v == 123456.f)
 #endif
@@ -267,7 +267,7 @@ MP_KERNEL __launch_bounds__(256, 2) void mp_gemm_f32_rows(GemmArgs g, int nTiles
             const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (m0 + ml < g.M) {
                 float v = acc[b][r] + bias;
-                if (g.relu) v = fmaxf(v, 0.f);
+                if (g.relu) v = relu_(v);
                 g.C[rowOffC[wave][ml] + n] = g.pairOut ? __uint_as_float(pair_of(v)) : v;
             }
         }
@@ -369,7 +369,7 @@ __device__ __forceinline__ void gemm_frag_body(const GemmArgs& g, int bid, int n
             const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (m0 + ml < g.M) {
                 float v = acc[b][r] + bias;
-                if (g.relu) v = fmaxf(v, 0.f);
+                if (g.relu) v = relu_(v);
 #if MP_GEMM_EXP == 1
                 if (v == 123456.f)
 #endif
@@ -541,7 +541,7 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_gemm_l2l1(GemmArgs g2, GemmArgs g1) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (FULL || m0 + ml < g1.M) Cb[roff[ml] + (n - ncol0)] = fmaxf(acc[b][r] + bias, 0.f);
+                if (FULL || m0 + ml < g1.M) Cb[roff[ml] + (n - ncol0)] = relu_(acc[b][r] + bias);
             }
         }
     }
@@ -630,7 +630,7 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_gemm_f32_wide(GemmArgs g) {
                 const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (FULL || m0 + ml < g.M) {
                     float v = acc[b][r] + bias1[ng][b];
-                    if (g.relu) v = fmaxf(v, 0.f);
+                    if (g.relu) v = relu_(v);
                     Cb[roff[ml] + (n - ncol0)] = v;
                 }
             }

@@ -147,7 +147,7 @@ MP_KERNEL __launch_bounds__(256) void mp_gemm_x3(GemmArgs g, int nTilesM, int nT
             for (int r = 0; r < 4; ++r) {
                 const int ml = wave * (BM / 4) + a * 16 + 4 * q + r;
                 float v = acc[a][b][r] * kPairWInv + bias;      // (W was split as 16 W: mp_lstm_dev.h pair_of)
-                if (g.relu) v = fmaxf(v, 0.f);
+                if (g.relu) v = relu_(v);
                 Os[ml * OPITCH + b * 16 + r16] = g.pairOut ? pair_of(v) : __float_as_uint(v);
             }
     }

@@ -40,6 +40,9 @@
 #ifndef MP_FLAGX
 #define MP_FLAGX 3        // bit 0: flagged hand-off in the four-wave 8-slice kernels, bit 1: in the 16-slice kernels (A/B builds)
 #endif
+#ifndef MP_TAGX
+#define MP_TAGX 1         // 1: those kernels exchange TAGGED words -- no flag, one L2 round trip per step ("TAGX" in the kernel body);
+#endif                    // 0: the flags of rounds 2-4 (A/B builds: the results are bit-identical)
 
 namespace {
 
@@ -123,13 +126,19 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
     constexpr int NXS = C::NXS, NXJ = C::NXJ, NOWN = C::NOWN, XL = FK ? 0 : C::XL, XR = NXS - XL, NPW = C::NPW;
     constexpr bool PER_UB = C::PER_UB;
     constexpr bool FLAGX = (WREG && (MP_FLAGX & 1)) || (H == 256 && NSLICE == 16 && TW == 1 && (MP_FLAGX & 2));   // flagged hand-off (below)
+    constexpr bool TAGX = FLAGX && (MP_TAGX != 0);                     // ... without the flags: every word carries a tag (below)
     constexpr int NP = NKS / 4 > 0 ? NKS / 4 : 1;                     // FLAGX: 16-byte pieces of h per lane (4 k-steps each)
     constexpr int PPP = NP / NPW > 0 ? NP / NPW : 1;                  //        pieces per producer slice
     // FLAGX: k-steps of the projection in front of the flag request / of the flag check + value request.  One k-step is
     // 256 cycles in the 8-slice kernels and 128 in the 16-slice ones, whose 16-step projection has to cover three memory
     // round trips (the producer's store acknowledgement, the flag, the values) -- everything sits as late as it can there.
-    constexpr int REQ_S = (!WREG && NXS == 16) ? 6 : NXS / 4;
-    constexpr int XSPLIT = (FLAGX && !WREG && NXS == 16) ? 11 : NXS / 2;
+#if MP_EXP >= 1000000      // timing experiment: 1PPRRXX = (PUB_S, REQ_S, XSPLIT) of the 16-slice kernels
+    constexpr int PUB16 = (MP_EXP / 10000) % 100, REQ16 = (MP_EXP / 100) % 100, XS16 = MP_EXP % 100, XT16 = MP_EXP % 100;
+#else
+    constexpr int PUB16 = 1, REQ16 = 6, XS16 = 11, XT16 = 8;
+#endif
+    constexpr int REQ_S = (!WREG && NXS == 16) ? REQ16 : NXS / 4;
+    constexpr int XSPLIT = (FLAGX && !WREG && NXS == 16) ? (TAGX ? XT16 : XS16) : NXS / 2;
     constexpr int NTHREADS = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* red = reinterpret_cast<f32x4*>(smem);                       // [finishing wave][source kq][o][lane]
@@ -253,11 +262,37 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
     // ALWAYS there at the first look -- the hand-off latency was never the problem, its instruction count was.
     // Word (row, unit j) sits where consumer lane (q = j & 3, row) finds k-steps 4i .. 4i+3 of its K quarter in one
     // 16-byte piece:  (((j >> 6) * 4 + ((j & 63) >> 4)) * 64 + (j & 3) * 16 + row) * 4 + ((j >> 2) & 3).
+    // TAGX (round 4, the product): the same words WITHOUT the flags.  Measured with the flags (tools/debug/prof_xproj.py,
+    // profiles/r04_handoff.md): a step's hand-off was a chain of two dependent L2 round trips -- flag, then values -- behind
+    // the producer's store acknowledgement, ~3 400 cycles that the 16-slice kernels' 2 300 cycles of projection MFMAs cannot
+    // cover (the wave sat ~1 100 cycles per step, whatever the three request points were set to) and the 8-slice kernels'
+    // 4 100 only just (~470).  Every word now carries a tag in bit 30 -- the top exponent bit, 0 for every |h| < 2, and
+    // h = o * tanh(c) never leaves [-1, 1] -- that alternates with every write to its parity slot: the consumer requests the
+    // 16-byte pieces ONCE, half-way through the projection, and at the end ORs all 16 (+4) words -- after an XOR that clears
+    // the tag on the steps that expect a set one: bit 30 of the result is set exactly when a word was stale (then: bounded
+    // re-request loop).  ~20 VALU instructions per step (they cost ~8 cycles each in a lone wave -- a first version with
+    // twice as many gave the round trip's cycles straight back) instead of a round trip; the initial state goes out as the
+    // words of "step -1", so step 0 is no special case; results are bit-identical to the flagged form, except that a
+    // one-step launch on a carried state no longer races (there a fast workgroup could write its final state over the
+    // initial state another one had yet to read as its step-0 operand -- each cell's initial h is now read by its owner only).
+    // A NaN h loses its NaN-ness on the way (bit 30 is the tag): the NaN still reaches every output of its sequence through
+    // the producing unit's own column of the layer output -- linear2 / the next layer sum over all columns -- but peers no
+    // longer turn NaN through the recurrence (a poisoned wave's cells are NaN for all 16 rows of the slab: same effect).
+    // Which tag a launch starts with: LstmPersistArgs::tag_flip.
     unsigned* hdL = reinterpret_cast<unsigned*>(hxL);                 // [2 parities][16 * H]
     unsigned* hfL = hdL + (size_t)4 * 16 * H;                         // flags: L [2][NSLICE * 4], then R [2][NSLICE * 4]
     constexpr unsigned HD_R = 2 * 16 * H * 4;                         // byte offset of the R copy of the values
     constexpr unsigned HF_R = 2 * NSLICE * 4;                         // word offset of the R flags
     unsigned spin_budget = a.max_spin;
+    // TAGX: tag of the h words written at `step` = -1 (the initial state, published before the loop: step 0 is a step like
+    // any other), 0, 1, ...: the ((step + 1) / 2)-th write of this launch to parity slot step & 1
+    auto tag_of = [&](int step) -> unsigned { return ((((unsigned)(step + 1) >> 1) ^ (a.tag_flip >> (step & 1))) & 1u) << 30; };
+    // ... and the word itself: h with bit 30 replaced by the tag.  (An inactive row keeps publishing the h it was given -- a
+    // caller's initial state may be anything: whatever its bit 30 was, the tag is what consumers find there.)
+    auto hword_of = [&](float h, int step) -> unsigned {
+        if (!TAGX) return __float_as_uint(h);
+        return (__float_as_uint(h) & ~kHTagBit) | tag_of(step);
+    };
     const long long tl_w = PROF ? (long long)__builtin_amdgcn_s_memrealtime() : 0;      // weight loads issued (not yet waited for)
     const unsigned my_xcc = xcc_id();
     bool src_local[NPW];                   // is the producer slice of each part of this wave's K quarter on my XCD?
@@ -359,6 +394,23 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
         for (int j = 0; j < FNJ; ++j) fxa[j] = *reinterpret_cast<const f32x4*>(fxp_cur + j * 16);
     }
     f32x4* fred = reinterpret_cast<f32x4*>(smem) + C::RED_F4 + (size_t)NWV * XL * NTG * 64;   // rider partials [kq][tile][lane]
+    if (TAGX) {
+        // the initial state goes out as the words of "step -1" (parity slot 1): step 0 requests and validates its recurrent
+        // operand like every other step -- no `step > 0` around the request, the check or the operand (each was a branch whose
+        // merge cost register copies on every step)
+        unsigned* hw = hdL + (size_t)16 * H;
+#pragma unroll
+        for (int o = 0; o < NOWN; ++o) {
+            const unsigned w0 = hword_of(hst[o], -1);
+            __hip_atomic_store(hw + hslot[o], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!all_local) __hip_atomic_store(hw + HD_R / 4 + hslot[o], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (FK && lane < 32) {
+            unsigned* fwd = hdL + F_WORD0 + 2048u + (unsigned)fdir * 1024u + fslot;
+            __hip_atomic_store(fwd, hword_of(0.f, -1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!all_local) __hip_atomic_store(fwd + F_TR, hword_of(0.f, -1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 
     // ---- x_0: this lane's A values of the input projection, k = kq*KQ + j*16 + q*4 + i  (x-step s = 4j+i)
     f32x4 xa[NXJ];
@@ -406,13 +458,22 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
     const long long tl_loop = PROF ? (long long)__builtin_amdgcn_s_memrealtime() : 0;   // first step starts
     const bool prof = PROF && a.prof != nullptr && threadIdx.x == 0;
     const long long t_start = PROF ? (long long)__builtin_amdgcn_s_memtime() : 0;
+#if MP_EXP == 7           // timing experiment: the five counters split the projection phase instead of the step
+#define PROF_T(i) do { } while (0)
+#define PROF_E(i) do { } while (0)
+#define SUB_T(i) do { if (PROF && prof) pt[i] -= (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define SUB_E(i) do { if (PROF && prof) pt[i] += (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
 #define PROF_T(i) do { if (PROF && prof) pt[i] -= (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #define PROF_E(i) do { if (PROF && prof) pt[i] += (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define SUB_T(i) do { } while (0)
+#define SUB_E(i) do { } while (0)
+#endif
 
     const f32x4* wxw = wxl + (size_t)wave * XL * NTG * 64 + lane;
 
     for (int step = 0; step < T; ++step) {
-        PROF_T(0);
+        PROF_T(0); SUB_T(0);
         if (LEAN) xp_cur = xp_nxt;
         if (FK) fxp_cur = fxp_nxt;
         if (SPLIT_X && !FLAGX) load_x(step, XJ_PRE, NXJ);
@@ -451,11 +512,11 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
 #pragma unroll
             for (int tg = 0; tg < NTG; ++tg) wl[tg] = wn[tg];
             if (FLAGX) {
-                constexpr int PUB_S = 1;
+                constexpr int PUB_S = (!WREG && NXS == 16) ? PUB16 : 1;
                 if (s == PUB_S) {
                     // the values this wave stored at the end of step-1 have had two k-steps of MFMAs to be acknowledged:
                     // wait for them, then raise the flag (parity of step-1 = the parity this step reads)
-                    if (step > 0) {
+                    if (!TAGX && step > 0) {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         if (lane == 0) {
                             unsigned* f = hfL + ((step + 1) & 1) * (NSLICE * 4) + slice * 4 + wave;
@@ -464,15 +525,17 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
                         }
                     }
                     if (SPLIT_X) load_x(step, XJ_PRE, NXJ);          // (behind the wait above, not in front of it)
+                    SUB_E(0); SUB_T(1);
                 }
-                if (s == REQ_S) hflags = __hip_atomic_load(hflag + ((step + 1) & 1) * (NSLICE * 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!TAGX && s == REQ_S) hflags = __hip_atomic_load(hflag + ((step + 1) & 1) * (NSLICE * 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 
         // ---- FK: the rider's input projection (independent of h: it lengthens the window that hides the hand-off)
         f32x4 facc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        if (FK) {
+        SUB_E(1); SUB_T(2);
+        auto rider_xproj = [&]() {
 #pragma unroll
             for (int i = 0; i < FNX; ++i) {
                 const float a_s = fxa[(i >> 2) % (FNJ > 0 ? FNJ : 1)][i & 3];
@@ -480,9 +543,11 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
                 facc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, fw[i % FNS][1], facc[1], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-        }
+        };
+        if (FK && !TAGX) rider_xproj();            // (TAGX: behind the request below -- it is part of what hides the round trip)
 
         // ---- request h_{step-1}: granule (row r16, unit kq*KW + 4*ks + q), 512 contiguous bytes per instruction
+        SUB_E(2); SUB_T(3);
         u64 gr[NKS];
         const unsigned epoch = a.epoch_base + (unsigned)step;  // written by the producers at the end of step-1
         const size_t goff = (size_t)((step + 1) & 1) * 16 * H + (size_t)kq * NKS * 64 + r16 * 4 + q;
@@ -501,7 +566,8 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
             // requested just below (measured in the K_in = 256 kernel: a full L2 round trip per step)
 #pragma unroll
             for (int j = 0; j < NXJ; ++j) asm volatile("" : "+v"(xa[j]));
-            if (step > 0) {
+            if (TAGX || step > 0) {
+                if (!TAGX) {
                 bool ok = hflags == epoch;
                 unsigned spins = 0; u64 wt0 = 0;
                 if (PROF && prof && !__all(ok)) pt[5] += 1;  // slow-path entries
@@ -514,6 +580,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
                     __builtin_amdgcn_s_sleep(1);
                     ok = __hip_atomic_load(hflag + ((step + 1) & 1) * (NSLICE * 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
                 }
+                }
                 const int par_off = ((step + 1) & 1) * (16 * H * 4);
 #pragma unroll
                 for (int i = 0; i < NP; ++i)
@@ -524,7 +591,9 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) gr[ks] = granule_load(srcp[ks / KSP] + (size_t)ks * 64);
         }
+        if (FK && TAGX) rider_xproj();
         // ---- second half of the input projection
+        SUB_E(3); SUB_T(4);
 #pragma unroll
         for (int s = XSPLIT; s < NXS; ++s) {
             const float a_s = xa[s >> 2][s & 3];
@@ -549,7 +618,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
 #pragma unroll
             for (int tg = 0; tg < NTG; ++tg) wl[tg] = wn[tg];
         }
-        PROF_E(0); PROF_T(1);
+        PROF_E(0); PROF_T(1); SUB_E(4);
 
         // ---- validate the granules; the slow path (cheap gate, then sweep) only runs when some were stale
         // (K_in = 512: the registers are full -- the words are requested only now and only when they are needed, and the
@@ -561,6 +630,49 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
 #pragma unroll
             for (int i = 0; i < NP; ++i) asm volatile("" : "+v"(hr[i]));
             if (FK) asm volatile("" : "+v"(fhr));
+            if (TAGX) {
+                // clear the expected tag, OR what is left: bit 30 set = some word is not (yet) the one of step - 1.  ONE copy of
+                // this code, in a loop whose body normally runs once (the re-request at its bottom writes the same registers:
+                // no phi copies -- the first version, with a separate slow path, cost 30-40 v_mov per step)
+                const unsigned etag = tag_of(step - 1);
+                const int par_off = ((step + 1) & 1) * (16 * H * 4);
+                unsigned spins = 0; u64 wt0 = 0;
+                while (true) {
+                    // (the XOR only when there is a tag to clear -- a scalar branch around 20 VALU instructions, which cost
+                    //  ~8 cycles each in a lone wave; in place, so nothing to merge behind it)
+                    if (etag) {
+#pragma unroll
+                        for (int i = 0; i < NP; ++i)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) hr[i][c] = __uint_as_float(__float_as_uint(hr[i][c]) ^ kHTagBit);
+                        if (FK) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) fhr[c] = __uint_as_float(__float_as_uint(fhr[c]) ^ kHTagBit);
+                        }
+                    }
+                    unsigned left = 0;
+#pragma unroll
+                    for (int i = 0; i < NP; ++i)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) left |= __float_as_uint(hr[i][c]);
+                    if (FK) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) left |= __float_as_uint(fhr[c]);
+                    }
+                    if (__all((left & kHTagBit) == 0u)) break;
+                    if (PROF && prof && spins == 0) pt[5] += 1;                          // slow-path entries
+                    if (wait_over(spins, spin_budget, wt0, a.max_ticks)) {               // bounded: flag the error and never wait again
+                        if (lane == 0) mp_set_error(a.err, 1 + step);
+                        spin_budget = 0; poison_cells(cst); fcst = __builtin_nanf("");
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                    for (int i = 0; i < NP; ++i)
+                        hr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, hvoff[i], par_off, 16 /* sc1 */));
+                    if (FK) fhr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(frs, fvoff, ((step + 1) & 1) * 8192, 16 /* sc1 */));
+                }
+            }
         } else if (step > 0) {
             if (!EARLY_GATHER) {
 #pragma unroll
@@ -715,13 +827,16 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
                 oval[o] = act ? hnew : 0.f;
             }
             unsigned* hw = hdL + (size_t)(step & 1) * 16 * H;
+            unsigned hword[NOWN];
+#pragma unroll
+            for (int o = 0; o < NOWN; ++o) hword[o] = hword_of(hst[o], step);
 #pragma unroll
             for (int o = 0; o < NOWN; ++o)
-                __hip_atomic_store(hw + hslot[o], __float_as_uint(hst[o]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(hw + hslot[o], hword[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (!all_local) {
 #pragma unroll
                 for (int o = 0; o < NOWN; ++o)
-                    __hip_atomic_store(hw + HD_R / 4 + hslot[o], __float_as_uint(hst[o]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(hw + HD_R / 4 + hslot[o], hword[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #pragma unroll
             for (int o = 0; o < NOWN; ++o)
@@ -746,12 +861,13 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
             fcst = fact ? fcnew : fcst;
             fhst = fact ? fhnew : fhst;
             unsigned* hw = hdL + (size_t)(step & 1) * 16 * H + hslot[0];
-            __hip_atomic_store(hw, __float_as_uint(hst[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (!all_local) __hip_atomic_store(hw + HD_R / 4, __float_as_uint(hst[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned hword = hword_of(hst[0], step), fhword = hword_of(fhst, step);
+            __hip_atomic_store(hw, hword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!all_local) __hip_atomic_store(hw + HD_R / 4, hword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (lane < 32) {
                 unsigned* fwd = hdL + F_WORD0 + (unsigned)(step & 1) * 2048u + (unsigned)fdir * 1024u + fslot;
-                __hip_atomic_store(fwd, __float_as_uint(fhst), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (!all_local) __hip_atomic_store(fwd + F_TR, __float_as_uint(fhst), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(fwd, fhword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (!all_local) __hip_atomic_store(fwd + F_TR, fhword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (frow < B) a.f_out[((size_t)ftt * B + frow) * 128 + fdir * 64 + funit] = fact ? fhnew : 0.f;
             }
             if (bidx[0] < B) *reinterpret_cast<float*>(reinterpret_cast<char*>(outb[0]) + (size_t)(unsigned)tt * out_row_bytes) = act ? hnew : 0.f;
@@ -772,8 +888,9 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
             }
             if (FLAGX) {   // plain words; this wave's flag follows at the top of the next step
                 unsigned* hw = hdL + (size_t)(step & 1) * 16 * H + hslot[o];
-                __hip_atomic_store(hw, __float_as_uint(hst[o]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (!all_local) __hip_atomic_store(hw + HD_R / 4, __float_as_uint(hst[o]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned hword = hword_of(hst[o], step);
+                __hip_atomic_store(hw, hword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (!all_local) __hip_atomic_store(hw + HD_R / 4, hword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
             const int gi = granule_index(q * 4 + reg0 + o, jown);
             granule_store_l2(hxL + doff + gi, a.epoch_base + (unsigned)(step + 1), hst[o]);
@@ -1190,6 +1307,10 @@ void mp_launch_lstm_persist_w(const LstmPersistArgs& a, int KIN, hipStream_t s) 
     else launch_fused<256, 8, 512, 1>(a, s);
 }
 
+bool mp_persist_tagged(int H, int nslice, bool four_wave) {
+    if (!MP_TAGX || H != 256) return false;
+    return (nslice == 8 && four_wave && (MP_FLAGX & 1)) || (nslice == 16 && (MP_FLAGX & 2));
+}
 int mp_persist_max_wg(int H, int nslice) { return H == 256 && nslice == 16 ? 512 : 256; }
 
 // both layers of a unidirectional 2-layer LSTM (H = 256, 16-slice packing) as one wavefront launch

@@ -404,3 +404,49 @@ def test_linear_layer_kernels_on_ragged_row_counts(torch_mod, net, weights, smpl
     assert np.abs(npy(contact)[rows] - rcontact).max() < TOL
     assert geodesic(npy(pose).reshape(B, T, 24, 3, 3)[rows].reshape(-1, 24, 3, 3), rpose).max() < TOL
     assert net.device_error() == 0
+
+
+def test_one_step_call_on_a_carried_state_vs_oracle(torch_mod, weights_trained, smpl):
+    """T = 1 with a carried velocity state: every fused layer launch is ONE step whose recurrent operand is the state the
+    previous call left in place.  (Until round 4 a workgroup read that operand for all 16 rows of its slab from the state
+    buffer while a faster workgroup of the same cluster could already be writing its final state there; the initial state now
+    travels through the exchange like every other step's.)  Five calls against the oracle, saturated-gate weights."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    from oracle import mp_oracle as O
+    B = 256
+    ref = O.OracleNet(weights_trained, smpl["J"])
+    with MobilePoserNet.from_numpy(weights_trained, smpl) as n:
+        n.set_lstm_mode(1)
+        for call in range(5):
+            imu = synthetic.make_imu(B, 1, seed=900 + call)
+            pose, joints, vel, contact = n.forward(cu(torch_mod, imu), [1] * B)
+            rpose, rjoints, rvel, rcontact = ref.forward(imu, [1] * B)
+            assert np.abs(npy(joints) - rjoints).max() < 1e-4, call
+            assert np.abs(npy(vel).reshape(rvel.shape) - rvel).max() < 1e-4, call
+            assert np.abs(npy(contact) - rcontact).max() < 1e-4, call
+        assert n.device_error() == 0
+
+
+def test_nan_sample_poisons_its_sequence_and_only_it(torch_mod, net, weights, smpl):
+    """One NaN in one IMU sample: the reference (torch: relu(NaN) = NaN, NaN gates) returns NaN joints, velocity and contact
+    for EVERY frame of that sequence (the bidirectional joints layers carry it both ways, the other blocks read the joints) and the
+    NaN -> 0 rule of r6d_to_rotation_matrix (angular.py:181) keeps the pose finite; every other sequence is untouched."""
+    from mobileposer_amd import synthetic
+    B, T, b, t = 40, 30, 17, 11
+    imu = synthetic.make_imu(B, T, seed=321)
+    net.reset_all()
+    clean = [x.clone() for x in net.forward(cu(torch_mod, imu), [T] * B)]
+    bad = imu.copy()
+    bad[b, t, 7] = np.nan
+    net.reset_all()
+    got = [x.clone() for x in net.forward(cu(torch_mod, bad), [T] * B)]
+    others = [i for i in range(B) if i != b]
+    pose = got[0].reshape(B, T, -1)
+    assert bool(torch_mod.isfinite(pose).all())
+    for k in (1, 2, 3):                                        # joints: all frames; velocity and contact read them
+        assert bool(torch_mod.isnan(got[k][b]).all()), k
+    for k in (1, 2, 3):
+        assert torch_mod.equal(got[k][others], clean[k][others])
+    assert torch_mod.equal(pose[others], clean[0].reshape(B, T, -1)[others])
+    assert net.device_error() == 0
