@@ -450,3 +450,29 @@ def test_nan_sample_poisons_its_sequence_and_only_it(torch_mod, net, weights, sm
         assert torch_mod.equal(got[k][others], clean[k][others])
     assert torch_mod.equal(pose[others], clean[0].reshape(B, T, -1)[others])
     assert net.device_error() == 0
+
+
+@pytest.mark.parametrize("B", [48, 256])
+def test_tagged_exchange_over_short_launches_vs_oracle(torch_mod, weights_trained, smpl, B):
+    """The tagged hidden-state exchange starts every launch with the tags the previous one did NOT leave behind (two bits per
+    exchange area, kept by the host: LstmPersistArgs::tag_flip).  How many times a parity slot is written depends on T, so
+    launches of T = 2, 3, 4, 7, 1, 6 alternate on ONE handle -- every (B, T) has its own areas, revisited three times each --
+    with the velocity state carried from call to call, against the oracle.  A wrong tag would either stall (device error) or
+    accept a word of the previous launch (wrong numbers)."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    from oracle import mp_oracle as O
+    ref = O.OracleNet(weights_trained, smpl["J"])
+    with MobilePoserNet.from_numpy(weights_trained, smpl) as n:
+        n.set_lstm_mode(1)
+        for rnd in range(3):
+            for T in (2, 3, 4, 7, 1, 6):
+                imu = synthetic.make_imu(B, T, seed=1000 + 10 * rnd + T)
+                L = [T] * B
+                L[B // 3] = max(1, T - 1)
+                pose, joints, vel, contact = n.forward(cu(torch_mod, imu), L)
+                rpose, rjoints, rvel, rcontact = ref.forward(imu, L)
+                assert np.abs(npy(joints) - rjoints).max() < 1e-4, (rnd, T)
+                assert np.abs(npy(vel).reshape(rvel.shape) - rvel).max() < 2e-4, (rnd, T)
+                assert np.abs(npy(contact) - rcontact).max() < 2e-4, (rnd, T)
+        assert n.device_error() == 0 and n.recovery_count == 0
