@@ -723,8 +723,10 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
             xp_nxt = adv ? xp_cur + dlt : xp_cur;
         }
         if (FK) {      // the rider's x of step + 1 (forward: t = step + 1, reverse: t = len - 2 - step, both clamped)
+            // (one signed stride, as for the layer's own x above: the direction is uniform but the compiler branched on it)
             const bool adv = fdir ? (alen - 2 - step >= 0) : (step + 1 < T);
-            fxp_nxt = adv ? (fdir ? fxp_cur - fxt : fxp_cur + fxt) : fxp_cur;
+            const long fdlt = fdir ? -(long)fxt : (long)fxt;
+            fxp_nxt = adv ? fxp_cur + fdlt : fxp_cur;
 #pragma unroll
             for (int j = 0; j < FNJ; ++j) fxa[j] = *reinterpret_cast<const f32x4*>(fxp_nxt + j * 16);
         }
@@ -733,15 +735,53 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
         PROF_E(1); PROF_T(2);
 
         // ---- recurrent part: h_{t-1} W_hh^T on top of the input projection
+        // RED3 (the four-wave 8-slice K_in = 256 kernel, round 4): the K reduction's LDS writes go out UNDER the last recurrent MFMAs.
+        // The last four k-steps run pair of tiles by pair of tiles (gate p of both unit blocks: two independent accumulators
+        // alternate, 64 cycles between dependent MFMAs), and while pair p + 1 is in the matrix pipe the finished tiles of pair p
+        // are stored as they are -- registers (0, 1) and (2, 3) as two 8-byte pieces, one ds_write2st64_b64 per tile, layout
+        // [tile][source kq][half][lane]; LDS instructions issue beside a wave's MFMAs (VALU ones do not, so the old form's 32
+        // v_mov that gathered {i, f, g, o} pieces could not have moved there).  The barrier that protects the previous step's
+        // reads of `red` moves in front of the recurrent part.  A finishing wave then reads its half of the four gate tiles of its
+        // unit block from the four sources (8 ds_read2st64_b64).  Same bytes, same summation order: bit-identical.  Measured
+        // (profiles/r04_handoff.md): reduction phase 725 -> 390 cycles, recurrent phase 4 252 -> 4 440 (the writes are not free),
+        // launch 551 -> 546 us; in the K_in = 512 kernel (LDS full: one copy of the scratch, the barrier stays) the same change
+        // moved the phases but not the launch time (783.7 vs 783.5 us), so it keeps the old form.
+        constexpr bool RED3 = WREG && C::ALLREG && !PER_UB && NUB == 2 && NOWN == 2 && NKS >= 8 && FLAGX;
+        // (K_in = 256: all weights in registers, LDS to spare -- two copies of the scratch, used in turn, and the barrier that
+        //  protects the previous step's reads is not needed at all: whoever writes copy s & 1 has passed the barrier of step
+        //  s - 1, which every wave reaches only after its reads of step s - 2)
+        constexpr bool RED_DB = RED3 && C::ALLREG;
+        float2* red2 = reinterpret_cast<float2*>(smem) + (RED_DB ? (size_t)(step & 1) * C::RED_F4 * 2 : 0);
+        if (RED3 && !RED_DB) barrier_lds_only();               // previous step's reads of `red` are done
         if (WREG) asm volatile("s_nop 3" ::: "memory");        // (step 0 writes the A operand with VALU moves just above)
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
+        for (int ks = 0; ks < (RED3 ? NKS - 4 : NKS); ++ks)
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
                 const float a_h = FLAGX ? hr[(ks >> 2) % NP][ks & 3] : DIRECT_GR ? __uint_as_float((unsigned)gr[ks]) : av[ks];
                 if (WREG) mfma_asm<false, true>(acc[t], a_h, wv[ks][t]);
                 else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_h, wv[ks][t], acc[t], 0, 0, 0);
             }
+        if (RED3) {
+#pragma unroll
+            for (int p = 0; p < NTW / 2; ++p) {
+#pragma unroll
+                for (int ks = NKS - 4; ks < NKS; ++ks) {
+#pragma unroll
+                    for (int t = 2 * p; t < 2 * p + 2; ++t) mfma_asm<false, true>(acc[t % NTW], hr[(ks >> 2) % NP][ks & 3], wv[ks][t % NTW]);
+                    if (p > 0 && ks == NKS - 3) {
+                        // (the tiles of pair p - 1: their last MFMAs were issued >= 4 MFMAs = 128 cycles ago)
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t = 2 * p - 2; t < 2 * p; ++t)
+#pragma unroll
+                            for (int hf = 0; hf < 2; ++hf)
+                                red2[(((t % NTW) * 4 + kq) * 2 + hf) * 64 + lane] = float2{acc[t % NTW][2 * hf], acc[t % NTW][2 * hf + 1]};
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
         if (FK) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -754,13 +794,19 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
 
         // ---- K reduction through LDS: the 4 K-quarter waves of a tile group hand each finishing wave the 4 gate
         // values of the accumulator regs it finishes (own share included: register indices stay compile-time)
-        __syncthreads();                                       // previous step's reads of `red` are done
+        if (!RED3) __syncthreads();                            // previous step's reads of `red` are done
         if (FK) {      // rider partials, transposed for the finishing lanes: [source kq][row 4q+reg][column][tile]
             float2* ft = reinterpret_cast<float2*>(fred) + (size_t)(kq * 16 + 4 * q) * 16 + r16;
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) ft[rg * 16] = float2{facc[0][rg], facc[1][rg]};
         }
-        if (!PER_UB) {
+        if (RED3) {                                            // (the last pair of tiles; the others went out above)
+#pragma unroll
+            for (int t = NTW - 2; t < NTW; ++t)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+                    red2[((t * 4 + kq) * 2 + hf) * 64 + lane] = float2{acc[t][2 * hf], acc[t][2 * hf + 1]};
+        } else if (!PER_UB) {
 #pragma unroll
             for (int dw = 0; dw < 4; ++dw) {
                 const int dub = NUB == 2 ? (dw & 1) : dw;
@@ -779,6 +825,20 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
         }
         __syncthreads();
         f32x4 gate[NOWN];
+        if (RED3) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int t = g * NUB + (wave & 1);
+                float2 v = red2[((t * 4 + 0) * 2 + (wave >> 1)) * 64 + lane];
+#pragma unroll
+                for (int sw = 1; sw < 4; ++sw) {
+                    const float2 u = red2[((t * 4 + sw) * 2 + (wave >> 1)) * 64 + lane];
+                    v.x += u.x; v.y += u.y;
+                }
+                gate[0][g] = v.x + bias4[g];
+                gate[NOWN - 1][g] = v.y + bias4[g];
+            }
+        } else
 #pragma unroll
         for (int o = 0; o < NOWN; ++o) {
             f32x4 v = red[((wave * 4 + 0) * NOWN + o) * 64 + lane];
@@ -1196,7 +1256,7 @@ constexpr int kExclusiveLds = 84 * 1024;                             // > half o
 template <int H, int NSLICE, int KIN, int TW>
 constexpr size_t fused_lds() {
     using C = Cfg<H, NSLICE, KIN, TW>;
-    return (size_t)C::RED_F4 * 16 + (size_t)C::NWV * C::XL * C::NTG * 64 * 16;
+    return (size_t)C::RED_F4 * 16 * (C::ALLREG ? 2 : 1) + (size_t)C::NWV * C::XL * C::NTG * 64 * 16;   // (ALLREG: two copies, RED_DB)
 }
 constexpr size_t kVfLds = fused_lds<256, 16, 256, 1>() + 4 * 2 * 64 * 16;      // + the rider's partial sums [kq][tile][lane]
 
