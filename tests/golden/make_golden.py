@@ -438,6 +438,28 @@ def main():
         g15["blend_vert_noshape"] = vg.numpy()
     np.savez_compressed(os.path.join(HERE, "g15_mesh6890.npz"), **g15)
 
+    # ---- G16 (round 4) corner semantics recorded from the reference instead of argued: (a) ONE NaN in one IMU sample of one
+    # sequence of a batch (F.relu keeps NaN, rnn.py:22; the NaN -> 0 rule of r6d_to_rotation_matrix, angular.py:181); (b) five
+    # consecutive forward() calls of ONE frame each, the velocity state carried from call to call (velocity.py:45-48)
+    g16 = {}
+    with torch.no_grad():
+        imu16 = synthetic.make_imu(5, 24, seed=161)
+        bad16 = imu16.copy()
+        bad16[2, 9, 7] = np.nan
+        g16["nan_imu"] = bad16
+        m = model_from(synthetic.make_weights(0))
+        pose, joints, vel, contact = m.forward(torch.from_numpy(bad16), [24] * 5)
+        g16["nan_pose"], g16["nan_joints"], g16["nan_vel"], g16["nan_contact"] = pose.numpy(), joints.numpy(), vel.numpy(), contact.numpy()
+        m = model_from(sd_tr)
+        one16 = synthetic.make_imu(4, 5, seed=162)                    # call k uses frame k of each of the 4 sequences
+        g16["one_imu"] = one16
+        for k in range(5):
+            pose, joints, vel, contact = m.forward(torch.from_numpy(one16[:, k:k + 1]), [1] * 4)
+            g16[f"one_joints{k}"], g16[f"one_vel{k}"], g16[f"one_contact{k}"] = joints.numpy(), vel.numpy(), contact.numpy()
+        h, c = m.velocity.rnn_state
+        g16["one_vel_h"], g16["one_vel_c"] = h.numpy(), c.numpy()
+    np.savez_compressed(os.path.join(HERE, "g16_corners.npz"), **g16)
+
     print("golden vectors written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         print("  %-24s %8d B" % (fn, os.path.getsize(os.path.join(HERE, fn))))

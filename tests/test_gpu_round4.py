@@ -476,3 +476,38 @@ def test_tagged_exchange_over_short_launches_vs_oracle(torch_mod, weights_traine
                 assert np.abs(npy(vel).reshape(rvel.shape) - rvel).max() < 2e-4, (rnd, T)
                 assert np.abs(npy(contact) - rcontact).max() < 2e-4, (rnd, T)
         assert n.device_error() == 0 and n.recovery_count == 0
+
+
+def test_g16_nan_sample_golden(torch_mod, net):
+    """G16a, recorded from the reference: a NaN in one IMU sample -> that sequence's joints / velocity / contact NaN in every
+    frame, its pose all-zero matrices (angular.py:181), the other four sequences as if nothing had happened."""
+    g = load_golden("g16_corners.npz")
+    net.reset_all()
+    pose, joints, vel, contact = net.forward(cu(torch_mod, g["nan_imu"]), [24] * 5)
+    for got, key in ((joints, "nan_joints"), (vel, "nan_vel"), (contact, "nan_contact")):
+        a, b = npy(got).reshape(g[key].shape), g[key]
+        assert (np.isnan(a) == np.isnan(b)).all(), key
+        m = ~np.isnan(b)
+        assert np.abs(a[m] - b[m]).max() < 1e-4, key
+    assert not np.isnan(npy(pose)).any() and np.abs(npy(pose).reshape(g["nan_pose"].shape) - g["nan_pose"]).max() < 1e-4
+    assert net.device_error() == 0
+
+
+def test_g16_one_frame_calls_golden(torch_mod, weights_trained, smpl):
+    """G16b, recorded from the reference: five forward() calls of one frame each on a carried velocity state (B = 4: the
+    32-slice kernels) -- and the same five calls with the four sequences repeated 64 times (B = 256: the tagged-exchange
+    kernels, every fused launch a single step)."""
+    from mobileposer_amd.net import MobilePoserNet
+    g = load_golden("g16_corners.npz")
+    for rep in (1, 64):
+        with MobilePoserNet.from_numpy(weights_trained, smpl) as n:
+            n.set_lstm_mode(1)
+            for k in range(5):
+                x = np.tile(g["one_imu"][:, k:k + 1], (rep, 1, 1))
+                pose, joints, vel, contact = n.forward(cu(torch_mod, x), [1] * (4 * rep))
+                for got, key in ((joints, f"one_joints{k}"), (vel, f"one_vel{k}"), (contact, f"one_contact{k}")):
+                    want = np.tile(g[key].reshape(4, -1), (rep, 1))
+                    assert np.abs(npy(got).reshape(4 * rep, -1) - want).max() < 1e-4, (rep, k, key)
+            h, c = n.velocity.rnn_state
+            assert np.abs(npy(h) - np.tile(g["one_vel_h"], (1, rep, 1))).max() < 1e-4
+            assert n.device_error() == 0

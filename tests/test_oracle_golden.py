@@ -294,3 +294,40 @@ def test_g15_mesh_at_6890_vertices():
     # pose blend shapes do move vertices (the golden is not vacuous)
     _, _, plain = O.forward_kinematics_mesh(g["pose"], big)
     assert np.abs(plain - g["blend_vert_noshape"]).max() > 1e-3
+
+
+def _same_nan_pattern_and_values(a, b, tol):
+    assert a.shape == b.shape and (np.isnan(a) == np.isnan(b)).all()
+    m = ~np.isnan(b)
+    assert np.abs(a[m] - b[m]).max() < tol
+
+
+def test_g16_nan_sample_follows_the_reference(smpl):
+    """G16a: one NaN in one IMU sample.  The reference returns NaN joints / velocity / contact for every frame of that sequence
+    and only there, and a finite pose everywhere (F.relu keeps the NaN, the bidirectional joints layers carry it both ways,
+    angular.py:181 turns NaN rotations into 0): the oracle reproduces the pattern and the finite values."""
+    from mobileposer_amd.synthetic import make_weights
+    g = load_golden("g16_corners.npz")
+    net = O.OracleNet(make_weights(0), smpl["J"])
+    with np.errstate(all="ignore"):
+        pose, joints, vel, contact = net.forward(g["nan_imu"], [24] * 5)
+    assert np.isnan(g["nan_joints"][2]).all() and not np.isnan(g["nan_joints"][[0, 1, 3, 4]]).any()
+    assert not np.isnan(g["nan_pose"]).any()
+    _same_nan_pattern_and_values(joints, g["nan_joints"], TOL)
+    _same_nan_pattern_and_values(vel.reshape(g["nan_vel"].shape), g["nan_vel"], TOL)
+    _same_nan_pattern_and_values(contact, g["nan_contact"], TOL)
+    # (the poisoned sequence's "rotations" are all-zero matrices: compared as numbers, an angle between them means nothing)
+    assert not np.isnan(pose).any() and np.abs(pose - g["nan_pose"]).max() < 1e-5
+
+
+def test_g16_one_frame_calls_on_a_carried_state(weights_trained, smpl):
+    """G16b: five forward() calls of ONE frame each, velocity state carried (velocity.py:45-48), trained-regime weights."""
+    g = load_golden("g16_corners.npz")
+    net = O.OracleNet(weights_trained, smpl["J"])
+    for k in range(5):
+        pose, joints, vel, contact = net.forward(g["one_imu"][:, k:k + 1], [1] * 4)
+        assert np.abs(joints - g[f"one_joints{k}"]).max() < TOL
+        assert np.abs(vel.reshape(g[f"one_vel{k}"].shape) - g[f"one_vel{k}"]).max() < TOL
+        assert np.abs(contact - g[f"one_contact{k}"]).max() < TOL
+    h, c = net.velocity_rnn_state
+    assert np.abs(h - g["one_vel_h"]).max() < TOL and np.abs(c - g["one_vel_c"]).max() < TOL
