@@ -19,8 +19,10 @@
 // h_t crosses workgroups (the NSLICE slices of a slab need each other's units every step) in one of two forms:
 //   * 8-byte {epoch, value} granules -- the data is its own flag, no fence / barrier / flag word (cdna_hip_programming.md
 //     Guideline 16, form R2): the H = 64 kernels and the eight-wave kernels (described in this header);
-//   * plain words + one flag per producer wave ("FLAGX" in the kernel body): the H = 256 kernels with one wave per SIMD,
-//     where 16 granule loads + 16 tag compares per lane and step cost more than the hand-off latency they hid.
+//   * plain 4-byte words in 16-byte pieces ("FLAGX" / "TAGX" in the kernel body): the H = 256 kernels with one wave per SIMD,
+//     where 16 granule loads + 16 tag compares per lane and step cost more than the hand-off latency they hid.  Rounds 2-4
+//     signalled them with one flag per producer wave (two dependent round trips per step); since round 4 every word carries a
+//     one-bit tag in bit 30 -- free, |h| <= 1 -- and a step is one round trip again (TAGX, the product).
 // Two transports, chosen per PRODUCER from where it really runs (its XCC id,
 // published once at kernel start), so the result never depends on placement, only the speed does:
 //   R: write-through (sc1) stores + sc1 loads -- coherent for any placement (fabric round trip, ~1 us);
