@@ -110,7 +110,10 @@ int mp_forward_offline(mp_handle* h, const float* imu_dev, const int32_t* length
 /* RNN.forward of one module (models/rnn.py:20-33): Linear+ReLU -> 2-layer LSTM (packed-sequence
  * semantics) -> Linear.  x_dev [B,T,n_in] -> y_dev [B,T,n_out].
  * state_in_dev / state_out_dev: optional (h then c, each [layers*dirs, B, H] contiguous, nn.LSTM
- * order l0, l0_reverse, l1, l1_reverse) -- the `h` argument / third return value of rnn.py:20,33. */
+ * order l0, l0_reverse, l1, l1_reverse) -- the `h` argument / third return value of rnn.py:20,33.
+ * Any state is accepted, as by nn.LSTM; an initial h with |h| >= 2 or NaN -- nothing an LSTM produces -- is outside what the
+ * fused layer kernels exchange between workgroups (device code 2000000): with recovery on (the default) the call is run by the
+ * per-step kernels and returns the exact result, with recovery off it reports MP_ERR_DEVICE like a starved call. */
 int mp_rnn_forward(mp_handle* h, int module, const float* x_dev, const int32_t* lengths_host,
                    int B, int T, float* y_dev, const float* state_in_dev, float* state_out_dev,
                    void* stream);

@@ -1496,7 +1496,8 @@ int pending_device_error(mp_handle* h, const char* where) {
     disable_xcd_tables(h);
     invalidate_carried_state(h);
     return fail(h, MP_ERR_DEVICE, "%s: a previous call's persistent LSTM kernel gave up a wait for another workgroup's "
-                "hidden state (code %d: 1+step, or 1000000 = start-up handshake; the GPU was shared?); the affected "
+                "hidden state (code %d: 1+step, or 1000000 = start-up handshake; the GPU was shared?  2000000 = an initial hidden state "
+                "outside (-2, 2) or NaN, which only the per-step kernels take: recovery on handles it); the affected "
                 "outputs of that call are NaN and the state it carried forward is lost: the velocity LSTM state has been "
                 "dropped and all streams reset.  Physical-XCD placement tables are now off for this handle", where, code);
 }
@@ -1556,8 +1557,8 @@ int finish_or_recover(mp_handle* h, Plan* p, const char* what, Restore restore, 
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->s_main));
     ++h->recoveries;
-    char buf[400];
-    snprintf(buf, sizeof(buf), "warning: %s: a fused LSTM layer grid was starved of compute units (code %d; is the GPU shared?); "
+    char buf[512];
+    snprintf(buf, sizeof(buf), "warning: %s: a fused LSTM layer grid was starved of compute units (code %d; is the GPU shared?  2000000 = an initial hidden state the fused kernels do not take); "
              "the call was run again with per-step kernels and its results are valid (recovery #%d)", what, code, h->recoveries);
     h->err = buf;
     return MP_OK;

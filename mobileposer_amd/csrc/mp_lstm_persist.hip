@@ -403,6 +403,9 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
         unsigned* hw = hdL + (size_t)16 * H;
 #pragma unroll
         for (int o = 0; o < NOWN; ++o) {
+            // (an initial h with bit 30 set -- |h| >= 2, which no LSTM produces, or a NaN -- cannot travel as a tagged word: say so
+            //  and poison the cell; with recovery on the call is run again by the per-step kernels, which take any state)
+            if (blen[o] > 0 && (__float_as_uint(hst[o]) & kHTagBit)) { mp_set_error(a.err, 2000000); cst[o] = __builtin_nanf(""); }
             const unsigned w0 = hword_of(hst[o], -1);
             __hip_atomic_store(hw + hslot[o], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (!all_local) __hip_atomic_store(hw + HD_R / 4 + hslot[o], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

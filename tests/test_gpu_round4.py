@@ -511,3 +511,34 @@ def test_g16_one_frame_calls_golden(torch_mod, weights_trained, smpl):
             h, c = n.velocity.rnn_state
             assert np.abs(npy(h) - np.tile(g["one_vel_h"], (1, rep, 1))).max() < 1e-4
             assert n.device_error() == 0
+
+
+def test_initial_state_no_lstm_produces_is_taken_by_the_per_step_kernels(torch_mod, weights, smpl):
+    """nn.LSTM accepts ANY (h0, c0).  The fused kernels exchange hidden states with a tag in bit 30 of the word, which is free
+    only for |h| < 2 -- every state an LSTM produced -- so an initial |h| >= 2 (or a NaN) is detected at launch (device code
+    2000000) and the call repaired by the per-step kernels (recovery on, the default): the result matches the oracle, one
+    recovery is counted, and the next ordinary call runs on the fused kernels again."""
+    import warnings
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    from oracle import mp_oracle as O
+    B, T = 256, 6
+    rng = np.random.Generator(np.random.PCG64(404))
+    x = (rng.standard_normal((B, T, 132)) * 0.5).astype(np.float32)
+    h0 = (rng.standard_normal((2, B, 256)) * 0.3).astype(np.float32)
+    c0 = (rng.standard_normal((2, B, 256)) * 0.5).astype(np.float32)
+    h0[0, 17, 5] = 3.25                                       # no LSTM output
+    h0[1, 200, 77] = -2.0
+    with MobilePoserNet.from_numpy(weights, smpl) as n:
+        n.set_lstm_mode(1)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            y, (h, c) = n.rnn_forward("velocity", cu(torch_mod, x), [T] * B, (cu(torch_mod, h0), cu(torch_mod, c0)))
+        assert n.recovery_count == 1 and any("2000000" in str(i.message) for i in w), [str(i.message) for i in w]
+        ry, (rh, rc) = O.rnn_forward(weights, O.PREFIX["velocity"], x, [T] * B, (h0, c0))
+        assert np.abs(npy(y) - ry).max() < 1e-4 and np.abs(npy(h) - rh).max() < 1e-4 and np.abs(npy(c) - rc).max() < 1e-4
+        h0[0, 17, 5], h0[1, 200, 77] = 0.25, -0.5
+        y, (h, c) = n.rnn_forward("velocity", cu(torch_mod, x), [T] * B, (cu(torch_mod, h0), cu(torch_mod, c0)))
+        ry, (rh, rc) = O.rnn_forward(weights, O.PREFIX["velocity"], x, [T] * B, (h0, c0))
+        assert np.abs(npy(y) - ry).max() < 1e-4 and np.abs(npy(h) - rh).max() < 1e-4
+        assert n.recovery_count == 1 and n.device_error() == 0
