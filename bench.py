@@ -145,6 +145,41 @@ def cpu_baseline(seconds=5.0):
     return out
 
 
+def verify_rows(outs, imu, B, T, rows=16, seed=11):
+    """`rows` sampled sequences of one step's seven outputs against the CPU oracle (oracle/mp_oracle.py: forward,
+    articulate/model.py:208-232 FK, models/net.py:130-154 solver), after and outside of the timed region.  Bounds: 1e-4 on
+    network outputs and rotation angles, 1 mm on translation (BASELINE north_star); raises above them."""
+    from mobileposer_amd import synthetic
+    from oracle import mp_oracle as O
+    pick = np.sort(np.random.Generator(np.random.PCG64(seed)).choice(B, min(rows, B), replace=False))
+    n = len(pick)
+    ref = O.OracleNet(synthetic.make_weights(0), synthetic.synthetic_smpl()["J"])
+    x = imu[torch.from_numpy(pick).to(imu.device)].cpu().numpy()
+    rpose, rjoints, rvel, rcontact = ref.forward(x, [T] * n)
+    rvel = rvel.reshape(n, T, 72)
+    rRg, rjg = O.forward_kinematics(rpose, ref.J)
+    rtran = np.stack([O.translate_offline(rjoints[i].reshape(T, 24, 3), rvel[i], rcontact[i], ref.floor_y) for i in range(n)])
+    g = {k: v.cpu().numpy() for k, v in outs.items()}
+
+    def angle(a, b):                       # geodesic angle between rotation matrices (rad), float64
+        d = np.swapaxes(a.astype(np.float64), -1, -2) @ b.astype(np.float64)
+        nrm = np.linalg.norm(d - np.eye(3), axis=(-1, -2))
+        return 2.0 * np.arcsin(np.clip(nrm / (2.0 * np.sqrt(2.0)), 0.0, 1.0))
+
+    err = {"joints": float(np.abs(g["joints"][pick] - rjoints).max()),
+           "vel": float(np.abs(g["vel"][pick] - rvel).max()),
+           "contact": float(np.abs(g["contact"][pick] - rcontact).max()),
+           "tran_m": float(np.abs(g["tran"][pick] - rtran).max()),
+           "pose_rad": float(angle(g["pose"].reshape(B, T, 24, 3, 3)[pick], rpose.reshape(n, T, 24, 3, 3)).max()),
+           "rglobal_rad": float(angle(g["rglob"].reshape(B, T, 24, 3, 3)[pick], rRg.reshape(n, T, 24, 3, 3)).max()),
+           "joint_global": float(np.abs(g["jglob"].reshape(B, T, 24, 3)[pick] - rjg.reshape(n, T, 24, 3)).max())}
+    bad = {k: v for k, v in err.items() if not v < (1e-3 if k == "tran_m" else 1e-4)}
+    if bad:
+        raise RuntimeError("bench.py: the timed call's outputs differ from the oracle beyond 1e-4 / 1 mm: %s" % bad)
+    return {"rows": int(n), "of": int(B), "against": "oracle/mp_oracle.py (numpy fp32), last timed step, headline mode",
+            "bounds": {"outputs_and_angles": 1e-4, "tran_m": 1e-3}, "max_err": {k: float("%.3e" % v) for k, v in err.items()}}
+
+
 def bench_stream(args, net, dev, dist, rank, world):
     """BASELINE configs[4]: S concurrent streams per GPU, one new 60-d frame per stream per tick; every tick runs
     the reference's forward_online semantics (45-frame window re-evaluated, net.py:173-219).  Timed twice in the same
@@ -361,12 +396,15 @@ def main():
         local_rank = 0
     dev = torch.device("cuda", local_rank)
 
+    # the library must be the build of the sources beside it (mp_build_id = their md5): every rank asks, rank 0 rebuilds a
+    # missing / stale one first (the build takes a file lock and re-checks under it, so a rank that gets there at the same
+    # time waits and finds the fresh file), and the binding refuses a library whose id is not the sources' md5
     import __graft_entry__
-    if not os.path.exists(__graft_entry__.LIB):
-        if rank == 0:
-            __graft_entry__.build()
-        if dist is not None:
-            dist.barrier()
+    if rank == 0:
+        __graft_entry__.compile_library()
+    if dist is not None:
+        host_barrier(dist)
+    __graft_entry__.compile_library()          # (no-op when fresh)
 
     from mobileposer_amd import synthetic
     from mobileposer_amd.dist import broadcast_model, gather_counts, shard_range
@@ -432,11 +470,16 @@ def main():
     other = "x3" if args.lstm_mode == "fp32" else "fp32"
     elapsed, elapsed_local = timed(args.lstm_mode, args.steps)          # the headline measurement: exactly K steps
     outs_head = [t.clone() for t in (joints, vel, contact, tran, pose)]
+    fk_head = [rglob.clone(), jglob.clone()]
     import hashlib
     sha = hashlib.sha1()
-    for t in outs_head + [rglob, jglob]:                 # every output of the headline mode's last step, bit for bit
+    for t in outs_head + fk_head:                        # every output of the headline mode's last step, bit for bit
         sha.update(t.cpu().numpy().tobytes())
     output_sha1 = sha.hexdigest()
+    # ---- un-timed: what was just timed is what the oracle computes (16 sampled sequences of the last step, all 7 outputs) ----
+    verified = verify_rows(dict(zip(("joints", "vel", "contact", "tran", "pose", "rglob", "jglob"), outs_head + fk_head)),
+                           imu, B, T, rows=16, seed=11 + rank) if rank == 0 else None
+    del fk_head
     other_steps = max(20, args.steps // 4)
     elapsed_other, _ = timed(other, other_steps)
     mode_dev = max(float((a - b).abs().max()) for a, b in zip(outs_head, (joints, vel, contact, tran, pose)))
@@ -446,8 +489,13 @@ def main():
     if err.value:
         raise RuntimeError("persistent-kernel wait timed out during the timed region (code %d)" % err.value)
     per_rank = None
+    info = net.device_info()
+    rank_info = [dict(info, rank=rank, local_rank=local_rank)]
     if dist is not None:
         per_rank = gather_counts(B * T * args.steps, elapsed_local, dev)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rank_info[0], group=HOST_GROUP)
+        rank_info = gathered
     seen = ranks_seen(dist, dev)
 
     # ---- BASELINE configs[3] beside the headline (weak-scaling runs only): GLOBAL batch 1024 split over the ranks ----
@@ -549,11 +597,11 @@ def main():
     # (2*FETCH_SIZE + WRITE_SIZE)*1024, corrected as MI355X_MICROARCH.md prescribes.  A PMC pass cannot run inside this timed
     # process, so the figure is quoted from the committed profile -- and ONLY while the library that just ran is the binary
     # that was profiled (the summary records its md5): a changed kernel must not inherit a stale counter.  null otherwise.
-    traffic, traffic_src = None, "no PMC summary of this library (profiles/r04_pmc_summary.json absent, or profiled from other sources / another binary)"
+    traffic, traffic_src = None, "no PMC summary of this library (profiles/r05_pmc_summary.json absent, or profiled from other sources / another binary)"
     import hashlib
     lib_md5 = hashlib.md5(open(__graft_entry__.LIB, "rb").read()).hexdigest()
     src_md5 = __graft_entry__.source_md5()       # (a rebuild of the same sources gives the same device code, another .so md5)
-    for prof in ("r04_pmc_summary.json",):
+    for prof in ("r05_pmc_summary.json", "r04_pmc_summary.json"):
         try:
             summ = json.load(open(os.path.join(REPO, "profiles", prof)))
             if summ.get("lib_md5") != lib_md5 and summ.get("src_md5") != src_md5:
@@ -595,6 +643,8 @@ def main():
                                 "blob in HBM)" if dist is not None else "single process, no process group"),
                    "device_index": local_rank, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")},
         "output_sha1": output_sha1,
+        "verified": verified,
+        "build_id": info["build_id"],
         "modes": {
             args.lstm_mode: {"value": round(value, 1), "ms_per_step": round(1e3 * elapsed / args.steps, 4), "headline": True},
             other: {"value": round(value_other, 1), "ms_per_step": round(1e3 * elapsed_other / other_steps, 4),
@@ -602,8 +652,12 @@ def main():
             "max_abs_output_difference_between_modes": mode_dev,
             "note": "fp32 (library default) = exact v_mfma_f32_16x16x4_f32 operands; x3 (opt-in, mp_set_lstm_mode(h, 3)) = each "
                     "fp32 product as hi*hi+hi*lo+lo*hi of fp16 halves (24-bit operands, weights pre-scaled by 16) on "
-                    "v_mfma_f32_16x16x32_f16 with fp32 accumulate and fp32 state; both pass the same parity tests at 1e-4 / 1 mm on "
-                    "init-scale and trained-regime weights (profiles/r04_accuracy.json)"},
+                    "v_mfma_f32_16x16x32_f16 with fp32 accumulate and fp32 state.  Both run the same parity tests: 1e-4 / 1 mm against the "
+                    "goldens and the oracle on init-scale weights; on the trained-regime net at 256 x 125, where fp32 "
+                    "implementations differ from each other by more than 1e-4, a mode is held to a multiple of the fp32 oracle's own "
+                    "distance from float64 (fp32: 2 x, x3: 5 x).  x3 is NOT bit-compatible with fp32: a 300-shape fuzz on "
+                    "trained-regime weights found outputs of the two modes up to 1.5e-3 apart (profiles/r04_validation5.txt); it is "
+                    "opt-in and carries no credit here"},
         "end_to_end": {"tflops": round(value * FLOP_PER_FRAME / 1e12, 3),      # algorithmic fp32 FLOPs of the 4 modules
                        "frac_of_fp32_mfma_peak": round(value / world * FLOP_PER_FRAME / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                        "hbm_gbps_compulsory": round(value / world * BYTES_PER_FRAME / 1e9, 2)},
@@ -617,7 +671,12 @@ def main():
     if strong is not None:
         out["configs3_strong"] = strong
     if per_rank is not None:
-        out["per_rank"] = [{"rank": r, "frames": int(v[0]), "seconds": round(float(v[1]), 6)} for r, v in enumerate(per_rank)]
+        out["per_rank"] = [dict({"rank": r, "frames": int(v[0]), "seconds": round(float(v[1]), 6)},
+                                **{k: rank_info[r][k] for k in ("device", "local_rank", "n_cu", "xcd_round_robin", "build_id")})
+                           for r, v in enumerate(per_rank)]
+    else:
+        out["per_rank"] = [dict({"rank": 0, "frames": B * T * args.steps, "seconds": round(elapsed_local, 6)},
+                                **{k: rank_info[0][k] for k in ("device", "local_rank", "n_cu", "xcd_round_robin", "build_id")})]
     if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed on rank 0 of the single-GPU run only
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))

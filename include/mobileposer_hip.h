@@ -59,6 +59,13 @@ enum { MP_MOD_JOINTS = 0, MP_MOD_POSE = 1, MP_MOD_FOOT_CONTACT = 2, MP_MOD_VELOC
  * Replaces: the `.pth` state_dict written by combine_weights.py:53-56. */
 size_t mp_weight_count(void);
 
+/* Build id of this binary: the md5 over the sources it was compiled from (mobileposer_amd/csrc/*.hip, *.h and include/*.h in
+ * name order -- mobileposer_amd/_lib.py source_md5()), baked in at compile time (-DMP_SRC_MD5).  The Python binding, bench.py
+ * and the tests compare it with the md5 of the sources beside them and rebuild (or refuse) on a mismatch, so a stale library
+ * can be neither timed nor tested silently.  "unknown" for a build outside of __graft_entry__.build().
+ * Replaces: nothing in the reference (pure Python: source and executable are the same file). */
+const char* mp_build_id(void);
+
 /* i-th manifest entry (0 <= i < 72): key name, number of dims (1|2), shape, offset in the blob.
  * Replaces: MobilePoserNet.state_dict() key/shape enumeration (utils/model_utils.py:11). */
 int mp_manifest_entry(int i, char* name, size_t name_cap, int* ndim, int64_t shape[2], size_t* offset);
@@ -83,6 +90,12 @@ int mp_create_body(mp_handle** out, int device, const int32_t parent[24], const 
 
 void mp_destroy(mp_handle* h);
 const char* mp_last_error(const mp_handle* h);   /* h may be NULL: error of a failed mp_create */
+
+/* What the handle found on its device at creation: the device index it is bound to, the number of compute units, and
+ * whether the probe saw workgroups dealt round robin over 8 XCDs (the side-by-side schedules' placement tables rest on it;
+ * speed only).  Any pointer may be NULL.  bench.py logs it per rank.  Replaces: nothing in the reference (`device` global,
+ * config.py:9). */
+int mp_device_info(const mp_handle* h, int* device, int* n_cu, int* xcd_round_robin);
 
 /* Read constants back: floor_y (models/net.py:49), feet_pos[2*3] (models/net.py:48). */
 int mp_get_constants(const mp_handle* h, float* floor_y, float feet_pos[6]);
@@ -111,9 +124,14 @@ int mp_forward_offline(mp_handle* h, const float* imu_dev, const int32_t* length
  * semantics) -> Linear.  x_dev [B,T,n_in] -> y_dev [B,T,n_out].
  * state_in_dev / state_out_dev: optional (h then c, each [layers*dirs, B, H] contiguous, nn.LSTM
  * order l0, l0_reverse, l1, l1_reverse) -- the `h` argument / third return value of rnn.py:20,33.
- * Any state is accepted, as by nn.LSTM; an initial h with |h| >= 2 or NaN -- nothing an LSTM produces -- is outside what the
- * fused layer kernels exchange between workgroups (device code 2000000): with recovery on (the default) the call is run by the
- * per-step kernels and returns the exact result, with recovery off it reports MP_ERR_DEVICE like a starved call. */
+ * Any state is accepted, as by nn.LSTM.  A finite initial |h| >= 2 (or inf) -- nothing an LSTM produces -- is outside what the
+ * fused layer kernels exchange between workgroups (device code 2000000, a STATE code: the handle's placement tables stay on):
+ * with recovery on (the default) the call is run by the per-step kernels and returns the exact result, with recovery off it
+ * reports MP_ERR_DEVICE like a starved call.  A NaN initial h -- what the reference's velocity.rnn_state holds for good after
+ * one NaN sample (velocity.py:45-48) -- is no error and costs nothing (round 5): that cell is NaN for the whole call, so every
+ * output of its sequence is (as in the reference); only the RETURNED state differs from nn.LSTM's when a row of the initial h
+ * is NaN in some units and finite in others: nn.LSTM returns NaN for the whole row, this library for those units (every
+ * output of that sequence is NaN either way, and stays so in later calls). */
 int mp_rnn_forward(mp_handle* h, int module, const float* x_dev, const int32_t* lengths_host,
                    int B, int T, float* y_dev, const float* state_in_dev, float* state_out_dev,
                    void* stream);
@@ -235,9 +253,11 @@ int mp_timing_enable(mp_handle* h, int on);
 int mp_timing_read(mp_handle* h, int cls, int* launches, float* ms, double* gflop);
 /* 0 (default): eager launches on the library's three streams; 1 (env MP_GRAPH=1): capture every (entry point, shape,
  * buffer set) once into a hipGraph and replay it; 2: the same as a SINGLE-BRANCH graph (every launch captured on one
- * stream, no parallel branches -- nothing for the graph executor's stream assignment to get wrong).  Opt-in because the multi-branch graph executor of the HIP runtime
- * in this image can crash in hipGraphLaunch depending on the hardware-queue placement of the streams a process has
- * created (profiles/r02_hipgraph_segv.md; GPU_MAX_HW_QUEUES=8 avoids it); outputs are bitwise identical either way. */
+ * stream, no parallel branches -- nothing for the graph executor's stream assignment to get wrong).  The multi-branch
+ * graph executor of the HIP runtime in this image can crash in hipGraphLaunch depending on the hardware-queue placement of
+ * the streams a process has created (profiles/r02_hipgraph_segv.md; GPU_MAX_HW_QUEUES=8 avoids it), so since round 5 a
+ * request for mode 1 gives mode 2 unless the environment says MP_GRAPH_MULTIBRANCH=1 (mode 2 is bitwise equal and as
+ * fast: 2.786 vs 2.782 ms per 512-stream tick); outputs are bitwise identical in all three modes. */
 int mp_set_graph_mode(mp_handle* h, int on);
 /* LSTM implementation of the H = 256 layers (the H = 64 foot-contact block always uses the fp32 kernels):
  *   1 (default; env MP_LSTM_MODE=fp32): fused persistent layer kernels, one launch per layer, exact-fp32 MFMA operands
@@ -248,7 +268,10 @@ int mp_set_graph_mode(mp_handle* h, int on);
  *       split as 16 w so that their low half stays a normal fp16 number): measured on init-scale AND on trained-regime weights
  *       (saturated gates, recurrent gain > 1) the outputs are as close to float64 as mode 1's and PyTorch's CPU path's are
  *       (profiles/r04_accuracy.json; 1.8-3.3 x the fp32 oracle's own noise at the worst element of a 256 x 125 batch, mode 1:
- *       0.9-1.5 x).  Not bit-identical to mode 1; operands above 65504 (weights: 4094) in magnitude turn into inf / NaN.
+ *       0.9-1.5 x).  NOT bit-compatible with mode 1: a 300-shape fuzz on trained-regime weights found outputs of the two modes
+ *       up to 1.5e-3 apart (profiles/r04_validation5.txt) although each is within the tests' bounds of the oracle at the tested
+ *       sizes; operands above 65504 (weights: 4094) in magnitude turn into inf / NaN.  Narrower than the reference's
+ *       arithmetic: never the credited configuration.
  *       (Rounds 1-3 used bf16 halves -- 17 bits: fine on init-scale weights, 2e-3 .. 2e-2 off on trained-regime ones.)
  *   2: mode 1 plus the unidirectional velocity block as ONE two-layer wavefront launch;
  *   0 (env MP_LSTM_MODE=step): input-projection GEMM + one launch per time step. */

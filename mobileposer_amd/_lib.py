@@ -7,7 +7,36 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MP_LIB_PATH") or os.path.join(_HERE, "libmobileposer_hip.so")   # override: kernel-variant A/B runs
+_DEFAULT_LIB = os.path.join(_HERE, "libmobileposer_hip.so")
+LIB_PATH = os.environ.get("MP_LIB_PATH") or _DEFAULT_LIB   # override: kernel-variant A/B runs (no build-id check then)
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+
+def source_md5():
+    """md5 over the sources the library is built from (csrc/*.hip, csrc/*.h, include/*.h, in name order).  The device code is a
+    function of these; the build bakes the value into the binary (mp_build_id) and load() compares."""
+    import glob
+    import hashlib
+    m = hashlib.md5()
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) +
+                    glob.glob(os.path.join(INCLUDE, "*.h"))):
+        m.update(os.path.basename(f).encode())
+        m.update(open(f, "rb").read())
+    return m.hexdigest()
+
+
+def file_build_id(path=None):
+    """The build id baked into a library FILE (without loading it): the text behind the MP_BUILD_ID= marker, or None."""
+    try:
+        blob = open(path or LIB_PATH, "rb").read()
+    except OSError:
+        return None
+    i = blob.find(b"MP_BUILD_ID=")
+    if i < 0:
+        return None
+    j = blob.find(b"\0", i)
+    return blob[i + 12:j].decode(errors="replace")
 
 MP_OK = 0
 MP_ERR_INVALID, MP_ERR_HIP, MP_ERR_STATE_SHAPE, MP_ERR_NO_STREAMS, MP_ERR_LENGTHS, MP_ERR_DEVICE = -1, -2, -3, -4, -5, -6
@@ -21,6 +50,7 @@ _ip = C.POINTER(C.c_int32)
 # include/mobileposer_hip_internal.h (mp_set_transport, mp_debug_*)
 SIGNATURES = {
     "mp_weight_count": (_sz, []),
+    "mp_build_id": (C.c_char_p, []),
     "mp_manifest_entry": (_i, [_i, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_i64), C.POINTER(_sz)]),
     "mp_create": (_i, [C.POINTER(_vp), _i, _fp, _sz, _ip, _fp]),
     "mp_create_from_device": (_i, [C.POINTER(_vp), _i, _vp, _sz, _ip, _fp]),
@@ -28,6 +58,7 @@ SIGNATURES = {
     "mp_destroy": (None, [_vp]),
     "mp_last_error": (C.c_char_p, [_vp]),
     "mp_get_constants": (_i, [_vp, _fp, _fp]),
+    "mp_device_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "mp_forward": (_i, [_vp, _vp, _ip, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_forward_offline": (_i, [_vp, _vp, _ip, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_rnn_forward": (_i, [_vp, _i, _vp, _ip, _i, _i, _vp, _vp, _vp, _vp]),
@@ -73,6 +104,20 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if LIB_PATH == _DEFAULT_LIB and file_build_id() != source_md5():
+        # missing, or built from other sources than the ones beside it: a stale library must be neither timed nor tested.
+        # Rebuild in place (hipcc is part of the image, here and on the GPU box; the build takes a file lock, so ranks that
+        # start together build once) -- before the library is mapped into this process.
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("__graft_entry__", os.path.join(os.path.dirname(_HERE), "__graft_entry__.py"))
+            ge = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(ge)
+            ge.compile_library()
+        except Exception as e:                                        # noqa: BLE001
+            raise RuntimeError(
+                "mobileposer_amd: %s is missing or stale (build id %r, sources %s) and rebuilding it failed: %s -- build it with "
+                "`python __graft_entry__.py` (hipcc, gfx950).  There is no CPU fallback." % (LIB_PATH, file_build_id(), source_md5(), e))
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "mobileposer_amd: %s not found -- build it with `python __graft_entry__.py` (hipcc, gfx950). "
@@ -89,8 +134,17 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if LIB_PATH == _DEFAULT_LIB:
+        got = lib.mp_build_id().decode()
+        if got != source_md5():
+            raise RuntimeError("mobileposer_amd: %s was built from other sources (build id %s, sources %s)" % (LIB_PATH, got, source_md5()))
     _lib = lib
     return lib
+
+
+def build_id():
+    """mp_build_id() of the loaded library."""
+    return load().mp_build_id().decode()
 
 
 def last_error(handle=None):

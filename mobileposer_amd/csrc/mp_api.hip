@@ -197,6 +197,7 @@ struct mp_handle {
     int excl_lds = 0;                // forward_body -> rnn_rec: LstmPersistArgs::min_lds of the launches being issued
     bool pose_slices8 = false;       // forward_body -> fp32_slices: this call runs the pose layers on 8 slices per slab (below)
     bool xcd_rr = false;             // probed at create: workgroups are dealt round robin over 8 XCDs
+    bool xcd_probe = false;          // ... what the probe said (xcd_rr is switched off after a starvation error; this is not)
     bool xcd_plan_on[4] = {false, false, false, false};   // forward_body -> rnn_rec: clusters per XCD of module id's layer launches
     unsigned char xcd_plan[4][8] = {};
     bool half_ok = true;             // MP_VARIANT half=0: no pose-on-half-the-chip schedule for 64 < B <= 128
@@ -445,19 +446,35 @@ struct DeviceScope {
 #define ON_DEVICE(h) DeviceScope dev_scope_((h)->device); \
     if (!dev_scope_.ok) return fail((h), MP_ERR_HIP, "hipSetDevice(%d) failed", (h)->device)
 
+// Multi-branch graphs (graph mode 1) can SIGSEGV inside hipGraphLaunch of this ROCm, depending on the process's stream history
+// (profiles/r02_hipgraph_segv.md): an option that can crash the host process is not one `int` away -- mode 1 means mode 2
+// (single-branch: bitwise-equal results, same speed) unless the environment asks for the real thing.
+bool multibranch_graphs_allowed() {
+    const char* e = getenv("MP_GRAPH_MULTIBRANCH");
+    return e && e[0] == '1';
+}
+
 int create_common(mp_handle** out, int device, const float* blob, bool blob_on_device, size_t n_floats,
                   const int32_t parent[24], const float J[72]) {
     if (!out || !parent || !J) return fail(nullptr, MP_ERR_INVALID, "mp_create: NULL argument");
     const bool body_only = blob == nullptr && n_floats == 0;
     if (!body_only && (!blob || n_floats != manifest_floats()))
         return fail(nullptr, MP_ERR_INVALID, "mp_create: weight blob has %zu floats, expected %zu", n_floats, manifest_floats());
+    {   // a device index this process cannot see is the caller's mistake, not a runtime failure (round 5: a clear MP_ERR_INVALID
+        // instead of whatever hipSetDevice says)
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) != hipSuccess) { (void)hipGetLastError(); n_dev = 0; }
+        if (device < 0 || device >= n_dev)
+            return fail(nullptr, MP_ERR_INVALID, "mp_create: device index %d, but this process sees %d device(s) "
+                        "(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES renumber them from 0)", device, n_dev);
+    }
     mp_handle* h = new mp_handle();
     h->device = device;
     h->has_weights = !body_only;
     auto bail = [&](int rc) { g_create_error = h->err; mp_destroy(h); return rc; };
     DeviceScope on_device(device);                      // (the caller's current device is restored on every return path)
     if (!on_device.ok) { h->err = "hipSetDevice failed"; return bail(MP_ERR_HIP); }
-    if (const char* e = getenv("MP_GRAPH")) { h->use_graph = e[0] && e[0] != '0'; h->graph_serial = e[0] == '2'; }
+    if (const char* e = getenv("MP_GRAPH")) { h->use_graph = e[0] && e[0] != '0'; h->graph_serial = e[0] == '2' || !multibranch_graphs_allowed(); }
     {   // dynamic-LDS limits of the persistent kernels are per-device attributes (and must not be set under capture)
         hipError_t ea = mp_lstm_persist_device_attrs();
         if (ea == hipSuccess) ea = mp_lstm_u8_device_attrs();
@@ -484,7 +501,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
                 bool ok = true;
                 for (int b = 0; b < 64; ++b) ok = ok && probe[b] >= 0 && probe[b] < 8 && probe[b] == probe[b & 7];
                 for (int b = 0; b < 8 && ok; ++b) seen |= 1u << probe[b];
-                h->xcd_rr = ok && seen == 0xffu;
+                h->xcd_rr = h->xcd_probe = ok && seen == 0xffu;
             }
             (void)hipHostFree(probe);
         }
@@ -558,7 +575,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     h->s_gp = h->s_vel;
     for (hipEvent_t& ev : h->ev_x) e = e ? e : hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (!e) e = hipHostMalloc((void**)&h->err_host, 64, hipHostMallocMapped | hipHostMallocCoherent);
-    if (!e) { *h->err_host = 0; e = hipHostGetDevicePointer((void**)&h->err_dev, h->err_host, 0); }
+    if (!e) { memset(h->err_host, 0, 64); e = hipHostGetDevicePointer((void**)&h->err_dev, h->err_host, 0); }
     hipEvent_t* evs[5] = {&h->ev_in, &h->ev_out, &h->ev_j, &h->ev_v, &h->ev_f};
     for (hipEvent_t* ev : evs) e = e ? e : hipEventCreateWithFlags(ev, hipEventDisableTiming);
     if (e != hipSuccess) { h->err = std::string("stream/event creation failed: ") + hipGetErrorString(e); return bail(MP_ERR_HIP); }
@@ -951,6 +968,9 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         //  32-bit epochs -- wrote to it last; the tags a launch starts with follow from what the previous one left: hx_flip)
         const bool tagged = !use_x3(h, m) && mp_persist_tagged(H, nsl, wreg || nsl == 16);
         unsigned epoch_base = 0;
+        // (recovery off: calls are enqueued without a sync, so a launch that lost a workgroup may already have reported it while
+        //  this one is being issued -- the words it left behind are not what hx_flip describes: start from a zeroed area.  ADVICE r4)
+        if (h->err_host && *(volatile int*)h->err_host) w.hx_epoch = 0;
         if (!use_x3(h, m)) {
             if (!epoch_ok || w.hx_epoch == 0 || w.hx_epoch > 0xf0000000u || w.hx_tagged != tagged) {
                 HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
@@ -1480,20 +1500,45 @@ void invalidate_carried_state(mp_handle* h) {
     h->vstate.B = 0;
     StreamCtx& c = h->sc;
     if (!c.S) return;
+    // (on s_main, which is a non-blocking stream: null-stream memsets are not ordered against its later work -- ADVICE r4 --
+    //  and the host buffer must outlive the asynchronous copy: wait for it)
     (void)hipStreamSynchronize(h->s_main);
     std::vector<float> lf((size_t)c.S * 6);
     for (int s = 0; s < c.S; ++s) memcpy(&lf[(size_t)s * 6], h->feet_pos, sizeof(h->feet_pos));
-    (void)hipMemcpy(c.st.last_foot, lf.data(), lf.size() * sizeof(float), hipMemcpyHostToDevice);
-    (void)hipMemset(c.fresh, 1, c.S);
-    (void)hipMemset(c.st.root_y, 0, (size_t)c.S * sizeof(double));
-    (void)hipMemset(c.st.root_pos, 0, (size_t)c.S * 3 * sizeof(float));
+    (void)hipMemcpyAsync(c.st.last_foot, lf.data(), lf.size() * sizeof(float), hipMemcpyHostToDevice, h->s_main);
+    (void)hipMemsetAsync(c.fresh, 1, c.S, h->s_main);
+    (void)hipMemsetAsync(c.st.root_y, 0, (size_t)c.S * sizeof(double), h->s_main);
+    (void)hipMemsetAsync(c.st.root_pos, 0, (size_t)c.S * 3 * sizeof(float), h->s_main);
+    (void)hipStreamSynchronize(h->s_main);
+}
+
+// The handle's error words (pinned host memory the kernels store to): [0] = a bounded wait gave up (1 + step, or 1000000 =
+// the start-up handshake) -- STARVATION: a workgroup may be missing, the exchange areas are in an unknown state and the
+// physical-XCD placement is no longer trusted; [1] = 2000000, an initial hidden state the tagged words cannot carry -- a
+// property of the caller's STATE: every workgroup ran, nothing about placement or the exchange areas is wrong (round 5: the
+// two used to share one word, and a state code paid the starvation remedy -- tables off for the handle's lifetime).
+// Returns the code (starvation first) and clears both words; *starved = whether word [0] was set.
+int take_device_error(mp_handle* h, bool* starved) {
+    if (starved) *starved = false;
+    if (!h->err_host) return 0;
+    volatile int* e = (volatile int*)h->err_host;
+    const int c0 = e[0], c1 = e[1];
+    if (!c0 && !c1) return 0;
+    e[0] = 0; e[1] = 0;
+    if (starved) *starved = c0 != 0;
+    return c0 ? c0 : c1;
+}
+bool device_error_pending(const mp_handle* h) {
+    if (!h->err_host) return false;
+    const volatile int* e = (const volatile int*)h->err_host;
+    return e[0] != 0 || e[1] != 0;
 }
 
 int pending_device_error(mp_handle* h, const char* where) {
-    const int code = h->err_host ? *(volatile int*)h->err_host : 0;
+    bool starved = false;
+    const int code = take_device_error(h, &starved);
     if (!code) return MP_OK;
-    *(volatile int*)h->err_host = 0;
-    disable_xcd_tables(h);
+    if (starved) disable_xcd_tables(h);
     invalidate_carried_state(h);
     return fail(h, MP_ERR_DEVICE, "%s: a previous call's persistent LSTM kernel gave up a wait for another workgroup's "
                 "hidden state (code %d: 1+step, or 1000000 = start-up handshake; the GPU was shared?  2000000 = an initial hidden state "
@@ -1544,10 +1589,10 @@ template <class Restore, class Again>
 int finish_or_recover(mp_handle* h, Plan* p, const char* what, Restore restore, Again again) {
     if (!h->recovery || h->capturing) return MP_OK;
     HIPCHK(h, hipStreamSynchronize(h->s_main));
-    const int code = h->err_host ? *(volatile int*)h->err_host : 0;
+    bool starved = false;
+    const int code = take_device_error(h, &starved);
     if (!code) return MP_OK;
-    *(volatile int*)h->err_host = 0;
-    disable_xcd_tables(h);
+    if (starved) disable_xcd_tables(h);
     const bool persist = h->persist, uni2 = h->uni2, x3 = h->x3, graph = h->use_graph;
     h->persist = false; h->uni2 = false; h->x3 = false; h->use_graph = false;
     int rc = p ? ensure_step_ws(h, p) : MP_OK;
@@ -1570,6 +1615,12 @@ int finish_or_recover(mp_handle* h, Plan* p, const char* what, Restore restore, 
 extern "C" {
 
 size_t mp_weight_count(void) { return manifest_floats(); }
+
+#ifndef MP_SRC_MD5
+#define MP_SRC_MD5 "unknown"
+#endif
+// (the marker in front lets __graft_entry__._needs_build find the id in the file without loading it)
+const char* mp_build_id(void) { static const char id[] = "MP_BUILD_ID=" MP_SRC_MD5; return id + 12; }
 
 int mp_manifest_entry(int i, char* name, size_t name_cap, int* ndim, int64_t shape[2], size_t* offset) {
     const std::vector<Entry>& m = manifest();
@@ -1600,9 +1651,9 @@ void mp_destroy(mp_handle* h) {
     if (!h) return;
     DeviceScope on_device(h->device);
     (void)hipDeviceSynchronize();
-    if (h->err_host && *(volatile int*)h->err_host)     // nobody asked (mp_finish / mp_device_error / a later call): say it
+    if (device_error_pending(h))                        // nobody asked (mp_finish / mp_device_error / a later call): say it
         fprintf(stderr, "libmobileposer_hip: mp_destroy: an unreported device error was pending (code %d): a persistent LSTM "
-                        "kernel gave up a wait; the affected outputs of that call were NaN\n", *(volatile int*)h->err_host);
+                        "kernel gave up a wait; the affected outputs of that call were NaN\n", take_device_error(h, nullptr));
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second.exec);
     for (auto& kv : h->plans) {
         for (void* p : kv.second->allocs) (void)hipFree(p);
@@ -1646,6 +1697,14 @@ void mp_destroy(mp_handle* h) {
 }
 
 const char* mp_last_error(const mp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mp_device_info(const mp_handle* h, int* device, int* n_cu, int* xcd_round_robin) {
+    if (!h) return MP_ERR_INVALID;
+    if (device) *device = h->device;
+    if (n_cu) *n_cu = h->n_cu;
+    if (xcd_round_robin) *xcd_round_robin = h->xcd_probe ? 1 : 0;
+    return MP_OK;
+}
 
 int mp_get_constants(const mp_handle* h, float* floor_y, float feet_pos[6]) {
     if (!h) return MP_ERR_INVALID;
@@ -2228,9 +2287,10 @@ int mp_device_error(mp_handle* h, int* code) {
     if (!h || !code) return MP_ERR_INVALID;
     ON_DEVICE(h);
     HIPCHK(h, hipStreamSynchronize(h->s_main));
-    *code = *(volatile int*)h->err_host;
-    *(volatile int*)h->err_host = 0;
-    if (*code) { disable_xcd_tables(h); invalidate_carried_state(h); }
+    bool starved = false;
+    *code = take_device_error(h, &starved);
+    if (starved) disable_xcd_tables(h);
+    if (*code) invalidate_carried_state(h);
     return MP_OK;
 }
 
@@ -2250,7 +2310,7 @@ int mp_set_recovery(mp_handle* h, int on) {
 int mp_recovery_count(const mp_handle* h) { return h ? h->recoveries : 0; }
 
 namespace {
-MP_KERNEL void mp_poke_error(int* err, int code) { mp_set_error(err, code); }
+MP_KERNEL void mp_poke_error(int* err, int code) { mp_set_error(code == 2000000 ? err + 1 : err, code); }
 }
 
 int mp_debug_poke_error(mp_handle* h, int code) {
@@ -2302,7 +2362,7 @@ int mp_set_graph_mode(mp_handle* h, int on) {
     if (!h || on < 0 || on > 2) return MP_ERR_INVALID;
     ON_DEVICE(h);
     h->use_graph = on != 0;
-    h->graph_serial = on == 2;
+    h->graph_serial = on == 2 || (on == 1 && !multibranch_graphs_allowed());
     return MP_OK;
 }
 

@@ -11,9 +11,22 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 static __device__ __forceinline__ float sigmoidf_(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
+// tanh = 1 - 2 / (exp(2x) + 1) cancels for small |x|: its ABSOLUTE error stays ~1e-7 where libm's is relative (1e-10 at
+// |x| = 1e-3).  MP_TANH_POLY (round-5 experiment, verdict r4 item 4; tools/accuracy.py): the odd Taylor polynomial below
+// |x| = 0.125 (next term 62/2835 x^9: 1.3e-9 relative there), selected branch-free.
+#ifndef MP_TANH_POLY
+#define MP_TANH_POLY 0
+#endif
 static __device__ __forceinline__ float tanhf_(float x) {
     const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * x);
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+#if MP_TANH_POLY
+    const float x2 = x * x;
+    const float p = x + x * x2 * (-0.33333333333f + x2 * (0.13333333333f + x2 * -0.05396825397f));
+    return __builtin_fabsf(x) < 0.125f ? p : big;
+#else
+    return big;
+#endif
 }
 
 // A bounded wait gave up: leave a code in the handle's error word.  The word lives in pinned, coherent HOST memory (every

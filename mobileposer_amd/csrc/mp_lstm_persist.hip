@@ -403,9 +403,18 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
         unsigned* hw = hdL + (size_t)16 * H;
 #pragma unroll
         for (int o = 0; o < NOWN; ++o) {
-            // (an initial h with bit 30 set -- |h| >= 2, which no LSTM produces, or a NaN -- cannot travel as a tagged word: say so
-            //  and poison the cell; with recovery on the call is run again by the per-step kernels, which take any state)
-            if (blen[o] > 0 && (__float_as_uint(hst[o]) & kHTagBit)) { mp_set_error(a.err, 2000000); cst[o] = __builtin_nanf(""); }
+            // (an initial h with bit 30 set cannot travel as a tagged word.  Finite |h| >= 2 / inf -- which no LSTM produces: say so
+            //  (state code 2000000, error word [1]) and poison the cell; with recovery on the call is run again by the per-step
+            //  kernels, which take any state.  NaN -- what the reference carries forward in velocity.rnn_state after ONE NaN sample
+            //  (velocity.py:45-48 keeps the state, golden G16) -- is no error: it is treated like a NaN that turns up in the middle
+            //  of a sequence: the cell is poisoned (its h, and with it its column of the layer output, is NaN for every step, so
+            //  every output of that sequence is) and peers get a finite word with a clean tag that only reaches that sequence's
+            //  own gates.  Round 4 raised the code for NaN too, which put every later call of a handle with one glitched stream
+            //  on the fail-then-recover path, per-step kernels and a warning per call.)
+            if (blen[o] > 0 && (__float_as_uint(hst[o]) & kHTagBit)) {
+                if (hst[o] == hst[o]) mp_set_error(a.err + 1, 2000000);
+                cst[o] = __builtin_nanf("");
+            }
             const unsigned w0 = hword_of(hst[o], -1);
             __hip_atomic_store(hw + hslot[o], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (!all_local) __hip_atomic_store(hw + HD_R / 4 + hslot[o], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

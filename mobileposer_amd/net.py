@@ -67,22 +67,22 @@ class _VelocityView:
     def rnn_state(self):
         net = self._net
         b = C.c_int(0)
-        _lib.check(net._lib.mp_get_velocity_state(net._h, None, C.byref(b)), net._h)
+        net._check(net._lib.mp_get_velocity_state(net._h, None, C.byref(b)))
         if b.value == 0:
             return None
         buf = torch.empty(2, 2, b.value, 256, device=net.device, dtype=torch.float32)
-        _lib.check(net._lib.mp_get_velocity_state(net._h, _ptr(buf), C.byref(b)), net._h)
+        net._check(net._lib.mp_get_velocity_state(net._h, _ptr(buf), C.byref(b)))
         return buf[0], buf[1]
 
     @rnn_state.setter
     def rnn_state(self, value):
         net = self._net
         if value is None:
-            _lib.check(net._lib.mp_reset_state(net._h, 1), net._h)
+            net._check(net._lib.mp_reset_state(net._h, 1))
             return
         h, c = value
         buf = torch.stack((h, c)).to(device=net.device, dtype=torch.float32).contiguous()
-        _lib.check(net._lib.mp_set_velocity_state(net._h, _ptr(buf), int(h.shape[1])), net._h)
+        net._check(net._lib.mp_set_velocity_state(net._h, _ptr(buf), int(h.shape[1])))
 
 
 class MobilePoserNet:
@@ -176,12 +176,12 @@ class MobilePoserNet:
         _LIVE.add(self)
         fy = C.c_float()
         fp = (C.c_float * 6)()
-        _lib.check(self._lib.mp_get_constants(self._h, C.byref(fy), fp), self._h)
+        self._check(self._lib.mp_get_constants(self._h, C.byref(fy), fp))
         assert abs(fy.value - self.floor_y) < 1e-6
         self._stream_S = 0
         # Python owns the graph mode: a fresh handle re-reads MP_GRAPH in C, which may differ from what set_graph_mode() last
         # chose -- and a library that captures while the facade hands it fresh tensors every call captures on every call
-        _lib.check(self._lib.mp_set_graph_mode(self._h, int(self._graph)), self._h)
+        self._check(self._lib.mp_set_graph_mode(self._h, int(self._graph)))
         self._graph_bufs = {}
         self._mesh_state = {}
         upload_mesh(self._lib, self._h, self.bodymodel, self._mesh_state)
@@ -198,6 +198,15 @@ class MobilePoserNet:
             if rc and not sys.is_finalizing():
                 raise RuntimeError("libmobileposer_hip: %s (status %d)" % (msg, rc))
 
+    def _check(self, rc):
+        """Raise on a failed library call.  A reported device error resets device-side state (mp_api.hip
+        invalidate_carried_state: streams reset, velocity state dropped), so the read-back cache of the state attributes
+        must not survive it."""
+        if rc != _lib.MP_OK:
+            self._tick += 1
+            self._state_cache = {}
+        _lib.check(rc, self._h)
+
     def _after_call(self):
         """A call that was repaired by the library's recovery path (include/mobileposer_hip.h, mp_set_recovery) is
         reported as a Python warning: its results are valid, but the GPU is evidently shared."""
@@ -209,15 +218,21 @@ class MobilePoserNet:
     def set_recovery(self, on):
         """True (default): every network call waits for itself and repairs a starved fused-LSTM launch by re-running with
         per-step kernels; False: asynchronous calls, errors surface at the next call / ``finish()`` / ``close()``."""
-        _lib.check(self._lib.mp_set_recovery(self._h, int(bool(on))), self._h)
+        self._check(self._lib.mp_set_recovery(self._h, int(bool(on))))
 
     def finish(self):
         """Wait for everything enqueued; raises if a persistent kernel gave up a wait (recovery off)."""
-        _lib.check(self._lib.mp_finish(self._h), self._h)
+        self._check(self._lib.mp_finish(self._h))
 
     @property
     def recovery_count(self):
         return int(self._lib.mp_recovery_count(self._h)) if self._h is not None else 0
+
+    def device_info(self):
+        """dict(device, n_cu, xcd_round_robin, build_id): what the handle found on its device (mp_device_info)."""
+        d, n, x = C.c_int(-1), C.c_int(0), C.c_int(0)
+        self._check(self._lib.mp_device_info(self._h, C.byref(d), C.byref(n), C.byref(x)))
+        return {"device": d.value, "n_cu": n.value, "xcd_round_robin": bool(x.value), "build_id": _lib.build_id()}
 
     def __enter__(self):
         return self
@@ -274,15 +289,15 @@ class MobilePoserNet:
         pass ``clear_velocity=True`` to ``reset_all`` or set ``model.velocity.rnn_state = None`` for that."""
         self.rnn_state = None
         if self._h is not None and self._stream_S:        # imu = None, current_root_y = 0, last_root_pos = 0
-            _lib.check(self._lib.mp_stream_reset(self._h, None, 0), self._h)
+            self._check(self._lib.mp_stream_reset(self._h, None, 0))
             self._tick += 1
 
     def reset_all(self, clear_velocity=True):
         self.reset()
         if self._h is not None and clear_velocity:
-            _lib.check(self._lib.mp_reset_state(self._h, 1), self._h)
+            self._check(self._lib.mp_reset_state(self._h, 1))
             if self._stream_S:
-                _lib.check(self._lib.mp_stream_reset(self._h, None, 1), self._h)
+                self._check(self._lib.mp_stream_reset(self._h, None, 1))
 
     def _prob_to_weight(self, p):
         lo, hi = self.prob_threshold
@@ -335,7 +350,7 @@ class MobilePoserNet:
         B, T = imu.shape[0], imu.shape[1]
         rc = self._lib.mp_forward(self._h, _ptr(imu), lengths_c, B, T, _ptr(pose), _ptr(joints), _ptr(vel),
                                   _ptr(contact), _ptr(r6d), self._stream())
-        _lib.check(rc, self._h)
+        self._check(rc)
         self._after_call()
 
     def forward(self, batch, input_lengths=None, return_r6d=False):
@@ -371,29 +386,39 @@ class MobilePoserNet:
         o = self._outputs(B, T, ("pose", "joints", "vel", "contact", "tran"))
         rc = self._lib.mp_forward_offline(self._h, _ptr(x), lens, B, T, _ptr(o["pose"]), _ptr(o["joints"]),
                                           _ptr(o["vel"]), _ptr(o["contact"]), _ptr(o["tran"]), None, None, self._stream())
-        _lib.check(rc, self._h)
+        self._check(rc)
         self._after_call()
         o = {k: self._result(v) for k, v in o.items()}
         if B == 1:
             return o["pose"], o["joints"], o["tran"][0], o["contact"][0]
         return o["pose"], o["joints"], o["tran"], o["contact"]
 
+    def forward_offline_into(self, imu, lengths_c, pose, joints, vel, contact, tran, rglobal=None, joint_global=None):
+        """mp_forward_offline on caller-owned contiguous fp32 cuda buffers: forward + translation solver and, when ``rglobal``
+        [B*T,24,3,3] / ``joint_global`` [B*T,24,3] are given, SMPL forward kinematics of the predicted pose in the same call
+        (articulate/model.py:208-232) -- the call bench.py times."""
+        B, T = imu.shape[0], imu.shape[1]
+        rc = self._lib.mp_forward_offline(self._h, _ptr(imu), lengths_c, B, T, _ptr(pose), _ptr(joints), _ptr(vel),
+                                          _ptr(contact), _ptr(tran), _ptr(rglobal), _ptr(joint_global), self._stream())
+        self._check(rc)
+        self._after_call()
+
     def translate_offline_into(self, joints, vel, contact, lengths_c, tran):
         B, T = joints.shape[0], joints.shape[1]
         rc = self._lib.mp_translate_offline(self._h, _ptr(joints), _ptr(vel), _ptr(contact), lengths_c, B, T,
                                             _ptr(tran), self._stream())
-        _lib.check(rc, self._h)
+        self._check(rc)
 
     # ---- streaming ---------------------------------------------------------------------------
     def stream_create(self, S):
         self._require_weights()
-        _lib.check(self._lib.mp_stream_create(self._h, int(S)), self._h)
+        self._check(self._lib.mp_stream_create(self._h, int(S)))
         self._stream_S = int(S)
 
     def stream_step_into(self, frames, pose, joints, root, contact):
         rc = self._lib.mp_stream_step(self._h, _ptr(frames), _ptr(pose), _ptr(joints), _ptr(root), _ptr(contact),
                                       self._stream())
-        _lib.check(rc, self._h)
+        self._check(rc)
         self._tick += 1
         self._after_call()
 
@@ -426,8 +451,8 @@ class MobilePoserNet:
         assert tuple(q.shape) == (S, 5, 4) and tuple(a.shape) == (S, 5, 3) and tuple(M.shape) == (S, 3, 3)
         assert tuple(D.shape) == (S, 5, 3, 3) and O.numel() == S * 15
         out = torch.empty(S, 60, device=self.device, dtype=torch.float32)
-        _lib.check(self._lib.mp_live_form_frames(self._h, _ptr(q), _ptr(a), _ptr(M), _ptr(D), _ptr(O), int(keep_mask), S,
-                                                 _ptr(out), self._stream()), self._h)
+        self._check(self._lib.mp_live_form_frames(self._h, _ptr(q), _ptr(a), _ptr(M), _ptr(D), _ptr(O), int(keep_mask), S,
+                                                 _ptr(out), self._stream()))
         return out
 
     def stream_reset(self, mask=None, clear_velocity=False):
@@ -435,7 +460,7 @@ class MobilePoserNet:
         m = None
         if mask is not None:
             m = (C.c_uint8 * self._stream_S)(*[1 if bool(v) else 0 for v in mask])
-        _lib.check(self._lib.mp_stream_reset(self._h, m, int(bool(clear_velocity))), self._h)
+        self._check(self._lib.mp_stream_reset(self._h, m, int(bool(clear_velocity))))
         self._tick += 1
 
     @torch.no_grad()
@@ -468,7 +493,7 @@ class MobilePoserNet:
         feet = (C.c_float * 6)()
         root = (C.c_float * 3)()
         y, fresh = C.c_double(0), C.c_int(0)
-        _lib.check(self._lib.mp_stream_get_state(self._h, int(s), _ptr(win), feet, C.byref(y), root, C.byref(fresh)), self._h)
+        self._check(self._lib.mp_stream_get_state(self._h, int(s), _ptr(win), feet, C.byref(y), root, C.byref(fresh)))
         t = lambda a: torch.tensor(list(a), device=self.device, dtype=torch.float32)
         st = {"imu": None if fresh.value else win, "current_root_y": y.value if not fresh.value else 0,
               "last_root_pos": t(root), "last_lfoot_pos": t(feet[0:3]), "last_rfoot_pos": t(feet[3:6])}
@@ -497,8 +522,8 @@ class MobilePoserNet:
             l = value if name == "last_lfoot_pos" else cur["last_lfoot_pos"]
             r = value if name == "last_rfoot_pos" else cur["last_rfoot_pos"]
             feet = (C.c_float * 6)(*(list(f3(l)) + list(f3(r))))
-        _lib.check(self._lib.mp_stream_set_state(self._h, int(s), _ptr(win), feet, C.byref(y) if y is not None else None,
-                                                 root, C.byref(fresh) if fresh is not None else None), self._h)
+        self._check(self._lib.mp_stream_set_state(self._h, int(s), _ptr(win), feet, C.byref(y) if y is not None else None,
+                                                 root, C.byref(fresh) if fresh is not None else None))
         self._tick += 1                         # invalidates the read-back cache
 
     # Reads return COPIES of the device state (one round trip per tick, shared by the five attributes); assignment
@@ -520,7 +545,7 @@ class MobilePoserNet:
         self._require_weights()
         r = reduced_pose.to(device=self.device, dtype=torch.float32).reshape(-1, 96).contiguous()
         out = torch.empty(r.shape[0], 24, 3, 3, device=self.device, dtype=torch.float32)
-        _lib.check(self._lib.mp_reduced_global_to_full(self._h, _ptr(r), r.shape[0], _ptr(out), self._stream()), self._h)
+        self._check(self._lib.mp_reduced_global_to_full(self._h, _ptr(r), r.shape[0], _ptr(out), self._stream()))
         return out
 
     def forward_kinematics(self, pose, tran=None, calc_mesh=False, shape=None):
@@ -535,7 +560,7 @@ class MobilePoserNet:
         self._require_weights()
         r = torch.as_tensor(r6d).to(device=self.device, dtype=torch.float32).reshape(-1, 6).contiguous()
         out = torch.empty(r.shape[0], 3, 3, device=self.device, dtype=torch.float32)
-        _lib.check(self._lib.mp_r6d_to_rotation_matrix(self._h, _ptr(r), r.shape[0], _ptr(out), self._stream()), self._h)
+        self._check(self._lib.mp_r6d_to_rotation_matrix(self._h, _ptr(r), r.shape[0], _ptr(out), self._stream()))
         return out
 
     def eval_metrics(self, pose_p, pose_t, tran_p=None, tran_t=None, fps=60, align_joint=0, joint_mask=None, ignored=()):
@@ -555,9 +580,9 @@ class MobilePoserNet:
                 raise ValueError("joint indices must be in 0..23, got %s" % (js,))
             return sum(1 << j for j in set(js))
         table = torch.empty(10, 2, device=self.device, dtype=torch.float32)
-        _lib.check(self._lib.mp_eval_metrics(self._h, _ptr(pp), _ptr(pt), _ptr(tp), _ptr(tt), N, int(fps), int(align_joint),
+        self._check(self._lib.mp_eval_metrics(self._h, _ptr(pp), _ptr(pt), _ptr(tp), _ptr(tt), N, int(fps), int(align_joint),
                                              bits(joint_mask), bits(ignored), int(self.n_vertex > 0), _ptr(table),
-                                             self._stream()), self._h)
+                                             self._stream()))
         return table
 
     def rnn_forward(self, module, x, input_lengths, state=None):
@@ -574,40 +599,43 @@ class MobilePoserNet:
         if state is not None:
             st_in = torch.stack((state[0], state[1])).to(device=self.device, dtype=torch.float32).contiguous()
         rc = self._lib.mp_rnn_forward(self._h, mod, _ptr(x), lens, B, T, _ptr(y), _ptr(st_in), _ptr(st_out), self._stream())
-        _lib.check(rc, self._h)
+        self._check(rc)
         self._after_call()
         return y, (st_out[0], st_out[1])
 
     # ---- measurement hooks -----------------------------------------------------------------------
     def timing_enable(self, on):
-        _lib.check(self._lib.mp_timing_enable(self._h, int(bool(on))), self._h)
+        self._check(self._lib.mp_timing_enable(self._h, int(bool(on))))
 
     def timing_read(self, cls):
         """(launches, event-measured ms, algorithmic GFLOP) of a kernel class in the last timed call."""
         n, ms, gf = C.c_int(0), C.c_float(0), C.c_double(0)
-        _lib.check(self._lib.mp_timing_read(self._h, cls, C.byref(n), C.byref(ms), C.byref(gf)), self._h)
+        self._check(self._lib.mp_timing_read(self._h, cls, C.byref(n), C.byref(ms), C.byref(gf)))
         return n.value, ms.value, gf.value
 
     def set_lstm_mode(self, mode):
         """1 (default): fused persistent layers on exact-fp32 MFMA operands; 3: the same on split-fp16 operands (opt-in
         fast mode); 2: mode 1 + two-layer wavefront velocity kernel; 0: per-step kernels.  (include/mobileposer_hip.h)"""
-        _lib.check(self._lib.mp_set_lstm_mode(self._h, int(mode)), self._h)
+        self._check(self._lib.mp_set_lstm_mode(self._h, int(mode)))
 
     def set_transport(self, force_remote):
         """Test hook: force the any-placement (sc1) hidden-state transport of the persistent kernels."""
-        _lib.check(self._lib.mp_set_transport(self._h, int(bool(force_remote))), self._h)
+        self._check(self._lib.mp_set_transport(self._h, int(bool(force_remote))))
 
     def device_error(self):
         """0 = ok; otherwise 1+step at which a persistent-kernel wait timed out (synchronises)."""
         code = C.c_int(0)
-        _lib.check(self._lib.mp_device_error(self._h, C.byref(code)), self._h)
+        self._check(self._lib.mp_device_error(self._h, C.byref(code)))
+        if code.value:                        # reported: the library has reset the carried state (see _check)
+            self._tick += 1
+            self._state_cache = {}
         return code.value
 
     def set_graph_mode(self, on):
         """0 / False: eager launches (default); 1 / True: replay captured hipGraphs (multi-branch); 2: single-branch graphs
         (every launch on one stream: nothing for the runtime's graph executor to mis-assign; include/mobileposer_hip.h)."""
         mode = int(on)
-        _lib.check(self._lib.mp_set_graph_mode(self._h, mode), self._h)
+        self._check(self._lib.mp_set_graph_mode(self._h, mode))
         self._graph = mode
         self._graph_bufs = {}
 

@@ -251,7 +251,8 @@ for a, b in zip(outs[0], outs[1]):
     assert torch.equal(a, b)
 print("GRAPH_OK")
 ''' % REPO
-    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    # (round 5: graph mode 1 means mode 2 unless MP_GRAPH_MULTIBRANCH=1 -- this test is the one that asks for the real thing)
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", MP_GRAPH_MULTIBRANCH="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "GRAPH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
