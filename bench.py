@@ -48,10 +48,10 @@ X3_NAMES = {         # the same timing classes when the H = 256 blocks run on sp
 
 KERNEL_CLASSES = {   # timing classes of the C ABI (include/mobileposer_hip.h, mp_timing_read)
     0: "mp_gemm_f32_frag (linear1 / linear2; pose|velocity|foot-contact linear1 and velocity+foot-contact linear2 as one launch each)",
-    1: "mp_lstm_fused<256,8,256,1> bidirectional layer 0 (joints, pose)",
-    4: "mp_lstm_fused<256,8,512,1> bidirectional layer 1 (joints, pose)",
-    5: "mp_lstm_fused<256,16,256,1,FK> unidirectional layers (velocity, the foot-contact layers riding in its workgroups)",
-    6: "mp_lstm_fused<64,4,*,1> (foot contact as launches of its own: B <= 128)",
+    1: "mp_lstm_fused<256,8,256> bidirectional layer 0 (joints; pose with foot-contact layer 0 riding in its workgroups)",
+    4: "mp_lstm_fused<256,8,512> bidirectional layer 1 (joints, pose)",
+    5: "mp_lstm_fused<256,8,256,WF> velocity: both unidirectional layers as ONE two-layer wavefront launch, foot-contact layer 1 riding",
+    6: "mp_lstm_fused<64,4,*> (foot contact as launches of its own: B <= 128)",
     7: "mp_lstm_step (per-step fallback)",
     2: "mp_r6d_ik",
 }
@@ -608,8 +608,8 @@ def main():
                 continue
             pmc = summ["kernels"]
             # (kernel names as rocprofv3 prints them; matched by prefix)
-            key = {1: "mp_lstm_fused<256, 8, 256, 1, false", 4: "mp_lstm_fused<256, 8, 512, 1, false",
-                   5: "mp_lstm_fused<256, 16, 256, 1, false", 0: "mp_gemm_f32_frag<2, 5>"}.get(dominant)
+            key = {1: "mp_lstm_fused<256, 8, 256, false", 4: "mp_lstm_fused<256, 8, 512, false",
+                   5: "mp_lstm_fused<256, 8, 256, false", 0: "mp_gemm_f32_frag<2, 5>"}.get(dominant)
             if args.lstm_mode == "x3":
                 key = {1: "mp_lstm_x3<8, 256, false>", 4: "mp_lstm_x3w<512, false>", 5: "mp_lstm_x3<8, 256, false>",
                        0: "mp_gemm_x3<128, 64>"}.get(dominant)

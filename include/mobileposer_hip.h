@@ -59,7 +59,7 @@ enum { MP_MOD_JOINTS = 0, MP_MOD_POSE = 1, MP_MOD_FOOT_CONTACT = 2, MP_MOD_VELOC
  * Replaces: the `.pth` state_dict written by combine_weights.py:53-56. */
 size_t mp_weight_count(void);
 
-/* Build id of this binary: the md5 over the sources it was compiled from (mobileposer_amd/csrc/*.hip, *.h and include/*.h in
+/* Build id of this binary: the md5 over the sources it was compiled from (the .hip and .h files of mobileposer_amd/csrc and the headers of include/, in
  * name order -- mobileposer_amd/_lib.py source_md5()), baked in at compile time (-DMP_SRC_MD5).  The Python binding, bench.py
  * and the tests compare it with the md5 of the sources beside them and rebuild (or refuse) on a mismatch, so a stale library
  * can be neither timed nor tested silently.  "unknown" for a build outside of __graft_entry__.build().

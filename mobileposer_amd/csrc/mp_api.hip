@@ -89,17 +89,16 @@ struct ModuleW {
     int n_in = 0, n_out = 0, H = 0, dirs = 0, nslice = 0, nsliceX = 0;   // slices per slab: fp32 kernels | split-bf16 kernels
     Packed lin1, ih[2], lin2;
     float* whh[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};    // per-step kernel layout
-    float* whhP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // persistent kernel layout
-    float* wihP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // W_ih, persistent kernel layout
+    float* whhP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // persistent kernel layout for `nslice` slices per slab
+    float* wihP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // W_ih, the same
     float* whhX[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // split-bf16 kernel layout (H = 256 modules)
     float* wihX[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     float* whhP16[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // 16-slice packing of the bidirectional H = 256 blocks (small
     float* wihP16[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  //  batches; a unidirectional block's whhP / wihP already is it)
-    float* whhPW[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // 8-slice / 4-wave (WREG) packing, bidirectional H = 256 blocks
-    float* wihPW[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    float* whhP8[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // 8-slice packing of the unidirectional H = 256 block (the
+    float* wihP8[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   //  two-layer wavefront launch; a bidirectional block's whhP / wihP already is it)
     float* whhU8[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // 32 slices of 8 units (mp_lstm_u8): small batches, H = 256 blocks
     float* wihU8[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    float* wihG1 = nullptr;          // unidirectional H=256 block: layer-1 W_ih in granule k-order (wavefront kernel)
     float* wVF[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};     // H = 64 block: rider fragments of mp_lstm_fused<..., FK> ("VF")
 };
 struct ModuleWS {
@@ -181,10 +180,6 @@ struct mp_handle {
                                      // constant clock (env MP_WAIT_MS: tests of the starvation path shorten it)
     int n_cu = 256;                  // compute units of this device: bounds the co-resident persistent grids
     bool persist = true;
-    bool uni2 = false;               // velocity block as ONE two-layer wavefront launch (mp_set_lstm_mode(h, 2) / env
-                                     // MP_VARIANT uni2=1).  Off by default: it is 20 % faster than two launches but fills every
-                                     // CU's registers and LDS, so the foot-contact layers and pose's linear2 / IK / FK can no
-                                     // longer run beside the velocity block and the forward as a whole gets slower.
     bool x3 = false;                 // false (default, mode 1): H = 256 layers on exact-fp32 MFMA operands -- the reference's
                                      // arithmetic; true (mode 3, mp_set_lstm_mode(h, 3) / MP_LSTM_MODE=x3): the opt-in fast
                                      // mode, split-bf16 MFMA operands (mp_lstm_x3.hip)
@@ -204,9 +199,6 @@ struct mp_handle {
     bool fuse_pv = true;             // MP_VARIANT fuse_pv=0: separate linear1 launches for pose and velocity
     Packed lin1_pv;                  // pose.linear1 and velocity.linear1 stacked (split-bf16 mode: one GEMM over the shared rows)
     Packed lin1_pvf;                 // ... with foot_contact.linear1 on top (exact-fp32 mode, B > 128: one GEMM, three outputs)
-    int wreg_mask = 3;               // fp32 mode, 8-slice bidirectional layers on the four-wave / AccVGPR-weight configuration
-                                     // (mp_lstm_fused<256,8,KIN,1>): bit 0 K_in = 512, bit 1 K_in = 256 (MP_VARIANT wreg; 0 = the
-                                     // eight-wave kernels).  Measured on one box: 4.47 -> 4.35 ms per 256 x 125 forward.
     int x3w_mask = 2;                // split-bf16 layers run by the 4-wave kernel mp_lstm_x3w: bit 0 K_in = 256, bit 1 K_in = 512
                                      // (default: the K_in = 512 layers, measured 373 vs 391 us; K_in = 256: 300 vs 285 us; MP_VARIANT x3w)
     int nslice_env = 0;              // 0: pick per module (8 slices / 8 waves for bidirectional layers that fill the
@@ -299,10 +291,12 @@ int pack_weights(mp_handle* h, const float* blob) {
                     if (int rc = dev_alloc(h, (void**)&m.wihU8[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
                 }
                 if (m.H == 256 && m.nslice != 16) {
-                    if (int rc = dev_alloc(h, (void**)&m.whhPW[l][d], mp_whh_pack_floats(m.H) * sizeof(float))) return rc;
-                    if (int rc = dev_alloc(h, (void**)&m.wihPW[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
                     if (int rc = dev_alloc(h, (void**)&m.whhP16[l][d], mp_whh_pack_floats(m.H) * sizeof(float))) return rc;
                     if (int rc = dev_alloc(h, (void**)&m.wihP16[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
+                }
+                if (m.H == 256 && m.nslice != 8 && m.dirs == 1) {
+                    if (int rc = dev_alloc(h, (void**)&m.whhP8[l][d], mp_whh_pack_floats(m.H) * sizeof(float))) return rc;
+                    if (int rc = dev_alloc(h, (void**)&m.wihP8[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
                 }
                 if (m.H == 64)
                     if (int rc = dev_alloc(h, (void**)&m.wVF[l][d], mp_foot_vf_floats(kin) * sizeof(float))) return rc;
@@ -337,27 +331,23 @@ int pack_weights(mp_handle* h, const float* blob) {
                                    m.ih[l].W, m.ih[l].bias, m.H, m.ih[l].K, m.ih[l].Kpad, d * 4 * m.H, h->s_main);
                 mp_launch_pack_whh(find(s.id, K_WHH, l, d), m.whh[l][d], m.H, h->s_main);
                 mp_launch_pack_whh_persist(find(s.id, K_WHH, l, d), m.whhP[l][d], m.H, m.nslice, h->s_main);
-                mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP[l][d], m.H, m.ih[l].K, m.nslice, 0, h->s_main);
+                mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP[l][d], m.H, m.ih[l].K, m.nslice, h->s_main);
                 if (m.wVF[l][d]) mp_launch_pack_foot_vf(find(s.id, K_WIH, l, d), find(s.id, K_WHH, l, d), m.wVF[l][d], m.ih[l].K, h->s_main);
                 if (m.whhU8[l][d]) {
                     mp_launch_pack_w_u8(find(s.id, K_WHH, l, d), m.whhU8[l][d], m.H, h->s_main);
                     mp_launch_pack_w_u8(find(s.id, K_WIH, l, d), m.wihU8[l][d], m.ih[l].K, h->s_main);
                 }
-                if (m.whhPW[l][d]) {
-                    mp_launch_pack_whh_persist_w(find(s.id, K_WHH, l, d), m.whhPW[l][d], h->s_main);
-                    mp_launch_pack_wih_persist_w(find(s.id, K_WIH, l, d), m.wihPW[l][d], m.ih[l].K, h->s_main);
+                if (m.whhP8[l][d]) {
+                    mp_launch_pack_whh_persist(find(s.id, K_WHH, l, d), m.whhP8[l][d], m.H, 8, h->s_main);
+                    mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP8[l][d], m.H, m.ih[l].K, 8, h->s_main);
                 }
                 if (m.whhP16[l][d]) {
                     mp_launch_pack_whh_persist(find(s.id, K_WHH, l, d), m.whhP16[l][d], m.H, 16, h->s_main);
-                    mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP16[l][d], m.H, m.ih[l].K, 16, 0, h->s_main);
+                    mp_launch_pack_wih_persist(find(s.id, K_WIH, l, d), m.wihP16[l][d], m.H, m.ih[l].K, 16, h->s_main);
                 }
                 if (m.H == 256) {
                     mp_launch_pack_w_x3(find(s.id, K_WHH, l, d), m.whhX[l][d], m.H, m.nsliceX, h->s_main);
                     mp_launch_pack_w_x3(find(s.id, K_WIH, l, d), m.wihX[l][d], m.ih[l].K, m.nsliceX, h->s_main);
-                }
-                if (l == 1 && m.dirs == 1 && m.H == 256 && m.nslice == 16) {
-                    if (int rc = dev_alloc(h, (void**)&m.wihG1, (size_t)4 * m.H * m.ih[1].K * sizeof(float))) return rc;
-                    mp_launch_pack_wih_persist(find(s.id, K_WIH, 1, 0), m.wihG1, m.H, m.ih[1].K, 16, 1, h->s_main);
                 }
             }
     }
@@ -514,13 +504,11 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     if (const char* e = getenv("MP_WAIT_MS")) { const double ms = atof(e); if (ms > 0.0 && ms < 60000.0) h->wait_ticks = (unsigned long long)(ms * 1e5); }
     // MP_VARIANT: ONE debug switch for the kernel / schedule variants kept for cross-checks and A/B runs -- a comma-separated
     // list of key=value (tests/test_gpu_parity.py exercises them; nothing here changes results beyond summation order):
-    //   wreg=0..3      8-slice bidirectional fp32 layers on the four-wave / AccVGPR kernels: bit 0 K_in=512, bit 1 K_in=256 (3)
     //   x3w=0..3       split-bf16 layers on the four-wave kernel: bit 0 K_in=256, bit 1 K_in=512 (2)
     //   slices=8|16    force the slices per slab of the fp32 H=256 layers;  slices16=0 / slices32=0: no 16- / 32-slice kernels
     //   wide=0         never run pose / velocity / foot contact side by side;  half=0: no pose-on-half-the-chip schedule
     //   exclusive=0    no LDS padding / XCD tables for concurrent persistent launches;  fuse_pv=0: separate linear1 launches
     //   epoch_tags=0   zero the exchange area before every fp32 layer launch;  epoch_start=N: first epoch base (wrap tests)
-    //   uni2=1         velocity block as one two-layer wavefront launch (= mp_set_lstm_mode(h, 2))
     //   vf=0           foot-contact layers as launches of their own beside velocity (B > 128), not as riders in its workgroups
     //   late_pair=0    64 < B <= 128: both pose layers on 8 slices beside velocity (schedules 2 / 3) instead of schedule 4
     if (const char* e = getenv("MP_VARIANT")) {
@@ -535,7 +523,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
             if (eq == std::string::npos) continue;
             const std::string key = tok.substr(0, eq);
             const unsigned long v = strtoul(tok.c_str() + eq + 1, nullptr, 0);
-            if (key == "wreg") h->wreg_mask = (int)(v & 3);
+            if (key == "wreg") { /* (round 5: the eight-wave kernels are gone; accepted and ignored) */ }
             else if (key == "x3w") h->x3w_mask = (int)(v & 3);
             else if (key == "slices") h->nslice_env = v == 8 ? 8 : (v == 16 ? 16 : 0);
             else if (key == "slices16") h->slices16_ok = v != 0;
@@ -546,7 +534,6 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
             else if (key == "fuse_pv") h->fuse_pv = v != 0;
             else if (key == "epoch_tags") h->epoch_tags = v != 0;
             else if (key == "epoch_start") { if (v >= 1 && v < 0xf0000000ul) h->epoch_start = (unsigned)v; }
-            else if (key == "uni2") h->uni2 = v != 0;
             else if (key == "gemm_staged") {}                  // read by mp_launch_gemm
             else if (key == "kin_scalar") {}                   // read by mp_kin.hip
             else if (key == "gemm_frag") {}                    // read by mp_launch_gemm
@@ -779,7 +766,7 @@ struct RnnJob {
 // linear1's output X1 normally lives in out1's memory (dead until layer 1 writes it); the two-layer wavefront
 // kernel writes out1 while layer 0 is still reading X1, so there X1 goes to the (otherwise unused) out0
 // split-bf16 operands for this module's LSTM layers?  (X1 and the layer-0 output are then stored as pairs)
-bool use_x3(const mp_handle* h, const ModuleW& m) { return h->persist && h->x3 && !h->uni2 && m.H == 256; }
+bool use_x3(const mp_handle* h, const ModuleW& m) { return h->persist && h->x3 && m.H == 256; }
 
 // Slices per slab of an exact-fp32 layer launch: a bidirectional H = 256 layer normally uses 8 slices (8-wave workgroups, one
 // per CU at B = 256); when the batch is small enough that 16 slices still fit the chip (B <= 128), the 16-slice / 4-wave
@@ -793,7 +780,7 @@ int fp32_slices(const mp_handle* h, const ModuleW& m, int B) {
     // (the joints block always has the chip to itself: 32 slices while its 2 * nslab clusters find an XCD each, B <= 64)
     // (without placement tables only blocks that have the chip to themselves use them: joints, and pose in the serial schedule)
     const int max32 = &m == &h->mod[MP_MOD_JOINTS] ? 4 : ((!h->xcd_rr && &m == &h->mod[MP_MOD_VELOCITY]) ? 0 : 2);
-    if (m.H == 256 && m.whhU8[0][0] && h->slices32_ok && h->slices16_ok && nslab <= max32 && cus == 256 && !h->uni2) return 32;
+    if (m.H == 256 && m.whhU8[0][0] && h->slices32_ok && h->slices16_ok && nslab <= max32 && cus == 256) return 32;
     if (m.H == 256 && m.nslice == 8 && m.whhP16[0][0] && h->slices16_ok && m.dirs * nslab * 16 <= cus) return 16;
     return m.nslice;
 }
@@ -804,7 +791,8 @@ int layer_workgroups(const mp_handle* h, const ModuleW& m, int B) {
 }
 
 float* x1_buffer(const mp_handle* h, const ModuleW& m, ModuleWS& w) {
-    return (h->persist && h->uni2 && m.wihG1) ? w.out0 : w.out1;
+    (void)h; (void)m;
+    return w.out1;
 }
 
 int rnn_g0(const RnnJob& j, hipStream_t s) {
@@ -848,7 +836,7 @@ bool rnn_g0_pose_velocity(const RnnJob& jp, const RnnJob& jv, hipStream_t s, int
     const ModuleW& mp = h->mod[jp.id];
     const ModuleW& mv = h->mod[jv.id];
     *rc = MP_OK;
-    if (!h->fuse_pv || !h->lin1_pv.Wp || !h->persist || use_x3(h, mp) != use_x3(h, mv) || h->uni2) return false;
+    if (!h->fuse_pv || !h->lin1_pv.Wp || !h->persist || use_x3(h, mp) != use_x3(h, mv)) return false;
     const bool x3 = use_x3(h, mp);
     if (jp.mode != STATE_ZERO || !(jv.mode == STATE_ZERO || (jv.out_h == jv.in_h && jv.out_h))) return false;
     if (jp.a0.base != jv.a0.base || jp.a1.base != jv.a1.base) return false;
@@ -890,7 +878,7 @@ bool rnn_g2_g0_fused(const RnnJob& jj, const RnnJob& jp, const RnnJob& jv, const
     const ModuleW& mp = h->mod[jp.id];
     const ModuleW& mv = h->mod[jv.id];
     const ModuleW& mf = h->mod[jf.id];
-    if (!h->persist || h->uni2 || !h->fuse_pv || use_x3(h, mj) || use_x3(h, mp) || use_x3(h, mv) || !h->lin1_pvf.Wf || !mj.lin2.Wf) return false;
+    if (!h->persist || !h->fuse_pv || use_x3(h, mj) || use_x3(h, mp) || use_x3(h, mv) || !h->lin1_pvf.Wf || !mj.lin2.Wf) return false;
     if (jj.out_h || jp.mode != STATE_ZERO || jf.mode != STATE_ZERO || !(jv.mode == STATE_ZERO || (jv.out_h == jv.in_h && jv.out_h))) return false;
     // the stacked GEMM must read exactly what linear2 writes: cat(pred_joints, imu) with pred_joints = this call's output
     if (jp.a0.base != jj.y || jv.a0.base != jj.y || jf.a0.base != jj.y || jp.a1.base != jv.a1.base || jp.a1.base != jf.a1.base) return false;
@@ -921,37 +909,10 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
     ModuleWS& w = j.p->ws[j.id];
     const int B = j.p->B, T = j.p->T, H = m.H, dirs = m.dirs;
     float* out = l == 0 ? w.out0 : w.out1;
-    if (h->persist && h->uni2 && m.wihG1) {
-        // two-layer wavefront launch: layer 0 and layer 1 together when asked for layer 0, nothing for layer 1
-        if (l == 1) return MP_OK;
-        HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
-        w.hx_epoch = 0;
-        const int nslab = (B + 15) / 16;
-        const int chunk = (h->n_cu < 256 ? h->n_cu : 256) / 16 > 0 ? (h->n_cu < 256 ? h->n_cu : 256) / 16 : 1;   // one workgroup per CU
-        SegScope seg(h, s, 5, (nslab + chunk - 1) / chunk, 2.0 * (double)B * T * 4.0 * H * (4.0 * H));
-        const bool inplace = j.out_h == j.in_h && j.out_h;
-        for (int s0 = 0; s0 < nslab; s0 += chunk) {
-            LstmPersistArgs a;
-            a.lengths = j.p->lengths_dev; a.ndir = 2; a.B = B; a.T = T;
-            a.slab0 = s0; a.nslab = nslab - s0 < chunk ? nslab - s0 : chunk;
-            a.hx = w.hx + (size_t)2 * s0 * ((size_t)4 * 16 * H + 16);
-            a.err = h->err_dev; a.max_spin = 1u; a.max_ticks = h->wait_ticks; a.prof = nullptr;
-            a.zero_state = j.mode == STATE_ZERO ? 1 : 0; a.force_remote = h->force_remote ? 1 : 0;
-            for (int ll = 0; ll < 2; ++ll) {
-                LstmDir& dd = a.d[ll];
-                dd.wpack = m.whhP[ll][0]; dd.xproj = nullptr; dd.out = w.out1;
-                dd.hbuf = inplace ? j.out_h + (size_t)ll * B * H : w.hbuf[ll][0];
-                dd.cbuf = inplace ? j.out_c + (size_t)ll * B * H : w.cbuf[ll][0];
-                dd.xprojStride = 0; dd.outStride = H; dd.reverse = 0;
-                dd.wihpack = ll == 0 ? m.wihP[0][0] : m.wihG1; dd.bias = m.ih[ll].bias; dd.xin = x1_buffer(h, m, w);
-            }
-            mp_launch_lstm_uni2(a, s);
-        }
-    } else if (h->persist) {
+    if (h->persist) {
         const int nslab = (B + 15) / 16;
         // every polled word is re-zeroed before every launch: all granules (fp32 kernels) or the flags (split-bf16 kernels)
         // (split-bf16 kernels: the flags of layer 0's area were zeroed by the linear1 GEMM, those of layer 1's area by the layer-0 launch)
-        const int kin_l = l == 0 ? H : dirs * H;
         // exact-fp32 kernels: mp_lstm_fused tags its granules with a per-launch epoch base, so the area is zeroed only when
         // something else may have written to it (first use, another kernel family, graph capture -- replays repeat the same
         // base -- or an imminent wrap of the 32-bit tag); the split-bf16 kernels re-arm themselves
@@ -962,11 +923,10 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         const bool epoch_ok = !use_x3(h, m) && !h->capturing && h->epoch_tags && !crowded16;
         const int nsl = use_x3(h, m) ? m.nsliceX : fp32_slices(h, m, B);
         const bool p16 = !use_x3(h, m) && nsl == 16 && m.nslice != 16;      // 16-slice packing of a bidirectional block
-        const bool wreg = !use_x3(h, m) && H == 256 && nsl == 8 && m.whhPW[0][0] &&
-                          (h->wreg_mask & (kin_l == 512 ? 1 : 2));
+        const bool p8 = !use_x3(h, m) && nsl == 8 && m.nslice != 8;         // 8-slice packing of the unidirectional block
         // (tagged-word kernels: one tag bit per word, so the area is also zeroed when the other kernel family -- granules with
         //  32-bit epochs -- wrote to it last; the tags a launch starts with follow from what the previous one left: hx_flip)
-        const bool tagged = !use_x3(h, m) && mp_persist_tagged(H, nsl, wreg || nsl == 16);
+        const bool tagged = !use_x3(h, m) && H == 256 && (nsl == 8 || nsl == 16);
         unsigned epoch_base = 0;
         // (recovery off: calls are enqueued without a sync, so a launch that lost a workgroup may already have reported it while
         //  this one is being issued -- the words it left behind are not what hx_flip describes: start from a zeroed area.  ADVICE r4)
@@ -1017,13 +977,13 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             a.out_pairs = x3 ? 1 : 0;                          // both layers feed split-bf16 consumers (layer 1 / linear2)
             for (int d = 0; d < dirs; ++d) {
                 LstmDir& dd = a.d[d];
-                dd.wpack = x3 ? m.whhX[l][d] : (u8 ? m.whhU8[l][d] : wreg ? m.whhPW[l][d] : (p16 ? m.whhP16[l][d] : m.whhP[l][d]));
+                dd.wpack = x3 ? m.whhX[l][d] : (u8 ? m.whhU8[l][d] : p8 ? m.whhP8[l][d] : (p16 ? m.whhP16[l][d] : m.whhP[l][d]));
                 dd.xproj = nullptr; dd.out = outp + (size_t)d * H;
                 const bool inplace = j.out_h == j.in_h && j.out_h;
                 dd.hbuf = inplace ? j.out_h + (size_t)(l * dirs + d) * B * H : w.hbuf[l][d];
                 dd.cbuf = inplace ? j.out_c + (size_t)(l * dirs + d) * B * H : w.cbuf[l][d];
                 dd.xprojStride = 0; dd.outStride = dirs * H; dd.reverse = d;
-                dd.wihpack = x3 ? m.wihX[l][d] : (u8 ? m.wihU8[l][d] : wreg ? m.wihPW[l][d] : (p16 ? m.wihP16[l][d] : m.wihP[l][d])); dd.bias = m.ih[l].bias + (size_t)d * 4 * H; dd.xin = xin;
+                dd.wihpack = x3 ? m.wihX[l][d] : (u8 ? m.wihU8[l][d] : p8 ? m.wihP8[l][d] : (p16 ? m.wihP16[l][d] : m.wihP[l][d])); dd.bias = m.ih[l].bias + (size_t)d * 4 * H; dd.xin = xin;
             }
             if (dirs == 1) a.d[1] = a.d[0];
             // the foot-contact layer l of the same slabs as a rider of this velocity launch (forward_body decides)
@@ -1039,7 +999,6 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             else if (x3 && nsl == 8 && (h->x3w_mask & (kin == 256 ? 1 : 2))) mp_launch_lstm_x3w(a, kin, s);
             else if (x3) mp_launch_lstm_x3(a, kin, nsl, s);
             else if (u8) mp_launch_lstm_u8(a, kin, s);
-            else if (wreg) mp_launch_lstm_persist_w(a, kin, s);
             else mp_launch_lstm_persist(a, H, kin, nsl, s);
         }
         if (epoch_base) w.hx_epoch += (unsigned)T + 1u;       // tags base .. base + T are used up
@@ -1180,7 +1139,7 @@ bool place_clusters(const mp_handle* h, const XcdJob* jobs, int njobs, int load[
 // on 16 slices with the chip to itself, then pose layer 1 on 8 slices beside the velocity layers that carry the foot-contact
 // layers as riders.  Fills the per-XCD cluster tables of the three blocks (h->xcd_plan).
 int side_by_side_plan(mp_handle* h, int B) {
-    if (h->uni2 || !h->wide_ok) return 0;
+    if (!h->wide_ok) return 0;
     const ModuleW& pm = h->mod[MP_MOD_POSE];
     const ModuleW& vm = h->mod[MP_MOD_VELOCITY];
     const ModuleW& fm = h->mod[MP_MOD_FOOT_CONTACT];
@@ -1197,7 +1156,7 @@ int side_by_side_plan(mp_handle* h, int B) {
     // are each partly resident wait for CUs the other holds until their waits time out): no tables, no side-by-side schedule
     if (!h->xcd_rr || !h->exclusive_ok) return 0;
     if (place_clusters(h, all, 3, load, h->xcd_plan)) return 1;
-    if (!h->half_ok || !pm.whhPW[0][0] || (h->wreg_mask & 3) != 3 || pslices != 16) return 0;
+    if (!h->half_ok || pm.nslice != 8 || pslices != 16) return 0;
     all[0].wgs = pm.nslice;                   // pose on 8 slices per slab (four-wave kernels)
     for (int x = 0; x < 8; ++x) load[x] = 0;
     // schedule 4 wherever it applies (every B that does not fit schedule 1): its two halves take 797 and 2 x 404 us, after 396 us
@@ -1251,7 +1210,7 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
     // (tail_pending): the translation solver does not read the pose.
     {
         const ModuleW& vmod = h->mod[MP_MOD_VELOCITY];
-        const bool vf = h->vf_ok && p->B > 128 && h->persist && !h->uni2 && !use_x3(h, vmod) && vmod.nslice == 16 &&
+        const bool vf = h->vf_ok && p->B > 128 && h->persist && !use_x3(h, vmod) && vmod.nslice == 16 &&
                         fp32_slices(h, vmod, p->B) == 16 && h->mod[MP_MOD_FOOT_CONTACT].wVF[0][0] != nullptr;
         static const bool one_stream_ok = !(getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "one_stream=0"));
         if (vf && one_stream_ok && h->lin1_pvf.Wf && mp_gemm_frag_enabled() && h->fuse_pv && !use_x3(h, h->mod[MP_MOD_POSE]) &&
@@ -1377,7 +1336,7 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         // "VF": the foot-contact layers ride in the workgroups of the velocity layer launches (mp_lstm_fused<256,16,256,1,*,FK>)
         // instead of running as launches of their own beside them -- exact-fp32 16-slice velocity kernel, zero initial state
         const ModuleW& vmod = h->mod[MP_MOD_VELOCITY];
-        const bool fuse_vf = h->vf_ok && p->B > 128 && h->persist && !h->uni2 && !use_x3(h, vmod) && vmod.nslice == 16 &&
+        const bool fuse_vf = h->vf_ok && p->B > 128 && h->persist && !use_x3(h, vmod) && vmod.nslice == 16 &&
                              fp32_slices(h, vmod, p->B) == 16 && h->mod[MP_MOD_FOOT_CONTACT].wVF[0][0] != nullptr;
         if (fuse_vf) RC(rec(4, sf));                             // linear1 of foot contact is done
         int rc_pv = MP_OK;
@@ -1593,12 +1552,12 @@ int finish_or_recover(mp_handle* h, Plan* p, const char* what, Restore restore, 
     const int code = take_device_error(h, &starved);
     if (!code) return MP_OK;
     if (starved) disable_xcd_tables(h);
-    const bool persist = h->persist, uni2 = h->uni2, x3 = h->x3, graph = h->use_graph;
-    h->persist = false; h->uni2 = false; h->x3 = false; h->use_graph = false;
+    const bool persist = h->persist, x3 = h->x3, graph = h->use_graph;
+    h->persist = false; h->x3 = false; h->use_graph = false;
     int rc = p ? ensure_step_ws(h, p) : MP_OK;
     if (!rc) rc = restore();
     if (!rc) rc = again();
-    h->persist = persist; h->uni2 = uni2; h->x3 = x3; h->use_graph = graph;
+    h->persist = persist; h->x3 = x3; h->use_graph = graph;
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->s_main));
     ++h->recoveries;
@@ -1668,8 +1627,8 @@ void mp_destroy(mp_handle* h) {
             if (m.whh[l][d]) (void)hipFree(m.whh[l][d]);
             if (m.whhP[l][d]) (void)hipFree(m.whhP[l][d]);
             if (m.wihP[l][d]) (void)hipFree(m.wihP[l][d]);
-            if (m.whhPW[l][d]) (void)hipFree(m.whhPW[l][d]);
-            if (m.wihPW[l][d]) (void)hipFree(m.wihPW[l][d]);
+            if (m.whhP8[l][d]) (void)hipFree(m.whhP8[l][d]);
+            if (m.wihP8[l][d]) (void)hipFree(m.wihP8[l][d]);
             if (m.whhU8[l][d]) (void)hipFree(m.whhU8[l][d]);
             if (m.wihU8[l][d]) (void)hipFree(m.wihU8[l][d]);
             if (m.whhP16[l][d]) (void)hipFree(m.whhP16[l][d]);
@@ -1678,7 +1637,6 @@ void mp_destroy(mp_handle* h) {
             if (m.wVF[l][d]) (void)hipFree(m.wVF[l][d]);
             if (m.wihX[l][d]) (void)hipFree(m.wihX[l][d]);
         }
-        if (m.wihG1) (void)hipFree(m.wihG1);
     }
     void* misc[] = {h->parent_dev, h->depth_dev, h->bone_dev, h->vstate.h, h->vstate.c, h->sc.window, h->sc.fresh,
                     h->sc.mask_dev, h->sc.st.last_foot, h->sc.st.root_y, h->sc.st.root_pos, h->sc.joints, h->sc.vel,
@@ -1734,7 +1692,7 @@ int mp_forward(mp_handle* h, const float* imu_dev, const int32_t* lengths_host, 
     if (int rc = snapshot_vstate(h, B, has_state)) return rc;
     GraphKey key;
     memset(&key, 0, sizeof(key));
-    key.kind = 0; key.B = B; key.T = T; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0) | (h->uni2 ? 4 : 0) | (h->x3 ? 8 : 0);
+    key.kind = 0; key.B = B; key.T = T; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0) | (h->x3 ? 8 : 0);
     key.p[0] = imu_dev; key.p[1] = pose_dev; key.p[2] = joints_dev; key.p[3] = vel_dev; key.p[4] = contact_dev;
     key.p[5] = r6d; key.p[6] = h->vstate.h;
     auto body = [&]() {
@@ -1773,7 +1731,7 @@ int mp_forward_offline(mp_handle* h, const float* imu_dev, const int32_t* length
     if (int rc = snapshot_vstate(h, B, has_state)) return rc;
     GraphKey key;
     memset(&key, 0, sizeof(key));
-    key.kind = 2; key.B = B; key.T = T; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0) | (h->uni2 ? 4 : 0) | (h->x3 ? 8 : 0);
+    key.kind = 2; key.B = B; key.T = T; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0) | (h->x3 ? 8 : 0);
     key.p[0] = imu_dev; key.p[1] = pose_dev; key.p[2] = joints_dev; key.p[3] = vel_dev; key.p[4] = contact_dev;
     key.p[5] = tran_dev; key.p[6] = h->vstate.h; key.p[7] = rglobal_dev;
     auto body = [&]() {
@@ -2152,7 +2110,7 @@ int mp_stream_step(mp_handle* h, const float* frames_dev, float* pose_dev, float
     }
     GraphKey key;
     memset(&key, 0, sizeof(key));
-    key.kind = 1; key.B = S; key.T = W; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0) | (h->uni2 ? 4 : 0) | (h->x3 ? 8 : 0);
+    key.kind = 1; key.B = S; key.T = W; key.flags = (has_state ? 1 : 0) | (h->persist ? 2 : 0) | (h->x3 ? 8 : 0);
     key.p[0] = frames_dev; key.p[1] = pose_dev; key.p[2] = joints; key.p[3] = root_pos_dev; key.p[4] = contact_dev;
     key.p[6] = h->vstate.h;
     auto net_and_solver = [&]() {
@@ -2342,9 +2300,8 @@ int mp_set_lstm_mode(mp_handle* h, int mode) {
     if (!h || mode < 0 || mode > 3) return MP_ERR_INVALID;
     ON_DEVICE(h);
     HIPCHK(h, hipDeviceSynchronize());
-    h->persist = mode != 0;
-    h->uni2 = mode == 2;
-    h->x3 = mode == 3;
+    h->persist = mode != 0;              // (mode 2, rounds 1-4's separate two-layer wavefront kernel: since round 5 the velocity
+    h->x3 = mode == 3;                   //  block of mode 1's full-batch schedule IS a two-layer wavefront -- 2 means 1)
     return MP_OK;
 }
 

@@ -115,7 +115,7 @@ struct LstmPersistArgs {
     int* err;                     // device error word (0 = ok, 1+step = a gather timed out)
     int ndir, B, T, slab0, nslab;
     int zero_state;               // 1: start from h = c = 0 without reading hbuf / cbuf
-    int force_remote;             // test hook: use the any-placement (sc1) transport even inside one XCD
+    int force_remote;             // test hook (PROF instantiation): use the any-placement (sc1) transport even inside one XCD
     unsigned max_spin;            // 0: never wait (a test hook); otherwise waits are allowed, bounded by max_ticks
     unsigned long long max_ticks; // bound of every wait in ticks of the constant 100 MHz clock (s_memrealtime); mp_api: 0.25 s
     long long* prof;              // optional [grid][6] cycle sums per phase (debug), else nullptr
@@ -172,10 +172,9 @@ static __device__ __forceinline__ int mp_xcd_first(const LstmPersistArgs& a, int
     __builtin_memcpy(w, a.xcd_base, 16);
     return (int)(((xcd & 4 ? w[1] : w[0]) >> (16 * (xcd & 3))) & 0xffffu);
 }
-// nslice: workgroups sharing one slab of an H = 256 layer: 16 (4-wave workgroups, two per CU) or 8 (8-wave, one per CU)
+// nslice: workgroups sharing one slab -- H = 256: 16 (four 256-register waves, two workgroups per CU) or 8 (four 512-register
+// waves with AccVGPR-resident weights, one per CU); H = 64: 4.  The H = 256 kernels exchange tagged words (LstmPersistArgs::tag_flip)
 void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice, hipStream_t s);
-// does the mp_lstm_fused launch of this shape exchange tagged words (LstmPersistArgs::tag_flip)?  four_wave: mp_launch_lstm_persist_w / _vf
-bool mp_persist_tagged(int H, int nslice, bool four_wave);
 // the unidirectional H = 256, K_in = 256 layer on 16 slices with an H = 64 bidirectional layer riding along (fk = its K_in: 64 | 128)
 void mp_launch_lstm_vf(const LstmPersistArgs& a, int fk, hipStream_t s);
 size_t mp_foot_vf_floats(int fk);     // per direction
@@ -187,14 +186,8 @@ void mp_launch_lstm_u8(const LstmPersistArgs& a, int KIN, hipStream_t s);
 void mp_launch_pack_w_u8(const float* w, float* dst, int K, hipStream_t s);
 hipError_t mp_lstm_u8_device_attrs();
 void mp_launch_pack_whh_persist(const float* whh, float* dst, int H, int nslice, hipStream_t s);
-void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, int nslice, int korder, hipStream_t s);
-// H = 256, 8 slices, four 512-register waves per workgroup with AccVGPR-resident weights (mp_lstm_fused<256,8,KIN,1>)
-void mp_launch_pack_whh_persist_w(const float* whh, float* dst, hipStream_t s);
-void mp_launch_pack_wih_persist_w(const float* wih, float* dst, int KIN, hipStream_t s);
-void mp_launch_lstm_persist_w(const LstmPersistArgs& a, int KIN, hipStream_t s);
+void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, int nslice, hipStream_t s);
 int mp_persist_max_wg(int H, int nslice);    // largest grid that is co-resident
-// both layers of a unidirectional 2-layer H = 256 LSTM as one wavefront launch (d[0] = layer 0, d[1] = layer 1)
-void mp_launch_lstm_uni2(const LstmPersistArgs& a, hipStream_t s);
 
 // split-bf16 variant of the persistent layer (mp_lstm_x3.hip), H = 256 only: xin and (out_pairs) out hold pairs,
 // wpack / wihpack come from mp_launch_pack_w_x3 (W_hh: K = 256; W_ih: K = K_in)

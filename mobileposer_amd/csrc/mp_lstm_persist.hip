@@ -36,54 +36,43 @@
 // timeout raises a device-side error word instead of hanging the GPU.
 #include "mp_lstm_dev.h"
 
-#ifndef MP_EXP
-#define MP_EXP 0          // timing experiments (tools/debug/build_exp.sh); 0 = the product
-#endif
-#ifndef MP_FLAGX
-#define MP_FLAGX 3        // bit 0: flagged hand-off in the four-wave 8-slice kernels, bit 1: in the 16-slice kernels (A/B builds)
-#endif
-#ifndef MP_TAGX
-#define MP_TAGX 1         // 1: those kernels exchange TAGGED words -- no flag, one L2 round trip per step ("TAGX" in the kernel body);
-#endif                    // 0: the flags of rounds 2-4 (A/B builds: the results are bit-identical)
-
 namespace {
 
 // granule index of (row, hidden unit j) inside one [16][H] slab-parity block
 __device__ __forceinline__ int granule_index(int row, int j) { return (((j >> 2) * 16 + row) << 2) + (j & 3); }
 
-// Wave layout: 4*TW waves.  Wave w takes K quarter kq = w & 3 of both GEMM parts and tile group tw = w >> 2:
-//   TW = 1  : every wave computes all 4*NUB gate tiles                          (H = 64:  4 waves)
-//   TW = NUB: wave (kq, tw) computes the 4 gate tiles of unit block ub = tw     (H = 256: 8 waves, 2 per SIMD,
-//             so no wave needs more than 256 registers and the MFMA pipe always has a second wave to issue)
-template <int H, int NSLICE, int KIN, int TW>
+// Wave layout: four waves, one per SIMD.  Wave kq takes K quarter kq of both GEMM parts and computes all 4 * NUB gate tiles.
+// (Rounds 1-4 also had an eight-wave layout, two waves per SIMD with <= 256 registers each; the four-wave kernels with
+//  AccVGPR-resident weights replaced it in round 3 and it was removed in round 5 -- git has it.)
+template <int H, int NSLICE, int KIN>
 struct Cfg {
-    static constexpr int U = H / NSLICE;              // hidden units per workgroup (32 | 64)
-    static constexpr int NUB = U / 16;                // 16-unit blocks per workgroup (2 | 4)
-    static constexpr int NWV = 4 * TW;                // waves per workgroup
-    static constexpr int NTW = 4 * NUB / TW;          // MFMA tiles per wave
+    static constexpr int U = H / NSLICE;              // hidden units per workgroup (16 | 32)
+    static constexpr int NUB = U / 16;                // 16-unit blocks per workgroup (1 | 2)
+    static constexpr int NWV = 4;                     // waves per workgroup
+    static constexpr int NTW = 4 * NUB;               // MFMA tiles per wave
     static constexpr int NTG = NTW / 4;               // 16-byte groups of 4 tiles per wave
     static constexpr int KW = H / 4;                  // h: K range of one wave (64 | 16)
     static constexpr int NKS = KW / 4;                // h: k-steps per wave (16 | 4)
     static constexpr int KQ = KIN / 4;                // x: K range of one wave
     static constexpr int NXS = KQ / 4;                // x: k-steps per wave
     static constexpr int NXJ = KQ / 16;               // x: 16-byte loads per lane per step
-    // PER_UB: every wave's tiles are the 4 gates of ONE unit block -> finishing wave (kq, tw) takes accumulator
-    // reg kq of unit block tw; otherwise (TW = 1, several unit blocks per wave) a wave finishes NOWN regs of one block
-    static constexpr bool PER_UB = TW == NUB;
-    static constexpr int NOWN = PER_UB ? 1 : (NUB == 2 ? 2 : 4);
+    // PER_UB (one unit block per workgroup): finishing wave kq takes accumulator reg kq of every gate tile; otherwise
+    // (two unit blocks) a wave finishes NOWN regs of one block
+    static constexpr bool PER_UB = NUB == 1;
+    static constexpr int NOWN = PER_UB ? 1 : 2;
     static constexpr int NPW = NSLICE >= 4 ? NSLICE / 4 : 1;   // producer slices inside one wave's K quarter
     static constexpr int RED_F4 = NWV * 4 * NOWN * 64;   // float4 slots: [finishing wave][source kq][o][lane]
     // LDS budget 160 KB: reduction scratch + as many x k-steps of W_ih as fit; the rest lives in registers
     static constexpr int STEP_BYTES = NWV * NTG * 64 * 16;                     // all waves, one k-step
-    static constexpr int LDS_BUDGET = (NWV == 4 && NSLICE == 16) ? 80 * 1024 : 160 * 1024;   // 2 workgroups per CU
+    static constexpr int LDS_BUDGET = NSLICE == 16 ? 80 * 1024 : 160 * 1024;   // 2 workgroups per CU
     static constexpr int LDS_STEPS_MAX = (LDS_BUDGET - RED_F4 * 16) / STEP_BYTES;
     // (four-wave 8-slice configuration, K_in = 256: ALL of W_ih fits the AccVGPRs beside W_hh -- no weight comes from LDS)
-    static constexpr bool ALLREG = H == 256 && NSLICE == 8 && TW == 1 && KIN == 256;
+    static constexpr bool ALLREG = H == 256 && NSLICE == 8 && KIN == 256;
     static constexpr int XL = ALLREG ? 0 : (NXS <= LDS_STEPS_MAX ? NXS : (LDS_STEPS_MAX / 4) * 4);  // x k-steps served from LDS
     static constexpr int XR = NXS - XL;                                        // x k-steps served from registers
     static constexpr bool BIG = KIN > H;              // part of W_ih in registers: late gather, split x prefetch
-    static constexpr int WG_PER_CU = NWV == 4 && NSLICE == 16 ? 2 : 1;         // co-resident workgroups wanted
-    static_assert(TW == 1 || TW == NUB, "tile groups are whole unit blocks");
+    static constexpr int WG_PER_CU = NSLICE == 16 ? 2 : 1;                     // co-resident workgroups wanted
+    static_assert(NUB == 1 || NUB == 2, "16 or 32 hidden units per workgroup");
 };
 
 // WREG configuration (H = 256, 8 slices, FOUR waves with up to 512 registers each instead of eight with 256): the
@@ -115,32 +104,24 @@ __device__ __forceinline__ void mfma_drain() {
 // the same flags.  Why: run as a kernel of its own beside this one, the H = 64 layer and this layer slow each other on every
 // shared SIMD (profiles/r03_class_times.txt: 335 -> 398 us and 180 -> 450 us per layer); inside these waves it costs its
 // instructions and nothing else.
-template <int H, int NSLICE, int KIN, int TW, bool PROF, int FK = 0>
-MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_CU)) void mp_lstm_fused(LstmPersistArgs a) {
+template <int H, int NSLICE, int KIN, bool PROF, int FK = 0>
+MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void mp_lstm_fused(LstmPersistArgs a) {
     // test hook (mp_debug_drop_workgroup): a workgroup that never shows up.  Only in the PROF instantiation, which the launcher
     // picks when the hook is armed -- the product kernels carry no test code (round 4)
     if (PROF && a.debug_drop && (int)blockIdx.x == a.debug_drop - 1) return;
     const long long tl_entry = PROF ? (long long)__builtin_amdgcn_s_memrealtime() : 0;   // (PROF: launch timeline, 100 MHz)
-    using C = Cfg<H, NSLICE, KIN, TW>;
-    constexpr bool WREG = H == 256 && NSLICE == 8 && TW == 1;
+    using C = Cfg<H, NSLICE, KIN>;
+    constexpr bool WREG = H == 256 && NSLICE == 8;
     constexpr int U = C::U, NUB = C::NUB, NWV = C::NWV, NTW = C::NTW, NTG = C::NTG, KW = C::KW, NKS = C::NKS, KQ = C::KQ;
     // (FK: one workgroup per CU and 512 registers per lane to spend: the W_ih slice lives in registers, not in LDS)
     constexpr int NXS = C::NXS, NXJ = C::NXJ, NOWN = C::NOWN, XL = FK ? 0 : C::XL, XR = NXS - XL, NPW = C::NPW;
     constexpr bool PER_UB = C::PER_UB;
-    constexpr bool FLAGX = (WREG && (MP_FLAGX & 1)) || (H == 256 && NSLICE == 16 && TW == 1 && (MP_FLAGX & 2));   // flagged hand-off (below)
-    constexpr bool TAGX = FLAGX && (MP_TAGX != 0);                     // ... without the flags: every word carries a tag (below)
-    constexpr int NP = NKS / 4 > 0 ? NKS / 4 : 1;                     // FLAGX: 16-byte pieces of h per lane (4 k-steps each)
-    constexpr int PPP = NP / NPW > 0 ? NP / NPW : 1;                  //        pieces per producer slice
-    // FLAGX: k-steps of the projection in front of the flag request / of the flag check + value request.  One k-step is
-    // 256 cycles in the 8-slice kernels and 128 in the 16-slice ones, whose 16-step projection has to cover three memory
-    // round trips (the producer's store acknowledgement, the flag, the values) -- everything sits as late as it can there.
-#if MP_EXP >= 1000000      // timing experiment: 1PPRRXX = (PUB_S, REQ_S, XSPLIT) of the 16-slice kernels
-    constexpr int PUB16 = (MP_EXP / 10000) % 100, REQ16 = (MP_EXP / 100) % 100, XS16 = MP_EXP % 100, XT16 = MP_EXP % 100;
-#else
-    constexpr int PUB16 = 1, REQ16 = 6, XS16 = 11, XT16 = 8;
-#endif
-    constexpr int REQ_S = (!WREG && NXS == 16) ? REQ16 : NXS / 4;
-    constexpr int XSPLIT = (FLAGX && !WREG && NXS == 16) ? (TAGX ? XT16 : XS16) : NXS / 2;
+    constexpr bool TAGX = H == 256;                                   // plain words with a tag in bit 30 (below); H = 64: granules
+    constexpr int NP = NKS / 4 > 0 ? NKS / 4 : 1;                     // TAGX: 16-byte pieces of h per lane (4 k-steps each)
+    constexpr int PPP = NP / NPW > 0 ? NP / NPW : 1;                  //       pieces per producer slice
+    // k-steps of the projection in front of the request for h_{t-1}: half of them (one k-step is 256 cycles in the 8-slice
+    // kernels and 128 in the 16-slice ones)
+    constexpr int XSPLIT = NXS / 2;
     constexpr int NTHREADS = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* red = reinterpret_cast<f32x4*>(smem);                       // [finishing wave][source kq][o][lane]
@@ -160,7 +141,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
     const int dir = cl / a.nslab, slab = cl % a.nslab;
     const LstmDir d = a.d[dir];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int kq = wave & 3, tw = wave >> 2;
+    const int kq = wave;
     const int q = lane >> 4, r16 = lane & 15;
     const int B = a.B, T = a.T;
     const int brow0 = (a.slab0 + slab) * 16;
@@ -213,8 +194,8 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
     }
 
     // ---- the (sequence, unit) pairs this lane finishes: accumulator regs of tile column r16
-    const int ubo = PER_UB ? tw : (NUB == 2 ? (kq & 1) : kq);              // unit block this wave finishes
-    const int reg0 = PER_UB ? kq : (NUB == 2 ? 2 * (kq >> 1) : 0);         // first accumulator reg it finishes
+    const int ubo = PER_UB ? 0 : (kq & 1);                                 // unit block this wave finishes
+    const int reg0 = PER_UB ? kq : 2 * (kq >> 1);                          // first accumulator reg it finishes
     const int jown = slice * U + ubo * 16 + r16;                           // hidden unit
     const f32x4 bias4 = *reinterpret_cast<const f32x4*>(d.bias + 4 * jown);
     float cst[NOWN], hst[NOWN];
@@ -253,22 +234,16 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
     u64* hxL = a.hx + (size_t)cl * SLABW;
     u64* hxR = hxL + (size_t)2 * 16 * H;
     u64* xtab = hxL + (size_t)4 * 16 * H;
-    // FLAGX (the four-wave 8-slice kernels): the same area holds plain 4-byte words h[parity][16 * H] for both transports
-    // and ONE flag word per (parity, producer slice, producer wave) instead of a tag in every granule.  A producer wave
-    // stores its values, waits until they are acknowledged (s_waitcnt vmcnt(0) -- under the first projection MFMAs of the
-    // next step, so nobody sits in that wait) and then stores epoch_base + step + 1 into its flag; a consumer wave reads
-    // the 8 flags of the two slices its K quarter comes from a quarter of the way through the projection, checks them half
-    // way (ONE compare; stale -> bounded poll) and only then requests the values: 4 x 16 bytes per lane instead of 16 x 8,
-    // nothing to validate afterwards.  Measured on the granule form (profiles/r02_flagx.md): the 16 requests cost 700
+    // TAGX (the H = 256 kernels): the same area holds plain 4-byte words h[parity][16 * H] for both transports: 4 x 16 bytes
+    // per lane and step instead of 16 x 8 (measured on the granule form, profiles/r02_flagx.md: the 16 requests cost 700
     // cycles of issue inside the projection and their 16 compare / s_and pairs 600 cycles, while the words themselves were
-    // ALWAYS there at the first look -- the hand-off latency was never the problem, its instruction count was.
+    // ALWAYS there at the first look -- the hand-off latency was never the problem, its instruction count was).
     // Word (row, unit j) sits where consumer lane (q = j & 3, row) finds k-steps 4i .. 4i+3 of its K quarter in one
     // 16-byte piece:  (((j >> 6) * 4 + ((j & 63) >> 4)) * 64 + (j & 3) * 16 + row) * 4 + ((j >> 2) & 3).
-    // TAGX (round 4, the product): the same words WITHOUT the flags.  Measured with the flags (tools/debug/prof_xproj.py,
-    // profiles/r04_handoff.md): a step's hand-off was a chain of two dependent L2 round trips -- flag, then values -- behind
-    // the producer's store acknowledgement, ~3 400 cycles that the 16-slice kernels' 2 300 cycles of projection MFMAs cannot
-    // cover (the wave sat ~1 100 cycles per step, whatever the three request points were set to) and the 8-slice kernels'
-    // 4 100 only just (~470).  Every word now carries a tag in bit 30 -- the top exponent bit, 0 for every |h| < 2, and
+    // Rounds 2-4 signalled these words with one flag per (parity, producer slice, producer wave) -- a chain of two dependent
+    // L2 round trips per step, flag then values, behind the producer's store acknowledgement: ~3 400 cycles that the 16-slice
+    // kernels' 2 300 cycles of projection MFMAs could not cover (profiles/r04_handoff.md; the flagged form was removed in round
+    // 5 -- git has it).  Since round 4 every word carries a tag in bit 30 -- the top exponent bit, 0 for every |h| < 2, and
     // h = o * tanh(c) never leaves [-1, 1] -- that alternates with every write to its parity slot: the consumer requests the
     // 16-byte pieces ONCE, half-way through the projection, and at the end ORs all 16 (+4) words -- after an XOR that clears
     // the tag on the steps that expect a set one: bit 30 of the result is set exactly when a word was stale (then: bounded
@@ -282,9 +257,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
     // longer turn NaN through the recurrence (a poisoned wave's cells are NaN for all 16 rows of the slab: same effect).
     // Which tag a launch starts with: LstmPersistArgs::tag_flip.
     unsigned* hdL = reinterpret_cast<unsigned*>(hxL);                 // [2 parities][16 * H]
-    unsigned* hfL = hdL + (size_t)4 * 16 * H;                         // flags: L [2][NSLICE * 4], then R [2][NSLICE * 4]
     constexpr unsigned HD_R = 2 * 16 * H * 4;                         // byte offset of the R copy of the values
-    constexpr unsigned HF_R = 2 * NSLICE * 4;                         // word offset of the R flags
     unsigned spin_budget = a.max_spin;
     // TAGX: tag of the h words written at `step` = -1 (the initial state, published before the loop: step 0 is a step like
     // any other), 0, 1, ...: the ((step + 1) / 2)-th write of this launch to parity slot step & 1
@@ -323,7 +296,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
 #pragma unroll
         for (int i = 0; i < NPW; ++i) src_local[i] = (same >> (NPW * kq + i)) & 1;   // k-steps of part i come from slice NPW*kq+i
         if (__ballot(peer == ~0u)) { spin_budget = 0; poison_cells(cst); fcst = __builtin_nanf(""); }
-        if (a.force_remote) {                               // test hook: exercise the any-placement transport
+        if (PROF && a.force_remote) {                       // test hook (PROF instantiation only): the any-placement transport
             all_local = false;
             same_xcd = 0;
 #pragma unroll
@@ -331,21 +304,14 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
         }
     }
 
-    // ---- FLAGX: consumer offsets (piece i comes from producer slice NPW*kq + i/PPP), flag pointer, store slots
+    // ---- TAGX: consumer offsets (piece i comes from producer slice NPW*kq + i/PPP), store slots
     __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(hdL, 0, 4 * 16 * H * 4, 0x00020000);
     unsigned hvoff[NP];
-    const unsigned* hflag = hfL;
     unsigned hslot[NOWN];
     f32x4 hr[NP];                                                      // recurrent A operand: k-steps 4i .. 4i+3 in hr[i]
-    unsigned hflags = 0;
-    if (FLAGX) {
+    if (TAGX) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) hvoff[i] = (src_local[(i / PPP) % NPW] ? 0u : HD_R) + (unsigned)(((kq * NP + i) * 64 + lane) * 16);
-        // (lane l watches wave l & 3 of producer slice NPW*kq + (l >> 2) % NPW: 4 * NPW flags, the other lanes see copies)
-        bool fl_local = src_local[0];
-#pragma unroll
-        for (int i = 1; i < NPW; ++i) fl_local = (((lane >> 2) & (NPW - 1)) == i) ? src_local[i] : fl_local;
-        hflag = hfL + (fl_local ? 0 : HF_R) + 4 * NPW * kq + (lane & (4 * NPW - 1));
 #pragma unroll
         for (int o = 0; o < NOWN; ++o) {
             const int row = q * 4 + reg0 + o;
@@ -359,7 +325,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
     // (x-step i < FNX), h k = kq*16 + 4*ks + q (ks < 4).  Exchange words of the rider: [transport][parity][direction][1024]
     // behind the flags of this cluster's area; word (row, unit u) at ((u/16*4 + u%4)*16 + row)*4 + (u/4)%4, so that consumer
     // lane (kq, q, row) finds its four k-steps in one 16-byte piece.  Producers of a piece: slices 8*dir + 2*kq (+1).
-    static_assert(FK == 0 || (H == 256 && NSLICE == 16 && KIN == 256 && TW == 1 && FLAGX), "the rider lives in the 16-slice velocity kernel");
+    static_assert(FK == 0 || (H == 256 && NSLICE == 16 && KIN == 256), "the rider lives in the 16-slice velocity kernel");
     constexpr int FNX = FK / 16, FNS = FNX + 4, FNJ = FK / 64;
     constexpr unsigned F_WORD0 = 4 * 16 * H + 1024;                  // first rider word of the cluster's area
     constexpr unsigned F_TR = 2 * 2 * 1024;                           // words per transport
@@ -384,11 +350,6 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
         const int fs0 = fdir * 8 + 2 * kq;                             // producer slices of this wave's piece
         const bool floc = ((same_xcd >> fs0) & 1) && ((same_xcd >> (fs0 + 1)) & 1);
         fvoff = (floc ? 0u : F_TR * 4u) + (unsigned)fdir * 4096u + (unsigned)(((kq * 4 + q) * 16 + r16) * 16);
-        // lanes 16..23 watch the flags of those two slices' four waves (lanes 0..15: this layer's own producers)
-        if (lane >= 16 && lane < 24) {
-            const int fs = fs0 + ((lane - 16) >> 2);
-            hflag = hfL + (((same_xcd >> fs) & 1) ? 0 : HF_R) + 4 * fs + (lane & 3);
-        }
         fxt = (size_t)B * FK;
         fxp_cur = a.f_xin + (size_t)(arow_in ? arow : 0) * FK + kq * (FK / 4) + q * 4 + (size_t)(fdir && alen > 0 ? alen - 1 : 0) * fxt;
         fxp_nxt = fxp_cur;
@@ -432,7 +393,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
     // granules: the second half of x_t is then fetched at the top of step t (it is first used ~2000 cycles later).
     constexpr bool SPLIT_X = C::BIG && H == 256;            // (H = 64: registers to spare -- the whole row one step ahead)
     constexpr int XJ_PRE = SPLIT_X ? NXJ / 2 : NXJ;        // 16-byte pieces prefetched one step ahead
-    // LEAN (one wave per SIMD: the 16-slice / 4-wave and the H = 64 configurations): VALU instructions do not hide under
+    // LEAN (one wave per SIMD -- every configuration since round 5): VALU instructions do not hide under
     // MFMAs on this hardware (profiles/r02_persist_phases.md) and a lone wave has nobody to cover them, so the step is put on
     // a VALU diet -- (1) x_t of this lane's row is read UNCONDITIONALLY from a clamped time index (a row past its length
     // multiplies whatever finite values it finds there: row r of the A operand only reaches row r of the gates, and an
@@ -440,9 +401,8 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
     // a pointer that is stepped, not re-multiplied: forward t = min(step, T-1), reverse t = max(len-1-step, 0); (2) the
     // granules are requested on every step and feed the recurrent MFMAs straight from their low words (a load under a
     // branch made `gr` a phi of defined / undefined values: 60-80 v_mov per step).  Measured, same box: velocity layers
-    // 577 -> 504-513 us, foot-contact layers 426-440 -> 408-414 us.  The two-waves-per-SIMD kernels keep the old code:
-    // there the same source changes made the K_in = 512 layer 12 % SLOWER (register allocation at the 256-VGPR limit).
-    constexpr bool LEAN = TW == 1;
+    // 577 -> 504-513 us, foot-contact layers 426-440 -> 408-414 us.
+    constexpr bool LEAN = true;
     const float* xp_cur = xbase + (size_t)(d.reverse ? (alen > 0 ? alen - 1 : 0) : 0) * xtstride;   // time index of `step`
     const float* xp_nxt = xp_cur;                                                                  // ... of `step + 1`
     auto load_x = [&](int step, int j0, int j1) {
@@ -472,25 +432,16 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
     const long long tl_loop = PROF ? (long long)__builtin_amdgcn_s_memrealtime() : 0;   // first step starts
     const bool prof = PROF && a.prof != nullptr && threadIdx.x == 0;
     const long long t_start = PROF ? (long long)__builtin_amdgcn_s_memtime() : 0;
-#if MP_EXP == 7           // timing experiment: the five counters split the projection phase instead of the step
-#define PROF_T(i) do { } while (0)
-#define PROF_E(i) do { } while (0)
-#define SUB_T(i) do { if (PROF && prof) pt[i] -= (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#define SUB_E(i) do { if (PROF && prof) pt[i] += (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
 #define PROF_T(i) do { if (PROF && prof) pt[i] -= (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #define PROF_E(i) do { if (PROF && prof) pt[i] += (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#define SUB_T(i) do { } while (0)
-#define SUB_E(i) do { } while (0)
-#endif
 
     const f32x4* wxw = wxl + (size_t)wave * XL * NTG * 64 + lane;
 
     for (int step = 0; step < T; ++step) {
-        PROF_T(0); SUB_T(0);
+        PROF_T(0);
         if (LEAN) xp_cur = xp_nxt;
         if (FK) fxp_cur = fxp_nxt;
-        if (SPLIT_X && !FLAGX) load_x(step, XJ_PRE, NXJ);
+        if (SPLIT_X && !TAGX) load_x(step, XJ_PRE, NXJ);
         f32x4 acc[NTW];
         if (!WREG) {                                           // (WREG: the first MFMA of every tile has C = 0)
 #pragma unroll
@@ -525,30 +476,17 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tg = 0; tg < NTG; ++tg) wl[tg] = wn[tg];
-            if (FLAGX) {
-                constexpr int PUB_S = (!WREG && NXS == 16) ? PUB16 : 1;
+            if (TAGX) {
+                constexpr int PUB_S = 1;
                 if (s == PUB_S) {
-                    // the values this wave stored at the end of step-1 have had two k-steps of MFMAs to be acknowledged:
-                    // wait for them, then raise the flag (parity of step-1 = the parity this step reads)
-                    if (!TAGX && step > 0) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        if (lane == 0) {
-                            unsigned* f = hfL + ((step + 1) & 1) * (NSLICE * 4) + slice * 4 + wave;
-                            __hip_atomic_store(f, a.epoch_base + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (!all_local) __hip_atomic_store(f + HF_R, a.epoch_base + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
-                    if (SPLIT_X) load_x(step, XJ_PRE, NXJ);          // (behind the wait above, not in front of it)
-                    SUB_E(0); SUB_T(1);
+                    if (SPLIT_X) load_x(step, XJ_PRE, NXJ);          // (second half of a K_in = 512 row: first used 14 k-steps on)
                 }
-                if (!TAGX && s == REQ_S) hflags = __hip_atomic_load(hflag + ((step + 1) & 1) * (NSLICE * 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 
         // ---- FK: the rider's input projection (independent of h: it lengthens the window that hides the hand-off)
         f32x4 facc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        SUB_E(1); SUB_T(2);
         auto rider_xproj = [&]() {
 #pragma unroll
             for (int i = 0; i < FNX; ++i) {
@@ -558,10 +496,9 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-        if (FK && !TAGX) rider_xproj();            // (TAGX: behind the request below -- it is part of what hides the round trip)
+        // (the rider's projection sits behind the request below -- it is part of what hides the round trip)
 
         // ---- request h_{step-1}: granule (row r16, unit kq*KW + 4*ks + q), 512 contiguous bytes per instruction
-        SUB_E(2); SUB_T(3);
         u64 gr[NKS];
         const unsigned epoch = a.epoch_base + (unsigned)step;  // written by the producers at the end of step-1
         const size_t goff = (size_t)((step + 1) & 1) * 16 * H + (size_t)kq * NKS * 64 + r16 * 4 + q;
@@ -573,28 +510,14 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
         //  request them after the projection instead; the second wave on the SIMD covers the L2 latency)
         constexpr bool EARLY_GATHER = !C::BIG || WREG;         // (WREG: 512 registers per wave -- room for the granules)
         // (LEAN: requested on EVERY step, step 0 included -- there the words are simply not looked at)
-        if (FLAGX) {
+        if (TAGX) {
             // every piece of x_t has been requested long ago (the previous step's prefetch; the second half of a K_in = 512
             // row 14 k-steps ago): have the compiler wait for them HERE -- its own placement, piece by piece inside the rest
             // of the projection with counts that assume nothing younger is in flight, would also wait for the h words
             // requested just below (measured in the K_in = 256 kernel: a full L2 round trip per step)
 #pragma unroll
             for (int j = 0; j < NXJ; ++j) asm volatile("" : "+v"(xa[j]));
-            if (TAGX || step > 0) {
-                if (!TAGX) {
-                bool ok = hflags == epoch;
-                unsigned spins = 0; u64 wt0 = 0;
-                if (PROF && prof && !__all(ok)) pt[5] += 1;  // slow-path entries
-                while (!__all(ok)) {
-                    if (wait_over(spins, spin_budget, wt0, a.max_ticks)) {               // bounded: flag the error and never wait again
-                        if (lane == 0) mp_set_error(a.err, 1 + step);
-                        spin_budget = 0; poison_cells(cst); fcst = __builtin_nanf("");
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                    ok = __hip_atomic_load(hflag + ((step + 1) & 1) * (NSLICE * 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
-                }
-                }
+            {
                 const int par_off = ((step + 1) & 1) * (16 * H * 4);
 #pragma unroll
                 for (int i = 0; i < NP; ++i)
@@ -605,9 +528,8 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) gr[ks] = granule_load(srcp[ks / KSP] + (size_t)ks * 64);
         }
-        if (FK && TAGX) rider_xproj();
+        if (FK) rider_xproj();
         // ---- second half of the input projection
-        SUB_E(3); SUB_T(4);
 #pragma unroll
         for (int s = XSPLIT; s < NXS; ++s) {
             const float a_s = xa[s >> 2][s & 3];
@@ -632,19 +554,19 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
 #pragma unroll
             for (int tg = 0; tg < NTG; ++tg) wl[tg] = wn[tg];
         }
-        PROF_E(0); PROF_T(1); SUB_E(4);
+        PROF_E(0); PROF_T(1);
 
         // ---- validate the granules; the slow path (cheap gate, then sweep) only runs when some were stale
         // (K_in = 512: the registers are full -- the words are requested only now and only when they are needed, and the
         //  recurrent A operand is extracted into 16 registers so that the 32 of `gr` die before the MFMAs)
-        constexpr bool DIRECT_GR = EARLY_GATHER && LEAN && !FLAGX;   // recurrent MFMAs read the low words of `gr` directly
-        if (FLAGX) {
+        constexpr bool DIRECT_GR = EARLY_GATHER && LEAN && !TAGX;    // recurrent MFMAs read the low words of `gr` directly
+        if (TAGX) {
             // the values were requested half a projection ago: make the compiler wait for them HERE, before the prefetch
             // of x_{t+1} below is issued (a wait placed after it would also drain those HBM loads)
 #pragma unroll
             for (int i = 0; i < NP; ++i) asm volatile("" : "+v"(hr[i]));
             if (FK) asm volatile("" : "+v"(fhr));
-            if (TAGX) {
+            {
                 // clear the expected tag, OR what is left: bit 30 set = some word is not (yet) the one of step - 1.  ONE copy of
                 // this code, in a loop whose body normally runs once (the re-request at its bottom writes the same registers:
                 // no phi copies -- the first version, with a separate slow path, cost 30-40 v_mov per step)
@@ -760,7 +682,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
         // (profiles/r04_handoff.md): reduction phase 725 -> 390 cycles, recurrent phase 4 252 -> 4 440 (the writes are not free),
         // launch 551 -> 546 us; in the K_in = 512 kernel (LDS full: one copy of the scratch, the barrier stays) the same change
         // moved the phases but not the launch time (783.7 vs 783.5 us), so it keeps the old form.
-        constexpr bool RED3 = WREG && C::ALLREG && !PER_UB && NUB == 2 && NOWN == 2 && NKS >= 8 && FLAGX;
+        constexpr bool RED3 = WREG && C::ALLREG && !PER_UB && NUB == 2 && NOWN == 2 && NKS >= 8 && TAGX;
         // (K_in = 256: all weights in registers, LDS to spare -- two copies of the scratch, used in turn, and the barrier that
         //  protects the previous step's reads is not needed at all: whoever writes copy s & 1 has passed the barrier of step
         //  s - 1, which every wave reaches only after its reads of step s - 2)
@@ -772,7 +694,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
         for (int ks = 0; ks < (RED3 ? NKS - 4 : NKS); ++ks)
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
-                const float a_h = FLAGX ? hr[(ks >> 2) % NP][ks & 3] : DIRECT_GR ? __uint_as_float((unsigned)gr[ks]) : av[ks];
+                const float a_h = TAGX ? hr[(ks >> 2) % NP][ks & 3] : DIRECT_GR ? __uint_as_float((unsigned)gr[ks]) : av[ks];
                 if (WREG) mfma_asm<false, true>(acc[t], a_h, wv[ks][t]);
                 else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_h, wv[ks][t], acc[t], 0, 0, 0);
             }
@@ -823,8 +745,8 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
         } else if (!PER_UB) {
 #pragma unroll
             for (int dw = 0; dw < 4; ++dw) {
-                const int dub = NUB == 2 ? (dw & 1) : dw;
-                const int dreg0 = NUB == 2 ? 2 * (dw >> 1) : 0;
+                const int dub = dw & 1;
+                const int dreg0 = 2 * (dw >> 1);
 #pragma unroll
                 for (int o = 0; o < NOWN; ++o)
                     red[((dw * 4 + kq) * NOWN + o) * 64 + lane] =
@@ -833,8 +755,8 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
             }
         } else {
 #pragma unroll
-            for (int dk = 0; dk < 4; ++dk)                     // finishing wave (dk, tw) takes accumulator reg dk
-                red[(((tw * 4 + dk) * 4 + kq)) * 64 + lane] =
+            for (int dk = 0; dk < 4; ++dk)                     // finishing wave dk takes accumulator reg dk
+                red[((dk * 4 + kq)) * 64 + lane] =
                     f32x4{acc[0][dk], acc[1 % NTW][dk], acc[2 % NTW][dk], acc[3 % NTW][dk]};
         }
         __syncthreads();
@@ -880,7 +802,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
 #pragma unroll
         for (int j = 0; j < XJ_PRE; ++j) asm volatile("" : "+v"(xa[j]));
         const size_t doff = (size_t)(step & 1) * 16 * H;
-        if (WREG && FLAGX) {
+        if (WREG) {
             // two cells per lane: both are computed first, branch-free (an inactive row's gates are whatever its clamped input
             // row gives -- finite or not, they are never kept), and all stores follow -- one basic block, so the scheduler
             // interleaves the two dependent exp / rcp chains instead of running them one after the other
@@ -960,7 +882,7 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
                 hst[o] = og * tanhf_(cst[o]);
                 oval = hst[o];
             }
-            if (FLAGX) {   // plain words; this wave's flag follows at the top of the next step
+            if (TAGX) {
                 unsigned* hw = hdL + (size_t)(step & 1) * 16 * H + hslot[o];
                 const unsigned hword = hword_of(hst[o], step);
                 __hip_atomic_store(hw, hword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -994,259 +916,32 @@ MP_KERNEL __launch_bounds__(256 * TW, (FK ? 1 : Cfg<H, NSLICE, KIN, TW>::WG_PER_
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Two stacked UNIDIRECTIONAL layers in one launch (the velocity block, models/velocity.py:29: nn.LSTM(256, 256,
-// 2 layers)).  Layer 1 at time t needs only h0_t, so the layers form a wavefront: at step s a workgroup
-// advances layer 0 to time s and layer 1 to time s-1.  h0_{s-1}, which is exchanged anyway for layer 0's
-// recurrence, IS layer 1's input x1_{s-1}.  T+1 steps instead of 2T, twice the MFMA work per step (the two
-// layers cover each other's latencies on every SIMD), no layer-0 output round trip through HBM, one launch.
-// 16 slices x 16 units; 8 waves: wave (kq, layer) takes K quarter kq of layer `layer` (2 waves per SIMD, <= 256
-// VGPRs each).  W_hh0 / W_hh1 in VGPRs, W_ih0 / W_ih1 as two 64 KB LDS images, 32 KB reduction scratch = 160 KB.
-// d[0] / d[1] describe layer 0 / layer 1.
-template <int H>
-MP_KERNEL __launch_bounds__(512, 1) void mp_lstm_fused_uni2(LstmPersistArgs a) {
-    if (a.debug_drop && (int)blockIdx.x == a.debug_drop - 1) return;      // test hook: a workgroup that never shows up
-    constexpr int NSLICE = 16, U = 16, KW = H / 4, NKS = KW / 4, KQ = H / 4, NXS = KQ / 4, NXJ = KQ / 16, NPW = 4;
-    constexpr int KSP = NKS / NPW;
-    constexpr int IMG_F4 = 4 * NXS * 64;                                // one W_ih LDS image, in float4
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    f32x4* red = reinterpret_cast<f32x4*>(smem);                        // [layer][finishing wave][source kq][lane]
-    f32x4* wximg = reinterpret_cast<f32x4*>(smem) + 2 * 4 * 4 * 64;     // [layer][wave kq][k-step][lane]
 
-    const int ncl = a.nslab;
-    const int slab = ((int)(blockIdx.x >> 3) / NSLICE) * 8 + (int)(blockIdx.x & 7);     // same block -> XCD trick as above
-    const int slice = (int)(blockIdx.x >> 3) % NSLICE;
-    if (slab >= ncl) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int kq = wave & 3, layer = wave >> 2;
-    const LstmDir d = a.d[layer];
-    const int q = lane >> 4, r16 = lane & 15;
-    const int B = a.B, T = a.T;
-    const int brow0 = (a.slab0 + slab) * 16;
-
-    {   // LDS images (the k-steps of a slice's 4 K-quarter waves are contiguous in the packed arrays)
-        const f32x4* s0 = reinterpret_cast<const f32x4*>(a.d[0].wihpack) + (size_t)slice * IMG_F4;
-        const f32x4* s1 = reinterpret_cast<const f32x4*>(a.d[1].wihpack) + (size_t)slice * IMG_F4;
-        for (int i = threadIdx.x; i < IMG_F4; i += 512) { wximg[i] = s0[i]; wximg[IMG_F4 + i] = s1[i]; }
-    }
-    float wv[NKS][4];
-    {
-        const float* p = d.wpack + ((size_t)(slice * 4 + kq) * NKS * 4) * 64 + lane;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) wv[ks][t] = p[(size_t)(ks * 4 + t) * 64];
-    }
-
-    // the (sequence, unit) this lane finishes in its layer: accumulator reg kq of tile column r16
-    const int jown = slice * U + r16;
-    const int bown = brow0 + q * 4 + kq;
-    const bool inb = bown < B;
-    const int blen = inb ? a.lengths[bown] : 0;
-    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(d.bias + 4 * jown);
-    float cst = (inb && !a.zero_state) ? d.cbuf[(size_t)bown * H + jown] : 0.f;
-    float hst = (inb && !a.zero_state) ? d.hbuf[(size_t)bown * H + jown] : 0.f;
-
-    const int arow = brow0 + r16;
-    const bool arow_in = arow < B;
-    const int alen = arow_in ? a.lengths[arow] : 0;
-    const float* xbase = a.d[0].xin + (size_t)(arow_in ? arow : 0) * H + kq * KQ + q * 4;
-    const size_t xtstride = (size_t)B * H;
-    // A operands at step 0: h0_init for the layer-0 recurrence; layer 1 is idle at step 0 (its inputs are zeroed)
-    float av[NKS];
-    {
-        const float* p = d.hbuf + (size_t)(arow_in ? arow : 0) * H + kq * KW + q;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) av[ks] = (arow_in && !a.zero_state) ? p[4 * ks] : 0.f;
-    }
-
-    constexpr size_t SLABW = (size_t)4 * 16 * H + 16;
-    u64* hx0L = a.hx + (size_t)slab * SLABW;                 // layer 0: cluster index = slab
-    u64* hx1L = a.hx + (size_t)(a.nslab + slab) * SLABW;     // layer 1: cluster index = nslab + slab
-    u64* hx0R = hx0L + (size_t)2 * 16 * H;
-    u64* hx1R = hx1L + (size_t)2 * 16 * H;
-    u64* hxoL = layer ? hx1L : hx0L;                         // where this wave publishes
-    u64* hxoR = layer ? hx1R : hx0R;
-    u64* xtab = hx0L + (size_t)4 * 16 * H;
-    unsigned spin_budget = a.max_spin;
-    const unsigned my_xcc = xcc_id();
-    bool src_local[NPW];
-    bool all_local = true;
-    {
-        if (threadIdx.x == 0) granule_store(xtab + slice, XCC_TAG, __uint_as_float(my_xcc));
-        unsigned peer = my_xcc;
-        if (lane < NSLICE) {
-            unsigned spins = 0; u64 wt0 = 0;
-            while (true) {
-                const u64 g = granule_load(xtab + lane);
-                if ((unsigned)(g >> 32) == XCC_TAG) { peer = (unsigned)g; break; }
-                if (wait_over(spins, spin_budget, wt0, a.max_ticks)) { mp_set_error(a.err, 1000000); peer = ~0u; break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        const unsigned long long same = __ballot(peer == my_xcc);
-        all_local = (same & 0xFFFFull) == 0xFFFFull;
-#pragma unroll
-        for (int i = 0; i < NPW; ++i) src_local[i] = (same >> (NPW * kq + i)) & 1;
-        if (__ballot(peer == ~0u)) { spin_budget = 0; poison_cells(cst); }
-        if (a.force_remote) {
-            all_local = false;
-#pragma unroll
-            for (int i = 0; i < NPW; ++i) src_local[i] = false;
-        }
-    }
-
-    f32x4 xa[NXJ];
-    auto load_x = [&](int step) {
-        const bool on = layer == 0 && step < alen;
-        const float* p = xbase + (size_t)(on ? step : 0) * xtstride;
-#pragma unroll
-        for (int j = 0; j < NXJ; ++j) xa[j] = on ? *reinterpret_cast<const f32x4*>(p + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    load_x(0);
-    __syncthreads();
-
-    const f32x4* wxw = wximg + (size_t)layer * IMG_F4 + (size_t)kq * NXS * 64 + lane;
-
-    // gather the 16 granules of this lane from buffers (bufL|bufR) published with tag `epoch`; bounded wait
-    auto gather = [&](u64* bufL, u64* bufR, unsigned epoch, int step, float (&out)[NKS]) {
-        const size_t goff = (size_t)((step + 1) & 1) * 16 * H + (size_t)kq * NKS * 64 + r16 * 4 + q;
-        const u64* sp[NPW];
-#pragma unroll
-        for (int i = 0; i < NPW; ++i) sp[i] = (src_local[i] ? bufL : bufR) + goff;
-        u64 g[NKS];
-        bool ok = true;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) g[ks] = granule_load(sp[ks / KSP] + (size_t)ks * 64);
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) ok = ok && ((unsigned)(g[ks] >> 32) == epoch);
-        unsigned spins = 0; u64 wt0 = 0;
-        bool timed_out = false;
-        while (!__all(ok) && !timed_out) {
-            while (true) {                                            // cheap gate: one granule per producer
-                bool ready = true;
-#pragma unroll
-                for (int i = 0; i < NPW; ++i)
-                    if (lane == i) ready = (unsigned)(granule_load(sp[i] + (size_t)(i * KSP) * 64) >> 32) == epoch;
-                if (__all(ready)) break;
-                if (wait_over(spins, spin_budget, wt0, a.max_ticks)) { timed_out = true; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            ok = true;
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                g[ks] = granule_load(sp[ks / KSP] + (size_t)ks * 64);
-                ok = ok && ((unsigned)(g[ks] >> 32) == epoch);
-            }
-            if (wait_over(spins, spin_budget, wt0, a.max_ticks)) timed_out = true;
-        }
-        if (timed_out) {
-            if (lane == 0) mp_set_error(a.err, 1 + step);
-            spin_budget = 0; poison_cells(cst);
-        }
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) out[ks] = __uint_as_float((unsigned)g[ks]);
-    };
-
-    for (int step = 0; step <= T; ++step) {
-        f32x4 acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const unsigned epoch = (unsigned)step;               // everything consumed now was published at the end of step-1
-        // ---- input projection.  Layer 0: x_s (prefetched from HBM).  Layer 1: x1_{s-1} = h0_{s-1} (granules).
-        float xin[NKS];
-        if (layer == 1) {
-            if (step > 0) gather(hx0L, hx0R, epoch, step, xin);
-            else {
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) xin[ks] = 0.f;
-            }
-        }
-        {
-            f32x4 wl = wxw[0];
-#pragma unroll
-            for (int s = 0; s < NXS; ++s) {
-                // k mapping of the LDS image: x-step s <-> k = kq*KQ + (s/4)*16 + q*4 + (s%4)   (HBM rows, layer 0)
-                // granules arrive as k = kq*KW + 4*ks + q                                          (layer 1)
-                // -> layer 1 walks the image in granule order: ks = 4*(s%4) + s/4 has k = kq*64 + 16*(s%4) + 4*(s/4) + q
-                const float a_s = layer == 0 ? xa[s >> 2][s & 3] : xin[s];
-                f32x4 wn = wl;
-                if (s + 1 < NXS) wn = wxw[(size_t)(s + 1) * 64];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, wl[i], acc[i], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                wl = wn;
-            }
-        }
-        // ---- recurrence: layer 0 uses h0_{s-1}, layer 1 uses h1_{s-2}; both published at the end of step s-1
-        if (step > 0) gather(layer ? hx1L : hx0L, layer ? hx1R : hx0R, epoch, step, av);
-        load_x(step + 1);
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], wv[ks][t], acc[t], 0, 0, 0);
-
-        // ---- K reduction (per layer) through LDS
-        __syncthreads();
-#pragma unroll
-        for (int dk = 0; dk < 4; ++dk)
-            red[((layer * 4 + dk) * 4 + kq) * 64 + lane] = f32x4{acc[0][dk], acc[1][dk], acc[2][dk], acc[3][dk]};
-        __syncthreads();
-        f32x4 gt = red[((layer * 4 + kq) * 4 + 0) * 64 + lane];
-#pragma unroll
-        for (int sw = 1; sw < 4; ++sw) gt += red[((layer * 4 + kq) * 4 + sw) * 64 + lane];
-        gt += bias4;
-
-        // ---- cell: layer 0 at time s, layer 1 at time s-1
-        const int tcur = step - layer;
-        const bool act = tcur >= 0 && tcur < blen;
-        float oval = 0.f;
-        if (act) {
-            const float ig = sigmoidf_(gt[0]), fg = sigmoidf_(gt[1]), gg = tanhf_(gt[2]), og = sigmoidf_(gt[3]);
-            cst = fg * cst + ig * gg;
-            hst = og * tanhf_(cst);
-            oval = hst;
-        }
-        const size_t doff = (size_t)(step & 1) * 16 * H;
-        const int gi = granule_index(q * 4 + kq, jown);
-        granule_store_l2(hxoL + doff + gi, (unsigned)(step + 1), hst);
-        if (!all_local) granule_store(hxoR + doff + gi, (unsigned)(step + 1), hst);
-        if (layer == 1 && inb && tcur >= 0 && tcur < T) d.out[((size_t)tcur * B + bown) * d.outStride + jown] = oval;
-    }
-    if (inb) {
-        d.hbuf[(size_t)bown * H + jown] = hst;
-        d.cbuf[(size_t)bown * H + jown] = cst;
-    }
-}
-
-// tile lt of wave w = (kq = w & 3, tw = w >> 2):  TW == 1: g = lt / NUB, ub = lt % NUB;   TW == NUB: g = lt, ub = tw
-// W_hh: dst[(((slice*NWV + w)*NKS + ks)*NTW + lt)*64 + lane]
+// tile lt of wave kq:  g = lt / NUB, ub = lt % NUB
+// W_hh: dst[(((slice*4 + kq)*NKS + ks)*NTW + lt)*64 + lane]
 //         = W_hh[g*H + slice*U + ub*16 + (lane&15)][kq*KW + 4*ks + (lane>>4)]
-template <int H, int NSLICE, int TW>
+template <int H, int NSLICE>
 MP_KERNEL void mp_pack_whh_persist(const float* __restrict__ whh, float* __restrict__ dst) {
-    constexpr int U = H / NSLICE, NUB = U / 16, NWV = 4 * TW, NTW = 4 * NUB / TW, KW = H / 4, NKS = KW / 4;
+    constexpr int U = H / NSLICE, NUB = U / 16, NWV = 4, NTW = 4 * NUB, KW = H / 4, NKS = KW / 4;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)4 * H * H) return;
     const int lane = idx & 63;
     size_t rest = idx >> 6;
     const int lt = rest % NTW; rest /= NTW;
     const int ks = rest % NKS; rest /= NKS;
-    const int w = rest % NWV; rest /= NWV;
+    const int kq = rest % NWV; rest /= NWV;
     const int slice = (int)rest;
-    const int kq = w & 3, tw = w >> 2;
-    const int g = TW == 1 ? lt / NUB : lt, ub = TW == 1 ? lt % NUB : tw;
+    const int g = lt / NUB, ub = lt % NUB;
     const int row = g * H + slice * U + ub * 16 + (lane & 15);
     const int col = kq * KW + 4 * ks + (lane >> 4);
     dst[idx] = whh[(size_t)row * H + col];
 }
 
-// W_ih: dst[((((slice*NWV + w)*NXS + s)*NTG + tg)*64 + lane)*4 + i]   (tile lt = tg*4 + i)
+// W_ih: dst[((((slice*4 + kq)*NXS + s)*NTG + tg)*64 + lane)*4 + i]   (tile lt = tg*4 + i)
 //         = W_ih[g*H + slice*U + ub*16 + (lane&15)][kq*KQ + (s/4)*16 + (lane>>4)*4 + (s%4)]
-// korder != 0: k-steps in granule order, k = kq*KQ + 4*s + (lane>>4) (layer 1 of the two-layer wavefront kernel,
-// whose input arrives as granules rather than as 16-byte row pieces)
-template <int H, int NSLICE, int TW>
-MP_KERNEL void mp_pack_wih_persist(const float* __restrict__ wih, float* __restrict__ dst, int KIN, int korder) {
-    constexpr int U = H / NSLICE, NUB = U / 16, NWV = 4 * TW, NTW = 4 * NUB / TW, NTG = NTW / 4;
+template <int H, int NSLICE>
+MP_KERNEL void mp_pack_wih_persist(const float* __restrict__ wih, float* __restrict__ dst, int KIN) {
+    constexpr int U = H / NSLICE, NUB = U / 16, NWV = 4, NTW = 4 * NUB, NTG = NTW / 4;
     const int KQ = KIN / 4, NXS = KQ / 4;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)4 * H * KIN) return;
@@ -1255,24 +950,23 @@ MP_KERNEL void mp_pack_wih_persist(const float* __restrict__ wih, float* __restr
     size_t rest = idx >> 8;
     const int tg = rest % NTG; rest /= NTG;
     const int s = rest % NXS; rest /= NXS;
-    const int w = rest % NWV; rest /= NWV;
+    const int kq = rest % NWV; rest /= NWV;
     const int slice = (int)rest;
-    const int kq = w & 3, tw = w >> 2;
     const int lt = tg * 4 + i;
-    const int g = TW == 1 ? lt / NUB : lt, ub = TW == 1 ? lt % NUB : tw;
+    const int g = lt / NUB, ub = lt % NUB;
     const int row = g * H + slice * U + ub * 16 + (lane & 15);
-    const int col = korder ? kq * KQ + 4 * s + (lane >> 4) : kq * KQ + (s >> 2) * 16 + (lane >> 4) * 4 + (s & 3);
+    const int col = kq * KQ + (s >> 2) * 16 + (lane >> 4) * 4 + (s & 3);
     dst[idx] = wih[(size_t)row * KIN + col];
 }
 
 constexpr int kExclusiveLds = 84 * 1024;                             // > half of a CU's 160 KB
 
-template <int H, int NSLICE, int KIN, int TW>
+template <int H, int NSLICE, int KIN>
 constexpr size_t fused_lds() {
-    using C = Cfg<H, NSLICE, KIN, TW>;
+    using C = Cfg<H, NSLICE, KIN>;
     return (size_t)C::RED_F4 * 16 * (C::ALLREG ? 2 : 1) + (size_t)C::NWV * C::XL * C::NTG * 64 * 16;   // (ALLREG: two copies, RED_DB)
 }
-constexpr size_t kVfLds = fused_lds<256, 16, 256, 1>() + 4 * 2 * 64 * 16;      // + the rider's partial sums [kq][tile][lane]
+constexpr size_t kVfLds = fused_lds<256, 16, 256>() + 4 * 2 * 64 * 16;         // + the rider's partial sums [kq][tile][lane]
 
 template <int FK>
 void launch_vf(const LstmPersistArgs& a, hipStream_t s) {
@@ -1286,15 +980,16 @@ void launch_vf(const LstmPersistArgs& a, hipStream_t s) {
         most = (a.nslab * a.ndir + 7) / 8;
     }
     const dim3 grid(8 * most * 16);
-    if (a.prof || a.debug_drop) hipLaunchKernelGGL((mp_lstm_fused<256, 16, 256, 1, true, FK>), grid, dim3(256), lds, s, b);
-    else hipLaunchKernelGGL((mp_lstm_fused<256, 16, 256, 1, false, FK>), grid, dim3(256), lds, s, b);
+    // (PROF instantiation: phase counters and the test hooks -- a dropped workgroup, the forced any-placement transport)
+    if (a.prof || a.debug_drop || a.force_remote) hipLaunchKernelGGL((mp_lstm_fused<256, 16, 256, true, FK>), grid, dim3(256), lds, s, b);
+    else hipLaunchKernelGGL((mp_lstm_fused<256, 16, 256, false, FK>), grid, dim3(256), lds, s, b);
 }
 template <int FK>
 hipError_t vf_attrs() {
-    hipError_t e = hipFuncSetAttribute((const void*)mp_lstm_fused<256, 16, 256, 1, true, FK>,
+    hipError_t e = hipFuncSetAttribute((const void*)mp_lstm_fused<256, 16, 256, true, FK>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVfLds);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)mp_lstm_fused<256, 16, 256, 1, false, FK>,
+    return hipFuncSetAttribute((const void*)mp_lstm_fused<256, 16, 256, false, FK>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVfLds);
 }
 
@@ -1317,10 +1012,10 @@ MP_KERNEL void mp_pack_foot_vf(const float* __restrict__ wih, const float* __res
     else dst[idx] = whh[(size_t)row * 64 + kq * 16 + 4 * (st - FNX) + q];
 }
 
-template <int H, int NSLICE, int KIN, int TW>
+template <int H, int NSLICE, int KIN>
 void launch_fused(const LstmPersistArgs& a, hipStream_t s) {
-    using C = Cfg<H, NSLICE, KIN, TW>;
-    size_t lds = fused_lds<H, NSLICE, KIN, TW>();
+    using C = Cfg<H, NSLICE, KIN>;
+    size_t lds = fused_lds<H, NSLICE, KIN>();
     if ((size_t)a.min_lds > lds) lds = (size_t)a.min_lds;
     LstmPersistArgs b = a;
     int most = 0, total = 0;
@@ -1330,80 +1025,51 @@ void launch_fused(const LstmPersistArgs& a, hipStream_t s) {
         most = (a.nslab * a.ndir + 7) / 8;
     }
     const dim3 grid(8 * most * NSLICE);
-    if (a.prof || a.debug_drop) hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, TW, true>), grid, dim3(64 * C::NWV), lds, s, b);
-    else hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, TW, false>), grid, dim3(64 * C::NWV), lds, s, b);
+    if (a.prof || a.debug_drop || a.force_remote) hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, true>), grid, dim3(64 * C::NWV), lds, s, b);
+    else hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, false>), grid, dim3(64 * C::NWV), lds, s, b);
 }
 
 // the dynamic-LDS limit is a per-device function attribute: set for the CURRENT device, outside of any capture
-template <int H, int NSLICE, int KIN, int TW>
+template <int H, int NSLICE, int KIN>
 hipError_t fused_attrs() {
-    int lds = (int)fused_lds<H, NSLICE, KIN, TW>();
+    int lds = (int)fused_lds<H, NSLICE, KIN>();
     if (lds < kExclusiveLds) lds = kExclusiveLds;                  // (LstmPersistArgs::min_lds)
-    hipError_t e = hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, TW, true>,
+    hipError_t e = hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, TW, false>,
+    return hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
-constexpr size_t kUni2Lds = (size_t)(2 * 4 * 4 * 64 + 2 * 4 * (256 / 16) * 64) * 16;    // 32 KB + 2 x 64 KB
-
 }  // namespace
 
-// nslice selects the decomposition of the H = 256 layers: 16 (4-wave workgroups, two per CU) or 8 (8-wave, one per CU)
+// nslice: slices per slab -- H = 256: 16 or 8 (one four-wave workgroup per slice either way); H = 64: 4
 void mp_launch_pack_whh_persist(const float* whh, float* dst, int H, int nslice, hipStream_t s) {
     const size_t n = (size_t)4 * H * H;
     const int grid = (int)((n + 255) / 256);
-    if (H == 256 && nslice == 16) hipLaunchKernelGGL((mp_pack_whh_persist<256, 16, 1>), dim3(grid), dim3(256), 0, s, whh, dst);
-    else if (H == 256) hipLaunchKernelGGL((mp_pack_whh_persist<256, 8, 2>), dim3(grid), dim3(256), 0, s, whh, dst);
-    else hipLaunchKernelGGL((mp_pack_whh_persist<64, 4, 1>), dim3(grid), dim3(256), 0, s, whh, dst);
+    if (H == 256 && nslice == 16) hipLaunchKernelGGL((mp_pack_whh_persist<256, 16>), dim3(grid), dim3(256), 0, s, whh, dst);
+    else if (H == 256) hipLaunchKernelGGL((mp_pack_whh_persist<256, 8>), dim3(grid), dim3(256), 0, s, whh, dst);
+    else hipLaunchKernelGGL((mp_pack_whh_persist<64, 4>), dim3(grid), dim3(256), 0, s, whh, dst);
 }
 
-void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, int nslice, int korder, hipStream_t s) {
+void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, int nslice, hipStream_t s) {
     const size_t n = (size_t)4 * H * KIN;
     const int grid = (int)((n + 255) / 256);
-    if (H == 256 && nslice == 16) hipLaunchKernelGGL((mp_pack_wih_persist<256, 16, 1>), dim3(grid), dim3(256), 0, s, wih, dst, KIN, korder);
-    else if (H == 256) hipLaunchKernelGGL((mp_pack_wih_persist<256, 8, 2>), dim3(grid), dim3(256), 0, s, wih, dst, KIN, korder);
-    else hipLaunchKernelGGL((mp_pack_wih_persist<64, 4, 1>), dim3(grid), dim3(256), 0, s, wih, dst, KIN, korder);
+    if (H == 256 && nslice == 16) hipLaunchKernelGGL((mp_pack_wih_persist<256, 16>), dim3(grid), dim3(256), 0, s, wih, dst, KIN);
+    else if (H == 256) hipLaunchKernelGGL((mp_pack_wih_persist<256, 8>), dim3(grid), dim3(256), 0, s, wih, dst, KIN);
+    else hipLaunchKernelGGL((mp_pack_wih_persist<64, 4>), dim3(grid), dim3(256), 0, s, wih, dst, KIN);
 }
 
-// WREG configuration (H = 256, 8 slices, four 512-register waves): its own fragment order (TW = 1)
-void mp_launch_pack_whh_persist_w(const float* whh, float* dst, hipStream_t s) {
-    const size_t n = (size_t)4 * 256 * 256;
-    hipLaunchKernelGGL((mp_pack_whh_persist<256, 8, 1>), dim3((int)((n + 255) / 256)), dim3(256), 0, s, whh, dst);
-}
-void mp_launch_pack_wih_persist_w(const float* wih, float* dst, int KIN, hipStream_t s) {
-    const size_t n = (size_t)4 * 256 * KIN;
-    hipLaunchKernelGGL((mp_pack_wih_persist<256, 8, 1>), dim3((int)((n + 255) / 256)), dim3(256), 0, s, wih, dst, KIN, 0);
-}
-void mp_launch_lstm_persist_w(const LstmPersistArgs& a, int KIN, hipStream_t s) {
-    if (KIN == 256) launch_fused<256, 8, 256, 1>(a, s);
-    else launch_fused<256, 8, 512, 1>(a, s);
-}
-
-bool mp_persist_tagged(int H, int nslice, bool four_wave) {
-    if (!MP_TAGX || H != 256) return false;
-    return (nslice == 8 && four_wave && (MP_FLAGX & 1)) || (nslice == 16 && (MP_FLAGX & 2));
-}
 int mp_persist_max_wg(int H, int nslice) { return H == 256 && nslice == 16 ? 512 : 256; }
-
-// both layers of a unidirectional 2-layer LSTM (H = 256, 16-slice packing) as one wavefront launch
-void mp_launch_lstm_uni2(const LstmPersistArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((mp_lstm_fused_uni2<256>), dim3(((a.nslab + 7) / 8) * 8 * 16), dim3(512), kUni2Lds, s, a);
-}
 
 hipError_t mp_lstm_persist_device_attrs() {
     hipError_t e = hipSuccess;
-    if (!e) e = fused_attrs<256, 16, 256, 1>();
-    if (!e) e = fused_attrs<256, 16, 512, 1>();
-    if (!e) e = fused_attrs<256, 8, 256, 2>();
-    if (!e) e = fused_attrs<256, 8, 512, 2>();
-    if (!e) e = fused_attrs<256, 8, 256, 1>();
-    if (!e) e = fused_attrs<256, 8, 512, 1>();
-    if (!e) e = fused_attrs<64, 4, 64, 1>();
-    if (!e) e = fused_attrs<64, 4, 128, 1>();
-    if (!e) e = hipFuncSetAttribute((const void*)mp_lstm_fused_uni2<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)kUni2Lds);
+    if (!e) e = fused_attrs<256, 16, 256>();
+    if (!e) e = fused_attrs<256, 16, 512>();
+    if (!e) e = fused_attrs<256, 8, 256>();
+    if (!e) e = fused_attrs<256, 8, 512>();
+    if (!e) e = fused_attrs<64, 4, 64>();
+    if (!e) e = fused_attrs<64, 4, 128>();
     if (!e) e = vf_attrs<64>();
     if (!e) e = vf_attrs<128>();
     return e;
@@ -1421,13 +1087,13 @@ void mp_launch_pack_foot_vf(const float* wih, const float* whh, float* dst, int 
 
 void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice, hipStream_t s) {
     if (H == 256 && nslice == 16) {
-        if (KIN == 256) launch_fused<256, 16, 256, 1>(a, s);
-        else launch_fused<256, 16, 512, 1>(a, s);
-    } else if (H == 256) {
-        if (KIN == 256) launch_fused<256, 8, 256, 2>(a, s);
-        else launch_fused<256, 8, 512, 2>(a, s);
-    } else if (KIN == 64) launch_fused<64, 4, 64, 1>(a, s);      // H = 64 (foot contact): 4 slices of 16 units, small
-    else launch_fused<64, 4, 128, 1>(a, s);                       // footprint so that it fits beside the velocity layers
+        if (KIN == 256) launch_fused<256, 16, 256>(a, s);
+        else launch_fused<256, 16, 512>(a, s);
+    } else if (H == 256) {                                         // 8 slices: four 512-register waves, AccVGPR-resident weights
+        if (KIN == 256) launch_fused<256, 8, 256>(a, s);
+        else launch_fused<256, 8, 512>(a, s);
+    } else if (KIN == 64) launch_fused<64, 4, 64>(a, s);         // H = 64 (foot contact): 4 slices of 16 units, small
+    else launch_fused<64, 4, 128>(a, s);                          // footprint so that it fits beside the velocity layers
 }
 
 

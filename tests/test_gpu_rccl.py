@@ -54,9 +54,12 @@ def test_one_rank_rccl_launch_matches_the_plain_run():
     args = ["--steps", "50", "--warmup", "5"]
     plain = _bench(args, launcher=False)
     ranked = _bench(args, launcher=True)
-    _keep("r04_rccl_1rank_weak.json", ranked)
-    _keep("r04_plain_1gpu.json", plain)
-    assert plain["n_ranks_seen"] == 1 and "per_rank" not in plain
+    _keep("r05_rccl_1rank_weak.json", ranked)
+    _keep("r05_plain_1gpu.json", plain)
+    assert plain["n_ranks_seen"] == 1 and [p["rank"] for p in plain["per_rank"]] == [0]
+    assert plain["verified"]["rows"] == 16 and ranked["verified"]["rows"] == 16        # (bench.py checks what it timed)
+    assert plain["build_id"] == ranked["build_id"] == ranked["per_rank"][0]["build_id"]
+    assert ranked["per_rank"][0]["device"] == 0 and ranked["per_rank"][0]["xcd_round_robin"] is True
     assert ranked["n_gpus"] == 1 and ranked["n_ranks_seen"] == 1
     assert [p["rank"] for p in ranked["per_rank"]] == [0] and ranked["per_rank"][0]["frames"] == 256 * 125 * 50
     assert "RCCL" in ranked["config"]["launcher"] and ranked["config"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
@@ -71,9 +74,9 @@ def test_one_rank_rccl_launch_matches_the_plain_run():
 
 def test_one_rank_rccl_launch_strong_scaling_and_streams():
     strong = _bench(["--steps", "10", "--warmup", "2", "--scaling", "strong"], launcher=True)
-    _keep("r04_rccl_1rank_strong.json", strong)
+    _keep("r05_rccl_1rank_strong.json", strong)
     assert strong["n_ranks_seen"] == 1 and strong["scaling"] == "strong" and strong["config"]["global_batch"] == 1024
     assert strong["per_rank"][0]["frames"] == 1024 * 125 * 10
     stream = _bench(["--steps", "10", "--warmup", "2", "--workload", "stream", "--streams", "512"], launcher=True)
-    _keep("r04_rccl_1rank_stream.json", stream)
+    _keep("r05_rccl_1rank_stream.json", stream)
     assert stream["n_ranks_seen"] == 1 and stream["config"]["streams_per_gpu"] == 512 and stream["config"]["meets_60hz"]

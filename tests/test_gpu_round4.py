@@ -27,9 +27,9 @@ TOL_TRAN = 1e-3
 # tests, profiles/r04_parity_errors.txt); it now splits into fp16 halves with weights pre-scaled by 16 (24 bits, mp_lstm_dev.h
 # pair_of) and sits at fp32's own noise level (profiles/r04_accuracy.json).  At 256 x 125 on the trained-regime net, where fp32
 # implementations differ from each other by more than 1e-4, a mode is held to NOISE_FACTOR x the fp32 oracle's own distance
-# from float64 (measured: mode 1 0.9-1.5 x, mode 3 1.8-3.3 x).
+# from float64 (measured: mode 1 0.7-1.6 x, mode 3 1.8-3.3 x).
 MODE_TOL = {"fp32": 1e-4, "x3": 1e-4}
-NOISE_FACTOR = {"fp32": 3.0, "x3": 5.0}
+NOISE_FACTOR = {"fp32": 2.0, "x3": 5.0}      # (fp32: 3.0 until round 5; measured 0.7-1.6 x, profiles/r05_accuracy_256x125.json)
 
 
 def trained_tol(mode):
