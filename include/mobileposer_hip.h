@@ -92,8 +92,8 @@ void mp_destroy(mp_handle* h);
 const char* mp_last_error(const mp_handle* h);   /* h may be NULL: error of a failed mp_create */
 
 /* What the handle found on its device at creation: the device index it is bound to, the number of compute units, and
- * whether the probe saw workgroups dealt round robin over 8 XCDs (the side-by-side schedules' placement tables rest on it;
- * speed only).  Any pointer may be NULL.  bench.py logs it per rank.  Replaces: nothing in the reference (`device` global,
+ * whether the probe saw workgroups dealt round robin over 8 XCDs (bit 0; the side-by-side schedules' placement tables rest
+ * on it; speed only) and whether the handle still uses those tables (bit 1: cleared for good by a starvation error).  Any pointer may be NULL.  bench.py logs it per rank.  Replaces: nothing in the reference (`device` global,
  * config.py:9). */
 int mp_device_info(const mp_handle* h, int* device, int* n_cu, int* xcd_round_robin);
 

@@ -102,7 +102,9 @@ struct ModuleW {
     float* wVF[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};     // H = 64 block: rider fragments of mp_lstm_fused<..., FK> ("VF")
 };
 struct ModuleWS {
-    float *xproj = nullptr, *out0 = nullptr, *out1 = nullptr;   // X1 (linear1 output) aliases out1
+    float *xproj = nullptr, *out0 = nullptr, *out1 = nullptr;   // X1 (linear1 output) aliases out1 ...
+    float* x1 = nullptr;                // ... except in the unidirectional H = 256 block: its two layers run as a wavefront (layer 1
+                                        // writes out1 while layer 0 still reads X1), so X1 has a buffer of its own
     float* hbuf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     float* cbuf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     unsigned long long* hx = nullptr;   // hidden-state exchange buffer of the persistent kernels (split-bf16 mode: of layer 0)
@@ -110,6 +112,7 @@ struct ModuleWS {
     size_t hx_bytes = 0;
     unsigned hx_epoch = 0;              // next epoch base of `hx` (mp_lstm_fused launches); 0 = must be zeroed first
     unsigned hx_flip = 3;               // tagged-word launches (LstmPersistArgs::tag_flip): first tags of the next launch
+    unsigned hx_flipF = 3;              // ... of a rider's words in the same area (tag_flip_f): only launches that carry one write them
     bool hx_tagged = false;             // the area holds tagged words (else: granules / flagged words of the epoch family)
 };
 struct VelState { float* h = nullptr; float* c = nullptr; int B = 0; int cap = 0; };   // [2][B][256] each
@@ -214,6 +217,7 @@ struct mp_handle {
     StreamCtx sc;
     OnlineState st_snap;             // recovery: per-stream solver state a streaming tick started from
     bool vf_ok = true;               // MP_VARIANT vf=0: the foot-contact layers always run as launches of their own
+    bool wf_ok = true;               // MP_VARIANT wf=0: velocity as two 16-slice layer launches (rounds 3-4), not as ONE two-layer wavefront launch
     bool late_pair_ok = true;        // MP_VARIANT late_pair=0: no schedule 4 (pose layer 0 alone, then pose layer 1 beside velocity + rider) for 64 < B <= 128
     const void* vf_foot = nullptr;   // forward_body -> rnn_rec: the foot-contact job that rides in this call's velocity launches
     int dbg_drop_block = 0, dbg_drop_left = 0, dbg_drop_skip = 0;   // mp_debug_drop_workgroup
@@ -510,6 +514,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     //   exclusive=0    no LDS padding / XCD tables for concurrent persistent launches;  fuse_pv=0: separate linear1 launches
     //   epoch_tags=0   zero the exchange area before every fp32 layer launch;  epoch_start=N: first epoch base (wrap tests)
     //   vf=0           foot-contact layers as launches of their own beside velocity (B > 128), not as riders in its workgroups
+    //   wf=0           velocity layers as two 16-slice launches (rounds 3-4), not as one two-layer wavefront launch (B > 128)
     //   late_pair=0    64 < B <= 128: both pose layers on 8 slices beside velocity (schedules 2 / 3) instead of schedule 4
     if (const char* e = getenv("MP_VARIANT")) {
         std::string all(e);
@@ -541,6 +546,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
             else if (key == "gemm_wide") {}                    // read by mp_launch_gemm: 0 = wide linear1 layers on mp_gemm_f32_frag's small tiles
             else if (key == "one_stream") {}                   // read by forward_body: 0 = the round-3 three-stream serial schedule
             else if (key == "vf") h->vf_ok = v != 0;
+            else if (key == "wf") h->wf_ok = v != 0;
             else if (key == "late_pair") h->late_pair_ok = v != 0;
             else if (key == "recovery") h->recovery = v != 0;   // (= mp_set_recovery)
             else { h->err = "MP_VARIANT: unknown key '" + key + "'"; return bail(MP_ERR_INVALID); }
@@ -631,6 +637,8 @@ int get_plan(mp_handle* h, int B, int T, Plan** out) {
         w.xproj = nullptr;                                   // gate pre-activations: per-step mode only, allocated on demand
         if (int rc = dev_alloc(h, (void**)&w.out0, M * m.dirs * m.H * sizeof(float), &p->allocs)) return rc;
         if (int rc = dev_alloc(h, (void**)&w.out1, M * m.dirs * m.H * sizeof(float), &p->allocs)) return rc;
+        if (m.H == 256 && m.dirs == 1)
+            if (int rc = dev_alloc(h, (void**)&w.x1, M * m.H * sizeof(float), &p->allocs)) return rc;
         for (int l = 0; l < 2; ++l)
             for (int d = 0; d < m.dirs; ++d) {
                 if (int rc = dev_alloc(h, (void**)&w.hbuf[l][d], (size_t)2 * B * m.H * sizeof(float), &p->allocs)) return rc;
@@ -792,7 +800,7 @@ int layer_workgroups(const mp_handle* h, const ModuleW& m, int B) {
 
 float* x1_buffer(const mp_handle* h, const ModuleW& m, ModuleWS& w) {
     (void)h; (void)m;
-    return w.out1;
+    return w.x1 ? w.x1 : w.out1;
 }
 
 int rnn_g0(const RnnJob& j, hipStream_t s) {
@@ -903,12 +911,23 @@ bool rnn_g2_g0_fused(const RnnJob& jj, const RnnJob& jp, const RnnJob& jv, const
 
 inline int fm_kin0(const mp_handle* h) { return h->mod[MP_MOD_FOOT_CONTACT].H; }   // K_in of the rider's layer 0 (= its H)
 
+// Do the two layers of module m (the unidirectional H = 256 block) run as ONE two-layer wavefront launch of the 8-slice kernel
+// (mp_lstm_fused<256,8,256,*,*,WF>) at this shape?  Full batches only (B > 128: the schedules of smaller batches place 16-slice
+// velocity clusters beside pose clusters with XCD tables), exact-fp32 operands, and a layer-0 output the kernel can address
+// with 32-bit byte offsets.
+bool wavefront_applies(const mp_handle* h, const ModuleW& m, int B, int T) {
+    return h->persist && h->wf_ok && !use_x3(h, m) && m.H == 256 && m.dirs == 1 && m.whhP8[0][0] != nullptr && B > 128 &&
+           fp32_slices(h, m, B) == 16 && (size_t)B * T * m.H * sizeof(float) < 0x7fffffffull;
+}
+
 int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
     mp_handle* h = j.h;
     const ModuleW& m = h->mod[j.id];
     ModuleWS& w = j.p->ws[j.id];
     const int B = j.p->B, T = j.p->T, H = m.H, dirs = m.dirs;
     float* out = l == 0 ? w.out0 : w.out1;
+    const bool wf = wavefront_applies(h, m, B, T) && !h->xcd_plan_on[j.id];
+    if (wf && l == 1) return MP_OK;                          // both layers went out with the layer-0 call (below)
     if (h->persist) {
         const int nslab = (B + 15) / 16;
         // every polled word is re-zeroed before every launch: all granules (fp32 kernels) or the flags (split-bf16 kernels)
@@ -921,7 +940,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         //  at 128 x 125; the memset between the launches is the boundary that prevents it.  The 8-slice kernels own their CU.)
         const bool crowded16 = !use_x3(h, m) && dirs == 2 && fp32_slices(h, m, B) == 16 && dirs * nslab * 16 > 128;
         const bool epoch_ok = !use_x3(h, m) && !h->capturing && h->epoch_tags && !crowded16;
-        const int nsl = use_x3(h, m) ? m.nsliceX : fp32_slices(h, m, B);
+        const int nsl = wf ? 8 : (use_x3(h, m) ? m.nsliceX : fp32_slices(h, m, B));
         const bool p16 = !use_x3(h, m) && nsl == 16 && m.nslice != 16;      // 16-slice packing of a bidirectional block
         const bool p8 = !use_x3(h, m) && nsl == 8 && m.nslice != 8;         // 8-slice packing of the unidirectional block
         // (tagged-word kernels: one tag bit per word, so the area is also zeroed when the other kernel family -- granules with
@@ -936,6 +955,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
                 HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
                 w.hx_epoch = epoch_ok ? h->epoch_start : 0u;
                 w.hx_flip = 3u;
+                w.hx_flipF = 3u;
             }
             w.hx_tagged = tagged;
             epoch_base = epoch_ok ? w.hx_epoch : 0u;
@@ -946,21 +966,31 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         const bool u8 = !use_x3(h, m) && H == 256 && nsl == 32;
         const int cus = h->n_cu < 256 ? h->n_cu : 256;
         // slabs per launch: grid <= #CUs, one workgroup per CU
-        const int chunk = cus / (dirs * nsl) > 0 ? cus / (dirs * nsl) : 1;
+        const int chunk = cus / ((wf ? 2 : dirs) * nsl) > 0 ? cus / ((wf ? 2 : dirs) * nsl) : 1;
         const int kin = l == 0 ? H : dirs * H;
         // timing classes: 1 = H256 bidirectional K_in=256, 4 = H256 bidirectional K_in=512, 5 = H256 unidirectional
         const int cls = H != 256 ? 6 : (dirs == 1 ? 5 : (kin == 256 ? 1 : 4));
         // (a velocity launch that carries the foot-contact layer as a rider is credited with that layer's FLOPs as well)
-        const double rider_flop = (j.id == MP_MOD_VELOCITY && h->vf_foot) ? 2.0 * 2 * (double)B * T * 4.0 * 64 * ((l == 0 ? 64 : 128) + 64) : 0.0;
-        SegScope seg(h, s, cls, (nslab + chunk - 1) / chunk, 2.0 * dirs * (double)B * T * 4.0 * H * (kin + H) + rider_flop);
-        const float* xin = l == 0 ? w.out1 /* X1 */ : w.out0;
+        // the foot-contact layer that rides in this launch (forward_body decides that one does -- ScheduleScope::rider -- this
+        // function which): 16-slice velocity layer l carries foot-contact layer l (rounds 3-4; B <= 128 today); the velocity
+        // wavefront carries layer 1, and layer 0 rides in pose layer 0 (8 slices) in front of it (round 5)
+        const RnnJob* fj = nullptr;
+        int f_layer = 0;
+        if (h->vf_foot && !use_x3(h, m) && kin == 256) {
+            if (j.id == MP_MOD_VELOCITY && wf) { fj = static_cast<const RnnJob*>(h->vf_foot); f_layer = 1; }
+            else if (j.id == MP_MOD_VELOCITY && nsl == 16 && !p16) { fj = static_cast<const RnnJob*>(h->vf_foot); f_layer = l; }
+            else if (j.id == MP_MOD_POSE && nsl == 8 && l == 0) { fj = static_cast<const RnnJob*>(h->vf_foot); f_layer = 0; }
+        }
+        const double rider_flop = fj ? 2.0 * 2 * (double)B * T * 4.0 * 64 * ((f_layer == 0 ? 64 : 128) + 64) : 0.0;
+        SegScope seg(h, s, cls, (nslab + chunk - 1) / chunk, (wf ? 2.0 : 1.0) * 2.0 * dirs * (double)B * T * 4.0 * H * (kin + H) + rider_flop);
+        const float* xin = l == 0 ? x1_buffer(h, m, w) /* X1 */ : w.out0;
         float* outp = l == 0 ? w.out0 : w.out1;
         // layer 1 overwrites out1, which still holds X1 while layer 0 runs -- layer 0 has finished by then
         for (int s0 = 0; s0 < nslab; s0 += chunk) {
             LstmPersistArgs a;
-            a.lengths = j.p->lengths_dev; a.ndir = dirs; a.B = B; a.T = T;
+            a.lengths = j.p->lengths_dev; a.ndir = wf ? 2 : dirs; a.B = B; a.T = T;
             a.slab0 = s0; a.nslab = nslab - s0 < chunk ? nslab - s0 : chunk;
-            a.hx = hx_l + (size_t)dirs * s0 * ((size_t)4 * 16 * H + 16);
+            a.hx = hx_l + (size_t)(wf ? 2 : dirs) * s0 * ((size_t)4 * 16 * H + 16);
             a.hx_next = (use_x3(h, m) && l == 0) ? w.hx2 + (size_t)dirs * s0 * ((size_t)4 * 16 * H + 16) : nullptr;
             static const int prof_layer = getenv("MP_PERSIST_PROF_LAYER") ? atoi(getenv("MP_PERSIST_PROF_LAYER")) : -1;
             a.err = h->err_dev; a.max_spin = 1u; a.max_ticks = h->wait_ticks;
@@ -972,6 +1002,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             const bool x3 = use_x3(h, m);
             a.epoch_base = epoch_base;
             a.tag_flip = w.hx_flip;
+            a.tag_flip_f = w.hx_flipF;
             a.min_lds = x3 ? 0 : h->excl_lds;
             if (!x3 && h->xcd_plan_on[j.id] && a.nslab == nslab) { mp_fill_xcd_table(a, h->xcd_plan[j.id]); a.xcd_physical = 1; }
             a.out_pairs = x3 ? 1 : 0;                          // both layers feed split-bf16 consumers (layer 1 / linear2)
@@ -986,16 +1017,30 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
                 dd.wihpack = x3 ? m.wihX[l][d] : (u8 ? m.wihU8[l][d] : p8 ? m.wihP8[l][d] : (p16 ? m.wihP16[l][d] : m.wihP[l][d])); dd.bias = m.ih[l].bias + (size_t)d * 4 * H; dd.xin = xin;
             }
             if (dirs == 1) a.d[1] = a.d[0];
-            // the foot-contact layer l of the same slabs as a rider of this velocity launch (forward_body decides)
-            const RnnJob* fj = (j.id == MP_MOD_VELOCITY && !x3 && nsl == 16 && !p16 && kin == 256) ? static_cast<const RnnJob*>(h->vf_foot) : nullptr;
+            if (wf) {
+                // the wavefront: "direction" 1 = layer 1, fed by layer 0's output; in-place state of both layers; clusters
+                // (slab, layer) are dealt to the XCDs slab by slab, so that the two layers of a slab share an L2
+                LstmDir& d1 = a.d[1];
+                const bool inplace = j.out_h == j.in_h && j.out_h;
+                d1.wpack = m.whhP8[1][0]; d1.wihpack = m.wihP8[1][0]; d1.bias = m.ih[1].bias; d1.xin = w.out0; d1.out = w.out1;
+                d1.hbuf = inplace ? j.out_h + (size_t)1 * B * H : w.hbuf[1][0];
+                d1.cbuf = inplace ? j.out_c + (size_t)1 * B * H : w.cbuf[1][0];
+                d1.xproj = nullptr; d1.xprojStride = 0; d1.outStride = H; d1.reverse = 0;
+                unsigned char cnt[8];
+                for (int x = 0; x < 8; ++x) cnt[x] = (unsigned char)(2 * ((a.nslab + 7 - x) / 8));
+                mp_fill_xcd_table(a, cnt);
+            }
             if (fj) {
                 const ModuleW& fm = h->mod[MP_MOD_FOOT_CONTACT];
                 ModuleWS& fws = fj->p->ws[MP_MOD_FOOT_CONTACT];
-                for (int fd = 0; fd < 2; ++fd) { a.f_w[fd] = fm.wVF[l][fd]; a.f_bias[fd] = fm.ih[l].bias + (size_t)fd * 4 * fm.H; }
-                a.f_xin = l == 0 ? fws.out1 /* X1 */ : fws.out0;
-                a.f_out = l == 0 ? fws.out0 : fws.out1;
+                for (int fd = 0; fd < 2; ++fd) { a.f_w[fd] = fm.wVF[f_layer][fd]; a.f_bias[fd] = fm.ih[f_layer].bias + (size_t)fd * 4 * fm.H; }
+                a.f_xin = f_layer == 0 ? x1_buffer(h, fm, fws) /* X1 */ : fws.out0;
+                a.f_out = f_layer == 0 ? fws.out0 : fws.out1;
             }
-            if (fj) mp_launch_lstm_vf(a, l == 0 ? fm_kin0(h) : 2 * h->mod[MP_MOD_FOOT_CONTACT].H, s);
+            const int fk = fj ? (f_layer == 0 ? fm_kin0(h) : 2 * h->mod[MP_MOD_FOOT_CONTACT].H) : 0;
+            if (wf || (fj && nsl == 8)) {
+                if (!mp_launch_lstm_persist8(a, fk, wf, s)) return fail(h, MP_ERR_INVALID, "internal: 8-slice launch (rider %d, wavefront %d) not built", fk, (int)wf);
+            } else if (fj) mp_launch_lstm_vf(a, fk, s);
             else if (x3 && nsl == 8 && (h->x3w_mask & (kin == 256 ? 1 : 2))) mp_launch_lstm_x3w(a, kin, s);
             else if (x3) mp_launch_lstm_x3(a, kin, nsl, s);
             else if (u8) mp_launch_lstm_u8(a, kin, s);
@@ -1004,7 +1049,11 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         if (epoch_base) w.hx_epoch += (unsigned)T + 1u;       // tags base .. base + T are used up
         // parity slot 0 was written (T + 1) / 2 times (steps 0, 2, ...), slot 1 1 + T / 2 times (the initial state as "step -1",
         // then steps 1, 3, ...), tags alternating: an odd count turns the slot's next first tag around
-        if (tagged && epoch_ok) w.hx_flip ^= (unsigned)(((T + 1) / 2) & 1) | ((unsigned)((1 + T / 2) & 1) << 1);
+        if (tagged && epoch_ok) {
+            const unsigned turn = (unsigned)(((T + 1) / 2) & 1) | ((unsigned)((1 + T / 2) & 1) << 1);
+            w.hx_flip ^= turn;
+            if (fj) w.hx_flipF ^= turn;                       // (the rider's words: written by this launch only if it carried one)
+        }
     } else {
         SegScope seg(h, s, 7, T, 2.0 * dirs * (double)B * T * 4.0 * H * H);
         LstmStepArgs a;
@@ -1222,14 +1271,26 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
                 if (!rnn_g0_pose_velocity(P, V, sm, &rc_pv, &F)) return fail(h, MP_ERR_INVALID, "internal: stacked linear1 refused");
             }
             RC(rc_pv);
-            RC(rnn_rec(P, 0, sm)); RC(rnn_rec(P, 1, sm));                                   // net.py:106-107
-            HIPCHK(h, hipEventRecord(h->ev_x[2], sm));
+            // round 5: the velocity layers as ONE two-layer wavefront launch of the 8-slice kernel (wavefront_applies); the
+            // foot-contact layers ride in pose layer 0 (its layer 0: both directions must be complete before its layer 1
+            // starts) and in the wavefront launch (its layer 1).  Every CU is then taken by four 512-register waves from the
+            // joints block to the end of the velocity block, so pose's linear2 / IK / FK tail can no longer run beside the
+            // velocity layers: it forks off BEHIND them and runs beside velocity's / foot contact's linear2 and the solver.
+            const bool wfv = wavefront_applies(h, vmod, p->B, p->T);
+            {
+                ScheduleScope sched(h);
+                if (wfv) sched.rider(&F);
+                RC(rnn_rec(P, 0, sm));                                                      // net.py:106-107
+            }
+            RC(rnn_rec(P, 1, sm));
+            if (!wfv) HIPCHK(h, hipEventRecord(h->ev_x[2], sm));
             {
                 ScheduleScope sched(h);
                 sched.rider(&F);
                 RC(rnn_rec(V, 0, sm));                                                      // net.py:113-117
                 RC(rnn_rec(V, 1, sm));
             }
+            if (wfv) HIPCHK(h, hipEventRecord(h->ev_x[2], sm));
             RC(rnn_g2_pair(V, F, sm));
             HIPCHK(h, hipStreamWaitEvent(sp, h->ev_x[2], 0));
             RC(rnn_g2(P, sp));
@@ -1660,7 +1721,7 @@ int mp_device_info(const mp_handle* h, int* device, int* n_cu, int* xcd_round_ro
     if (!h) return MP_ERR_INVALID;
     if (device) *device = h->device;
     if (n_cu) *n_cu = h->n_cu;
-    if (xcd_round_robin) *xcd_round_robin = h->xcd_probe ? 1 : 0;
+    if (xcd_round_robin) *xcd_round_robin = (h->xcd_probe ? 1 : 0) | (h->xcd_rr ? 2 : 0);   // bit 0: probed at creation, bit 1: tables still in use
     return MP_OK;
 }
 

@@ -119,9 +119,10 @@ struct LstmPersistArgs {
     unsigned max_spin;            // 0: never wait (a test hook); otherwise waits are allowed, bounded by max_ticks
     unsigned long long max_ticks; // bound of every wait in ticks of the constant 100 MHz clock (s_memrealtime); mp_api: 0.25 s
     long long* prof;              // optional [grid][6] cycle sums per phase (debug), else nullptr
-    // mp_lstm_fused<256,16,256,1,*,FK> only ("VF"): a bidirectional H = 64 layer -- the foot-contact block -- rides along in the
-    // workgroups of this unidirectional H = 256 launch: slice j of a slab also carries units 8*(j & 7) .. +7 of direction
-    // j >> 3 of that slab's H = 64 layer (zero initial state, same lengths).  f_w: fragments from mp_launch_pack_foot_vf.
+    // mp_lstm_fused<256,16|8,256,*,FK> only: a bidirectional H = 64 layer -- the foot-contact block -- rides along in the
+    // workgroups of this H = 256 launch (zero initial state, same lengths).  16 slices ("VF", unidirectional carrier): slice j
+    // of a slab also carries units 8*(j & 7) .. +7 of direction j >> 3 of that slab's H = 64 layer; 8 slices (two clusters per
+    // slab): slice j of cluster direction d carries units 8*j .. +7 of direction d.  f_w: fragments from mp_launch_pack_foot_vf.
     const float* f_w[2] = {nullptr, nullptr};
     const float* f_bias[2] = {nullptr, nullptr};   // per direction: gate-interleaved b_ih + b_hh [4 * 64]
     const float* f_xin = nullptr;                  // rider's layer input, time-major [T][B][FK]
@@ -141,6 +142,9 @@ struct LstmPersistArgs {
     // tags) and zeroes the area when another kernel family wrote to it, after a device error, and where launches are
     // replayed (graphs).
     unsigned tag_flip = 3;
+    // ... and the same two bits for the words of a riding H = 64 layer (f_w != nullptr): a bookkeeping of their own, because only
+    // launches that carry a rider write them (round 5: pose layer 0 carries foot-contact layer 0, pose layer 1 nothing)
+    unsigned tag_flip_f = 3;
     // mp_lstm_fused, host side only: ask for at least this much dynamic LDS (bytes) although the kernel uses less.  With
     // more than half a CU's LDS per workgroup no CU takes two persistent workgroups -- of this launch or of a launch
     // running beside it -- as long as CUs are free: a workgroup that shares its SIMDs slows its whole lock-stepped cluster.
@@ -175,6 +179,10 @@ static __device__ __forceinline__ int mp_xcd_first(const LstmPersistArgs& a, int
 // nslice: workgroups sharing one slab -- H = 256: 16 (four 256-register waves, two workgroups per CU) or 8 (four 512-register
 // waves with AccVGPR-resident weights, one per CU); H = 64: 4.  The H = 256 kernels exchange tagged words (LstmPersistArgs::tag_flip)
 void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice, hipStream_t s);
+// the H = 256, K_in = 256 kernel on 8 slices with a riding H = 64 layer (fk = its K_in: 0 | 64 | 128) and / or as the two-layer
+// wavefront of a unidirectional block (wf: ndir = 2, d[0] = layer 0, d[1] = layer 1 with d[1].xin = d[0].out, cluster index =
+// slab * 2 + layer; mp_lstm_persist.hip).  false = combination not built, nothing launched
+bool mp_launch_lstm_persist8(const LstmPersistArgs& a, int fk, bool wf, hipStream_t s);
 // the unidirectional H = 256, K_in = 256 layer on 16 slices with an H = 64 bidirectional layer riding along (fk = its K_in: 64 | 128)
 void mp_launch_lstm_vf(const LstmPersistArgs& a, int fk, hipStream_t s);
 size_t mp_foot_vf_floats(int fk);     // per direction

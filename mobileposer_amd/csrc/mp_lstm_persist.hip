@@ -98,14 +98,34 @@ __device__ __forceinline__ void mfma_drain() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// FK != 0 (only <256, 16, 256, 1>, "VF"): a bidirectional H = 64, K_in = FK layer -- the foot-contact block of the same slab --
-// rides along: slice j also computes units 8*(j & 7) .. +7 of direction j >> 3 of it (two extra MFMA tiles: gates i|f and
-// g|o of 8 units), K split over the four waves like everything else, its hidden state exchanged through the same area under
-// the same flags.  Why: run as a kernel of its own beside this one, the H = 64 layer and this layer slow each other on every
-// shared SIMD (profiles/r03_class_times.txt: 335 -> 398 us and 180 -> 450 us per layer); inside these waves it costs its
-// instructions and nothing else.
-template <int H, int NSLICE, int KIN, bool PROF, int FK = 0>
-MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void mp_lstm_fused(LstmPersistArgs a) {
+// FK != 0 (the K_in = 256 kernels on 16 or on 8 slices): a bidirectional H = 64, K_in = FK layer -- the foot-contact block of the
+// same slab -- rides along: a slice also computes 8 units of one direction of it (two extra MFMA tiles: gates i|f and g|o of 8
+// units), K split over the four waves like everything else, its hidden state exchanged through the same area with the same
+// kind of tagged words.  16 slices (one direction of the carrier): slice j carries units 8*(j & 7) .. +7 of rider direction
+// j >> 3.  8 slices (two clusters per slab): slice j of cluster direction d carries units 8*j .. +7 of rider direction d.
+// Why: run as a kernel of its own beside this one, the H = 64 layer and this layer slow each other on every shared SIMD
+// (profiles/r03_class_times.txt: 335 -> 398 us and 180 -> 450 us per layer); inside these waves it costs its instructions and
+// nothing else.
+//
+// WF (round 5; <256, 8, 256> only): the two "directions" of the launch are the two LAYERS of a unidirectional 2-layer LSTM
+// (the velocity block, models/velocity.py:29) -- a wavefront: d[0] = layer 0, d[1] = layer 1 with d[1].xin = d[0].out, both
+// forward in time.  Layer 1 at time t needs layer 0's output at time t and nothing else of layer 0, so the two layers of a
+// slab run side by side, layer 1 one to two steps behind, at the speed of ONE 8-slice launch instead of two 16-slice launches
+// that each carry a full step's fixed cost on half the MFMAs (rounds 3-4: 2 x 397 us at 0.62 of peak).
+//   * cluster index: cl = slab * 2 + layer, so that the four clusters of an XCD are two slabs x both layers and the link
+//     stays inside one L2 (placement only decides speed: the transport is chosen from the real XCC ids, as for h);
+//   * link layer 0 -> layer 1: layer 1 reads layer 0's OUTPUT buffer ([T][B][256], written once per step and never
+//     overwritten within a launch), not the two-slot exchange words -- nothing holds layer 0 back, it may run any number of
+//     steps ahead.  Every layer-0 wave raises ONE progress word (epoch_base + number of finished steps) after the
+//     s_waitcnt vmcnt(0) that acknowledges its output stores -- at the second k-step of the next step's projection, where the
+//     stores are long done -- and once more after its last step; a layer-1 wave requests the 8 words of the two slices its K
+//     quarter of x comes from at the top of a step and compares (>=) before it issues the prefetch of x_{t+1}: off the
+//     critical path once layer 1 has fallen far enough behind that the words are there at first look (a wait makes it fall
+//     behind further: the lag settles by itself).  x is read with sc1 loads (never through a CU's L1: a line is requested
+//     only after its producers said it is complete); when the two clusters do not share an XCD the output stores and the
+//     progress words are written through (sc1), like the R transport of h.
+template <int H, int NSLICE, int KIN, bool PROF, int FK = 0, bool WF = false>
+MP_KERNEL __launch_bounds__(256, (FK || WF ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void mp_lstm_fused(LstmPersistArgs a) {
     // test hook (mp_debug_drop_workgroup): a workgroup that never shows up.  Only in the PROF instantiation, which the launcher
     // picks when the hook is armed -- the product kernels carry no test code (round 4)
     if (PROF && a.debug_drop && (int)blockIdx.x == a.debug_drop - 1) return;
@@ -123,6 +143,7 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
     // kernels and 128 in the 16-slice ones)
     constexpr int XSPLIT = NXS / 2;
     constexpr int NTHREADS = 64 * NWV;
+    static_assert(!WF || (H == 256 && NSLICE == 8 && KIN == 256), "the two-layer wavefront lives in the all-register 8-slice kernel");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* red = reinterpret_cast<f32x4*>(smem);                       // [finishing wave][source kq][o][lane]
     f32x4* wxl = reinterpret_cast<f32x4*>(smem) + C::RED_F4;           // [wave][x-step < XL][tile group][lane]
@@ -138,7 +159,7 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
     if (kth >= mp_xcd_count(a, xcd)) return;
     const int cl = mp_xcd_first(a, xcd) + kth;
     if (cl >= ncl) return;
-    const int dir = cl / a.nslab, slab = cl % a.nslab;
+    const int dir = WF ? (cl & 1) : cl / a.nslab, slab = WF ? (cl >> 1) : cl % a.nslab;
     const LstmDir d = a.d[dir];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kq = wave;
@@ -274,6 +295,7 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
 #pragma unroll
     for (int i = 0; i < NPW; ++i) src_local[i] = true;
     bool all_local = true;
+    bool link_local = true;                // WF: all eight slices of the partner cluster (the other layer of this slab) on my XCD
     unsigned long long same_xcd = ~0ull;   // bit s: producer slice s runs on my XCD
     if (NSLICE > 1) {
         // (epoch_base != 0: the exchange area is NOT zeroed between launches -- every launch uses tags nobody has written
@@ -281,10 +303,12 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
         const unsigned xtag = a.epoch_base ? a.epoch_base : XCC_TAG;
         if (threadIdx.x == 0) granule_store(xtab + slice, xtag, __uint_as_float(my_xcc));
         unsigned peer = my_xcc;
-        if (lane < NSLICE) {
+        // (WF: lanes NSLICE .. 2*NSLICE-1 read the table of the partner cluster, cl ^ 1)
+        const u64* xlook = (WF && lane >= NSLICE) ? a.hx + (size_t)(cl ^ 1) * SLABW + (size_t)4 * 16 * H + (lane - NSLICE) : xtab + lane;
+        if (lane < (WF ? 2 * NSLICE : NSLICE)) {
             unsigned spins = 0; u64 wt0 = 0;
             while (true) {
-                const u64 g = granule_load(xtab + lane);
+                const u64 g = granule_load(xlook);
                 if ((unsigned)(g >> 32) == xtag) { peer = (unsigned)g; break; }
                 if (wait_over(spins, spin_budget, wt0, a.max_ticks)) { mp_set_error(a.err, 1000000); peer = ~0u; break; }
                 __builtin_amdgcn_s_sleep(2);
@@ -293,16 +317,51 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
         const unsigned long long same = __ballot(peer == my_xcc);
         same_xcd = same;
         all_local = (same & ((1ull << NSLICE) - 1)) == ((1ull << NSLICE) - 1);
+        if (WF) link_local = ((same >> NSLICE) & ((1ull << NSLICE) - 1)) == ((1ull << NSLICE) - 1);
 #pragma unroll
         for (int i = 0; i < NPW; ++i) src_local[i] = (same >> (NPW * kq + i)) & 1;   // k-steps of part i come from slice NPW*kq+i
         if (__ballot(peer == ~0u)) { spin_budget = 0; poison_cells(cst); fcst = __builtin_nanf(""); }
         if (PROF && a.force_remote) {                       // test hook (PROF instantiation only): the any-placement transport
             all_local = false;
+            link_local = false;
             same_xcd = 0;
 #pragma unroll
             for (int i = 0; i < NPW; ++i) src_local[i] = false;
         }
     }
+    // ---- WF: the link.  Progress words of layer 0 live in ITS cluster's area (cl & ~1), in the 1024 words between the h words
+    // and the rider's: word [slice * 4 + wave].  A layer-1 wave watches the words of slices 2*kq and 2*kq + 1 -- all lanes load
+    // (8 distinct addresses), so nothing about the check is per lane.
+    unsigned* plink = reinterpret_cast<unsigned*>(a.hx + (size_t)(cl & ~1) * SLABW) + (size_t)4 * 16 * H;
+    const unsigned* pwatch = plink + 8 * kq + (lane & 7);
+    const unsigned pbase = a.epoch_base;
+    unsigned pw = 0, link_waits = 0;
+    const bool wf_l0 = WF && dir == 0, wf_l1 = WF && dir == 1;
+    // wait until layer 0 has finished `need` steps (bounded like every wait; a wave that gives up poisons its cells)
+    auto link_wait = [&](int need, int step) {
+        unsigned spins = 0; u64 wt0 = 0;
+        // (a word of THIS launch is pbase + n with need <= n <= T; anything else -- a zeroed word, an earlier launch's smaller
+        //  value -- is far outside that window whatever pbase is: one unsigned compare, no wrap-around case.  A signed
+        //  "pw - (pbase + need) >= 0" took the zeros of a freshly zeroed area for progress when pbase was above 2^31.)
+        while (!__all(pw - pbase - (unsigned)need <= (unsigned)(T - need))) {
+            if (PROF && spins == 0) ++link_waits;
+            if (wait_over(spins, spin_budget, wt0, a.max_ticks)) {
+                if (lane == 0) mp_set_error(a.err, 1 + step);
+                spin_budget = 0; poison_cells(cst); fcst = __builtin_nanf("");
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            pw = __hip_atomic_load(pwatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto link_publish = [&](int done) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's output stores of the steps before are acknowledged
+        if (lane == 0) {
+            unsigned* f = plink + slice * 4 + wave;
+            if (link_local) __hip_atomic_store(f, pbase + (unsigned)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_store(f, pbase + (unsigned)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
 
     // ---- TAGX: consumer offsets (piece i comes from producer slice NPW*kq + i/PPP), store slots
     __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(hdL, 0, 4 * 16 * H * 4, 0x00020000);
@@ -325,11 +384,17 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
     // (x-step i < FNX), h k = kq*16 + 4*ks + q (ks < 4).  Exchange words of the rider: [transport][parity][direction][1024]
     // behind the flags of this cluster's area; word (row, unit u) at ((u/16*4 + u%4)*16 + row)*4 + (u/4)%4, so that consumer
     // lane (kq, q, row) finds its four k-steps in one 16-byte piece.  Producers of a piece: slices 8*dir + 2*kq (+1).
-    static_assert(FK == 0 || (H == 256 && NSLICE == 16 && KIN == 256), "the rider lives in the 16-slice velocity kernel");
+    static_assert(FK == 0 || (H == 256 && (NSLICE == 16 || NSLICE == 8) && KIN == 256), "the rider lives in the K_in = 256 kernels");
     constexpr int FNX = FK / 16, FNS = FNX + 4, FNJ = FK / 64;
     constexpr unsigned F_WORD0 = 4 * 16 * H + 1024;                  // first rider word of the cluster's area
     constexpr unsigned F_TR = 2 * 2 * 1024;                           // words per transport
-    const int fdir = slice >> 3, fug = slice & 7;
+    // rider direction, unit group, and which of the area's two rider blocks the words live in (16 slices: one cluster carries
+    // both rider directions; 8 slices: the cluster's direction IS the rider's, block 0)
+    const int fdir = NSLICE == 16 ? slice >> 3 : dir, fug = slice & 7, fblk = NSLICE == 16 ? fdir : 0;
+    // TAGX tags of the rider's words: a bookkeeping of their own (LstmPersistArgs::tag_flip_f) -- a launch without a rider
+    // leaves them alone
+    auto ftag_of = [&](int step) -> unsigned { return ((((unsigned)(step + 1) >> 1) ^ (a.tag_flip_f >> (step & 1))) & 1u) << 30; };
+    auto fword_of = [&](float h, int step) -> unsigned { return (__float_as_uint(h) & ~kHTagBit) | ftag_of(step); };
     float fw[FK ? FNS : 1][2];
     f32x4 fbias4 = f32x4{0.f, 0.f, 0.f, 0.f}, fxa[FNJ > 0 ? FNJ : 1], fhr = f32x4{0.f, 0.f, 0.f, 0.f};
     int flen = 0, frow = 0, funit = 0;
@@ -347,16 +412,51 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
         flen = (lane < 32 && frow < B) ? a.lengths[frow] : 0;
         fbias4 = *reinterpret_cast<const f32x4*>(a.f_bias[fdir] + 4 * funit);
         fslot = (unsigned)((((funit >> 4) * 4 + (funit & 3)) * 16 + 4 * kq + ((lane >> 3) & 3)) * 4 + ((funit >> 2) & 3));
-        const int fs0 = fdir * 8 + 2 * kq;                             // producer slices of this wave's piece
+        const int fs0 = fblk * 8 + 2 * kq;                             // producer slices of this wave's piece
         const bool floc = ((same_xcd >> fs0) & 1) && ((same_xcd >> (fs0 + 1)) & 1);
-        fvoff = (floc ? 0u : F_TR * 4u) + (unsigned)fdir * 4096u + (unsigned)(((kq * 4 + q) * 16 + r16) * 16);
+        fvoff = (floc ? 0u : F_TR * 4u) + (unsigned)fblk * 4096u + (unsigned)(((kq * 4 + q) * 16 + r16) * 16);
         fxt = (size_t)B * FK;
         fxp_cur = a.f_xin + (size_t)(arow_in ? arow : 0) * FK + kq * (FK / 4) + q * 4 + (size_t)(fdir && alen > 0 ? alen - 1 : 0) * fxt;
         fxp_nxt = fxp_cur;
 #pragma unroll
         for (int j = 0; j < FNJ; ++j) fxa[j] = *reinterpret_cast<const f32x4*>(fxp_cur + j * 16);
     }
-    f32x4* fred = reinterpret_cast<f32x4*>(smem) + C::RED_F4 + (size_t)NWV * XL * NTG * 64;   // rider partials [kq][tile][lane]
+    // rider partials [kq][tile][lane] behind the reduction scratch (ALLREG: two copies of both, used in turn -- RED_DB below)
+    f32x4* fred0 = reinterpret_cast<f32x4*>(smem) + C::RED_F4 * (C::ALLREG ? 2 : 1) + (size_t)NWV * XL * NTG * 64;
+    if (TAGX && NSLICE > 1 && !all_local) {
+        // The R copies (any-placement transport) are written only by launches whose cluster does NOT share an XCD, the host's
+        // tag bookkeeping (tag_flip) advances with every launch: what an earlier launch left in an R copy may carry exactly the
+        // tag this launch expects (round 5: found by toggling the transport test hook between calls -- a consumer that looked
+        // early took a stale word; placement itself is stable from launch to launch, so the product never got here).  So a
+        // cluster on the R transport first makes its R words INVALID for this launch -- every owner writes the complement of
+        // the tag its first write to that slot will carry -- and meets once more (second table, in the gap behind the h words)
+        // before anybody publishes or reads: whoever has seen all peers' second entries knows every R word is either this
+        // launch's or recognisably not.  all_local is the same for all workgroups of a cluster (one workgroup elsewhere makes
+        // it false for everybody), so they all come here or none does.  Nothing of this runs on the L transport.
+#pragma unroll
+        for (int o = 0; o < NOWN; ++o) {
+            __hip_atomic_store(hdL + HD_R / 4 + hslot[o], tag_of(0) ^ kHTagBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(hdL + (size_t)16 * H + HD_R / 4 + hslot[o], tag_of(-1) ^ kHTagBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (FK && lane < 32) {
+            unsigned* fwd = hdL + F_WORD0 + F_TR + (unsigned)fblk * 1024u + fslot;
+            __hip_atomic_store(fwd, ftag_of(0) ^ kHTagBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fwd + 2048u, ftag_of(-1) ^ kHTagBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                       // all four waves' words are out
+        u64* xtab2 = hxL + (size_t)2 * 16 * H + 64;            // words 16512 .. of the area (16 entries)
+        const unsigned xtag = a.epoch_base ? a.epoch_base : XCC_TAG;
+        if (threadIdx.x == 0) granule_store(xtab2 + slice, xtag, 1.0f);
+        if (lane < NSLICE) {
+            unsigned spins = 0; u64 wt0 = 0;
+            while ((unsigned)(granule_load(xtab2 + lane) >> 32) != xtag) {
+                if (wait_over(spins, spin_budget, wt0, a.max_ticks)) { mp_set_error(a.err, 1000000); spin_budget = 0; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        if (__ballot(spin_budget == 0)) { spin_budget = 0; poison_cells(cst); fcst = __builtin_nanf(""); }
+    }
     if (TAGX) {
         // the initial state goes out as the words of "step -1" (parity slot 1): step 0 requests and validates its recurrent
         // operand like every other step -- no `step > 0` around the request, the check or the operand (each was a branch whose
@@ -381,9 +481,9 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
             if (!all_local) __hip_atomic_store(hw + HD_R / 4 + hslot[o], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (FK && lane < 32) {
-            unsigned* fwd = hdL + F_WORD0 + 2048u + (unsigned)fdir * 1024u + fslot;
-            __hip_atomic_store(fwd, hword_of(0.f, -1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (!all_local) __hip_atomic_store(fwd + F_TR, hword_of(0.f, -1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned* fwd = hdL + F_WORD0 + 2048u + (unsigned)fblk * 1024u + fslot;
+            __hip_atomic_store(fwd, fword_of(0.f, -1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!all_local) __hip_atomic_store(fwd + F_TR, fword_of(0.f, -1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 
@@ -405,8 +505,18 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
     constexpr bool LEAN = true;
     const float* xp_cur = xbase + (size_t)(d.reverse ? (alen > 0 ? alen - 1 : 0) : 0) * xtstride;   // time index of `step`
     const float* xp_nxt = xp_cur;                                                                  // ... of `step + 1`
+    // WF: x through a buffer resource over the whole [T][B][K_in] array with sc1 loads (the host takes the wavefront only when
+    // the array is smaller than 4 GB); byte offsets instead of pointers, both layers forward in time
+    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.xin), 0,
+                                                                   WF ? (int)((size_t)T * xtstride * 4) : 0, 0x00020000);
+    unsigned xo_cur = (unsigned)(((size_t)(arow_in ? arow : 0) * KIN + kq * KQ + q * 4) * 4), xo_nxt = xo_cur;
     auto load_x = [&](int step, int j0, int j1) {
-        if (LEAN) {
+        if (WF) {
+            const unsigned o = step & 0x40000000 ? xo_nxt : xo_cur;
+#pragma unroll
+            for (int j = 0; j < NXJ; ++j)
+                if (j >= j0 && j < j1) xa[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, o, j * 64, 16 /* sc1 */));
+        } else if (LEAN) {
             const float* p = step & 0x40000000 ? xp_nxt : xp_cur;       // (bit 30 = "the prefetch of the next step")
 #pragma unroll
             for (int j = 0; j < NXJ; ++j)
@@ -421,6 +531,10 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
                 if (j >= j0 && j < j1) xa[j] = on ? *reinterpret_cast<const f32x4*>(p + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
+    if (wf_l1) {                                              // x_0 of layer 1 = layer 0's first output
+        pw = __hip_atomic_load(pwatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        link_wait(1, 0);
+    }
     load_x(0, 0, XJ_PRE);
     __syncthreads();                                          // W_ih LDS image complete
     // (x_0 has arrived before the loop is entered, x_{t+1} before the stores of step t are issued -- see the cell update --
@@ -440,6 +554,8 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
     for (int step = 0; step < T; ++step) {
         PROF_T(0);
         if (LEAN) xp_cur = xp_nxt;
+        if (WF) xo_cur = xo_nxt;
+        if (wf_l1) pw = __hip_atomic_load(pwatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // looked at before the prefetch of x_{t+1}
         if (FK) fxp_cur = fxp_nxt;
         if (SPLIT_X && !TAGX) load_x(step, XJ_PRE, NXJ);
         f32x4 acc[NTW];
@@ -481,18 +597,32 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
                 if (s == PUB_S) {
                     if (SPLIT_X) load_x(step, XJ_PRE, NXJ);          // (second half of a K_in = 512 row: first used 14 k-steps on)
                 }
+                // WF, layer 0: steps 0 .. step-1 are in the output buffer -- said as late as the projection allows (the request
+                // for h behind k-step XSPLIT - 1 must not be in flight when vmcnt(0) is waited for): the stores of the last step
+                // have had 6 k-steps = 1 500 cycles to be acknowledged, and layer 1 is a step or two behind anyway
+                if (WF && s == XSPLIT - 2) { if (wf_l0 && step > 0) link_publish(step); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 
         // ---- FK: the rider's input projection (independent of h: it lengthens the window that hides the hand-off)
+        // (WREG: the rider's MFMAs are inline asm with VGPR operands like the carrier's.  As builtins the compiler put `facc`
+        //  into AccVGPRs -- all 256 of which hold the carrier's weights -- and moved the displaced weights through ONE AccVGPR with
+        //  a v_accvgpr_write right in front of each asm MFMA that reads it: a VALU-write -> MFMA-read hazard the hazard recogniser
+        //  cannot see inside asm.  First GPU run of round 5: pose and velocity off by 5e-3, the rider itself right.  The two
+        //  accumulators alternate, so dependent MFMAs are 64 cycles apart; mfma_drain() below covers the reads of the results.)
         f32x4 facc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         auto rider_xproj = [&]() {
 #pragma unroll
             for (int i = 0; i < FNX; ++i) {
                 const float a_s = fxa[(i >> 2) % (FNJ > 0 ? FNJ : 1)][i & 3];
-                facc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, fw[i % FNS][0], facc[0], 0, 0, 0);
-                facc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, fw[i % FNS][1], facc[1], 0, 0, 0);
+                if (WREG) {
+                    if (i == 0) { mfma_asm<true, false>(facc[0], a_s, fw[i % FNS][0]); mfma_asm<true, false>(facc[1], a_s, fw[i % FNS][1]); }
+                    else { mfma_asm<false, false>(facc[0], a_s, fw[i % FNS][0]); mfma_asm<false, false>(facc[1], a_s, fw[i % FNS][1]); }
+                } else {
+                    facc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, fw[i % FNS][0], facc[0], 0, 0, 0);
+                    facc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_s, fw[i % FNS][1], facc[1], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -570,7 +700,7 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
                 // clear the expected tag, OR what is left: bit 30 set = some word is not (yet) the one of step - 1.  ONE copy of
                 // this code, in a loop whose body normally runs once (the re-request at its bottom writes the same registers:
                 // no phi copies -- the first version, with a separate slow path, cost 30-40 v_mov per step)
-                const unsigned etag = tag_of(step - 1);
+                const unsigned etag = tag_of(step - 1), fetag = FK ? ftag_of(step - 1) : 0u;
                 const int par_off = ((step + 1) & 1) * (16 * H * 4);
                 unsigned spins = 0; u64 wt0 = 0;
                 while (true) {
@@ -581,10 +711,10 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
                         for (int i = 0; i < NP; ++i)
 #pragma unroll
                             for (int c = 0; c < 4; ++c) hr[i][c] = __uint_as_float(__float_as_uint(hr[i][c]) ^ kHTagBit);
-                        if (FK) {
+                    }
+                    if (FK && fetag) {                     // (the rider's words: tags of their own, LstmPersistArgs::tag_flip_f)
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) fhr[c] = __uint_as_float(__float_as_uint(fhr[c]) ^ kHTagBit);
-                        }
+                        for (int c = 0; c < 4; ++c) fhr[c] = __uint_as_float(__float_as_uint(fhr[c]) ^ kHTagBit);
                     }
                     unsigned left = 0;
 #pragma unroll
@@ -653,10 +783,16 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) gr[ks] = (u64)__float_as_uint(av[ks]);
         }
+        // WF, layer 1: is layer 0's output of step t + 1 complete?  Looked at HERE, right behind the wait for the h words -- every
+        // older load, the progress words among them, has arrived, so the compiler's vmcnt(0) in front of the compare costs
+        // nothing.  (First version: behind the rider's x loads of step t + 1 -- the same vmcnt(0) then sat out their whole
+        // latency, 760 cycles per step in layer 1, profiles/r05_wavefront.md.)
+        if (wf_l1) link_wait(step + 2 < T ? step + 2 : T, step);
         if (LEAN) {   // time index of step + 1, clamped
             const bool adv = d.reverse ? (alen - 2 - step >= 0) : (step + 1 < T);
             const long dlt = d.reverse ? -(long)xtstride : (long)xtstride;
             xp_nxt = adv ? xp_cur + dlt : xp_cur;
+            if (WF) xo_nxt = step + 1 < T ? xo_cur + (unsigned)(xtstride * 4) : xo_cur;
         }
         if (FK) {      // the rider's x of step + 1 (forward: t = step + 1, reverse: t = len - 2 - step, both clamped)
             // (one signed stride, as for the layer's own x above: the direction is uniform but the compiler branched on it)
@@ -688,6 +824,7 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
         //  s - 1, which every wave reaches only after its reads of step s - 2)
         constexpr bool RED_DB = RED3 && C::ALLREG;
         float2* red2 = reinterpret_cast<float2*>(smem) + (RED_DB ? (size_t)(step & 1) * C::RED_F4 * 2 : 0);
+        f32x4* fred = fred0 + (RED_DB ? (size_t)(step & 1) * (4 * 2 * 64) : 0);
         if (RED3 && !RED_DB) barrier_lds_only();               // previous step's reads of `red` are done
         if (WREG) asm volatile("s_nop 3" ::: "memory");        // (step 0 writes the A operand with VALU moves just above)
 #pragma unroll
@@ -721,8 +858,13 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
         if (FK) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                facc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fhr[ks], fw[(FNX + ks) % FNS][0], facc[0], 0, 0, 0);
-                facc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fhr[ks], fw[(FNX + ks) % FNS][1], facc[1], 0, 0, 0);
+                if (WREG) {
+                    mfma_asm<false, false>(facc[0], fhr[ks], fw[(FNX + ks) % FNS][0]);
+                    mfma_asm<false, false>(facc[1], fhr[ks], fw[(FNX + ks) % FNS][1]);
+                } else {
+                    facc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fhr[ks], fw[(FNX + ks) % FNS][0], facc[0], 0, 0, 0);
+                    facc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fhr[ks], fw[(FNX + ks) % FNS][1], facc[1], 0, 0, 0);
+                }
             }
         }
         if (WREG) mfma_drain();
@@ -822,6 +964,17 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
                 hst[o] = act ? hnew : hst[o];
                 oval[o] = act ? hnew : 0.f;
             }
+            // (FK: the rider's cell -- row 4*kq + lane/8, unit lane%8 on lanes 0..31 -- in the same block: a third chain to interleave)
+            const bool fact = FK && step < flen;                 // (flen = 0 on lanes 32..63 and for rows past the batch)
+            const int ftt = fact ? (fdir ? flen - 1 - step : step) : step;
+            float fhnew = 0.f;
+            if (FK) {
+                const float fig = sigmoidf_(gi), ffg = sigmoidf_(gf), fgv = tanhf_(gg), fog = sigmoidf_(go);
+                const float fcnew = ffg * fcst + fig * fgv;
+                fhnew = fog * tanhf_(fcnew);
+                fcst = fact ? fcnew : fcst;
+                fhst = fact ? fhnew : fhst;
+            }
             unsigned* hw = hdL + (size_t)(step & 1) * 16 * H;
             unsigned hword[NOWN];
 #pragma unroll
@@ -834,9 +987,24 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
                 for (int o = 0; o < NOWN; ++o)
                     __hip_atomic_store(hw + HD_R / 4 + hslot[o], hword[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (FK && lane < 32) {
+                const unsigned fhword = fword_of(fhst, step);
+                unsigned* fwd = hdL + F_WORD0 + (unsigned)(step & 1) * 2048u + (unsigned)fblk * 1024u + fslot;
+                __hip_atomic_store(fwd, fhword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (!all_local) __hip_atomic_store(fwd + F_TR, fhword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (frow < B) a.f_out[((size_t)ftt * B + frow) * 128 + fdir * 64 + funit] = fact ? fhnew : 0.f;
+            }
+            if (WF && !link_local) {       // the other layer's cluster is on another XCD: layer 0's output is written through
+#pragma unroll
+                for (int o = 0; o < NOWN; ++o)
+                    if (bidx[o] < B)
+                        __hip_atomic_store(reinterpret_cast<unsigned*>(reinterpret_cast<char*>(outb[o]) + (size_t)(unsigned)tt[o] * out_row_bytes),
+                                           __float_as_uint(oval[o]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
 #pragma unroll
             for (int o = 0; o < NOWN; ++o)
                 if (bidx[o] < B) *reinterpret_cast<float*>(reinterpret_cast<char*>(outb[o]) + (size_t)(unsigned)tt[o] * out_row_bytes) = oval[o];
+            }
         } else if (FK) {
             // this layer's cell and the rider's cell (row 4*kq + lane/8, unit lane%8 on lanes 0..31; the other lanes compute the
             // same numbers and keep nothing) in ONE branch-free block, all stores behind it: the scheduler interleaves the two
@@ -857,11 +1025,11 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
             fcst = fact ? fcnew : fcst;
             fhst = fact ? fhnew : fhst;
             unsigned* hw = hdL + (size_t)(step & 1) * 16 * H + hslot[0];
-            const unsigned hword = hword_of(hst[0], step), fhword = hword_of(fhst, step);
+            const unsigned hword = hword_of(hst[0], step), fhword = fword_of(fhst, step);
             __hip_atomic_store(hw, hword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (!all_local) __hip_atomic_store(hw + HD_R / 4, hword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (lane < 32) {
-                unsigned* fwd = hdL + F_WORD0 + (unsigned)(step & 1) * 2048u + (unsigned)fdir * 1024u + fslot;
+                unsigned* fwd = hdL + F_WORD0 + (unsigned)(step & 1) * 2048u + (unsigned)fblk * 1024u + fslot;
                 __hip_atomic_store(fwd, fhword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (!all_local) __hip_atomic_store(fwd + F_TR, fhword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (frow < B) a.f_out[((size_t)ftt * B + frow) * 128 + fdir * 64 + funit] = fact ? fhnew : 0.f;
@@ -896,12 +1064,13 @@ MP_KERNEL __launch_bounds__(256, (FK ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)) void
         }
         PROF_E(4);
     }
+    if (wf_l0) link_publish(T);                               // the last step's outputs are in the buffer
     if (PROF && prof) {
         long long* o = a.prof + (size_t)blockIdx.x * 8;
         for (int i = 0; i < 5; ++i) o[i] = pt[i];
         o[5] = T;
         o[6] = pt[5];
-        o[7] = (all_local ? 256 : 0) | my_xcc;                                     // placement: all slices on my XCD?, XCC id
+        o[7] = (all_local ? 256 : 0) | (link_local ? 512 : 0) | my_xcc | ((long long)link_waits << 16);   // placement: all slices on my XCD?, partner cluster too?, XCC id; WF: steps that waited for layer 0
         long long* tl = a.prof + 4096 + (size_t)blockIdx.x * 4;                    // launch timeline (tools/debug/launch_timeline.py)
         tl[0] = tl_entry; tl[1] = tl_w; tl[2] = tl_loop; tl[3] = (long long)__builtin_amdgcn_s_memrealtime();
     }
@@ -1012,10 +1181,12 @@ MP_KERNEL void mp_pack_foot_vf(const float* __restrict__ wih, const float* __res
     else dst[idx] = whh[(size_t)row * 64 + kq * 16 + 4 * (st - FNX) + q];
 }
 
-template <int H, int NSLICE, int KIN>
+constexpr size_t kRiderLds8 = 2 * 4 * 2 * 64 * 16;                   // 8-slice kernels: two copies of the rider's partial sums
+
+template <int H, int NSLICE, int KIN, int FK = 0, bool WF = false>
 void launch_fused(const LstmPersistArgs& a, hipStream_t s) {
     using C = Cfg<H, NSLICE, KIN>;
-    size_t lds = fused_lds<H, NSLICE, KIN>();
+    size_t lds = fused_lds<H, NSLICE, KIN>() + (FK ? kRiderLds8 : 0);
     if ((size_t)a.min_lds > lds) lds = (size_t)a.min_lds;
     LstmPersistArgs b = a;
     int most = 0, total = 0;
@@ -1025,19 +1196,19 @@ void launch_fused(const LstmPersistArgs& a, hipStream_t s) {
         most = (a.nslab * a.ndir + 7) / 8;
     }
     const dim3 grid(8 * most * NSLICE);
-    if (a.prof || a.debug_drop || a.force_remote) hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, true>), grid, dim3(64 * C::NWV), lds, s, b);
-    else hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, false>), grid, dim3(64 * C::NWV), lds, s, b);
+    if (a.prof || a.debug_drop || a.force_remote) hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, true, FK, WF>), grid, dim3(64 * C::NWV), lds, s, b);
+    else hipLaunchKernelGGL((mp_lstm_fused<H, NSLICE, KIN, false, FK, WF>), grid, dim3(64 * C::NWV), lds, s, b);
 }
 
 // the dynamic-LDS limit is a per-device function attribute: set for the CURRENT device, outside of any capture
-template <int H, int NSLICE, int KIN>
+template <int H, int NSLICE, int KIN, int FK = 0, bool WF = false>
 hipError_t fused_attrs() {
-    int lds = (int)fused_lds<H, NSLICE, KIN>();
+    int lds = (int)(fused_lds<H, NSLICE, KIN>() + (FK ? kRiderLds8 : 0));
     if (lds < kExclusiveLds) lds = kExclusiveLds;                  // (LstmPersistArgs::min_lds)
-    hipError_t e = hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, true>,
+    hipError_t e = hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, true, FK, WF>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, false>,
+    return hipFuncSetAttribute((const void*)mp_lstm_fused<H, NSLICE, KIN, false, FK, WF>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
@@ -1068,6 +1239,9 @@ hipError_t mp_lstm_persist_device_attrs() {
     if (!e) e = fused_attrs<256, 16, 512>();
     if (!e) e = fused_attrs<256, 8, 256>();
     if (!e) e = fused_attrs<256, 8, 512>();
+    if (!e) e = fused_attrs<256, 8, 256, 64>();                   // pose layer 0 with foot-contact layer 0 riding
+    if (!e) e = fused_attrs<256, 8, 256, 128, true>();            // velocity wavefront with foot-contact layer 1 riding
+    if (!e) e = fused_attrs<256, 8, 256, 0, true>();              // velocity wavefront alone
     if (!e) e = fused_attrs<64, 4, 64>();
     if (!e) e = fused_attrs<64, 4, 128>();
     if (!e) e = vf_attrs<64>();
@@ -1083,6 +1257,18 @@ size_t mp_foot_vf_floats(int fk) { return (size_t)8 * 4 * (fk / 16 + 4) * 2 * 64
 void mp_launch_pack_foot_vf(const float* wih, const float* whh, float* dst, int fk, hipStream_t s) {
     const size_t n = mp_foot_vf_floats(fk);
     hipLaunchKernelGGL(mp_pack_foot_vf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, wih, whh, dst, fk);
+}
+
+// the K_in = 256 kernel on 8 slices with its options: fk = K_in of a riding H = 64 layer (0: none; 64 = its layer 0 in a
+// bidirectional launch, 128 = its layer 1 in a wavefront launch), wf = the two "directions" are the two layers of a
+// unidirectional block (d[0] = layer 0, d[1] = layer 1, d[1].xin = d[0].out)
+bool mp_launch_lstm_persist8(const LstmPersistArgs& a, int fk, bool wf, hipStream_t s) {
+    if (fk == 0 && !wf) launch_fused<256, 8, 256>(a, s);
+    else if (fk == 64 && !wf) launch_fused<256, 8, 256, 64>(a, s);
+    else if (fk == 128 && wf) launch_fused<256, 8, 256, 128, true>(a, s);
+    else if (fk == 0 && wf) launch_fused<256, 8, 256, 0, true>(a, s);
+    else return false;
+    return true;
 }
 
 void mp_launch_lstm_persist(const LstmPersistArgs& a, int H, int KIN, int nslice, hipStream_t s) {

@@ -229,10 +229,11 @@ class MobilePoserNet:
         return int(self._lib.mp_recovery_count(self._h)) if self._h is not None else 0
 
     def device_info(self):
-        """dict(device, n_cu, xcd_round_robin, build_id): what the handle found on its device (mp_device_info)."""
+        """dict(device, n_cu, xcd_round_robin, placement_tables, build_id): what the handle found on its device (mp_device_info)."""
         d, n, x = C.c_int(-1), C.c_int(0), C.c_int(0)
         self._check(self._lib.mp_device_info(self._h, C.byref(d), C.byref(n), C.byref(x)))
-        return {"device": d.value, "n_cu": n.value, "xcd_round_robin": bool(x.value), "build_id": _lib.build_id()}
+        return {"device": d.value, "n_cu": n.value, "xcd_round_robin": bool(x.value & 1), "placement_tables": bool(x.value & 2),
+                "build_id": _lib.build_id()}
 
     def __enter__(self):
         return self

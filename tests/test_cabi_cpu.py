@@ -110,3 +110,50 @@ def test_no_packed_fp32_instructions_in_device_code():
     text = _devcode.disassemble(_lib.LIB_PATH)
     assert len(re.findall(r"v_mfma_f32_16x16x32[_a-z0-9]*f16", text)) > 0, "split-fp16 kernels (mode 3) missing from the library"
     assert re.findall(r"v_pk_(?:mul|add|fma)_f32", text) == []
+
+
+def test_inline_asm_mfma_kernels_have_no_hazards_the_assembler_cannot_see():
+    """The 8-slice fp32 layer kernels issue their MFMAs as inline asm that names AccVGPR-resident weights (mp_lstm_persist.hip
+    mfma_asm); the compiler's hazard recogniser does not look inside asm.  Round 5's first rider build showed what that costs:
+    builtin MFMAs of the riding layer took AccVGPRs, the displaced weights travelled through one AccVGPR with a v_accvgpr_write
+    directly in front of each asm MFMA that read it, and pose / velocity came out 5e-3 off.  So: in those kernels no
+    v_accvgpr_* instruction at all, and no VALU write of a register within two instructions in front of an MFMA that reads it
+    as SrcA / SrcB."""
+    import os
+    import re
+    from mobileposer_amd import _devcode, _lib
+    if not os.path.exists(os.path.join(_devcode.LLVM_BIN, "llvm-objdump")):
+        pytest.skip("llvm-objdump not available")
+    text = _devcode.disassemble(_lib.LIB_PATH)
+
+    def regs(tok):
+        tok = tok.strip().rstrip(",")
+        m = re.match(r"^([va])\[(\d+):(\d+)\]$", tok)
+        if m:
+            return {(m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1)}
+        m = re.match(r"^([va])(\d+)$", tok)
+        return {(m.group(1), int(m.group(2)))} if m else set()
+
+    kernels, cur = {}, None
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = []
+        elif cur is not None and line.startswith("\t"):
+            ins = line.strip().split("//")[0].strip()
+            if ins:
+                kernels[cur].append(ins)
+    mine = {k: v for k, v in kernels.items() if "mp_lstm_fusedILi256ELi8E" in k}
+    assert len(mine) >= 10, sorted(kernels)[:5]                 # K_in 256 / 512, rider and wavefront variants, PROF twins
+    for name, L in mine.items():
+        assert not [l for l in L if "accvgpr" in l], name
+        for i, l in enumerate(L):
+            if not l.startswith("v_mfma"):
+                continue
+            ops = l.split(None, 1)[1].split(",")
+            src = regs(ops[1]) | regs(ops[2])
+            for k in (1, 2):
+                p = L[i - k] if i - k >= 0 else ""
+                if p.startswith("v_") and not p.startswith("v_mfma"):
+                    assert not (regs(p.split(None, 1)[1].split(",")[0]) & src), (name, i, p, l)

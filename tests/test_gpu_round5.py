@@ -196,6 +196,7 @@ def test_state_code_does_not_switch_the_placement_tables_off(torch_mod, weights,
             warnings.simplefilter("always")
             net.rnn_forward("velocity", x, [4] * B, (cu(torch_mod, h0), cu(torch_mod, np.zeros_like(h0))))
         assert net.recovery_count == 1 and any("2000000" in str(i.message) for i in w)
+        assert net.device_info()["placement_tables"]
         after = ms(net)
         print("64 x 60 forward: %.3f ms before, %.3f ms after a state-code recovery" % (before, after))
         assert after < 1.10 * before + 0.02
