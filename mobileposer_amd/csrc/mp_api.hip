@@ -1290,6 +1290,9 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
                 RC(rnn_rec(V, 0, sm));                                                      // net.py:113-117
                 RC(rnn_rec(V, 1, sm));
             }
+            // (measured and dropped in round 5: linear2 of all three blocks as ONE launch with K split over wave pairs, two waves per
+            //  SIMD -- 85 us against ~65 us for the two launches side by side on two streams, 3.662 vs 3.636 ms per step;
+            //  profiles/NOTES_r05.md)
             if (wfv) HIPCHK(h, hipEventRecord(h->ev_x[2], sm));
             RC(rnn_g2_pair(V, F, sm));
             HIPCHK(h, hipStreamWaitEvent(sp, h->ev_x[2], 0));

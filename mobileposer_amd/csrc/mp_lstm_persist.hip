@@ -141,6 +141,8 @@ MP_KERNEL __launch_bounds__(256, (FK || WF ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)
     constexpr int PPP = NP / NPW > 0 ? NP / NPW : 1;                  //       pieces per producer slice
     // k-steps of the projection in front of the request for h_{t-1}: half of them (one k-step is 256 cycles in the 8-slice
     // kernels and 128 in the 16-slice ones)
+    // (round 5 A/B on one box, 2/8, 3/8, 5/8 of the projection in front of the request instead of 4/8: 3.635 / 3.631 / 3.629 vs
+    //  3.625 ms per step, outputs bit-identical -- the ~530 cycles of the validation phase are its instructions, not a wait)
     constexpr int XSPLIT = NXS / 2;
     constexpr int NTHREADS = 64 * NWV;
     static_assert(!WF || (H == 256 && NSLICE == 8 && KIN == 256), "the two-layer wavefront lives in the all-register 8-slice kernel");
@@ -948,30 +950,42 @@ MP_KERNEL __launch_bounds__(256, (FK || WF ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)
             // two cells per lane: both are computed first, branch-free (an inactive row's gates are whatever its clamped input
             // row gives -- finite or not, they are never kept), and all stores follow -- one basic block, so the scheduler
             // interleaves the two dependent exp / rcp chains instead of running them one after the other
-            float oval[NOWN];
+            float oval[NOWN], cnew[NOWN], hnew[NOWN];
             int tt[NOWN];
+#pragma unroll
+            for (int o = 0; o < NOWN; ++o) {
+                const float ig = sigmoidf_(gate[o][0]);
+                const float fg = sigmoidf_(gate[o][1]);
+                const float gv = tanhf_(gate[o][2]);
+                const float og = sigmoidf_(gate[o][3]);
+                cnew[o] = fg * cst[o] + ig * gv;
+                hnew[o] = og * tanhf_(cnew[o]);
+            }
+            // (FK: the rider's cell -- row 4*kq + lane/8, unit lane%8 on lanes 0..31 -- in the same block: a third chain to interleave)
+            float fcnew = 0.f, fhnew = 0.f;
+            if (FK) {
+                const float fig = sigmoidf_(gi), ffg = sigmoidf_(gf), fgv = tanhf_(gg), fog = sigmoidf_(go);
+                fcnew = ffg * fcst + fig * fgv;
+                fhnew = fog * tanhf_(fcnew);
+            }
+            // Every chain's results are USED here, whether their row is active or not: without this the compiler sinks each chain
+            // into an exec-masked region of its own (`act ? cnew : cst` -- why compute what an inactive lane drops) and the two or
+            // three dependent exp / rcp chains run one after the other instead of interleaved (the ISA of rounds 3-4 had exactly
+            // that: two s_and_saveexec blocks back to back, although the source was written branch-free)
+            if (NOWN == 2) asm volatile("" : "+v"(cnew[0]), "+v"(hnew[0]), "+v"(cnew[NOWN - 1]), "+v"(hnew[NOWN - 1]));
+            else asm volatile("" : "+v"(cnew[0]), "+v"(hnew[0]));
+            if (FK) asm volatile("" : "+v"(fcnew), "+v"(fhnew));
 #pragma unroll
             for (int o = 0; o < NOWN; ++o) {
                 const bool act = step < blen[o];
                 tt[o] = act ? (d.reverse ? blen[o] - 1 - step : step) : step;
-                const float ig = sigmoidf_(gate[o][0]);
-                const float fg = sigmoidf_(gate[o][1]);
-                const float gg = tanhf_(gate[o][2]);
-                const float og = sigmoidf_(gate[o][3]);
-                const float cnew = fg * cst[o] + ig * gg;
-                const float hnew = og * tanhf_(cnew);
-                cst[o] = act ? cnew : cst[o];
-                hst[o] = act ? hnew : hst[o];
-                oval[o] = act ? hnew : 0.f;
+                cst[o] = act ? cnew[o] : cst[o];
+                hst[o] = act ? hnew[o] : hst[o];
+                oval[o] = act ? hnew[o] : 0.f;
             }
-            // (FK: the rider's cell -- row 4*kq + lane/8, unit lane%8 on lanes 0..31 -- in the same block: a third chain to interleave)
             const bool fact = FK && step < flen;                 // (flen = 0 on lanes 32..63 and for rows past the batch)
             const int ftt = fact ? (fdir ? flen - 1 - step : step) : step;
-            float fhnew = 0.f;
             if (FK) {
-                const float fig = sigmoidf_(gi), ffg = sigmoidf_(gf), fgv = tanhf_(gg), fog = sigmoidf_(go);
-                const float fcnew = ffg * fcst + fig * fgv;
-                fhnew = fog * tanhf_(fcnew);
                 fcst = fact ? fcnew : fcst;
                 fhst = fact ? fhnew : fhst;
             }
