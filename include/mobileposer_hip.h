@@ -216,6 +216,21 @@ int mp_stream_create(mp_handle* h, int S);
 /* frames [S,60] -> pose [S,24,9], joints [S,45,72] (optional NULL), root_pos [S,3], contact [S,2] */
 int mp_stream_step(mp_handle* h, const float* frames_dev, float* pose_dev, float* joints_dev,
                    float* root_pos_dev, float* contact_dev, void* stream);
+/* N consecutive MobilePoserNet.forward_online calls of ONE stream (mp_stream_create(h, 1)) in one call -- what evaluate.py:62-64
+ * does with `[model.forward_online(f) for f in torch.cat((x, x[-1].repeat(5, 1)))]`, T + 5 calls per sequence.
+ *   frames_dev   [N,60]     in   the frames in call order
+ *   pose_dev     [N,24,9]   out  pose of window index 40 of every call (net.py:181)
+ *   joints_dev   [N,45,72]  out  pred_joints of every call's window, or NULL
+ *   root_pos_dev [N,3]      out  last_root_pos after every call (net.py:208)
+ *   contact_dev  [N,2]      out  foot-contact logits of window index 40 (net.py:187)
+ * Same semantics and carried state as N calls of mp_stream_step (the window before the first call, the velocity LSTM state --
+ * every call runs its 45 steps ON the state the previous one left, SURVEY Q6 --, last foot positions, root height / position;
+ * all of them are left as the N-th call leaves them), but the joints / pose / foot-contact blocks of all N windows run as ONE
+ * N x 45 batch and the velocity block as one N*45-step sequence.  Results agree with the tick-by-tick path to fp32 noise (other
+ * kernels serve the other batch shape), not bit for bit.  Exact-fp32 operands only. */
+int mp_stream_replay(mp_handle* h, const float* frames_dev, int N, float* pose_dev, float* joints_dev, float* root_pos_dev,
+                     float* contact_dev, void* stream);
+
 /* reset(): all streams (mask_host == NULL) or those with mask_host[s] != 0.  Like the reference's
  * reset() it leaves the velocity LSTM state alone unless clear_velocity != 0. */
 int mp_stream_reset(mp_handle* h, const uint8_t* mask_host, int clear_velocity);

@@ -78,6 +78,7 @@ SIGNATURES = {
     "mp_set_velocity_state": (_i, [_vp, _vp, _i]),
     "mp_stream_create": (_i, [_vp, _i]),
     "mp_stream_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mp_stream_replay": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "mp_stream_reset": (_i, [_vp, C.POINTER(C.c_uint8), _i]),
     "mp_live_form_frames": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint, _i, _vp, _vp]),
     "mp_stream_get_state": (_i, [_vp, _i, _vp, _fp, C.POINTER(C.c_double), _fp, C.POINTER(_i)]),

@@ -144,6 +144,8 @@ struct StreamCtx {
     uint8_t* mask_dev = nullptr;     // [S]
     OnlineState st;
     float *joints = nullptr, *vel = nullptr, *contact = nullptr;
+    float* replay_ws = nullptr;      // mp_stream_replay: frame history | index-40 velocity rows | joints / contact of the batch
+    size_t replay_bytes = 0;
 };
 
 }  // namespace
@@ -1702,7 +1704,7 @@ void mp_destroy(mp_handle* h) {
             if (m.wihX[l][d]) (void)hipFree(m.wihX[l][d]);
         }
     }
-    void* misc[] = {h->parent_dev, h->depth_dev, h->bone_dev, h->vstate.h, h->vstate.c, h->sc.window, h->sc.fresh,
+    void* misc[] = {h->parent_dev, h->depth_dev, h->bone_dev, h->vstate.h, h->vstate.c, h->sc.window, h->sc.replay_ws, h->sc.fresh,
                     h->sc.mask_dev, h->sc.st.last_foot, h->sc.st.root_y, h->sc.st.root_pos, h->sc.joints, h->sc.vel,
                     h->sc.contact, h->jrest_dev, h->vrest_dev, h->skinw_dev, h->lin1_pv.Wp, h->lin1_pv.W, h->lin1_pv.Wf, h->lin1_pv.bias, h->lin1_pvf.W, h->lin1_pvf.Wf, h->lin1_pvf.bias, h->prof_dev,
                     h->vtpl_dev, h->shapedirs_dev, h->jreg_dev, h->shape_ws, h->posedirsT_dev, h->rnn_snap,
@@ -2206,6 +2208,131 @@ int mp_stream_step(mp_handle* h, const float* frames_dev, float* pose_dev, float
             return (int)MP_OK;
         }, net_and_solver)) return rc2;
     h->vstate.B = S;
+    return leave(h, stream);
+}
+
+// N consecutive forward_online calls of a single stream as ONE call (round 5; evaluate.py:62-64 runs
+// `[model.forward_online(f) for f in ...]`, T + 5 of them per sequence, each a full launch chain on a 1 x 45 batch).
+// Three of the four blocks are stateless per window (net.py:103-114): joints, pose and foot contact of all N windows run as ONE
+// N x 45 batch -- the windows are never materialised, window k is rows k+1 .. k+45 of the frame history, which a RowMap with
+// strideB = strideT = 60 addresses in place.  The velocity block is not: every call runs its 45 steps ON the state the previous
+// call left (velocity.py:45-48), i.e. the N calls together are one 2-layer LSTM over a single sequence of N * 45
+// steps whose input is the stacked linear1 of the N windows -- computed in the batch, written in sequence order, then two layer
+// launches at B = 1, T = N * 45.  Only index 40 of every window is needed behind the layers (net.py:181-187): pose's and
+// velocity's linear2 / IK run on N rows.  The solver chain over the N frames is one serial kernel.
+int mp_stream_replay(mp_handle* h, const float* frames_dev, int N, float* pose_dev, float* joints_dev, float* root_pos_dev,
+                     float* contact_dev, void* stream) {
+    if (!h) return MP_ERR_INVALID;
+    StreamCtx& c = h->sc;
+    if (!c.S) return fail(h, MP_ERR_NO_STREAMS, "mp_stream_replay before mp_stream_create");
+    if (c.S != 1) return fail(h, MP_ERR_INVALID, "mp_stream_replay drives a single stream (S = %d)", c.S);
+    if (!frames_dev || !pose_dev || !root_pos_dev || !contact_dev || N < 1) return fail(h, MP_ERR_INVALID, "mp_stream_replay: NULL buffer or N < 1");
+    const int W = 45, PAST = 40;
+    if ((long)N * W > 0x3fffffffL / 256) return fail(h, MP_ERR_INVALID, "mp_stream_replay: %d frames in one call is beyond the supported size; split it", N);
+    if (h->vstate.B != 0 && h->vstate.B != 1)
+        return fail(h, MP_ERR_STATE_SHAPE, "carried velocity state has batch %d, the replayed stream has 1", h->vstate.B);
+    ON_DEVICE(h);
+    if (int rc = enter(h, stream)) return rc;
+    if (int rc = ensure_vstate(h, h->vstate, 1)) return rc;
+    const bool has_state = h->vstate.B == 1;
+    // workspaces: the batch plan (N windows x 45), the chain plan (1 sequence x N*45), history / index-40 rows
+    Plan *pb = nullptr, *pc = nullptr;
+    if (int rc = get_plan(h, N, W, &pb)) return rc;
+    if (int rc = get_plan(h, 1, N * W, &pc)) return rc;
+    {
+        std::vector<int32_t> len(N, W);
+        if (int rc = upload_lengths(h, pb, len.data())) return rc;
+        const int32_t one = N * W;
+        if (int rc = upload_lengths(h, pc, &one)) return rc;
+    }
+    const size_t need = ((size_t)(W + N) * 60 + (size_t)N * 72 + (size_t)N * W * 72 + (size_t)N * W * 2) * sizeof(float);
+    if (need > c.replay_bytes) {
+        HIPCHK(h, hipStreamSynchronize(h->s_main));
+        if (c.replay_ws) (void)hipFree(c.replay_ws);
+        c.replay_ws = nullptr; c.replay_bytes = 0;
+        if (int rc = dev_alloc(h, (void**)&c.replay_ws, need)) return rc;
+        c.replay_bytes = need;
+    }
+    float* hist = c.replay_ws;
+    float* vel40 = hist + (size_t)(W + N) * 60;
+    float* joints_own = vel40 + (size_t)N * 72;
+    float* contact_b = joints_own + (size_t)N * W * 72;
+    float* joints = joints_dev ? joints_dev : joints_own;
+    h->segs.clear(); h->ev_used = 0;
+    if (int rc = snapshot_vstate(h, 1, has_state)) return rc;
+    if (h->recovery) {
+        HIPCHK(h, hipMemcpyAsync(h->st_snap.last_foot, c.st.last_foot, 6 * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+        HIPCHK(h, hipMemcpyAsync(h->st_snap.root_y, c.st.root_y, sizeof(double), hipMemcpyDeviceToDevice, h->s_main));
+        HIPCHK(h, hipMemcpyAsync(h->st_snap.root_pos, c.st.root_pos, 3 * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+    }
+    mp_launch_replay_history(c.window, c.fresh, frames_dev, N, W, hist, h->s_main);
+    const RowMap none{nullptr, 0, 0, 0};
+    auto body = [&]() -> int {
+        hipStream_t sm = h->s_main;
+        const RowMap xi{hist + 60, 60, 60, 60};                            // window k, frame i = history row k + 1 + i
+        const RowMap xj = user_map(joints, W, 72);
+        RnnJob J{h, pb, MP_MOD_JOINTS, xi, none, joints, (long)W * 72, 72, STATE_ZERO, nullptr, nullptr, nullptr, nullptr};
+        RnnJob P{h, pb, MP_MOD_POSE, xj, xi, pb->r6d, (long)W * 96, 96, STATE_ZERO, nullptr, nullptr, nullptr, nullptr};
+        RnnJob F{h, pb, MP_MOD_FOOT_CONTACT, xj, xi, contact_b, (long)W * 2, 2, STATE_ZERO, nullptr, nullptr, nullptr, nullptr};
+        if (int r = run_rnn(J, sm)) return r;                              // net.py:103
+        if (int r = run_rnn(P, sm)) return r;                              // net.py:106-107
+        mp_launch_r6d_ik_strided(pb->r6d, N, (long)W * 96, (long)PAST * 96, pose_dev, h->parent_dev, sm);   // net.py:110,181
+        if (int r = run_rnn(F, sm)) return r;                              // net.py:113-114
+        // velocity (net.py:117): linear1 of every window in the batch, rows written in (window, frame) order = the chain's time order
+        const ModuleW& mv = h->mod[MP_MOD_VELOCITY];
+        ModuleWS& wc = pc->ws[MP_MOD_VELOCITY];
+        float* X1 = x1_buffer(h, mv, wc);
+        if (use_x3(h, mv)) return fail(h, MP_ERR_INVALID, "mp_stream_replay runs on exact-fp32 operands (LSTM mode 1 or 0)");
+        run_gemm(h, sm, xj, xi, mv.lin1, X1, (long)W * mv.H, mv.H, N * W, N, 1);
+        if (!h->persist && !wc.xproj) return fail(h, MP_ERR_INVALID, "internal: per-step workspace missing");
+        if (!h->persist) run_gemm(h, sm, internal_map(X1, 1, mv.H), none, mv.ih[0], wc.xproj, 4 * mv.H, (long)4 * mv.H, N * W, 1, 0);
+        RnnJob V{h, pc, MP_MOD_VELOCITY, none, none, nullptr, 0, 0, has_state ? STATE_FROM : STATE_ZERO, h->vstate.h, h->vstate.c, h->vstate.h, h->vstate.c};
+        if (!h->persist) {       // per-step kernels keep their state in the plan's buffers: stage it in and out
+            for (int l = 0; l < 2; ++l) {
+                const size_t n = (size_t)mv.H * sizeof(float);
+                if (has_state) {
+                    HIPCHK(h, hipMemcpyAsync(wc.hbuf[l][0], h->vstate.h + (size_t)l * mv.H, n, hipMemcpyDeviceToDevice, sm));
+                    HIPCHK(h, hipMemcpyAsync(wc.cbuf[l][0], h->vstate.c + (size_t)l * mv.H, n, hipMemcpyDeviceToDevice, sm));
+                } else {
+                    HIPCHK(h, hipMemsetAsync(wc.hbuf[l][0], 0, n, sm));
+                    HIPCHK(h, hipMemsetAsync(wc.cbuf[l][0], 0, n, sm));
+                }
+            }
+        }
+        if (int r = rnn_rec(V, 0, sm)) return r;
+        if (int r = rnn_g1(V, sm)) return r;
+        if (int r = rnn_rec(V, 1, sm)) return r;
+        if (!h->persist) {
+            const size_t fin = (size_t)((N * W) & 1) * mv.H;
+            for (int l = 0; l < 2; ++l) {
+                const size_t n = (size_t)mv.H * sizeof(float);
+                HIPCHK(h, hipMemcpyAsync(h->vstate.h + (size_t)l * mv.H, wc.hbuf[l][0] + fin, n, hipMemcpyDeviceToDevice, sm));
+                HIPCHK(h, hipMemcpyAsync(h->vstate.c + (size_t)l * mv.H, wc.cbuf[l][0], n, hipMemcpyDeviceToDevice, sm));
+            }
+        }
+        // linear2 on row 40 of every window only (net.py:196 reads nothing else)
+        run_gemm(h, sm, RowMap{wc.out1 + (size_t)PAST * mv.H, (long)W * mv.H, 0, mv.H}, none, mv.lin2, vel40, 72, 0, N, N, 0);
+        mp_launch_translate_replay(joints, vel40, contact_b, N, W, PAST, h->floor_y, c.st, root_pos_dev, contact_dev, sm);   // net.py:186-208
+        HIPCHK(h, hipGetLastError());
+        return (int)MP_OK;
+    };
+    int rc;
+    {
+        SegScope whole(h, h->s_main, 3, 1);
+        rc = body();
+    }
+    if (rc) return rc;
+    if (int rc2 = finish_or_recover(h, pb, "mp_stream_replay", [&]() {
+            if (int r = ensure_step_ws(h, pc)) return r;
+            if (int r = restore_vstate(h, 1, has_state)) return r;
+            HIPCHK(h, hipMemcpyAsync(c.st.last_foot, h->st_snap.last_foot, 6 * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+            HIPCHK(h, hipMemcpyAsync(c.st.root_y, h->st_snap.root_y, sizeof(double), hipMemcpyDeviceToDevice, h->s_main));
+            HIPCHK(h, hipMemcpyAsync(c.st.root_pos, h->st_snap.root_pos, 3 * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+            return (int)MP_OK;
+        }, body)) return rc2;
+    mp_launch_replay_window(hist, N, W, c.window, c.fresh, h->s_main);   // net.py:175: the stream's window after the last call
+    HIPCHK(h, hipGetLastError());
+    h->vstate.B = 1;
     return leave(h, stream);
 }
 

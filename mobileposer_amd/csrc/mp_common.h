@@ -263,6 +263,13 @@ void mp_launch_window_push(float* window, const float* frames, uint8_t* fresh, i
 // velH/velC (optional) rows of the carried velocity state [2][S][256] are zeroed as well
 void mp_launch_stream_reset(const uint8_t* mask, uint8_t* fresh, double* root_y, float* root_pos, float* velH,
                             float* velC, int S, hipStream_t s);
+// replay of N consecutive forward_online calls of one stream (mp_stream_replay): the frame history (the stream's 45-frame window
+// or, for a fresh stream, 45 copies of the first frame, then the N frames: window k = hist[k+1 .. k+45]), the window the stream
+// holds afterwards, and the serial solver over the N frames (joints / contact in batch layout [N][T][.], vel [N][72])
+void mp_launch_replay_history(const float* window, const uint8_t* fresh, const float* frames, int N, int W, float* hist, hipStream_t s);
+void mp_launch_replay_window(const float* hist, int N, int W, float* window, uint8_t* fresh, hipStream_t s);
+void mp_launch_translate_replay(const float* joints, const float* vel, const float* contact, int N, int T, int idx, float floor_y,
+                                OnlineState st, float* root_pos_out, float* contact_out, hipStream_t s);
 void mp_launch_translate_online(const float* joints, const float* vel, const float* contact, int S, int T, int idx,
                                 float floor_y, OnlineState st, float* root_pos_out, float* contact_out,
                                 hipStream_t s);

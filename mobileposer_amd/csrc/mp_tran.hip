@@ -189,6 +189,81 @@ MP_KERNEL void mp_stream_reset(const uint8_t* __restrict__ mask, uint8_t* __rest
 
 }  // namespace
 
+namespace {
+
+// ---- replay of N consecutive forward_online calls of ONE stream (mp_stream_replay; evaluate.py:62-64) ----
+// history = the 45 frames the stream's window held before the first call (a fresh stream: 45 copies of the first frame,
+// net.py:175) followed by the N new frames: window k of the replay is history[k + 1 .. k + 45]
+MP_KERNEL void mp_replay_history(const float* __restrict__ window, const uint8_t* __restrict__ fresh,
+                                  const float* __restrict__ frames, int N, int W, float* __restrict__ hist) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)(W + N) * 60;
+    if (i >= total) return;
+    const long row = i / 60;
+    const int c = (int)(i - row * 60);
+    if (row < W) hist[i] = fresh[0] ? frames[c] : window[i];
+    else hist[i] = frames[(row - W) * 60 + c];
+}
+// ... and the window the stream holds afterwards: the last 45 frames of the history
+MP_KERNEL void mp_replay_window(const float* __restrict__ hist, int N, int W, float* __restrict__ window, uint8_t* __restrict__ fresh) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W * 60) window[i] = hist[(long)N * 60 + i];
+    if (i == 0) fresh[0] = 0;
+}
+
+// the solver of forward_online (net.py:186-208) for frames k = 0 .. N-1 in order, on window index `idx` of every window:
+// joints [N][T][72], contact [N][T][2] (batch layout), vel [N][72] (row idx of every window only).  One thread: the chain
+// through last foot positions / root height / root position is serial (same arithmetic as mp_translate_online)
+MP_KERNEL void mp_translate_replay(const float* __restrict__ joints, const float* __restrict__ vel, const float* __restrict__ contact,
+                                    int N, int T, int idx, float floor_y_f, OnlineState st, float* __restrict__ root_pos_out,
+                                    float* __restrict__ contact_out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    float lf[6];
+    for (int i = 0; i < 6; ++i) lf[i] = st.last_foot[i];
+    double root_y = st.root_y[0];
+    float rp0 = st.root_pos[0], rp1 = st.root_pos[1], rp2 = st.root_pos[2];
+    const double floor_y = (double)floor_y_f;
+    for (int k = 0; k < N; ++k) {
+        const float* jt = joints + ((size_t)k * T + idx) * 72;
+        const float* vt = vel + (size_t)k * 72;
+        const float c0 = contact[((size_t)k * T + idx) * 2], c1 = contact[((size_t)k * T + idx) * 2 + 1];
+        const float lx = jt[30], ly = jt[31], lz = jt[32], rx = jt[33], ry = jt[34], rz = jt[35];
+        float cvx, cvy, cvz;
+        if (c0 > c1) { cvx = lf[0] - lx + 0.f; cvy = lf[1] - ly + GRAVITY_VELOCITY; cvz = lf[2] - lz + 0.f; }   // net.py:189-192
+        else         { cvx = lf[3] - rx + 0.f; cvy = lf[4] - ry + GRAVITY_VELOCITY; cvz = lf[5] - rz + 0.f; }
+        const float pvx = vt[0] / VEL_DIVISOR, pvy = vt[1] / VEL_DIVISOR, pvz = vt[2] / VEL_DIVISOR;             // net.py:196
+        const float w = prob_to_weight(fmaxf(c0, c1));      // raw logit, no sigmoid (net.py:197)
+        const float omw = 1.0f - w;
+        const float vx = pvx * omw + cvx * w;
+        float vy = pvy * omw + cvy * w;
+        const float vz = pvz * omw + cvz * w;
+        const double cur_foot = root_y + (double)fminf(ly, ry);                 // net.py:201
+        if (cur_foot + (double)vy <= floor_y) vy = (float)(floor_y - cur_foot); // net.py:202-203
+        root_y += (double)vy;                                                    // net.py:205
+        lf[0] = lx; lf[1] = ly; lf[2] = lz; lf[3] = rx; lf[4] = ry; lf[5] = rz;  // net.py:206
+        rp0 += vx; rp1 += vy; rp2 += vz;                                         // net.py:208
+        root_pos_out[k * 3 + 0] = rp0; root_pos_out[k * 3 + 1] = rp1; root_pos_out[k * 3 + 2] = rp2;
+        contact_out[k * 2 + 0] = c0; contact_out[k * 2 + 1] = c1;
+    }
+    for (int i = 0; i < 6; ++i) st.last_foot[i] = lf[i];
+    st.root_y[0] = root_y;
+    st.root_pos[0] = rp0; st.root_pos[1] = rp1; st.root_pos[2] = rp2;
+}
+
+}  // namespace
+
+void mp_launch_replay_history(const float* window, const uint8_t* fresh, const float* frames, int N, int W, float* hist, hipStream_t s) {
+    const long total = (long)(W + N) * 60;
+    hipLaunchKernelGGL(mp_replay_history, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, window, fresh, frames, N, W, hist);
+}
+void mp_launch_replay_window(const float* hist, int N, int W, float* window, uint8_t* fresh, hipStream_t s) {
+    hipLaunchKernelGGL(mp_replay_window, dim3((W * 60 + 255) / 256), dim3(256), 0, s, hist, N, W, window, fresh);
+}
+void mp_launch_translate_replay(const float* joints, const float* vel, const float* contact, int N, int T, int idx, float floor_y,
+                                OnlineState st, float* root_pos_out, float* contact_out, hipStream_t s) {
+    hipLaunchKernelGGL(mp_translate_replay, dim3(1), dim3(64), 0, s, joints, vel, contact, N, T, idx, floor_y, st, root_pos_out, contact_out);
+}
+
 void mp_launch_window_push(float* window, const float* frames, uint8_t* fresh, int S, int W, hipStream_t s) {
     hipLaunchKernelGGL(mp_window_push, dim3(S), dim3(256), 0, s, window, frames, fresh, S, W);
 }

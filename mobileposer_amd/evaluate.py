@@ -137,9 +137,14 @@ def evaluate_pose(model, dataset, num_past_frame=20, num_future_frame=5, evaluat
                 tran_errors[w].append(v)
         if online:
             feed = torch.cat((x, x[-1:].expand(num_future_frame, -1)))
-            frames = [model.forward_online(f) for f in feed]
-            pose_o = torch.stack([fr[0] for fr in frames])[num_future_frame:]
-            tran_o = torch.stack([fr[2] for fr in frames])[num_future_frame:]
+            if hasattr(model, "forward_online_replay") and not getenv("MP_ONLINE_TICKS"):
+                # the T + 5 forward_online calls of evaluate.py:62-64 as one library call (mp_stream_replay, round 5)
+                pose_all, _j, tran_all, _c = model.forward_online_replay(feed)
+                pose_o, tran_o = pose_all[num_future_frame:], tran_all[num_future_frame:]
+            else:
+                frames = [model.forward_online(f) for f in feed]
+                pose_o = torch.stack([fr[0] for fr in frames])[num_future_frame:]
+                tran_o = torch.stack([fr[2] for fr in frames])[num_future_frame:]
             tables["online"].append(evaluator.eval(pose_o, pose_gt, tran_p=tran_o, tran_t=tran_t))
         if hasattr(model, "finish"):
             model.finish()          # raises if a kernel of this sequence gave up a wait and was not repaired (recovery off)

@@ -476,6 +476,30 @@ class MobilePoserNet:
         pose, joints, root, contact = self.stream_step(data.reshape(1, 60))
         return pose[0], joints[0], root[0], contact[0]
 
+    @torch.no_grad()
+    def forward_online_replay(self, frames):
+        """``[self.forward_online(f) for f in frames]`` (evaluate.py:62-64) as ONE library call (mp_stream_replay): frames
+        [N,60] -> (pose [N,24,9], pred_joints [N,45,72], last_root_pos [N,3], contact [N,2]), row k = what the k-th call
+        returns.  State (window, velocity LSTM state, foot / root state) is left as the last call leaves it."""
+        self._require_weights()
+        if self._stream_S == 0:
+            self.stream_create(1)
+        if self._stream_S != 1:
+            raise RuntimeError("forward_online_replay drives a single stream; %d were created" % self._stream_S)
+        if getattr(self, "_lstm_mode", 1) == 3:           # (the replay runs on exact-fp32 operands; mode 3: the calls one by one)
+            outs = [self.forward_online(f) for f in frames.reshape(-1, 60)]
+            return tuple(torch.stack([o[i] for o in outs]) for i in range(4))
+        x = self._input(frames.reshape(-1, 60))
+        N, dev, f32 = int(x.shape[0]), self.device, torch.float32
+        pose = torch.empty(N, 24, 9, device=dev, dtype=f32)
+        joints = torch.empty(N, 45, 72, device=dev, dtype=f32)
+        root = torch.empty(N, 3, device=dev, dtype=f32)
+        contact = torch.empty(N, 2, device=dev, dtype=f32)
+        self._check(self._lib.mp_stream_replay(self._h, _ptr(x), N, _ptr(pose), _ptr(joints), _ptr(root), _ptr(contact), self._stream()))
+        self._tick += 1
+        self._after_call()
+        return pose, joints, root, contact
+
     # ---- the reference's state attributes (net.py:59-64,205-208), read back from the device ---------------
     def stream_state(self, s=0):
         """State of stream ``s``: dict(imu [45,60] or None before the first frame, current_root_y (float),
@@ -618,6 +642,7 @@ class MobilePoserNet:
         """1 (default): fused persistent layers on exact-fp32 MFMA operands; 3: the same on split-fp16 operands (opt-in
         fast mode); 2: mode 1 + two-layer wavefront velocity kernel; 0: per-step kernels.  (include/mobileposer_hip.h)"""
         self._check(self._lib.mp_set_lstm_mode(self._h, int(mode)))
+        self._lstm_mode = int(mode)
 
     def set_transport(self, force_remote):
         """Test hook: force the any-placement (sc1) hidden-state transport of the persistent kernels."""

@@ -250,3 +250,100 @@ def test_build_id_is_the_md5_of_the_sources(net):
     info = net.device_info()
     assert info["build_id"] == _lib.source_md5() == _lib.file_build_id()
     assert info["device"] == 0 and info["n_cu"] == 256
+
+
+# ---- mp_stream_replay: N forward_online calls as one library call (evaluate.py:62-64) ---------------------------------------
+def _check_online(torch_mod, got, g, keys, lo, hi, tol=TOL):
+    pose, joints, root, contact = (npy(t) for t in got)
+    for k in range(lo, hi):
+        i = k - lo
+        assert geodesic(pose[i].reshape(24, 3, 3), g[keys["pose"]][k].reshape(24, 3, 3)).max() < tol, k
+        assert np.abs(joints[i][40] - g[keys["joints40"]][k]).max() < tol, k
+        assert np.abs(contact[i] - g[keys["contact"]][k]).max() < tol, k
+        assert np.abs(root[i] - g[keys["tran"]][k]).max() < TOL_TRAN, k
+
+
+G5_KEYS = {"pose": "pose", "joints40": "joints40", "contact": "contact", "tran": "tran"}
+G14_KEYS = {"pose": "on_pose", "joints40": "on_joints40", "contact": "on_contact", "tran": "on_tran"}
+
+
+@pytest.mark.parametrize("split", [None, 25, 1])
+def test_replay_of_the_online_goldens(torch_mod, weights, smpl, split):
+    """Golden G5 (60 forward_online calls recorded from the reference) through mp_stream_replay: all 60 frames in one call, in
+    two calls (state carried between them: window, velocity LSTM state, foot positions, root), and one replayed frame
+    followed by 59 single ticks -- the same outputs and the same final velocity state within 1e-4 / 1 mm."""
+    from conftest import load_golden
+    from mobileposer_amd.net import MobilePoserNet
+    g = load_golden("g5_online.npz")
+    frames = cu(torch_mod, g["imu"])
+    n = len(g["imu"])
+    with MobilePoserNet.from_numpy(weights, smpl) as net:
+        net.set_lstm_mode(1)
+        net.reset()
+        if split is None:
+            _check_online(torch_mod, net.forward_online_replay(frames), g, G5_KEYS, 0, n)
+        elif split == 1:
+            _check_online(torch_mod, net.forward_online_replay(frames[:1]), g, G5_KEYS, 0, 1)
+            for k in range(1, n):
+                pose, joints, tran, contact = net.forward_online(frames[k])
+                _check_online(torch_mod, (pose[None], joints[None], tran[None], contact[None]), g, G5_KEYS, k, k + 1)
+        else:
+            _check_online(torch_mod, net.forward_online_replay(frames[:split]), g, G5_KEYS, 0, split)
+            st = net.stream_state(0)
+            assert np.array_equal(npy(st["imu"]), g["imu"][split - 45:split] if split >= 45 else
+                                  np.concatenate([np.repeat(g["imu"][:1], 45 - split, 0), g["imu"][:split]]))
+            _check_online(torch_mod, net.forward_online_replay(frames[split:]), g, G5_KEYS, split, n)
+        h, c = net.velocity.rnn_state
+        assert np.abs(npy(h) - g["vel_h"]).max() < TOL and np.abs(npy(c) - g["vel_c"]).max() < TOL
+        assert net.device_error() == 0 and net.recovery_count == 0
+
+
+def test_replay_of_the_trained_regime_online_golden(torch_mod, weights_trained, smpl):
+    from conftest import load_golden
+    from mobileposer_amd.net import MobilePoserNet
+    g = load_golden("g14_trained.npz")
+    with MobilePoserNet.from_numpy(weights_trained, smpl) as net:
+        net.set_lstm_mode(1)
+        net.reset_all()
+        _check_online(torch_mod, net.forward_online_replay(cu(torch_mod, g["on_imu"])), g, G14_KEYS, 0, len(g["on_imu"]))
+        h, c = net.velocity.rnn_state
+        assert np.abs(npy(c) - g["on_vel_c"]).max() < TOL * max(1.0, float(np.abs(g["on_vel_c"]).max()))
+        assert net.device_error() == 0
+
+
+def test_replay_equals_the_ticks_and_is_faster(torch_mod, weights, smpl):
+    """300 frames: the replay against the same frames fed one forward_online call at a time (fp32-noise-level differences: the
+    batch shape picks other kernels), and the wall time of both."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    n = 300
+    frames = cu(torch_mod, synthetic.make_imu(1, n, seed=44)[0])
+    with MobilePoserNet.from_numpy(weights, smpl) as net:
+        net.set_lstm_mode(1)
+        net.reset_all()
+        torch_mod.cuda.synchronize(); t0 = time.perf_counter()
+        ticks = [net.forward_online(f) for f in frames]
+        torch_mod.cuda.synchronize(); t_ticks = time.perf_counter() - t0
+        ticks = [torch_mod.stack([o[i] for o in ticks]) for i in range(4)]
+        h_t, c_t = net.velocity.rnn_state
+        net.reset_all()
+        net.last_lfoot_pos, net.last_rfoot_pos = net.feet_pos[0], net.feet_pos[1]   # (reset() keeps them, net.py:84-88)
+        net.forward_online_replay(frames[:2]); net.reset_all()
+        net.last_lfoot_pos, net.last_rfoot_pos = net.feet_pos[0], net.feet_pos[1]
+        torch_mod.cuda.synchronize(); t0 = time.perf_counter()
+        rep = net.forward_online_replay(frames)
+        torch_mod.cuda.synchronize(); t_rep = time.perf_counter() - t0
+        h_r, c_r = net.velocity.rnn_state
+        for name, a, b, tol in (("pose", ticks[0], rep[0], 2e-5), ("joints", ticks[1], rep[1], 2e-5), ("root", ticks[2], rep[2], 2e-4),
+                                ("contact", ticks[3], rep[3], 2e-5)):
+            assert float((a - b).abs().max()) < tol, (name, float((a - b).abs().max()))
+        assert float((h_t - h_r).abs().max()) < 2e-5 and float((c_t - c_r).abs().max()) < 2e-5
+        print("300 frames: %d ticks %.1f ms (%.3f ms per tick), replay %.1f ms" % (n, 1e3 * t_ticks, 1e3 * t_ticks / n, 1e3 * t_rep))
+        assert t_rep < 0.5 * t_ticks
+        assert net.device_error() == 0 and net.recovery_count == 0
+
+
+@pytest.fixture(scope="module")
+def weights_trained():
+    from mobileposer_amd.synthetic import make_weights
+    return make_weights(0, profile="trained")
