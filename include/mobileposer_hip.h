@@ -288,7 +288,8 @@ int mp_set_graph_mode(mp_handle* h, int on);
  *       sizes; operands above 65504 (weights: 4094) in magnitude turn into inf / NaN.  Narrower than the reference's
  *       arithmetic: never the credited configuration.
  *       (Rounds 1-3 used bf16 halves -- 17 bits: fine on init-scale weights, 2e-3 .. 2e-2 off on trained-regime ones.)
- *   2: mode 1 plus the unidirectional velocity block as ONE two-layer wavefront launch;
+ *   2: accepted and treated as 1 (rounds 1-4: mode 1 with the velocity block as one two-layer wavefront launch of a separate
+ *       kernel; since round 5 mode 1's full-batch schedule runs the velocity block as a wavefront of the 8-slice kernel anyway);
  *   0 (env MP_LSTM_MODE=step): input-projection GEMM + one launch per time step. */
 int mp_set_lstm_mode(mp_handle* h, int mode);
 /* ---- error behaviour of the persistent LSTM kernels ---------------------------------------------------------------

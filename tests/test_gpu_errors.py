@@ -107,9 +107,11 @@ def test_starved_call_without_recovery_is_loud(torch_mod, weights, smpl, monkeyp
 
 
 def test_starved_velocity_launch_poisons_its_rider_too(torch_mod, weights, smpl, monkeypatch):
-    """B = 256, exact-fp32: the foot-contact layers ride in the velocity launches (the fifth and sixth fused launch of a
-    forward).  A workgroup missing there leaves NaN -- not plausible numbers -- in the slab's velocity AND contact rows, and
-    therefore in its translation; joints and pose (earlier launches) are untouched.  With recovery the call is repaired."""
+    """B = 256, exact-fp32: foot-contact layer 1 rides in the velocity wavefront launch (round 5: the fifth fused launch of a
+    forward, both velocity layers in one; rounds 3-4: the fifth and sixth, one per layer).  A workgroup missing there -- block 8
+    = slice 1 of layer 0 of slab 0 -- starves that cluster AND the layer-1 cluster behind the link, and leaves NaN -- not
+    plausible numbers -- in the slab's velocity AND contact rows, and therefore in its translation; joints and pose (earlier
+    launches) are untouched.  With recovery the call is repaired."""
     from mobileposer_amd import synthetic
     from mobileposer_amd.net import MobilePoserNet
     monkeypatch.setenv("MP_WAIT_MS", "15")
@@ -121,7 +123,7 @@ def test_starved_velocity_launch_poisons_its_rider_too(torch_mod, weights, smpl,
         m.set_recovery(False)
         want = [t.clone() for t in m.forward_offline(x, [T] * B)]          # pose, joints, tran, contact
         m.reset_all()
-        _starve(m, skip=4)                                                  # joints L0/L1, pose L0/L1, then velocity L0
+        _starve(m, skip=4)                                                  # joints L0/L1, pose L0/L1, then the velocity wavefront
         got = [t.clone() for t in m.forward_offline(x, [T] * B)]
         with pytest.raises(RuntimeError, match="gave up a wait"):
             m.finish()

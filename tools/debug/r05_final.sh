@@ -12,4 +12,5 @@ timeout 600 python tools/debug/class_times.py 128 256 1024 > gpurun_out/r05_clas
 MP_VARIANT=wf=0 timeout 600 python tools/debug/class_times.py 256 1024 > gpurun_out/r05_class_times_wf0.txt 2>&1; cat gpurun_out/r05_class_times_wf0.txt
 timeout 600 python tools/configs.py > gpurun_out/r05_configs.txt 2>&1; tail -12 gpurun_out/r05_configs.txt
 timeout 300 python bench.py --workload stream --steps 100 --warmup 10 > gpurun_out/r05_bench_stream_fp32.json 2>/dev/null; cat gpurun_out/r05_bench_stream_fp32.json | cut -c1-400
+timeout 600 python tools/debug/online_timing.py 3000 2>&1 | tail -4 > gpurun_out/r05_online_timing.txt; cat gpurun_out/r05_online_timing.txt
 timeout 300 bash tools/debug/pmc_forward.sh > gpurun_out/r05_pmc_forward.txt 2>&1; cat gpurun_out/r05_pmc_forward.txt
