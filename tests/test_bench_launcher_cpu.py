@@ -61,3 +61,39 @@ def test_bench_refuses_a_world_that_is_not_gpus():
     r = _run(["--gpus", "1", "--dry-run"], env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0",
                                                      "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_bench_verify_rows_accepts_the_oracle_and_rejects_a_wrong_output():
+    """bench.py compares 16 rows of the step it timed with the oracle (verify_rows, round 5).  The check itself, on CPU: the
+    oracle's own outputs pass with zero error; a 2e-4 offset on one velocity row or a 2 mm offset on one translation row fails
+    the run; rows outside the sample do not matter."""
+    import numpy as np
+    import pytest
+    import torch
+    sys.path.insert(0, REPO)
+    import bench
+    from mobileposer_amd import synthetic
+    from oracle import mp_oracle as O
+    B, T = 8, 12
+    imu = synthetic.make_imu(B, T, seed=3)
+    ref = O.OracleNet(synthetic.make_weights(0), synthetic.synthetic_smpl()["J"])
+    pose, joints, vel, contact = ref.forward(imu, [T] * B)
+    vel = vel.reshape(B, T, 72)
+    rg, jg = O.forward_kinematics(pose, ref.J)
+    tran = np.stack([O.translate_offline(joints[b].reshape(T, 24, 3), vel[b], contact[b], ref.floor_y) for b in range(B)])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    outs = {"joints": t(joints), "vel": t(vel), "contact": t(contact), "tran": t(tran), "pose": t(pose), "rglob": t(rg), "jglob": t(jg)}
+    ok = bench.verify_rows(outs, t(imu), B, T, rows=4, seed=1)
+    assert ok["rows"] == 4 and ok["of"] == B and max(ok["max_err"].values()) < 1e-5   # (the oracle on 4 rows vs on 8: BLAS blocking)
+    pick = np.sort(np.random.Generator(np.random.PCG64(1)).choice(B, 4, replace=False))
+    other = [b for b in range(B) if b not in pick][0]
+    bad = dict(outs, vel=outs["vel"].clone())
+    bad["vel"][other] += 1.0                                   # not sampled: passes
+    bench.verify_rows(bad, t(imu), B, T, rows=4, seed=1)
+    bad["vel"][int(pick[0]), 3, 5] += 2e-4
+    with pytest.raises(RuntimeError, match="differ from the oracle"):
+        bench.verify_rows(bad, t(imu), B, T, rows=4, seed=1)
+    bad = dict(outs, tran=outs["tran"].clone())
+    bad["tran"][int(pick[1]), 0, 1] += 2e-3
+    with pytest.raises(RuntimeError, match="tran_m"):
+        bench.verify_rows(bad, t(imu), B, T, rows=4, seed=1)
