@@ -298,6 +298,38 @@ def test_replay_of_the_online_goldens(torch_mod, weights, smpl, split):
         assert net.device_error() == 0 and net.recovery_count == 0
 
 
+def test_replay_on_the_per_step_kernels_and_after_a_starved_launch(torch_mod, weights, smpl, monkeypatch):
+    """mp_stream_replay's other code path: LSTM mode 0 (per-step kernels: the state of the 2 700-step velocity chain is staged
+    through the plan's buffers) reproduces golden G5, and a replay whose first fused launch loses a workgroup repairs itself on
+    that path (recovery on) -- same outputs, one recovery, the carried state as if nothing had happened."""
+    import warnings
+    from conftest import load_golden
+    from mobileposer_amd.net import MobilePoserNet
+    g = load_golden("g5_online.npz")
+    frames = cu(torch_mod, g["imu"])
+    n = len(g["imu"])
+    monkeypatch.setenv("MP_WAIT_MS", "15")
+    with MobilePoserNet.from_numpy(weights, smpl) as net:
+        net.set_lstm_mode(0)
+        net.reset()
+        _check_online(torch_mod, net.forward_online_replay(frames), g, G5_KEYS, 0, n)
+        h, c = net.velocity.rnn_state
+        assert np.abs(npy(h) - g["vel_h"]).max() < TOL and np.abs(npy(c) - g["vel_c"]).max() < TOL
+    with MobilePoserNet.from_numpy(weights, smpl) as net:
+        net.set_lstm_mode(1)
+        net.reset()
+        _check_online(torch_mod, net.forward_online_replay(frames[:20]), g, G5_KEYS, 0, 20)
+        assert net._lib.mp_debug_drop_workgroup(net._h, 8, 0, 1) == 0           # the next fused launch loses block 8
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = net.forward_online_replay(frames[20:])
+        assert net.recovery_count == 1 and any("starved" in str(i.message) for i in w), [str(i.message) for i in w]
+        _check_online(torch_mod, got, g, G5_KEYS, 20, n)
+        h, c = net.velocity.rnn_state
+        assert np.abs(npy(h) - g["vel_h"]).max() < TOL and np.abs(npy(c) - g["vel_c"]).max() < TOL
+        assert net.device_error() == 0
+
+
 def test_replay_of_the_trained_regime_online_golden(torch_mod, weights_trained, smpl):
     from conftest import load_golden
     from mobileposer_amd.net import MobilePoserNet
