@@ -53,7 +53,7 @@ KERNEL_CLASSES = {   # timing classes of the C ABI (include/mobileposer_hip.h, m
     5: "mp_lstm_fused<256,8,256,WF> velocity: both unidirectional layers as ONE two-layer wavefront launch, foot-contact layer 1 riding",
     6: "mp_lstm_fused<64,4,*> (foot contact as launches of its own: B <= 128)",
     7: "mp_lstm_step (per-step fallback)",
-    2: "mp_r6d_ik",
+    2: "mp_r6d_ik_fk (6D -> SO(3), global -> local, SMPL FK: one launch)",
 }
 
 

@@ -544,6 +544,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
             else if (key == "gemm_staged") {}                  // read by mp_launch_gemm
             else if (key == "kin_scalar") {}                   // read by mp_kin.hip
             else if (key == "gemm_frag") {}                    // read by mp_launch_gemm
+            else if (key == "kin_fused") {}                    // read by mp_launch_r6d_ik_fk: 0 = IK and FK as two launches
             else if (key == "l2l1") {}                         // read by mp_launch_gemm_l2l1: 0 = joints.linear2 and the stacked linear1 as two launches
             else if (key == "gemm_wide") {}                    // read by mp_launch_gemm: 0 = wide linear1 layers on mp_gemm_f32_frag's small tiles
             else if (key == "one_stream") {}                   // read by forward_body: 0 = the round-3 three-stream serial schedule
@@ -1299,9 +1300,14 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
             RC(rnn_g2_pair(V, F, sm));
             HIPCHK(h, hipStreamWaitEvent(sp, h->ev_x[2], 0));
             RC(rnn_g2(P, sp));
-            { SegScope seg(h, sp, 2, 1);
-              mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sp); }   // net.py:110
-            if (fk_rglobal) mp_launch_fk(pose, nullptr, poseRows, h->bone_dev, h->parent_dev, h->depth_dev, fk_rglobal, fk_joint, sp);
+            {   // net.py:110 (+ articulate/model.py:208-232 when the caller wants the FK outputs: one launch for both)
+                SegScope seg(h, sp, 2, 1);
+                if (!(fk_rglobal && mp_launch_r6d_ik_fk(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->bone_dev, h->parent_dev,
+                                                        fk_rglobal, fk_joint, sp))) {
+                    mp_launch_r6d_ik_strided(r6d, poseRows, poseRowStride, poseRowOffset, pose, h->parent_dev, sp);
+                    if (fk_rglobal) mp_launch_fk(pose, nullptr, poseRows, h->bone_dev, h->parent_dev, h->depth_dev, fk_rglobal, fk_joint, sp);
+                }
+            }
             HIPCHK(h, hipEventRecord(h->ev_x[3], sp));
             if (tail_pending) *tail_pending = true;
             else HIPCHK(h, hipStreamWaitEvent(sm, h->ev_x[3], 0));

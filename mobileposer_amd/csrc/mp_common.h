@@ -214,6 +214,10 @@ void mp_launch_r6d_to_rot(const float* r6d, long n, float* out, hipStream_t s); 
 // frame n reads its 96 numbers at r6d + n*rowStride + rowOffset
 void mp_launch_r6d_ik_strided(const float* r6d, long N, long rowStride, long rowOffset, float* pose,
                               const int* parent_dev, hipStream_t s);
+// mp_launch_r6d_ik_strided + mp_launch_fk (one body, no translation) as ONE launch (mp_r6d_ik_fk); false = not applicable,
+// nothing launched
+bool mp_launch_r6d_ik_fk(const float* r6d, long N, long rowStride, long rowOffset, float* pose, const float* bone_dev,
+                         const int* parent_dev, float* rglobal, float* joint, hipStream_t s);
 // boneStride: 0 = one body (bone_dev [24][3]) for all frames, 72 = frame n uses bone_dev + n*72 (per-frame shapes)
 void mp_launch_fk(const float* pose, const float* tran, long N, const float* bone_dev, const int* parent_dev,
                   const int* depth_dev, float* rglobal, float* joint, hipStream_t s, long boneStride = 0);

@@ -104,40 +104,17 @@ MP_KERNEL __launch_bounds__(256) void mp_r6d_to_rot(const float* __restrict__ r6
     for (int k = 0; k < 9; ++k) o[k] = R[k];
 }
 
-// lanes = joints, 2 frames per wave; bone[24][3] = j_i - j_parent(i) (bone[0] = j_0 = 0), depth[24]
-// (boneStride: 0 = one body for all frames; 72 = frame n uses bone + n*72, forward_kinematics with per-frame shapes)
-MP_KERNEL __launch_bounds__(256) void mp_fk(const float* __restrict__ pose, const float* __restrict__ tran, long N,
-                                              const float* __restrict__ bone, long boneStride,
-                                              const int* __restrict__ parent,
-                                              const int* __restrict__ depth, float* __restrict__ rglobal,
-                                              float* __restrict__ joint) {
-    const int lane = threadIdx.x & 63;
-    const int i = lane & 31;                       // joint
-    const long n = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
-    const bool live = (i < 24) && (n < N);
-    float G[9], p[3], L[9], bv[3];
-    int par = 0, dep = -1;
-    if (live) {
-        const float* src = pose + (n * 24 + i) * 9;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { L[k] = src[k]; G[k] = L[k]; }
-        const float* bn = bone + n * boneStride;
-        bv[0] = bn[i * 3 + 0]; bv[1] = bn[i * 3 + 1]; bv[2] = bn[i * 3 + 2];
-        p[0] = bv[0]; p[1] = bv[1]; p[2] = bv[2];
-        par = i > 0 ? parent[i] : 0;
-        dep = depth[i];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { L[k] = 0.f; G[k] = 0.f; }
-        bv[0] = bv[1] = bv[2] = 0.f; p[0] = p[1] = p[2] = 0.f;
-    }
+// The tree walk and the outputs of mp_fk, shared with the fused mp_r6d_ik_fk: lane = (frame parity) * 32 + joint, G = p's frame's
+// local rotation of joint i (also the start value of its global one), p = bv = its bone vector, par = its parent
+__device__ __forceinline__ void fk_walk_and_store(bool live, int lane, int i, long n, float G[9], float p[3], int par,
+                                                  const float* __restrict__ tran, float* __restrict__ rglobal,
+                                                  float* __restrict__ joint) {
     // Tree walk by pointer jumping (round 4): every lane holds the transform (G | p) of its joint relative to its `anc`-th
     // ancestor's frame and doubles that distance per round -- 1, 2, 4, 8 levels: four rounds of 13 wavefront shuffles cover
     // the SMPL tree (depth 8; setup_smpl rejects deeper trees) where the level-by-level walk needed eight rounds of 12.  The
     // shuffles (ds_bpermute) are what this kernel is bound by: 21.6 -> 13 us for 32 000 frames.  Products are associated as
     // (T_a T_b)(T_c T_d) instead of ((T_a T_b) T_c) T_d: results differ from the sequential walk in the last bits only.
     int anc = live && i > 0 ? par : -1;               // nearest ancestor not yet folded in (-1: relative to the world)
-    (void)dep;
 #pragma unroll 1
     for (int round = 0; round < 4; ++round) {
         const int srcLane = (lane & 32) + (anc >= 0 ? anc : 0);
@@ -171,6 +148,37 @@ MP_KERNEL __launch_bounds__(256) void mp_fk(const float* __restrict__ pose, cons
         float* oj = joint + (n * 24 + i) * 3;
         oj[0] = p[0] + tx; oj[1] = p[1] + ty; oj[2] = p[2] + tz;
     }
+}
+
+// lanes = joints, 2 frames per wave; bone[24][3] = j_i - j_parent(i) (bone[0] = j_0 = 0), depth[24]
+// (boneStride: 0 = one body for all frames; 72 = frame n uses bone + n*72, forward_kinematics with per-frame shapes)
+MP_KERNEL __launch_bounds__(256) void mp_fk(const float* __restrict__ pose, const float* __restrict__ tran, long N,
+                                              const float* __restrict__ bone, long boneStride,
+                                              const int* __restrict__ parent,
+                                              const int* __restrict__ depth, float* __restrict__ rglobal,
+                                              float* __restrict__ joint) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 31;                       // joint
+    const long n = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    const bool live = (i < 24) && (n < N);
+    float G[9], p[3], L[9], bv[3];
+    int par = 0, dep = -1;
+    if (live) {
+        const float* src = pose + (n * 24 + i) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { L[k] = src[k]; G[k] = L[k]; }
+        const float* bn = bone + n * boneStride;
+        bv[0] = bn[i * 3 + 0]; bv[1] = bn[i * 3 + 1]; bv[2] = bn[i * 3 + 2];
+        p[0] = bv[0]; p[1] = bv[1]; p[2] = bv[2];
+        par = i > 0 ? parent[i] : 0;
+        dep = depth[i];
+        (void)dep;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { L[k] = 0.f; G[k] = 0.f; }
+        bv[0] = bv[1] = bv[2] = 0.f; p[0] = p[1] = p[2] = 0.f;
+    }
+    fk_walk_and_store(live, lane, i, n, G, p, par, tran, rglobal, joint);
 }
 
 // ---- coalesced forms (round 4).  The two kernels above move 36-byte records with nine scalar loads / stores per lane:
@@ -230,6 +238,74 @@ MP_KERNEL __launch_bounds__(192) void mp_r6d_ik_lds(const float* __restrict__ r6
     const f32x4* src = reinterpret_cast<const f32x4*>(sO);
     f32x4* dst = reinterpret_cast<f32x4*>(pose + n0 * 216);
     for (int e = tid; e < nf * 54; e += 192) dst[e] = src[e];
+}
+
+// mp_r6d_ik_lds and mp_fk in ONE kernel (round 5: the tail of a forward that also wants the FK outputs -- bench.py's call): the local
+// rotations go out to `pose` through LDS as above AND stay in registers as the start values of the tree walk; thread (frame f =
+// tid / 32, joint i = tid % 32 < 24) is lane (f & 1) * 32 + i of wave f / 2 -- mp_fk's mapping.  Same arithmetic in the same order
+// as the two kernels: bit-identical outputs; one launch and one read of the pose less (13 + 16 -> 20 us at 32 000 frames).
+MP_KERNEL __launch_bounds__(256) void mp_r6d_ik_fk(const float* __restrict__ r6d, long N, long rowStride, long rowOffset,
+                                                     float* __restrict__ pose, const float* __restrict__ bone,
+                                                     const int* __restrict__ parent, float* __restrict__ rglobal,
+                                                     float* __restrict__ joint) {
+    __shared__ __attribute__((aligned(16))) float sR[kFkFrames * 96];
+    __shared__ float sG[kFkFrames * 16 * 9];
+    __shared__ __attribute__((aligned(16))) float sO[kFkFrames * 216];
+    const long n0 = (long)blockIdx.x * kFkFrames;
+    const int nf = (int)(N - n0 < kFkFrames ? N - n0 : kFkFrames);
+    const int tid = threadIdx.x;
+    if (tid < kFkFrames * 24 && tid / 24 < nf)
+        reinterpret_cast<f32x4*>(sR)[tid] = *reinterpret_cast<const f32x4*>(r6d + (n0 + tid / 24) * rowStride + rowOffset + (tid % 24) * 4);
+    __syncthreads();
+    if (tid < kFkFrames * 16 && (tid >> 4) < nf) gram_schmidt(sR + (tid >> 4) * 96 + 6 * (tid & 15), sG + tid * 9);
+    __syncthreads();
+    const int f = tid >> 5, i = tid & 31, lane = tid & 63;
+    const bool live = i < 24 && f < nf;
+    float G[9], p[3];
+    int par = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) G[k] = 0.f;
+    p[0] = p[1] = p[2] = 0.f;
+    if (live) {
+        auto rot = [&](int jn, float R[9]) {
+            const int sl = c_slot[jn];
+            if (sl >= 0) {
+                const float* g = sG + (f * 16 + sl) * 9;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) R[k] = g[k];
+            } else {
+                R[0] = 1.f; R[1] = 0.f; R[2] = 0.f; R[3] = 0.f; R[4] = 1.f; R[5] = 0.f; R[6] = 0.f; R[7] = 0.f; R[8] = 1.f;
+            }
+        };
+        float Gg[9];
+        rot(i, Gg);
+        par = i > 0 ? parent[i] : 0;
+        if (i == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) G[k] = Gg[k];
+        } else if ((IGNORED_MASK >> i) & 1u) {
+            G[0] = 1.f; G[1] = 0.f; G[2] = 0.f; G[3] = 0.f; G[4] = 1.f; G[5] = 0.f; G[6] = 0.f; G[7] = 0.f; G[8] = 1.f;
+        } else {
+            float P[9];
+            rot(par, P);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    G[r * 3 + c] = P[0 * 3 + r] * Gg[0 * 3 + c] + P[1 * 3 + r] * Gg[1 * 3 + c] + P[2 * 3 + r] * Gg[2 * 3 + c];
+        }
+        float* o = sO + (f * 24 + i) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[k] = G[k];
+        p[0] = bone[i * 3 + 0]; p[1] = bone[i * 3 + 1]; p[2] = bone[i * 3 + 2];
+    }
+    __syncthreads();
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(sO);
+        f32x4* dst = reinterpret_cast<f32x4*>(pose + n0 * 216);
+        for (int e = tid; e < nf * 54; e += 256) dst[e] = src[e];
+    }
+    fk_walk_and_store(live, lane, i, n0 + f, G, p, par, nullptr, rglobal, joint);
 }
 
 // Linear blend skinning of the SMPL mesh on top of mp_fk's outputs (articulate/model.py:234-240, no pose
@@ -434,6 +510,20 @@ void mp_launch_r6d_ik_strided(const float* r6d, long N, long rowStride, long row
     const long threads = N * 24;
     hipLaunchKernelGGL(mp_r6d_ik, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, r6d, N, rowStride,
                        rowOffset, pose, parent_dev);
+}
+
+// r6d -> local pose AND its forward kinematics (shared body, no translation) in one launch; false = buffers not 16-byte aligned
+// (or MP_VARIANT kin_scalar=1 / kin_fused=0): the caller runs mp_launch_r6d_ik_strided + mp_launch_fk instead
+bool mp_launch_r6d_ik_fk(const float* r6d, long N, long rowStride, long rowOffset, float* pose, const float* bone_dev,
+                         const int* parent_dev, float* rglobal, float* joint, hipStream_t s) {
+    static const bool off = getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "kin_fused=0");
+    if (N <= 0) return true;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(r6d) | reinterpret_cast<uintptr_t>(pose)) & 15) == 0 &&
+                         ((rowStride | rowOffset) & 3) == 0;
+    if (!aligned || off || mp_kin_scalar_forced()) return false;
+    hipLaunchKernelGGL(mp_r6d_ik_fk, dim3((unsigned)((N + kFkFrames - 1) / kFkFrames)), dim3(256), 0, s, r6d, N, rowStride, rowOffset,
+                       pose, bone_dev, parent_dev, rglobal, joint);
+    return true;
 }
 
 void mp_launch_r6d_to_rot(const float* r6d, long n, float* out, hipStream_t s) {

@@ -252,6 +252,29 @@ def test_build_id_is_the_md5_of_the_sources(net):
     assert info["device"] == 0 and info["n_cu"] == 256
 
 
+@pytest.mark.parametrize("B,T", [(256, 40), (129, 3)])
+def test_fused_ik_fk_kernel_equals_the_two_kernels_bitwise(torch_mod, weights, smpl, B, T):
+    """mp_forward_offline with the FK outputs requested runs r6d -> local pose -> forward kinematics as ONE kernel (mp_r6d_ik_fk,
+    round 5).  Same arithmetic in the same order as mp_r6d_ik_lds + mp_fk: pose, R_global and joint positions are bit for bit
+    what the stand-alone entry points give on the same r6d (frame counts that are and are not multiples of the 8 frames per block)."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    x = cu(torch_mod, synthetic.make_imu(B, T, seed=B + T))
+    lens = (C.c_int32 * B)(*([T] * B))
+    with MobilePoserNet.from_numpy(weights, smpl) as net:
+        net.set_lstm_mode(1)
+        o = _offline_buffers(torch_mod, B, T)
+        net.reset_all()
+        net.forward_offline_into(x, lens, o["pose"], o["joints"], o["vel"], o["contact"], o["tran"], o["rglob"], o["jglob"])
+        net.reset_all()
+        pose2, _j, _v, _c, r6d = net.forward(x, [T] * B, return_r6d=True)
+        assert torch_mod.equal(o["pose"], pose2)
+        assert torch_mod.equal(o["pose"], net._reduced_global_to_full(r6d))
+        Rg, jg = net.forward_kinematics(o["pose"])
+        assert torch_mod.equal(o["rglob"], Rg.reshape(o["rglob"].shape)) and torch_mod.equal(o["jglob"], jg.reshape(o["jglob"].shape))
+        assert net.device_error() == 0
+
+
 # ---- mp_stream_replay: N forward_online calls as one library call (evaluate.py:62-64) ---------------------------------------
 def _check_online(torch_mod, got, g, keys, lo, hi, tol=TOL):
     pose, joints, root, contact = (npy(t) for t in got)
