@@ -14,7 +14,7 @@ __global__ __launch_bounds__(512) void rate(float* out, const u32x4* w, int iter
     for (int i = 0; i < 8; ++i) b[i] = w[i * 64 + (threadIdx.x & 63)];
     u32x4 a0 = w[512 + (threadIdx.x & 63)], a1 = w[576 + (threadIdx.x & 63)];
     f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    f32x16 big[2] = {};
+    f32x16 big[3] = {};
     long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
@@ -24,6 +24,7 @@ __global__ __launch_bounds__(512) void rate(float* out, const u32x4* w, int iter
             if (KIND == 0) acc[r % NACC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[r % NACC], 0, 0, 0);
             if (KIND == 1) acc[r % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[r & 3]), __uint_as_float(bv[r & 3]), acc[r % NACC], 0, 0, 0);
             if (KIND == 2) big[r % 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), big[r % 2], 0, 0, 0);
+            if (KIND == 3) big[r % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av[r & 3]), __uint_as_float(bv[r & 3]), big[r % NACC], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -63,5 +64,8 @@ int main() {
     run<1, 4>("mfma_f32_16x16x4_f32", 512, out, w, cyc);
     run<2, 2>("mfma_f32_32x32x16_bf16", 256, out, w, cyc);
     run<2, 2>("mfma_f32_32x32x16_bf16", 512, out, w, cyc);
+    run<3, 2>("mfma_f32_32x32x2_f32", 256, out, w, cyc);         // (round 5: what the linear-layer kernels issue)
+    run<3, 3>("mfma_f32_32x32x2_f32", 256, out, w, cyc);
+    run<3, 2>("mfma_f32_32x32x2_f32", 512, out, w, cyc);
     return 0;
 }
