@@ -113,7 +113,7 @@ struct ModuleWS {
     unsigned hx_epoch = 0;              // next epoch base of `hx` (mp_lstm_fused launches); 0 = must be zeroed first
     unsigned hx_flip = 3;               // tagged-word launches (LstmPersistArgs::tag_flip): first tags of the next launch
     unsigned hx_flipF = 3;              // ... of a rider's words in the same area (tag_flip_f): only launches that carry one write them
-    bool hx_tagged = false;             // the area holds tagged words (else: granules / flagged words of the epoch family)
+    bool hx_tagged = false;             // the area holds tagged words (else: granules / the 32-slice kernels' flagged words, the epoch family)
 };
 struct VelState { float* h = nullptr; float* c = nullptr; int B = 0; int cap = 0; };   // [2][B][256] each
 
@@ -779,7 +779,7 @@ struct RnnJob {
 // split-bf16 operands for this module's LSTM layers?  (X1 and the layer-0 output are then stored as pairs)
 bool use_x3(const mp_handle* h, const ModuleW& m) { return h->persist && h->x3 && m.H == 256; }
 
-// Slices per slab of an exact-fp32 layer launch: a bidirectional H = 256 layer normally uses 8 slices (8-wave workgroups, one
+// Slices per slab of an exact-fp32 layer launch: a bidirectional H = 256 layer normally uses 8 slices (four 512-register waves, one
 // per CU at B = 256); when the batch is small enough that 16 slices still fit the chip (B <= 128), the 16-slice / 4-wave
 // decomposition halves the matrix work per CU and step (7 600 instead of 11 900 cycles per step).
 int fp32_slices(const mp_handle* h, const ModuleW& m, int B) {

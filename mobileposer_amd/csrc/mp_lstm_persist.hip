@@ -18,11 +18,12 @@
 //   * x_{t+1}: prefetched from HBM into registers while step t finishes (16-byte loads, 64-byte segments).
 // h_t crosses workgroups (the NSLICE slices of a slab need each other's units every step) in one of two forms:
 //   * 8-byte {epoch, value} granules -- the data is its own flag, no fence / barrier / flag word (cdna_hip_programming.md
-//     Guideline 16, form R2): the H = 64 kernels and the eight-wave kernels (described in this header);
-//   * plain 4-byte words in 16-byte pieces ("FLAGX" / "TAGX" in the kernel body): the H = 256 kernels with one wave per SIMD,
-//     where 16 granule loads + 16 tag compares per lane and step cost more than the hand-off latency they hid.  Rounds 2-4
-//     signalled them with one flag per producer wave (two dependent round trips per step); since round 4 every word carries a
-//     one-bit tag in bit 30 -- free, |h| <= 1 -- and a step is one round trip again (TAGX, the product).
+//     Guideline 16, form R2): the H = 64 kernels (described in this header);
+//   * plain 4-byte words in 16-byte pieces with a one-bit tag in bit 30 of every word -- free, |h| <= 1 -- ("TAGX" in the kernel
+//     body): the H = 256 kernels, where 16 granule loads + 16 tag compares per lane and step cost more than the hand-off
+//     latency they hid; one L2 round trip per step (rounds 2-4 signalled these words with a flag per producer wave: two).
+// Round 5: the K_in = 256 kernel on 8 slices also runs the unidirectional velocity block as a two-layer wavefront (WF) and
+// carries the H = 64 foot-contact layers as riders (FK) -- see the comment at the kernel.
 // Two transports, chosen per PRODUCER from where it really runs (its XCC id,
 // published once at kernel start), so the result never depends on placement, only the speed does:
 //   R: write-through (sc1) stores + sc1 loads -- coherent for any placement (fabric round trip, ~1 us);
@@ -384,7 +385,7 @@ MP_KERNEL __launch_bounds__(256, (FK || WF ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)
 
     // ---- FK: the H = 64 rider.  Wave kq takes K quarter kq of both of its products: x k = kq*FK/4 + (i/4)*16 + q*4 + i%4
     // (x-step i < FNX), h k = kq*16 + 4*ks + q (ks < 4).  Exchange words of the rider: [transport][parity][direction][1024]
-    // behind the flags of this cluster's area; word (row, unit u) at ((u/16*4 + u%4)*16 + row)*4 + (u/4)%4, so that consumer
+    // behind the link words of this cluster's area; word (row, unit u) at ((u/16*4 + u%4)*16 + row)*4 + (u/4)%4, so that consumer
     // lane (kq, q, row) finds its four k-steps in one 16-byte piece.  Producers of a piece: slices 8*dir + 2*kq (+1).
     static_assert(FK == 0 || (H == 256 && (NSLICE == 16 || NSLICE == 8) && KIN == 256), "the rider lives in the K_in = 256 kernels");
     constexpr int FNX = FK / 16, FNS = FNX + 4, FNJ = FK / 64;
