@@ -6,7 +6,10 @@
   * a NaN sample no longer puts a handle on the slow path: S = 512 streams with one glitching sensor, and three forward
     calls at 256 x 125 (reference behaviour: velocity.py:45-48 keeps the NaN state, angular.py:181 zeroes the pose);
   * device index handling (mp_create on an index the process cannot see; a HIP_VISIBLE_DEVICES-remapped index 0);
-  * the library's build id equals the md5 of the sources beside it.
+  * the library's build id equals the md5 of the sources beside it;
+  * the fused IK + FK kernel of the forward's tail against the two stand-alone kernels, bitwise;
+  * mp_stream_replay (N forward_online calls as one call: evaluate.py:62-64) against goldens G5 / G14, split in two, continued by
+    single ticks, on the per-step kernels, after a starved launch, and against the calls one by one (values and wall time).
 """
 import ctypes as C
 import os
