@@ -99,6 +99,8 @@ struct ModuleW {
     float* wihP8[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   //  two-layer wavefront launch; a bidirectional block's whhP / wihP already is it)
     float* whhU8[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // 32 slices of 8 units (mp_lstm_u8): small batches, H = 256 blocks
     float* wihU8[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    float* whhR[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};    // torch's own row-major W_hh / W_ih (mp_lstm_v1: one sequence,
+    float* wihR[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};    //  H = 256 blocks)
     float* wVF[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};     // H = 64 block: rider fragments of mp_lstm_fused<..., FK> ("VF")
 };
 struct ModuleWS {
@@ -191,6 +193,7 @@ struct mp_handle {
     unsigned epoch_start = 1;        // first epoch base after a zeroing (MP_VARIANT epoch_start: start close to the wrap guard)
     bool epoch_tags = true;          // MP_VARIANT epoch_tags=0: zero the exchange area before every fp32 layer launch (as round 1 did)
     bool slices16_ok = true;         // MP_VARIANT slices16=0: bidirectional fp32 layers always on 8 slices
+    bool vec_ok = true;              // MP_VARIANT vec=0: B = 1 on the 32-slice MFMA kernel (mp_lstm_u8), not on the matrix-vector kernel (mp_lstm_v1)
     bool slices32_ok = true;         // MP_VARIANT slices32=0: no 32-slice kernels for batches of one or two slabs
     bool wide_ok = true;             // MP_VARIANT wide=0: never run pose / velocity / foot-contact side by side (small batches)
     bool exclusive_ok = true;        // MP_VARIANT exclusive=0: never pad the LDS request of concurrent persistent launches (below)
@@ -296,6 +299,8 @@ int pack_weights(mp_handle* h, const float* blob) {
                     if (int rc = dev_alloc(h, (void**)&m.whhU8[l][d], (size_t)4 * m.H * m.H * sizeof(float))) return rc;
                     if (int rc = dev_alloc(h, (void**)&m.wihU8[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
                 }
+                if (int rc = dev_alloc(h, (void**)&m.whhR[l][d], (size_t)4 * m.H * m.H * sizeof(float))) return rc;
+                if (int rc = dev_alloc(h, (void**)&m.wihR[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
                 if (m.H == 256 && m.nslice != 16) {
                     if (int rc = dev_alloc(h, (void**)&m.whhP16[l][d], mp_whh_pack_floats(m.H) * sizeof(float))) return rc;
                     if (int rc = dev_alloc(h, (void**)&m.wihP16[l][d], (size_t)4 * m.H * kin * sizeof(float))) return rc;
@@ -342,6 +347,10 @@ int pack_weights(mp_handle* h, const float* blob) {
                 if (m.whhU8[l][d]) {
                     mp_launch_pack_w_u8(find(s.id, K_WHH, l, d), m.whhU8[l][d], m.H, h->s_main);
                     mp_launch_pack_w_u8(find(s.id, K_WIH, l, d), m.wihU8[l][d], m.ih[l].K, h->s_main);
+                }
+                if (m.whhR[l][d]) {
+                    HIPCHK(h, hipMemcpyAsync(m.whhR[l][d], find(s.id, K_WHH, l, d), (size_t)4 * m.H * m.H * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+                    HIPCHK(h, hipMemcpyAsync(m.wihR[l][d], find(s.id, K_WIH, l, d), (size_t)4 * m.H * m.ih[l].K * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
                 }
                 if (m.whhP8[l][d]) {
                     mp_launch_pack_whh_persist(find(s.id, K_WHH, l, d), m.whhP8[l][d], m.H, 8, h->s_main);
@@ -474,6 +483,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     {   // dynamic-LDS limits of the persistent kernels are per-device attributes (and must not be set under capture)
         hipError_t ea = mp_lstm_persist_device_attrs();
         if (ea == hipSuccess) ea = mp_lstm_u8_device_attrs();
+        if (ea == hipSuccess) ea = mp_lstm_v1_device_attrs();
         if (ea == hipSuccess) ea = mp_lstm_x3_device_attrs();
         if (ea == hipSuccess) ea = mp_lstm_x3w_device_attrs();
         if (ea != hipSuccess) { h->err = std::string("hipFuncSetAttribute failed: ") + hipGetErrorString(ea); return bail(MP_ERR_HIP); }
@@ -535,6 +545,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
             else if (key == "slices") h->nslice_env = v == 8 ? 8 : (v == 16 ? 16 : 0);
             else if (key == "slices16") h->slices16_ok = v != 0;
             else if (key == "slices32") h->slices32_ok = v != 0;
+            else if (key == "vec") h->vec_ok = v != 0;
             else if (key == "wide") h->wide_ok = v != 0;
             else if (key == "half") h->half_ok = v != 0;
             else if (key == "exclusive") h->exclusive_ok = v != 0;
@@ -923,13 +934,22 @@ bool wavefront_applies(const mp_handle* h, const ModuleW& m, int B, int T) {
            fp32_slices(h, m, B) == 16 && (size_t)B * T * m.H * sizeof(float) < 0x7fffffffull;
 }
 
+// The same for ONE sequence on the matrix-vector kernel (mp_lstm_v1<256,*,true>): the chain of mp_stream_replay and the velocity
+// block of a one-stream tick.  Both clusters (32 workgroups each) on ONE XCD, two workgroups per CU -- the schedules count the
+// block as one cluster, as without the wavefront.
+bool wavefront1_applies(const mp_handle* h, const ModuleW& m, int B) {
+    return h->persist && h->wf_ok && h->vec_ok && !use_x3(h, m) && m.H == 256 && m.dirs == 1 && m.whhR[0][0] != nullptr && B == 1 &&
+           fp32_slices(h, m, B) == 32;
+}
+
 int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
     mp_handle* h = j.h;
     const ModuleW& m = h->mod[j.id];
     ModuleWS& w = j.p->ws[j.id];
     const int B = j.p->B, T = j.p->T, H = m.H, dirs = m.dirs;
     float* out = l == 0 ? w.out0 : w.out1;
-    const bool wf = wavefront_applies(h, m, B, T) && !h->xcd_plan_on[j.id];
+    const bool wf32 = wavefront1_applies(h, m, B);
+    const bool wf = wf32 || (wavefront_applies(h, m, B, T) && !h->xcd_plan_on[j.id]);
     if (wf && l == 1) return MP_OK;                          // both layers went out with the layer-0 call (below)
     if (h->persist) {
         const int nslab = (B + 15) / 16;
@@ -943,7 +963,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         //  at 128 x 125; the memset between the launches is the boundary that prevents it.  The 8-slice kernels own their CU.)
         const bool crowded16 = !use_x3(h, m) && dirs == 2 && fp32_slices(h, m, B) == 16 && dirs * nslab * 16 > 128;
         const bool epoch_ok = !use_x3(h, m) && !h->capturing && h->epoch_tags && !crowded16;
-        const int nsl = wf ? 8 : (use_x3(h, m) ? m.nsliceX : fp32_slices(h, m, B));
+        const int nsl = wf32 ? 32 : wf ? 8 : (use_x3(h, m) ? m.nsliceX : fp32_slices(h, m, B));
         const bool p16 = !use_x3(h, m) && nsl == 16 && m.nslice != 16;      // 16-slice packing of a bidirectional block
         const bool p8 = !use_x3(h, m) && nsl == 8 && m.nslice != 8;         // 8-slice packing of the unidirectional block
         // (tagged-word kernels: one tag bit per word, so the area is also zeroed when the other kernel family -- granules with
@@ -967,6 +987,11 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         }
         unsigned long long* hx_l = (use_x3(h, m) && l == 1) ? w.hx2 : w.hx;
         const bool u8 = !use_x3(h, m) && H == 256 && nsl == 32;
+        const bool v1 = u8 && B == 1 && h->vec_ok && m.whhR[0][0] != nullptr;   // one sequence: matrix-vector steps (mp_lstm_v1)
+        // ... and the H = 64 block of one sequence: a whole direction per workgroup (mp_lstm_v1s).  Only where the H = 256 blocks
+        // of this batch run on the 32-slice family too (fp32_slices: 256 CUs, round-robin dispatch where blocks run side by side)
+        const bool v1s = !use_x3(h, m) && H == 64 && B == 1 && h->vec_ok && m.whhR[0][0] != nullptr &&
+                         fp32_slices(h, h->mod[MP_MOD_VELOCITY], B) == 32;
         const int cus = h->n_cu < 256 ? h->n_cu : 256;
         // slabs per launch: grid <= #CUs, one workgroup per CU
         const int chunk = cus / ((wf ? 2 : dirs) * nsl) > 0 ? cus / ((wf ? 2 : dirs) * nsl) : 1;
@@ -980,7 +1005,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         const RnnJob* fj = nullptr;
         int f_layer = 0;
         if (h->vf_foot && !use_x3(h, m) && kin == 256) {
-            if (j.id == MP_MOD_VELOCITY && wf) { fj = static_cast<const RnnJob*>(h->vf_foot); f_layer = 1; }
+            if (j.id == MP_MOD_VELOCITY && wf && !wf32) { fj = static_cast<const RnnJob*>(h->vf_foot); f_layer = 1; }
             else if (j.id == MP_MOD_VELOCITY && nsl == 16 && !p16) { fj = static_cast<const RnnJob*>(h->vf_foot); f_layer = l; }
             else if (j.id == MP_MOD_POSE && nsl == 8 && l == 0) { fj = static_cast<const RnnJob*>(h->vf_foot); f_layer = 0; }
         }
@@ -1011,13 +1036,13 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
             a.out_pairs = x3 ? 1 : 0;                          // both layers feed split-bf16 consumers (layer 1 / linear2)
             for (int d = 0; d < dirs; ++d) {
                 LstmDir& dd = a.d[d];
-                dd.wpack = x3 ? m.whhX[l][d] : (u8 ? m.whhU8[l][d] : p8 ? m.whhP8[l][d] : (p16 ? m.whhP16[l][d] : m.whhP[l][d]));
+                dd.wpack = x3 ? m.whhX[l][d] : ((v1 || v1s) ? m.whhR[l][d] : u8 ? m.whhU8[l][d] : p8 ? m.whhP8[l][d] : (p16 ? m.whhP16[l][d] : m.whhP[l][d]));
                 dd.xproj = nullptr; dd.out = outp + (size_t)d * H;
                 const bool inplace = j.out_h == j.in_h && j.out_h;
                 dd.hbuf = inplace ? j.out_h + (size_t)(l * dirs + d) * B * H : w.hbuf[l][d];
                 dd.cbuf = inplace ? j.out_c + (size_t)(l * dirs + d) * B * H : w.cbuf[l][d];
                 dd.xprojStride = 0; dd.outStride = dirs * H; dd.reverse = d;
-                dd.wihpack = x3 ? m.wihX[l][d] : (u8 ? m.wihU8[l][d] : p8 ? m.wihP8[l][d] : (p16 ? m.wihP16[l][d] : m.wihP[l][d])); dd.bias = m.ih[l].bias + (size_t)d * 4 * H; dd.xin = xin;
+                dd.wihpack = x3 ? m.wihX[l][d] : ((v1 || v1s) ? m.wihR[l][d] : u8 ? m.wihU8[l][d] : p8 ? m.wihP8[l][d] : (p16 ? m.wihP16[l][d] : m.wihP[l][d])); dd.bias = m.ih[l].bias + (size_t)d * 4 * H; dd.xin = xin;
             }
             if (dirs == 1) a.d[1] = a.d[0];
             if (wf) {
@@ -1025,13 +1050,17 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
                 // (slab, layer) are dealt to the XCDs slab by slab, so that the two layers of a slab share an L2
                 LstmDir& d1 = a.d[1];
                 const bool inplace = j.out_h == j.in_h && j.out_h;
-                d1.wpack = m.whhP8[1][0]; d1.wihpack = m.wihP8[1][0]; d1.bias = m.ih[1].bias; d1.xin = w.out0; d1.out = w.out1;
+                d1.wpack = wf32 ? m.whhR[1][0] : m.whhP8[1][0]; d1.wihpack = wf32 ? m.wihR[1][0] : m.wihP8[1][0];
+                d1.bias = m.ih[1].bias; d1.xin = w.out0; d1.out = w.out1;
                 d1.hbuf = inplace ? j.out_h + (size_t)1 * B * H : w.hbuf[1][0];
                 d1.cbuf = inplace ? j.out_c + (size_t)1 * B * H : w.cbuf[1][0];
                 d1.xproj = nullptr; d1.xprojStride = 0; d1.outStride = H; d1.reverse = 0;
                 unsigned char cnt[8];
-                for (int x = 0; x < 8; ++x) cnt[x] = (unsigned char)(2 * ((a.nslab + 7 - x) / 8));
+                // (one sequence: both clusters where forward_body's table has the block's one cluster, else on XCD 0)
+                for (int x = 0; x < 8; ++x)
+                    cnt[x] = (unsigned char)(2 * (wf32 ? (a.xcd_physical ? h->xcd_plan[j.id][x] : (x == 0 ? 1 : 0)) : (a.nslab + 7 - x) / 8));
                 mp_fill_xcd_table(a, cnt);
+                if (wf32) a.min_lds = 0;                      // (two workgroups per CU are the point)
             }
             if (fj) {
                 const ModuleW& fm = h->mod[MP_MOD_FOOT_CONTACT];
@@ -1041,7 +1070,9 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
                 a.f_out = f_layer == 0 ? fws.out0 : fws.out1;
             }
             const int fk = fj ? (f_layer == 0 ? fm_kin0(h) : 2 * h->mod[MP_MOD_FOOT_CONTACT].H) : 0;
-            if (wf || (fj && nsl == 8)) {
+            if (v1) mp_launch_lstm_v1(a, kin, wf32, s);
+            else if (v1s) mp_launch_lstm_v1s(a, kin, s);
+            else if (wf || (fj && nsl == 8)) {
                 if (!mp_launch_lstm_persist8(a, fk, wf, s)) return fail(h, MP_ERR_INVALID, "internal: 8-slice launch (rider %d, wavefront %d) not built", fk, (int)wf);
             } else if (fj) mp_launch_lstm_vf(a, fk, s);
             else if (x3 && nsl == 8 && (h->x3w_mask & (kin == 256 ? 1 : 2))) mp_launch_lstm_x3w(a, kin, s);
@@ -1703,6 +1734,8 @@ void mp_destroy(mp_handle* h) {
             if (m.wihP8[l][d]) (void)hipFree(m.wihP8[l][d]);
             if (m.whhU8[l][d]) (void)hipFree(m.whhU8[l][d]);
             if (m.wihU8[l][d]) (void)hipFree(m.wihU8[l][d]);
+            if (m.whhR[l][d]) (void)hipFree(m.whhR[l][d]);
+            if (m.wihR[l][d]) (void)hipFree(m.wihR[l][d]);
             if (m.whhP16[l][d]) (void)hipFree(m.whhP16[l][d]);
             if (m.wihP16[l][d]) (void)hipFree(m.wihP16[l][d]);
             if (m.whhX[l][d]) (void)hipFree(m.whhX[l][d]);

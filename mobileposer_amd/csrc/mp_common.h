@@ -193,6 +193,10 @@ void mp_launch_xcc_probe(int* out64, hipStream_t s);                    // 64 wo
 void mp_launch_lstm_u8(const LstmPersistArgs& a, int KIN, hipStream_t s);
 void mp_launch_pack_w_u8(const float* w, float* dst, int K, hipStream_t s);
 hipError_t mp_lstm_u8_device_attrs();
+// mp_lstm_v1.hip: one sequence per cluster (B = 1), matrix-vector steps on the vector ALU; d[].wpack / wihpack = row-major W_hh / W_ih
+void mp_launch_lstm_v1(const LstmPersistArgs& a, int KIN, bool wavefront, hipStream_t s);
+void mp_launch_lstm_v1s(const LstmPersistArgs& a, int KIN, hipStream_t s);   // H = 64: one workgroup per (direction, sequence)
+hipError_t mp_lstm_v1_device_attrs();
 void mp_launch_pack_whh_persist(const float* whh, float* dst, int H, int nslice, hipStream_t s);
 void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, int nslice, hipStream_t s);
 int mp_persist_max_wg(int H, int nslice);    // largest grid that is co-resident

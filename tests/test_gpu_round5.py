@@ -401,6 +401,55 @@ def test_replay_equals_the_ticks_and_is_faster(torch_mod, weights, smpl):
         assert net.device_error() == 0 and net.recovery_count == 0
 
 
+def test_one_slab_velocity_wavefront_and_the_single_sequence_kernel(torch_mod, weights, smpl, monkeypatch):
+    """B <= 16, exact-fp32: the velocity block runs both layers as ONE launch -- layer 1 reads layer 0's output behind per-wave
+    progress words, one XCD per layer (mp_lstm_u8<256,*,true>; B = 1: mp_lstm_v1<256,*,true>) -- the same arithmetic as two
+    launches (MP_VARIANT wf=0), bit for bit: one sequence, partly filled and full slabs, ragged lengths, carried velocity state,
+    a long sequence, the zeroed-area variant, the any-placement transport; then the streaming tick and the replay chain (which
+    carry the state of both layers in place).  And B = 1 on the matrix-vector kernel (mp_lstm_v1: vector-ALU dot products, DPP /
+    permlane reductions, granule hand-off) against the 32-slice MFMA kernel (MP_VARIANT vec=0): another order of summation,
+    equal to fp32 rounding."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    rng = np.random.default_rng(71)
+    shapes = ((1, 45), (1, 1), (1, 2), (5, 31), (16, 45), (3, 900), (1, 700))
+    lens = {sh: [int(v) for v in rng.integers(1, sh[1] + 1, size=sh[0])] for sh in shapes}
+    frames = cu(torch_mod, synthetic.make_imu(1, 60, seed=5)[0])
+    outs = {}
+    for variant, remote in (("wf=0", 0), ("", 0), ("epoch_tags=0", 0), ("", 1), ("vec=0,wf=0", 0), ("vec=0", 0), ("vec=0", 1)):
+        monkeypatch.setenv("MP_VARIANT", variant)
+        with MobilePoserNet.from_numpy(weights, smpl) as n:
+            n.set_lstm_mode(1)
+            if remote:
+                n.set_transport(True)
+            o = []
+            for B, T in shapes:
+                L = list(lens[(B, T)])
+                L[0] = T
+                x = cu(torch_mod, synthetic.make_imu(B, T, seed=B + T))
+                o += [t.clone() for t in n.forward_offline(x, L)]
+                o += [t.clone() for t in n.forward_offline(x, L)]      # carried velocity state
+                n.reset_all()
+            for f in frames[:50]:
+                o += [t.clone() for t in n.forward_online(f)]
+            o += [t.clone() for t in n.velocity.rnn_state]
+            n.reset_all()
+            o += [t.clone() for t in n.forward_online_replay(frames)]
+            o += [t.clone() for t in n.velocity.rnn_state]
+            assert n.device_error() == 0 and n.recovery_count == 0
+        outs[(variant, remote)] = o
+    for ref, keys in ((("wf=0", 0), (("", 0), ("epoch_tags=0", 0), ("", 1))), (("vec=0,wf=0", 0), (("vec=0", 0), ("vec=0", 1)))):
+        for key in keys:
+            assert len(outs[ref]) == len(outs[key])
+            for i, (a, b) in enumerate(zip(outs[ref], outs[key])):
+                assert torch_mod.equal(a, b), (key, i, float((a - b).abs().max()))
+    worst = 0.0
+    for i, (a, b) in enumerate(zip(outs[("", 0)], outs[("vec=0", 0)])):
+        worst = max(worst, float((a - b).abs().max()))
+        assert float((a - b).abs().max()) < 2e-5, (i, float((a - b).abs().max()))
+    print("mp_lstm_v1 vs mp_lstm_u8 at B = 1: max abs difference %.2e" % worst)
+
+
 @pytest.fixture(scope="module")
 def weights_trained():
     from mobileposer_amd.synthetic import make_weights

@@ -38,4 +38,13 @@ with MobilePoserNet.from_numpy(sd, smpl) as net:
     net.reset_all(); net.forward_online_replay(feed); torch.cuda.synchronize()
     names = {0: "gemm", 1: "bi256", 4: "bi512", 5: "uni", 6: "foot", 2: "ik", 3: "whole"}
     print("replay classes (launches, ms):", {names[c]: (net.timing_read(c)[0], round(net.timing_read(c)[1], 2)) for c in names})
+    xo = torch.from_numpy(synthetic.make_imu(1, T, seed=61)).cuda()
+    net.timing_enable(False)
+    for _ in range(3):
+        net.reset_all(); net.forward_offline(xo, [T])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        net.forward_offline(xo, [T])
+    torch.cuda.synchronize()
+    print("forward_offline, one sequence of %d frames: %.3f ms" % (T, 1e2 * (time.perf_counter() - t0)))
     assert net.device_error() == 0
