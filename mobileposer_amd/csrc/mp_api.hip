@@ -1040,6 +1040,14 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
                 dd.xproj = nullptr; dd.out = outp + (size_t)d * H;
                 const bool inplace = j.out_h == j.in_h && j.out_h;
                 dd.hbuf = inplace ? j.out_h + (size_t)(l * dirs + d) * B * H : w.hbuf[l][d];
+                dd.hin = dd.hbuf;
+                // T = 1 on a carried state: every workgroup reads the whole initial h, nobody waits for anybody in a one-step
+                // launch, and the final state goes where the initial one was -- the step-0 operand comes from a copy (the
+                // second half of the plan's buffer, which only the per-step kernels use)
+                if (T == 1 && j.mode != STATE_ZERO) {
+                    HIPCHK(h, hipMemcpyAsync(w.hbuf[l][d] + (size_t)B * H, dd.hbuf, (size_t)B * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+                    dd.hin = w.hbuf[l][d] + (size_t)B * H;
+                }
                 dd.cbuf = inplace ? j.out_c + (size_t)(l * dirs + d) * B * H : w.cbuf[l][d];
                 dd.xprojStride = 0; dd.outStride = dirs * H; dd.reverse = d;
                 dd.wihpack = x3 ? m.wihX[l][d] : ((v1 || v1s) ? m.wihR[l][d] : u8 ? m.wihU8[l][d] : p8 ? m.wihP8[l][d] : (p16 ? m.wihP16[l][d] : m.wihP[l][d])); dd.bias = m.ih[l].bias + (size_t)d * 4 * H; dd.xin = xin;
@@ -1053,6 +1061,11 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
                 d1.wpack = wf32 ? m.whhR[1][0] : m.whhP8[1][0]; d1.wihpack = wf32 ? m.wihR[1][0] : m.wihP8[1][0];
                 d1.bias = m.ih[1].bias; d1.xin = w.out0; d1.out = w.out1;
                 d1.hbuf = inplace ? j.out_h + (size_t)1 * B * H : w.hbuf[1][0];
+                d1.hin = d1.hbuf;
+                if (T == 1 && j.mode != STATE_ZERO) {
+                    HIPCHK(h, hipMemcpyAsync(w.hbuf[1][0] + (size_t)B * H, d1.hbuf, (size_t)B * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+                    d1.hin = w.hbuf[1][0] + (size_t)B * H;
+                }
                 d1.cbuf = inplace ? j.out_c + (size_t)1 * B * H : w.cbuf[1][0];
                 d1.xproj = nullptr; d1.xprojStride = 0; d1.outStride = H; d1.reverse = 0;
                 unsigned char cnt[8];

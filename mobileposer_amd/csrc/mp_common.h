@@ -91,6 +91,11 @@ struct LstmDir {
     const float* wihpack; // W_ih in B-fragment order (mp_pack_wih_persist)
     const float* bias;    // [4H] gate-interleaved b_ih + b_hh of this direction
     const float* xin;     // layer input, time-major [T][B][K_in]
+    // persistent kernels: where the A operand of step 0 -- the initial h of ALL units, read by every workgroup of the cluster --
+    // comes from.  Normally hbuf itself; for T = 1 with a carried state the host passes a copy: nobody waits for anybody in a
+    // one-step launch, and a workgroup that starts late must not find the final state of a neighbour that has already finished
+    // where the initial state was (the streaming paths and the carried velocity state keep their state in place).
+    const float* hin;
 };
 struct LstmStepArgs {
     LstmDir d[2];

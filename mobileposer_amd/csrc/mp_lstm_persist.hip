@@ -248,7 +248,7 @@ MP_KERNEL __launch_bounds__(256, (FK || WF ? 1 : Cfg<H, NSLICE, KIN>::WG_PER_CU)
     // A operand of the recurrent part for step 0 from the initial state: h0[row r16][k = kq*KW + 4*ks + q]
     float av[NKS];
     {
-        const float* p = d.hbuf + (size_t)(arow_in ? arow : 0) * H + kq * KW + q;
+        const float* p = d.hin + (size_t)(arow_in ? arow : 0) * H + kq * KW + q;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) av[ks] = (arow_in && !a.zero_state) ? p[4 * ks] : 0.f;
     }

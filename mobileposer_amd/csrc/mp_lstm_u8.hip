@@ -135,7 +135,7 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_u8(LstmPersistArgs a) {
 #pragma unroll
         for (int i = 0; i < NHG; ++i) {
             hr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ab < B && !a.zero_state) hr[i] = *reinterpret_cast<const f32x4*>(d.hbuf + (size_t)ab * H + 64 * wave + 16 * i + 4 * q);
+            if (ab < B && !a.zero_state) hr[i] = *reinterpret_cast<const f32x4*>(d.hin + (size_t)ab * H + 64 * wave + 16 * i + 4 * q);
         }
     }
     // ---- x: this lane's row r16, K quarter `wave`: pieces [KQ wave + 16 i + 4 q .. + 3]

@@ -194,7 +194,8 @@ static __device__ __forceinline__ void v1_cluster(const LstmPersistArgs& a, floa
             __builtin_amdgcn_s_sleep(4);
         }
     };
-    auto link_publish = [&](int done) {                                 // (the caller has waited for its output stores)
+    auto link_publish = [&](int done) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's output stores of the steps before are acknowledged
         if (lane == 0) {
             if (link_local) __hip_atomic_store(plink + slice * 4 + wave, pbase + (unsigned)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else __hip_atomic_store(plink + slice * 4 + wave, pbase + (unsigned)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -208,7 +209,7 @@ static __device__ __forceinline__ void v1_cluster(const LstmPersistArgs& a, floa
     const float* hseg = hs + s * HSTR;
     {   // the initial state as h_{-1}: values 4 lane .. 4 lane + 3
         f32x4 h0 = {0.f, 0.f, 0.f, 0.f};
-        if (in && !a.zero_state) h0 = *reinterpret_cast<const f32x4*>(d.hbuf + (size_t)b * H + 4 * lane);
+        if (in && !a.zero_state) h0 = *reinterpret_cast<const f32x4*>(d.hin + (size_t)b * H + 4 * lane);
         *reinterpret_cast<f32x4*>(hs + (lane >> 3) * HSTR + 4 * (lane & 7)) = h0;
     }
     // ---- x: time row of step `st` (reverse direction: from the sequence's last frame down; padding steps re-read a valid row)
@@ -330,10 +331,7 @@ static __device__ __forceinline__ void v1_cluster(const LstmPersistArgs& a, floa
         }
         V1_E(4);
     }
-    if (wf_l0) {                                                        // the last steps' outputs are in the buffer
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        link_publish(T);
-    }
+    if (wf_l0) link_publish(T);                                         // the last steps' outputs are in the buffer
     if (PROF && prof) {
         long long* o = a.prof + (size_t)blockIdx.x * 8;
         for (int i = 0; i < 5; ++i) o[i] = pt[i];

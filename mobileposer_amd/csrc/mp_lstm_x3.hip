@@ -172,7 +172,7 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
     // A operand of the recurrent part for step 0 from the initial fp32 state: pairs of h0[row][kq*64 + c*32 + q*8 + e]
     u32x4 hw[NHC][2];
     {
-        const float* p = d.hbuf + (size_t)(arow_in ? arow : 0) * H + kq * 64 + q * 8;
+        const float* p = d.hin + (size_t)(arow_in ? arow : 0) * H + kq * 64 + q * 8;
 #pragma unroll
         for (int c = 0; c < NHC; ++c)
 #pragma unroll

@@ -150,7 +150,7 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
 
     u32x4 hw[NHC][2];
     {
-        const float* p = d.hbuf + (size_t)(arow_in ? arow : 0) * H + kq * 64 + q * 8;
+        const float* p = d.hin + (size_t)(arow_in ? arow : 0) * H + kq * 64 + q * 8;
 #pragma unroll
         for (int c = 0; c < NHC; ++c)
 #pragma unroll

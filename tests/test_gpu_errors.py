@@ -75,6 +75,45 @@ def test_starved_call_repairs_itself(torch_mod, weights, smpl, monkeypatch, mode
         assert m.recovery_count == 1 and m.device_error() == 0
 
 
+def test_starved_single_sequence_launches_repair_themselves(torch_mod, weights, smpl, monkeypatch):
+    """B = 1 (round 5: mp_lstm_v1 -- granule hand-off, every wave polls for itself; the velocity block as a two-layer wavefront on
+    one XCD): a workgroup that never shows up in the k-th layer launch ends every wait of its cluster -- and of the other layer of a
+    wavefront -- in the time bound; the call reports it, is re-run on the per-step kernels and returns the undisturbed values.
+    (mp_lstm_v1s, the H = 64 block in one workgroup, has no waits: the hook does nothing there.)"""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    monkeypatch.setenv("MP_WAIT_MS", "15")
+    monkeypatch.setenv("MP_VARIANT", "")
+    T = 60
+    x = cu(torch_mod, synthetic.make_imu(1, T, seed=79))
+    repaired = 0
+    with MobilePoserNet.from_numpy(weights, smpl) as m:
+        m.set_lstm_mode(1)
+        m.set_recovery(True)
+        want = [t.clone() for t in m.forward_offline(x, [T])]
+        for skip in range(7):
+            m.reset_all()
+            before = m.recovery_count
+            _starve(m, skip=skip)
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                got = m.forward_offline(x, [T])
+            assert m.recovery_count - before in (0, 1)
+            if m.recovery_count > before:
+                repaired += 1
+                assert any("starved" in str(i.message) for i in w), [str(i.message) for i in w]
+            for a, b in zip(want, got):
+                assert bool(torch_mod.isfinite(b).all())
+                assert float((a - b).abs().max()) < 2e-5, (skip, float((a - b).abs().max()))
+            assert m._lib.mp_debug_drop_workgroup(m._h, 0, 0, 0) == 0       # disarm (a launch without the hook left it armed)
+            assert m.device_error() == 0
+        m.reset_all()
+        again = m.forward_offline(x, [T])
+        for a, b in zip(want, again):
+            assert float((a - b).abs().max()) < 2e-5
+    assert repaired >= 5, repaired          # joints L0 / L1, pose L0 / L1, the velocity wavefront
+
+
 def test_starved_call_without_recovery_is_loud(torch_mod, weights, smpl, monkeypatch):
     """Recovery off: the starved call returns at once (asynchronous); its outputs are NaN, never plausible numbers;
     finish() raises MP_ERR_DEVICE; afterwards the handle works again."""

@@ -450,6 +450,31 @@ def test_one_slab_velocity_wavefront_and_the_single_sequence_kernel(torch_mod, w
     print("mp_lstm_v1 vs mp_lstm_u8 at B = 1: max abs difference %.2e" % worst)
 
 
+@pytest.mark.parametrize("B", [1, 7, 40, 200])
+def test_one_frame_calls_on_a_carried_state(torch_mod, weights, smpl, B):
+    """forward_offline on single frames (T = 1), five calls in a row: the velocity block starts every call from the state the
+    call before left IN PLACE.  In a one-step launch of the persistent kernels nobody waits for anybody while every workgroup
+    reads the whole initial h, so the step-0 operand comes from a copy (LstmDir::hin, round 5; a late workgroup could otherwise
+    have found a neighbour's final state there).  Against the per-step kernels (mode 0), which ping-pong their state."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    xs = [cu(torch_mod, synthetic.make_imu(B, 1, seed=100 + i)) for i in range(5)]
+    outs = {}
+    with MobilePoserNet.from_numpy(weights, smpl) as n:
+        for mode in (0, 1):
+            n.set_lstm_mode(mode)
+            n.reset_all()
+            o = []
+            for x in xs:
+                o += [t.clone() for t in n.forward_offline(x, [1] * B)]
+            o += [t.clone() for t in n.velocity.rnn_state]
+            outs[mode] = o
+            assert n.device_error() == 0
+    assert len(outs[0]) == len(outs[1])
+    for i, (a, b) in enumerate(zip(outs[0], outs[1])):
+        assert float((a - b).abs().max()) < 2e-5, (i, float((a - b).abs().max()))
+
+
 @pytest.fixture(scope="module")
 def weights_trained():
     from mobileposer_amd.synthetic import make_weights
