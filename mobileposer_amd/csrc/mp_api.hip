@@ -2283,6 +2283,8 @@ int mp_stream_replay(mp_handle* h, const float* frames_dev, int N, float* pose_d
     if ((long)N * W > 0x3fffffffL / 256) return fail(h, MP_ERR_INVALID, "mp_stream_replay: %d frames in one call is beyond the supported size; split it", N);
     if (h->vstate.B != 0 && h->vstate.B != 1)
         return fail(h, MP_ERR_STATE_SHAPE, "carried velocity state has batch %d, the replayed stream has 1", h->vstate.B);
+    if (use_x3(h, h->mod[MP_MOD_VELOCITY]))      // (before anything is enqueued; the Python facade feeds the frames tick by tick in mode 3)
+        return fail(h, MP_ERR_INVALID, "mp_stream_replay runs on exact-fp32 operands (LSTM mode 1 or 0)");
     ON_DEVICE(h);
     if (int rc = enter(h, stream)) return rc;
     if (int rc = ensure_vstate(h, h->vstate, 1)) return rc;
@@ -2334,7 +2336,6 @@ int mp_stream_replay(mp_handle* h, const float* frames_dev, int N, float* pose_d
         const ModuleW& mv = h->mod[MP_MOD_VELOCITY];
         ModuleWS& wc = pc->ws[MP_MOD_VELOCITY];
         float* X1 = x1_buffer(h, mv, wc);
-        if (use_x3(h, mv)) return fail(h, MP_ERR_INVALID, "mp_stream_replay runs on exact-fp32 operands (LSTM mode 1 or 0)");
         run_gemm(h, sm, xj, xi, mv.lin1, X1, (long)W * mv.H, mv.H, N * W, N, 1);
         if (!h->persist && !wc.xproj) return fail(h, MP_ERR_INVALID, "internal: per-step workspace missing");
         if (!h->persist) run_gemm(h, sm, internal_map(X1, 1, mv.H), none, mv.ih[0], wc.xproj, 4 * mv.H, (long)4 * mv.H, N * W, 1, 0);

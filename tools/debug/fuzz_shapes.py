@@ -11,7 +11,7 @@ from mobileposer_amd.net import MobilePoserNet
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 sd, smpl = synthetic.make_weights(0), synthetic.synthetic_smpl()
 new = MobilePoserNet.from_numpy(sd, smpl)
-os.environ["MP_VARIANT"] = "wf=0,vf=0,epoch_tags=0,wide=0,slices16=0,exclusive=0,half=0,slices32=0"
+os.environ["MP_VARIANT"] = "wf=0,vf=0,epoch_tags=0,wide=0,slices16=0,exclusive=0,half=0,slices32=0,vec=0"
 old = MobilePoserNet.from_numpy(sd, smpl)
 rng = np.random.default_rng(2024)
 worst = 0.0

@@ -14,3 +14,7 @@ timeout 600 python tools/configs.py > gpurun_out/r05_configs.txt 2>&1; tail -12 
 timeout 300 python bench.py --workload stream --steps 100 --warmup 10 > gpurun_out/r05_bench_stream_fp32.json 2>/dev/null; cat gpurun_out/r05_bench_stream_fp32.json | cut -c1-400
 timeout 600 python tools/debug/online_timing.py 3000 2>&1 | tail -4 > gpurun_out/r05_online_timing.txt; cat gpurun_out/r05_online_timing.txt
 timeout 300 bash tools/debug/pmc_forward.sh > gpurun_out/r05_pmc_forward.txt 2>&1; cat gpurun_out/r05_pmc_forward.txt
+# the one-sequence kernels (mp_lstm_v1 / v1s) against the MFMA path at B = 1: timings, timeline of one 3000-frame sequence, phase counters
+{ for v in "" "vec=0"; do echo "== MP_VARIANT='$v'"; MP_VARIANT="$v" timeout 600 python tools/debug/online_timing.py 3000 2>&1 | grep -v amdgpu.ids; done; } > gpurun_out/r05_v1_timing.txt 2>&1; cat gpurun_out/r05_v1_timing.txt
+(cd /tmp && export TMPDIR=/tmp && timeout 600 python $GRAFT_REPO_ROOT/tools/debug/timeline.py 1 3000) > gpurun_out/r05_timeline_1x3000.txt 2>&1; tail -22 gpurun_out/r05_timeline_1x3000.txt
+{ for v in "" "vec=0"; do for ml in "0 0" "0 1"; do MP_VARIANT="$v" timeout 300 python tools/debug/prof_b1.py $ml 3000 2>&1 | grep -v amdgpu.ids; done; done; timeout 300 python tools/debug/prof_replay.py 1000 2>&1 | grep -v amdgpu.ids; } > gpurun_out/r05_v1_phases.txt 2>&1; cat gpurun_out/r05_v1_phases.txt
