@@ -162,4 +162,17 @@ static __device__ __forceinline__ void store_word_dev(unsigned* p, unsigned v) {
 static __device__ __forceinline__ void store_word_plain(unsigned* p, unsigned v) {
     asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory");
 }
+// ... and a granule {epoch, value} the same way (mp_lstm_v1: with a store among the pending loads the wait for x_t at the top
+// of a step becomes vmcnt(0) and sits out the acknowledgement of the stores the step before ended with; replay chain 162 ->
+// 158 ms).  A store the compiler does not see can only make a wait for a LOAD stricter, never laxer: loads return in order,
+// so a load that is outstanding keeps every younger load outstanding, and the counter the wait was computed for is reached
+// no earlier.
+static __device__ __forceinline__ void store_granule_xcd(u64* p, unsigned epoch, float v) {
+    const u64 w = ((u64)epoch << 32) | (u64)__float_as_uint(v);
+    asm volatile("global_store_dwordx2 %0, %1, off sc0" :: "v"(p), "v"(w) : "memory");
+}
+static __device__ __forceinline__ void store_granule_dev(u64* p, unsigned epoch, float v) {
+    const u64 w = ((u64)epoch << 32) | (u64)__float_as_uint(v);
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(w) : "memory");
+}
 

@@ -34,6 +34,12 @@
 
 namespace {
 
+// mp_set_error for the step loop: the same system-scope store, as inline asm (a store the compiler sees anywhere in the loop --
+// even on this cold path -- makes its wait-count pass drain every pending load at the next wait: store_granule_xcd, mp_lstm_dev.h)
+static __device__ __forceinline__ void set_error_hidden(int* err, int code) {
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(err), "v"(code) : "memory");
+}
+
 template <int KIN>
 struct V1Cfg {
     static constexpr int H = 256, NSLICE = 32;
@@ -186,7 +192,7 @@ static __device__ __forceinline__ void v1_cluster(const LstmPersistArgs& a, floa
             if (spins == 0 && reached(need)) { seen = need; return; }
             if (PROF && spins == 0) ++link_waits;
             if (wait_over(spins, spin_budget, wt0, a.max_ticks)) {
-                if (lane == 0) mp_set_error(a.err, 1 + step);
+                if (lane == 0) set_error_hidden(a.err, 1 + step);
                 spin_budget = 0; poison_cells(cst);
                 seen = T;
                 return;
@@ -197,8 +203,8 @@ static __device__ __forceinline__ void v1_cluster(const LstmPersistArgs& a, floa
     auto link_publish = [&](int done) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's output stores of the steps before are acknowledged
         if (lane == 0) {
-            if (link_local) __hip_atomic_store(plink + slice * 4 + wave, pbase + (unsigned)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else __hip_atomic_store(plink + slice * 4 + wave, pbase + (unsigned)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (link_local) store_word_xcd(plink + slice * 4 + wave, pbase + (unsigned)done);
+            else store_word_dev(plink + slice * 4 + wave, pbase + (unsigned)done);
         }
     };
 
@@ -261,7 +267,10 @@ static __device__ __forceinline__ void v1_cluster(const LstmPersistArgs& a, floa
             for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(wx[4 * i + j], v[j], acc[j]);
         }
         V1_E(0); V1_T(1);
-        // ---- h_{t-1}: all 256 granules of the parity slot, epoch = epoch_base + step
+        // ---- h_{t-1}: all 256 granules of the parity slot, epoch = epoch_base + step.  (The first poll BEHIND the input
+        // projection: issued in front of it -- it then returns while x_t is consumed -- the replay chain took 166.7 instead of
+        // 158.2 ms and one 3000-frame sequence 12.25 instead of 12.11 ms, r05_v1_ab.txt: half of the early polls fail, and the
+        // retry costs a full round trip.)
         if (step > 0) {
             const unsigned want = a.epoch_base + (unsigned)step;
             const unsigned soff = (unsigned)((step + 1) & 1) * (H * 8);
@@ -274,7 +283,7 @@ static __device__ __forceinline__ void v1_cluster(const LstmPersistArgs& a, floa
                 if (PROF && prof) ++polls;
                 if (__all(ok)) break;
                 if (wait_over(spins, spin_budget, wt0, a.max_ticks)) {      // bounded: flag the error and never wait again
-                    if (lane == 0) mp_set_error(a.err, 1 + step);
+                    if (lane == 0) set_error_hidden(a.err, 1 + step);
                     spin_budget = 0; poison_cells(cst);
                     break;
                 }
@@ -319,15 +328,16 @@ static __device__ __forceinline__ void v1_cluster(const LstmPersistArgs& a, floa
         cst = act ? cnew : cst;
         hst = act ? hnew : hst;
         const float oval = act ? hnew : 0.f;
+        // (all stores of the loop as inline asm: store_granule_xcd in mp_lstm_dev.h)
         if (s == 0 && g == 0) {
             u64* gp = gown + (size_t)(step & 1) * H;
-            granule_store_l2(gp, a.epoch_base + (unsigned)step + 1u, hst);
-            if (!all_local) granule_store(gp + C::G_R, a.epoch_base + (unsigned)step + 1u, hst);
+            store_granule_xcd(gp, a.epoch_base + (unsigned)step + 1u, hst);
+            if (!all_local) store_granule_dev(gp + C::G_R, a.epoch_base + (unsigned)step + 1u, hst);
         }
         if (owner) {
-            float* op = reinterpret_cast<float*>(reinterpret_cast<char*>(outb) + (size_t)(unsigned)tt * out_row_bytes);
-            if (wf_l0 && !link_local) __hip_atomic_store(reinterpret_cast<unsigned*>(op), __float_as_uint(oval), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else *op = oval;
+            unsigned* op = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(outb) + (size_t)(unsigned)tt * out_row_bytes);
+            if (wf_l0 && !link_local) store_word_dev(op, __float_as_uint(oval));
+            else store_word_plain(op, __float_as_uint(oval));
         }
         V1_E(4);
     }
