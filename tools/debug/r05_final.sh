@@ -4,9 +4,10 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 md5sum mobileposer_amd/libmobileposer_hip.so > gpurun_out/r05_lib.md5
 timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -30 > gpurun_out/r05_suite.txt; tail -3 gpurun_out/r05_suite.txt
+timeout 1500 python tools/profile.py r05 > gpurun_out/r05_profile.log 2>&1; tail -30 gpurun_out/r05_profile.log
+cp gpurun_out/r05_pmc_summary.json profiles/r05_pmc_summary.json     # (bench.py quotes roofline.traffic from the summary of THIS binary)
 timeout 600 python bench.py > gpurun_out/r05_bench.json 2> gpurun_out/r05_bench.err; python -c "
 import json; d=json.load(open('gpurun_out/r05_bench.json')); print(d['ms_per_step'], d['value'], d['roofline']['frac'], d['end_to_end'], d['verified']['max_err'])"
-timeout 1500 python tools/profile.py r05 > gpurun_out/r05_profile.log 2>&1; tail -30 gpurun_out/r05_profile.log
 (cd /tmp && export TMPDIR=/tmp && timeout 600 python $GRAFT_REPO_ROOT/tools/debug/timeline.py 256 125) > gpurun_out/r05_timeline_256x125.txt 2>&1; tail -14 gpurun_out/r05_timeline_256x125.txt
 timeout 600 python tools/debug/class_times.py 128 256 1024 > gpurun_out/r05_class_times.txt 2>&1; cat gpurun_out/r05_class_times.txt
 MP_VARIANT=wf=0 timeout 600 python tools/debug/class_times.py 256 1024 > gpurun_out/r05_class_times_wf0.txt 2>&1; cat gpurun_out/r05_class_times_wf0.txt
