@@ -538,6 +538,39 @@ def main():
         del imu3, o3
         lib.mp_reset_state(h, 1)
 
+    # ---- BASELINE configs[0] beside the headline: the reference's own call shape, ONE sequence (evaluate.py:57-60), rank 0 only ----
+    single = None
+    if rank == 0 and args.lstm_mode == "fp32":
+        T1 = 3000
+        imu1 = torch.from_numpy(synthetic.make_imu(1, T1, seed=7)).to(dev)
+        o1 = [torch.empty(T1, 24, 3, 3, device=dev, dtype=f32), torch.empty(1, T1, 72, device=dev, dtype=f32),
+              torch.empty(1, T1, 72, device=dev, dtype=f32), torch.empty(1, T1, 2, device=dev, dtype=f32),
+              torch.empty(1, T1, 3, device=dev, dtype=f32)]
+        lens1 = (C.c_int32 * 1)(T1)
+
+        def step1():
+            lib.mp_reset_state(h, 1)
+            rc = lib.mp_forward_offline(h, vp(imu1), lens1, 1, T1, *[vp(t) for t in o1], None, None, stream)
+            if rc:
+                raise RuntimeError(lib.mp_last_error(h).decode())
+
+        net.set_lstm_mode(MODE_ID["fp32"])
+        for _ in range(3):
+            step1()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step1()
+        torch.cuda.synchronize(dev)
+        dt1 = (time.perf_counter() - t0) / 10
+        single = {"workload": "configs[0]-shaped: forward_offline (4 modules + r6d/IK + solver) of ONE sequence of %d frames, "
+                              "the call evaluate.py makes per sequence" % T1,
+                  "ms_per_call": round(1e3 * dt1, 3), "frames_per_s": round(T1 / dt1, 1),
+                  "note": "latency-bound: 4 bidirectional layers x %d serial steps on the one-sequence kernels (mp_lstm_v1 / "
+                          "mp_lstm_v1s, DESIGN.md section 4); not part of `value`" % T1}
+        del imu1, o1
+        lib.mp_reset_state(h, 1)
+
     # ---- per-kernel-class timing: HIP events around every launch, on the library stream that launches it ----
     kern, dominant = {}, None
     if rank == 0:
@@ -670,6 +703,8 @@ def main():
     }
     if strong is not None:
         out["configs3_strong"] = strong
+    if single is not None:
+        out["configs0_single_sequence"] = single
     if per_rank is not None:
         out["per_rank"] = [dict({"rank": r, "frames": int(v[0]), "seconds": round(float(v[1]), 6)},
                                 **{k: rank_info[r][k] for k in ("device", "local_rank", "n_cu", "xcd_round_robin", "build_id")})

@@ -401,7 +401,7 @@ def test_replay_equals_the_ticks_and_is_faster(torch_mod, weights, smpl):
         assert net.device_error() == 0 and net.recovery_count == 0
 
 
-def test_one_slab_velocity_wavefront_and_the_single_sequence_kernel(torch_mod, weights, smpl, monkeypatch):
+def test_single_sequence_kernel_and_its_velocity_wavefront(torch_mod, weights, smpl, monkeypatch):
     """B <= 16, exact-fp32: the velocity block runs both layers as ONE launch -- layer 1 reads layer 0's output behind per-wave
     progress words, one XCD per layer (mp_lstm_u8<256,*,true>; B = 1: mp_lstm_v1<256,*,true>) -- the same arithmetic as two
     launches (MP_VARIANT wf=0), bit for bit: one sequence, partly filled and full slabs, ragged lengths, carried velocity state,

@@ -2,7 +2,7 @@
 # mp_lstm_v1: first poll before (default) / behind (MP_V1_EARLY_POLL=0 build, libmp_latepoll.so) the input projection, one box
 mkdir -p gpurun_out
 {
-timeout 900 python -m pytest tests/test_gpu_round5.py tests/test_gpu_errors.py -q -m gpu -x -k "one_slab or replay or single_sequence or one_frame" 2>&1 | tail -4
+timeout 900 python -m pytest tests/test_gpu_round5.py tests/test_gpu_errors.py -q -m gpu -x -k "single_sequence or replay or one_frame" 2>&1 | tail -4
 for rep in 1 2; do
 for lib in "" "$PWD/mobileposer_amd/libmp_latepoll.so"; do
   echo "== MP_LIB_PATH='$lib'"
