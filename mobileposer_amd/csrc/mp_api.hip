@@ -555,6 +555,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
             else if (key == "gemm_staged") {}                  // read by mp_launch_gemm
             else if (key == "kin_scalar") {}                   // read by mp_kin.hip
             else if (key == "gemm_frag") {}                    // read by mp_launch_gemm
+            else if (key == "gemm_few") {}                     // read by mp_launch_gemm: 0 = M <= 128 rows on the tiles of the large batches
             else if (key == "kin_fused") {}                    // read by mp_launch_r6d_ik_fk: 0 = IK and FK as two launches
             else if (key == "l2l1") {}                         // read by mp_launch_gemm_l2l1: 0 = joints.linear2 and the stacked linear1 as two launches
             else if (key == "gemm_wide") {}                    // read by mp_launch_gemm: 0 = wide linear1 layers on mp_gemm_f32_frag's small tiles
@@ -1642,12 +1643,18 @@ int leave(mp_handle* h, void* stream) {
 
 // ---- recovery (mp_set_recovery) ------------------------------------------------------------------------------------
 // snapshot / restore of the carried velocity state around a call (the fused kernels update it in place)
-int snapshot_vstate(mp_handle* h, int B, bool has_state) {
-    if (!h->recovery || !has_state) return MP_OK;
-    if (int rc = ensure_vstate(h, h->vsnap, B)) return rc;
-    const size_t n = (size_t)2 * B * 256 * sizeof(float);
-    HIPCHK(h, hipMemcpyAsync(h->vsnap.h, h->vstate.h, n, hipMemcpyDeviceToDevice, h->s_main));
-    HIPCHK(h, hipMemcpyAsync(h->vsnap.c, h->vstate.c, n, hipMemcpyDeviceToDevice, h->s_main));
+// (`more`: further copies of the same snapshot -- the solver state of a streaming tick -- that go out in the same launch)
+int snapshot_vstate(mp_handle* h, int B, bool has_state, CopyJobs* more = nullptr) {
+    CopyJobs js;
+    if (more) js = *more;
+    if (h->recovery && has_state) {
+        if (int rc = ensure_vstate(h, h->vsnap, B)) return rc;
+        const size_t n = (size_t)2 * B * 256 * sizeof(float);
+        js.add(h->vsnap.h, h->vstate.h, n);
+        js.add(h->vsnap.c, h->vstate.c, n);
+    }
+    mp_launch_copy_words(js, h->s_main);
+    HIPCHK(h, hipGetLastError());
     return MP_OK;
 }
 int restore_vstate(mp_handle* h, int B, bool has_state) {
@@ -2220,11 +2227,14 @@ int mp_stream_step(mp_handle* h, const float* frames_dev, float* pose_dev, float
     float* joints = joints_dev ? joints_dev : c.joints;
     const bool has_state = h->vstate.B == S;
     h->segs.clear(); h->ev_used = 0;
-    if (int rc = snapshot_vstate(h, S, has_state)) return rc;
-    if (h->recovery) {      // the solver state of the tick (net.py:59-64): last foot positions, root height, root position
-        HIPCHK(h, hipMemcpyAsync(h->st_snap.last_foot, c.st.last_foot, (size_t)S * 6 * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
-        HIPCHK(h, hipMemcpyAsync(h->st_snap.root_y, c.st.root_y, (size_t)S * sizeof(double), hipMemcpyDeviceToDevice, h->s_main));
-        HIPCHK(h, hipMemcpyAsync(h->st_snap.root_pos, c.st.root_pos, (size_t)S * 3 * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+    {
+        CopyJobs js;
+        if (h->recovery) {      // the solver state of the tick (net.py:59-64): last foot positions, root height, root position
+            js.add(h->st_snap.last_foot, c.st.last_foot, (size_t)S * 6 * sizeof(float));
+            js.add(h->st_snap.root_y, c.st.root_y, (size_t)S * sizeof(double));
+            js.add(h->st_snap.root_pos, c.st.root_pos, (size_t)S * 3 * sizeof(float));
+        }
+        if (int rc = snapshot_vstate(h, S, has_state, &js)) return rc;      // (+ the velocity state: one launch)
     }
     GraphKey key;
     memset(&key, 0, sizeof(key));
@@ -2313,11 +2323,14 @@ int mp_stream_replay(mp_handle* h, const float* frames_dev, int N, float* pose_d
     float* contact_b = joints_own + (size_t)N * W * 72;
     float* joints = joints_dev ? joints_dev : joints_own;
     h->segs.clear(); h->ev_used = 0;
-    if (int rc = snapshot_vstate(h, 1, has_state)) return rc;
-    if (h->recovery) {
-        HIPCHK(h, hipMemcpyAsync(h->st_snap.last_foot, c.st.last_foot, 6 * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
-        HIPCHK(h, hipMemcpyAsync(h->st_snap.root_y, c.st.root_y, sizeof(double), hipMemcpyDeviceToDevice, h->s_main));
-        HIPCHK(h, hipMemcpyAsync(h->st_snap.root_pos, c.st.root_pos, 3 * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
+    {
+        CopyJobs js;
+        if (h->recovery) {
+            js.add(h->st_snap.last_foot, c.st.last_foot, 6 * sizeof(float));
+            js.add(h->st_snap.root_y, c.st.root_y, sizeof(double));
+            js.add(h->st_snap.root_pos, c.st.root_pos, 3 * sizeof(float));
+        }
+        if (int rc = snapshot_vstate(h, 1, has_state, &js)) return rc;
     }
     mp_launch_replay_history(c.window, c.fresh, frames_dev, N, W, hist, h->s_main);
     const RowMap none{nullptr, 0, 0, 0};

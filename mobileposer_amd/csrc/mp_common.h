@@ -272,6 +272,14 @@ struct OnlineState {       // per-stream state of forward_online (net.py:59-64,2
 };
 // streaming window maintenance (net.py:175): window[s] = fresh[s] ? frame x45 : cat(window[s][1:], frame)
 void mp_launch_window_push(float* window, const float* frames, uint8_t* fresh, int S, int W, hipStream_t s);
+// several small device-to-device copies (4-byte words, 4-byte aligned) as one launch: mp_tran.hip
+struct CopyJobs {
+    static constexpr int kMax = 6;
+    struct Job { void* dst; const void* src; unsigned words; } j[kMax] = {};
+    int n = 0;
+    void add(void* dst, const void* src, size_t bytes) { if (n < kMax) j[n++] = Job{dst, src, (unsigned)(bytes / 4)}; }
+};
+void mp_launch_copy_words(const CopyJobs& js, hipStream_t s);
 // reset() for the masked streams (mask == nullptr: all): fresh = 1, root_y = 0, root_pos = 0 (net.py:84-88);
 // velH/velC (optional) rows of the carried velocity state [2][S][256] are zeroed as well
 void mp_launch_stream_reset(const uint8_t* mask, uint8_t* fresh, double* root_y, float* root_pos, float* velH,

@@ -784,6 +784,11 @@ void mp_launch_gemm(const GemmArgs& g, int bn, hipStream_t s) {
         // columns per wave: all of a narrow output (linear2: N <= 96); 64 of a wide one (linear1: four waves per SIMD keep the
         // MFMA pipe busier than two waves with 128 columns each -- 78.6 vs 85.0 us for the stacked pose + velocity linear1)
         int tn = g.N <= 32 ? 1 : g.N <= 64 ? 2 : g.N <= 96 ? 3 : 2;
+        // a handful of rows (one 128-row tile: a one-stream tick has 45): one 32-column tile per wave -- a wave's MFMA stream is
+        // all there is (joints / pose linear2 at 45 rows: 768 MFMAs = 20 us for the one wave that owned 96 columns), so the
+        // columns go to as many workgroups as there are tiles.  Same k order per output element: bit-identical.
+        static const bool few_ok = !(getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "gemm_few=0"));
+        if (few_ok && g.M <= 128) tn = 1;
         if (frag_tn) tn = frag_tn;
         if (npad32 % tn == 0 && (g.nsplit == 0 || g.nsplit % (tn * 32) == 0) && (g.nsplit3 == 0 || g.nsplit3 % (tn * 32) == 0)) {
             const bool done = tn == 1 ? launch_frag_k<1>(g, s) : tn == 2 ? launch_frag_k<2>(g, s) : tn == 3 ? launch_frag_k<3>(g, s)

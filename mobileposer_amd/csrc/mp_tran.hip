@@ -250,7 +250,27 @@ MP_KERNEL void mp_translate_replay(const float* __restrict__ joints, const float
     st.root_pos[0] = rp0; st.root_pos[1] = rp1; st.root_pos[2] = rp2;
 }
 
+// up to six small device-to-device copies as ONE launch (the state a recoverable call starts from: five hipMemcpyAsync calls
+// were 60 us of a 400 us one-stream tick -- every copy is a kernel of its own with ~10 us between two of them)
+MP_KERNEL void mp_copy_words(CopyJobs js) {
+    const unsigned stride = gridDim.x * blockDim.x;
+#pragma unroll
+    for (int k = 0; k < CopyJobs::kMax; ++k) {
+        const unsigned* __restrict__ src = static_cast<const unsigned*>(js.j[k].src);
+        unsigned* __restrict__ dst = static_cast<unsigned*>(js.j[k].dst);
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < js.j[k].words; i += stride) dst[i] = src[i];
+    }
+}
+
 }  // namespace
+
+void mp_launch_copy_words(const CopyJobs& js, hipStream_t s) {
+    unsigned most = 0;
+    for (int k = 0; k < CopyJobs::kMax; ++k) most = js.j[k].words > most ? js.j[k].words : most;
+    if (!most) return;
+    const unsigned blocks = (most + 255) / 256 < 512 ? (most + 255) / 256 : 512;
+    hipLaunchKernelGGL(mp_copy_words, dim3(blocks), dim3(256), 0, s, js);
+}
 
 void mp_launch_replay_history(const float* window, const uint8_t* fresh, const float* frames, int N, int W, float* hist, hipStream_t s) {
     const long total = (long)(W + N) * 60;

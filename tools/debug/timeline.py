@@ -1,6 +1,6 @@
 """Timeline of ONE forward_offline: start offset / duration / queue of every kernel (rocprofv3 --kernel-trace).
 
-    cd /tmp && python $GRAFT_REPO_ROOT/tools/debug/timeline.py [B] [T]      (on the GPU box)
+    cd /tmp && python $GRAFT_REPO_ROOT/tools/debug/timeline.py [B] [T]      (on the GPU box; B = 0: one forward_online tick of one stream)
 
 Phase 1 (no argument `--child`): runs itself under rocprofv3; phase 2 parses the kernel trace and prints the last forward.
 """
@@ -9,7 +9,27 @@ import csv, glob, os, re, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def child_tick():
+    """one stream, forward_online calls (live_demo.py:238-241): the last tick is printed"""
+    import torch
+    sys.path.insert(0, ROOT)
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    net = MobilePoserNet.from_numpy(synthetic.make_weights(0), synthetic.synthetic_smpl())
+    net.set_lstm_mode(1)
+    frames = torch.from_numpy(synthetic.make_imu(1, 80, seed=1)[0]).cuda()
+    for f in frames:
+        net.forward_online(f)
+        torch.cuda.synchronize()
+    for f in frames[:6]:
+        time.sleep(0.05)
+        net.forward_online(f)
+        torch.cuda.synchronize()
+
+
 def child(B, T):
+    if B == 0:
+        return child_tick()
     import torch
     sys.path.insert(0, ROOT)
     from mobileposer_amd import synthetic
@@ -57,7 +77,7 @@ def main():
     rows = rows[cut:]
     t0 = int(rows[0]["Start_Timestamp"])
     end = max(int(r["End_Timestamp"]) for r in rows)
-    print("forward_offline %d x %d: %d kernels, %.1f us from first start to last end" % (B, T, len(rows), (end - t0) / 1e3))
+    print("%s: %d kernels, %.1f us from first start to last end" % ("forward_offline %d x %d" % (B, T) if B else "forward_online, one stream (S = 1 tick)", len(rows), (end - t0) / 1e3))
     print("%9s %9s %9s  %-6s %s" % ("start us", "dur us", "end us", "queue", "kernel  [grid x block]"))
     for r in rows:
         s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
