@@ -99,8 +99,8 @@ struct ModuleW {
     float* wihP8[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   //  two-layer wavefront launch; a bidirectional block's whhP / wihP already is it)
     float* whhU8[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // 32 slices of 8 units (mp_lstm_u8): small batches, H = 256 blocks
     float* wihU8[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    float* whhR[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};    // torch's own row-major W_hh / W_ih (mp_lstm_v1: one sequence,
-    float* wihR[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};    //  H = 256 blocks)
+    float* whhR[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};    // one sequence: W_hh / W_ih in mp_lstm_v1's per-lane order (H = 256)
+    float* wihR[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};    //  or as torch has them (H = 64, mp_lstm_v1s)
     float* wVF[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};     // H = 64 block: rider fragments of mp_lstm_fused<..., FK> ("VF")
 };
 struct ModuleWS {
@@ -348,7 +348,10 @@ int pack_weights(mp_handle* h, const float* blob) {
                     mp_launch_pack_w_u8(find(s.id, K_WHH, l, d), m.whhU8[l][d], m.H, h->s_main);
                     mp_launch_pack_w_u8(find(s.id, K_WIH, l, d), m.wihU8[l][d], m.ih[l].K, h->s_main);
                 }
-                if (m.whhR[l][d]) {
+                if (m.whhR[l][d] && m.H == 256) {                  // mp_lstm_v1: per-lane order
+                    mp_launch_pack_w_v1(find(s.id, K_WHH, l, d), m.whhR[l][d], m.H, h->s_main);
+                    mp_launch_pack_w_v1(find(s.id, K_WIH, l, d), m.wihR[l][d], m.ih[l].K, h->s_main);
+                } else if (m.whhR[l][d]) {                         // mp_lstm_v1s: the matrices as they are
                     HIPCHK(h, hipMemcpyAsync(m.whhR[l][d], find(s.id, K_WHH, l, d), (size_t)4 * m.H * m.H * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
                     HIPCHK(h, hipMemcpyAsync(m.wihR[l][d], find(s.id, K_WIH, l, d), (size_t)4 * m.H * m.ih[l].K * sizeof(float), hipMemcpyDeviceToDevice, h->s_main));
                 }

@@ -100,19 +100,21 @@ static __device__ __forceinline__ void v1_cluster(const LstmPersistArgs& a, floa
     const bool in = b < B;
     const int len = in ? a.lengths[b] : 0;
 
-    // ---- weights of gate row g * H + junit, segment s: straight from the row-major matrices
+    // ---- weights of gate row g * H + junit, segment s: packed [slice][wave][16-byte piece][lane] (mp_pack_w_v1), so that a
+    // wave's load is one contiguous KB (straight from the row-major matrices every lane walked a 128-byte line of its own, 64
+    // lines per load and 4 waves per CU: the prologue was 8 / 17 us of a 45-step launch)
     float wx[KS], wh[32];
     {
-        const float* px = d.wihpack + (size_t)(g * H + junit) * KIN + s * KS;
+        const f32x4* px = reinterpret_cast<const f32x4*>(d.wihpack) + (size_t)(slice * 4 + wave) * (KS / 4) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < KS / 4; ++i) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(px + 4 * i);
+            const f32x4 v = px[(size_t)i * 64];
             wx[4 * i] = v[0]; wx[4 * i + 1] = v[1]; wx[4 * i + 2] = v[2]; wx[4 * i + 3] = v[3];
         }
-        const float* ph = d.wpack + (size_t)(g * H + junit) * H + s * 32;
+        const f32x4* ph = reinterpret_cast<const f32x4*>(d.wpack) + (size_t)(slice * 4 + wave) * 8 * 64 + lane;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(ph + 4 * i);
+            const f32x4 v = ph[(size_t)i * 64];
             wh[4 * i] = v[0]; wh[4 * i + 1] = v[1]; wh[4 * i + 2] = v[2]; wh[4 * i + 3] = v[3];
         }
     }
@@ -524,6 +526,24 @@ MP_KERNEL __launch_bounds__(1024, 1) void mp_lstm_v1s(LstmPersistArgs a) {
     }
 }
 
+// W [4H][K] (H = 256, rows gate * H + unit) -> [slice][wave][piece][lane][4]: lane (s, u2, g) = (lane / 8, lane / 4 % 2, lane % 4)
+// holds row g * H + slice * 8 + wave * 2 + u2, k = s * K / 8 + 4 piece + e
+MP_KERNEL void mp_pack_w_v1(const float* __restrict__ w, float* __restrict__ dst, int K) {
+    constexpr int H = 256;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)4 * H * K) return;
+    const int NP = K / 32;                                               // pieces per lane
+    size_t rest = idx;
+    const int e = (int)(rest % 4); rest /= 4;
+    const int lane = (int)(rest % 64); rest /= 64;
+    const int p = (int)(rest % NP); rest /= NP;
+    const int wave = (int)(rest % 4); rest /= 4;
+    const int slice = (int)rest;
+    const int row = (lane & 3) * H + slice * 8 + wave * 2 + ((lane >> 2) & 1);
+    const int k = (lane >> 3) * (K / 8) + 4 * p + e;
+    dst[idx] = w[(size_t)row * K + k];
+}
+
 template <int KIN, bool WF>
 void launch_v1(const LstmPersistArgs& a, hipStream_t s) {
     LstmPersistArgs b = a;
@@ -550,14 +570,18 @@ hipError_t v1_attrs() {
 
 }  // namespace
 
-// a.nslab = number of sequences (one cluster per direction and sequence); d[].wpack / wihpack = the ROW-MAJOR W_hh [4H][H] /
-// W_ih [4H][K_in] of torch.nn.LSTM.  wavefront: a.ndir = 2, d[0] = layer 0, d[1] = layer 1 reading d[0].out (K_in = 256).
+// a.nslab = number of sequences (one cluster per direction and sequence); d[].wpack / wihpack = W_hh / W_ih from
+// mp_launch_pack_w_v1.  wavefront: a.ndir = 2, d[0] = layer 0, d[1] = layer 1 reading d[0].out (K_in = 256).
 void mp_launch_lstm_v1(const LstmPersistArgs& a, int KIN, bool wavefront, hipStream_t s) {
     if (wavefront) launch_v1<256, true>(a, s);
     else if (KIN == 256) launch_v1<256, false>(a, s);
     else launch_v1<512, false>(a, s);
 }
-// H = 64, one workgroup per (direction, sequence); same weight layouts (row-major W_hh [256][64], W_ih [256][K_in])
+void mp_launch_pack_w_v1(const float* w, float* dst, int K, hipStream_t s) {
+    const size_t n = (size_t)4 * 256 * K;
+    hipLaunchKernelGGL(mp_pack_w_v1, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, dst, K);
+}
+// H = 64, one workgroup per (direction, sequence); the ROW-MAJOR W_hh [256][64], W_ih [256][K_in] of torch.nn.LSTM
 void mp_launch_lstm_v1s(const LstmPersistArgs& a, int KIN, hipStream_t s) {
     LstmPersistArgs b = a;
     int most = 0, total = 0;
