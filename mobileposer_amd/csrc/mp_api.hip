@@ -628,19 +628,29 @@ void free_plan(mp_handle* h, Plan* p) {
     delete p;
 }
 
-constexpr size_t kMaxPlans = 8;     // evaluate.py feeds one sequence length after another: keep only recent shapes
+// evaluate.py feeds one sequence length after another: keep only recent shapes -- at most kMaxPlans of them and at most kMaxRows
+// rows (B * T, ~12.5 KB of workspace each: 25 GB) together.  (Round 5: 8 -> 24 plans.  The ONLINE=1 branch replays a sequence in
+// chunks of 1024, 512, ... 1 frames -- net.py forward_online_replay -- so that its workspaces, up to 1.7 GB for 3000 frames
+// and 60-90 ms to map, are the same few shapes for every sequence.)
+constexpr size_t kMaxPlans = 24;
+constexpr size_t kMaxRows = (size_t)2 << 20;
 
 int get_plan(mp_handle* h, int B, int T, Plan** out) {
     auto it = h->plans.find({B, T});
     if (it != h->plans.end()) { it->second->last_use = ++h->use_clock; *out = it->second; return MP_OK; }
-    if (h->plans.size() >= kMaxPlans) {
-        HIPCHK(h, hipDeviceSynchronize());
+    while (true) {
+        size_t rows = (size_t)B * T;
+        for (const auto& kv : h->plans) rows += (size_t)kv.second->B * kv.second->T;
+        if (h->plans.size() < kMaxPlans && rows <= kMaxRows) break;
         auto victim = h->plans.end();
         for (auto jt = h->plans.begin(); jt != h->plans.end(); ++jt) {
             if (h->sc.S && jt->first == std::make_pair(h->sc.S, 45)) continue;      // the streaming plan stays
             if (victim == h->plans.end() || jt->second->last_use < victim->second->last_use) victim = jt;
         }
-        if (victim != h->plans.end()) { free_plan(h, victim->second); h->plans.erase(victim); }
+        if (victim == h->plans.end()) break;
+        HIPCHK(h, hipDeviceSynchronize());
+        free_plan(h, victim->second);
+        h->plans.erase(victim);
     }
     // (the layer kernels step through their output with a 32-bit row pitch: B * 512 floats must stay below 4 GB)
     if ((size_t)B * 512 * sizeof(float) > 0xffffffffull)

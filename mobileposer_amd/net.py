@@ -495,10 +495,21 @@ class MobilePoserNet:
         joints = torch.empty(N, 45, 72, device=dev, dtype=f32)
         root = torch.empty(N, 3, device=dev, dtype=f32)
         contact = torch.empty(N, 2, device=dev, dtype=f32)
-        self._check(self._lib.mp_stream_replay(self._h, _ptr(x), N, _ptr(pose), _ptr(joints), _ptr(root), _ptr(contact), self._stream()))
+        # The library keeps workspaces per (batch, length) shape, and a replay of N frames needs ~0.6 MB per frame (1.7 GB for
+        # 3000 frames: 60-90 ms to map, against 160 ms of work).  Sequences come in every length, so a sequence is replayed in
+        # chunks of REPLAY_CHUNK frames and its remainder in powers of two: at most a dozen shapes for every sequence there will
+        # ever be (the state carries from call to call -- tests/test_gpu_round5.py::test_replay_of_the_online_goldens splits).
+        k = 0
+        while k < N:
+            n = self.REPLAY_CHUNK if N - k >= self.REPLAY_CHUNK else 1 << ((N - k).bit_length() - 1)
+            self._check(self._lib.mp_stream_replay(self._h, _ptr(x[k:k + n]), n, _ptr(pose[k:k + n]), _ptr(joints[k:k + n]),
+                                                   _ptr(root[k:k + n]), _ptr(contact[k:k + n]), self._stream()))
+            k += n
         self._tick += 1
         self._after_call()
         return pose, joints, root, contact
+
+    REPLAY_CHUNK = 1024
 
     # ---- the reference's state attributes (net.py:59-64,205-208), read back from the device ---------------
     def stream_state(self, s=0):

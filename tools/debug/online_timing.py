@@ -27,7 +27,10 @@ with MobilePoserNet.from_numpy(sd, smpl) as net:
     a = [net.forward_online(f) for f in feed]
     torch.cuda.synchronize(); t_ticks = time.perf_counter() - t0
     net.reset_all(); net.last_lfoot_pos, net.last_rfoot_pos = net.feet_pos[0], net.feet_pos[1]
-    net.forward_online_replay(feed[:64]); net.reset_all(); net.last_lfoot_pos, net.last_rfoot_pos = net.feet_pos[0], net.feet_pos[1]
+    # (warm-up with the same frames: the workspaces of the chunk shapes exist afterwards -- the first replay of a new shape maps
+    #  up to 1.7 GB, 60-90 ms; forward_online_replay cuts a sequence into chunks of 1024, 512, ... frames so that every sequence
+    #  finds them)
+    net.forward_online_replay(feed); net.reset_all(); net.last_lfoot_pos, net.last_rfoot_pos = net.feet_pos[0], net.feet_pos[1]
     torch.cuda.synchronize(); t0 = time.perf_counter()
     b = net.forward_online_replay(feed)
     torch.cuda.synchronize(); t_rep = time.perf_counter() - t0
@@ -38,6 +41,13 @@ with MobilePoserNet.from_numpy(sd, smpl) as net:
     net.reset_all(); net.forward_online_replay(feed); torch.cuda.synchronize()
     names = {0: "gemm", 1: "bi256", 4: "bi512", 5: "uni", 6: "foot", 2: "ik", 3: "whole"}
     print("replay classes (launches, ms):", {names[c]: (net.timing_read(c)[0], round(net.timing_read(c)[1], 2)) for c in names})
+    others = []
+    for n in (T - 100, T - 223, T - 7, T - 1001):                  # other lengths, each for the first time: the chunk shapes are there
+        net.reset_all()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        net.forward_online_replay(feed[:n])
+        torch.cuda.synchronize(); others.append((n, 1e3 * (time.perf_counter() - t0)))
+    print("replays of other lengths, first time each: " + ", ".join("%d frames %.1f ms" % o for o in others))
     xo = torch.from_numpy(synthetic.make_imu(1, T, seed=61)).cuda()
     net.timing_enable(False)
     for _ in range(3):
