@@ -38,9 +38,9 @@ with MobilePoserNet.from_numpy(sd, smpl) as net:
     print("ONLINE branch, T = %d (+5): %d forward_online calls %.1f ms (%.3f ms each); mp_stream_replay %.1f ms (%.1f x); max |difference| %.2e"
           % (T, T + 5, 1e3 * t_ticks, 1e3 * t_ticks / (T + 5), 1e3 * t_rep, t_ticks / t_rep, d))
     net.timing_enable(True)
-    net.reset_all(); net.forward_online_replay(feed); torch.cuda.synchronize()
+    net.reset_all(); net.forward_online_replay(feed[:1024]); torch.cuda.synchronize()     # (one chunk: the counters are per library call)
     names = {0: "gemm", 1: "bi256", 4: "bi512", 5: "uni", 6: "foot", 2: "ik", 3: "whole"}
-    print("replay classes (launches, ms):", {names[c]: (net.timing_read(c)[0], round(net.timing_read(c)[1], 2)) for c in names})
+    print("replay of one 1024-frame chunk, classes (launches, ms):", {names[c]: (net.timing_read(c)[0], round(net.timing_read(c)[1], 2)) for c in names})
     others = []
     for n in (T - 100, T - 223, T - 7, T - 1001):                  # other lengths, each for the first time: the chunk shapes are there
         net.reset_all()
