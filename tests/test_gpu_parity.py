@@ -342,10 +342,10 @@ def test_large_ragged_batch_chunked_launches(torch_mod, net, weights, smpl):
 def test_many_shapes_evict_plans(torch_mod, net):
     """evaluate.py-style stream of different sequence lengths: plans and graphs are evicted, results stay right."""
     from mobileposer_amd import synthetic
-    imu = synthetic.make_imu(1, 40, seed=23)
+    imu = synthetic.make_imu(1, 48, seed=23)
     net.reset_all()
     first = net.forward(cu(torch_mod, imu[:, :12]), [12])[1].clone()
-    for T in range(13, 26):                          # 13 more shapes > kMaxPlans
+    for T in range(13, 43):                          # 30 more shapes > kMaxPlans (24 since round 5)
         net.reset_all()
         net.forward(cu(torch_mod, imu[:, :T]), [T])
     net.reset_all()
