@@ -114,6 +114,42 @@ def test_starved_single_sequence_launches_repair_themselves(torch_mod, weights, 
     assert repaired >= 5, repaired          # joints L0 / L1, pose L0 / L1, the velocity wavefront
 
 
+@pytest.mark.parametrize("S", [1, 64])
+def test_starved_streaming_tick_repairs_itself(torch_mod, weights, smpl, monkeypatch, S):
+    """A streaming tick (forward_online semantics) that loses a workgroup, recovery on: the state the tick started from --
+    velocity h / c, last foot positions, root height, root position, snapshotted by ONE launch (mp_copy_words, round 5) -- is put
+    back and network + solver are re-run on the per-step kernels (the frame is not pushed a second time).  The starved tick and
+    every later one equal those of an undisturbed model fed the same frames."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    monkeypatch.setenv("MP_WAIT_MS", "15")
+    monkeypatch.setenv("MP_VARIANT", "")
+    frames = cu(torch_mod, synthetic.make_imu(S, 9, seed=83))
+    with MobilePoserNet.from_numpy(weights, smpl) as m, MobilePoserNet.from_numpy(weights, smpl) as fresh:
+        for n in (m, fresh):
+            n.set_lstm_mode(1)
+            n.set_recovery(True)
+            n.stream_create(S)
+        for k in range(9):
+            if k in (3, 6):
+                _starve(m, skip=(0 if k == 3 else 2))                    # joints layer 0 | a later layer launch of the tick
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                got = [t.clone() for t in m.stream_step(frames[:, k])]
+            want = fresh.stream_step(frames[:, k])
+            for a, b in zip(want, got):
+                assert bool(torch_mod.isfinite(b).all()), k
+                assert float((a - b).abs().max()) < 2e-5, (k, float((a - b).abs().max()))
+            assert m._lib.mp_debug_drop_workgroup(m._h, 0, 0, 0) == 0
+        assert m.recovery_count == 2 and fresh.recovery_count == 0
+        hm, cm = m.velocity.rnn_state
+        hf, cf = fresh.velocity.rnn_state
+        assert float((hm - hf).abs().max()) < 2e-5 and float((cm - cf).abs().max()) < 2e-5
+        for name in ("last_root_pos", "last_lfoot_pos", "last_rfoot_pos"):
+            assert float((m.stream_state(0)[name] - fresh.stream_state(0)[name]).abs().max()) < 2e-5, name
+        assert m.device_error() == 0
+
+
 def test_starved_call_without_recovery_is_loud(torch_mod, weights, smpl, monkeypatch):
     """Recovery off: the starved call returns at once (asynchronous); its outputs are NaN, never plausible numbers;
     finish() raises MP_ERR_DEVICE; afterwards the handle works again."""
