@@ -289,7 +289,8 @@ static __device__ __forceinline__ void v1_cluster(const LstmPersistArgs& a, floa
                     spin_budget = 0; poison_cells(cst);
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                // (no s_sleep in front of the retry: with s_sleep 1 the replay chain took 162 instead of 152 ms, with s_sleep 3
+                //  173 -- the retry is a full round trip already)
             }
             // values 2 lane, 2 lane + 1 and 128 + 2 lane, + 1
             float* w0 = hs + (lane >> 4) * HSTR + 2 * (lane & 15);
