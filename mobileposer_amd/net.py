@@ -28,6 +28,18 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def replay_chunks(n, chunk=1024):
+    """Sizes of the library calls a replay of ``n`` frames is cut into: whole chunks, then the remainder in powers of two --
+    every sequence length uses the same dozen workspace shapes (MobilePoserNet.forward_online_replay)."""
+    out = [chunk] * (n // chunk)
+    n %= chunk
+    while n:
+        p = 1 << (n.bit_length() - 1)
+        out.append(p)
+        n -= p
+    return out
+
+
 _LIVE = weakref.WeakSet()       # nets that own a native handle
 
 
@@ -500,8 +512,7 @@ class MobilePoserNet:
         # chunks of REPLAY_CHUNK frames and its remainder in powers of two: at most a dozen shapes for every sequence there will
         # ever be (the state carries from call to call -- tests/test_gpu_round5.py::test_replay_of_the_online_goldens splits).
         k = 0
-        while k < N:
-            n = self.REPLAY_CHUNK if N - k >= self.REPLAY_CHUNK else 1 << ((N - k).bit_length() - 1)
+        for n in replay_chunks(N, self.REPLAY_CHUNK):
             self._check(self._lib.mp_stream_replay(self._h, _ptr(x[k:k + n]), n, _ptr(pose[k:k + n]), _ptr(joints[k:k + n]),
                                                    _ptr(root[k:k + n]), _ptr(contact[k:k + n]), self._stream()))
             k += n

@@ -97,3 +97,17 @@ def test_bench_verify_rows_accepts_the_oracle_and_rejects_a_wrong_output():
     bad["tran"][int(pick[1]), 0, 1] += 2e-3
     with pytest.raises(RuntimeError, match="tran_m"):
         bench.verify_rows(bad, t(imu), B, T, rows=4, seed=1)
+
+
+def test_replay_chunks_cover_every_length_with_a_dozen_shapes():
+    """forward_online_replay cuts a sequence into chunks of 1024 frames and a power-of-two remainder (net.py replay_chunks): the
+    pieces add up, keep the order of the frames, and all lengths together use at most 11 shapes (1024, 512, ... 1)."""
+    from mobileposer_amd.net import replay_chunks
+    shapes = set()
+    for n in list(range(1, 2200)) + [3005, 4096, 10000, 12345]:
+        c = replay_chunks(n)
+        assert sum(c) == n and all(v == 1024 or (v < 1024 and v & (v - 1) == 0) for v in c)
+        assert c == sorted(c, reverse=True) and len(c) <= n // 1024 + 10
+        shapes.update(c)
+    assert shapes == {1 << k for k in range(11)}
+    assert replay_chunks(7, chunk=4) == [4, 2, 1]
