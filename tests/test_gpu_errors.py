@@ -261,18 +261,20 @@ def test_state_attributes_can_be_assigned(torch_mod, net):
     assert net.device_error() == 0
 
 
-@pytest.mark.parametrize("B", [256, 128])
+@pytest.mark.parametrize("B", [256, 128, 1])
 def test_two_handles_two_threads_overlapping_full_chip_calls(torch_mod, weights, smpl, monkeypatch, B):
     """Real contention: two handles driven from two host threads, each issuing full-chip (256-workgroup) fused-LSTM launches
     at the same time (ctypes releases the GIL inside a call).  Every call plans for a GPU it has to itself, so grids of the
     two handles can starve each other; with recovery on every call still returns the undisturbed result -- repaired calls
     are counted, none raises, nothing hangs (all waits are time-bounded).  B = 128: each handle itself runs two grids side by
-    side on host-chosen XCDs (schedule 4) until its first repaired call switches the placement tables off."""
+    side on host-chosen XCDs (schedule 4) until its first repaired call switches the placement tables off.  B = 1 (round 5): the
+    one-sequence kernels of both handles want the same XCDs -- whole XCDs for a cluster, two workgroups per CU for the velocity
+    wavefront -- so their clusters may be resident only in part."""
     import threading
     from mobileposer_amd import synthetic
     from mobileposer_amd.net import MobilePoserNet
     monkeypatch.setenv("MP_WAIT_MS", "40")
-    T, reps = 16, 6
+    T, reps = (16, 6) if B > 1 else (400, 12)
     xs = [cu(torch_mod, synthetic.make_imu(B, T, seed=90 + k)) for k in range(2)]
     nets = [MobilePoserNet.from_numpy(weights, smpl) for _ in range(2)]
     try:
