@@ -299,7 +299,7 @@ class OracleNet:
         contact, _ = rnn_forward(self.sd, PREFIX["foot_contact"], x132, input_lengths)            # :114
         vel, self.velocity_rnn_state = rnn_forward(self.sd, PREFIX["velocity"], x132, input_lengths,
                                                    self.velocity_rnn_state)                        # :117, velocity.py:45-48
-        self._last_r6d = r6d
+        self._last_r6d, self._last_vel = r6d, vel
         return pose, joints, vel, contact
 
     def forward_offline(self, imu, input_lengths):

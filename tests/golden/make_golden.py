@@ -460,6 +460,44 @@ def main():
         g16["one_vel_h"], g16["one_vel_c"] = h.numpy(), c.numpy()
     np.savez_compressed(os.path.join(HERE, "g16_corners.npz"), **g16)
 
+    # ---- G17 (round 6) the reference's OWN call shape with trained-regime weights: evaluate.py:54-58 calls forward_offline
+    # (net.py:121-155) on ONE sequence of thousands of frames.  Three lengths x three input seeds (combos vary).  At this length
+    # the trained-regime net amplifies rounding until two fp32 evaluations differ by 1e-4 ... 1e-3 somewhere, so beside the
+    # reference's outputs (every 8th frame of r6d / joints / velocity, contact and translation in full) the file records how far
+    # each member of an ENSEMBLE of fp32 evaluations is from the float64 result over ALL frames: the reference itself (torch
+    # CPU), the numpy oracle, and the oracle with three permuted summation orders (oracle/ensemble.py) -- the band a kernel with
+    # yet another summation order has to stay inside (tests/test_gpu_round6.py).
+    from oracle import ensemble as ENS
+    g17 = {"lengths": np.array([2000, 2500, 3000]), "seeds": np.array([171, 172, 173]), "stride": np.array(8),
+           "members": np.array(["reference", "oracle", "perm0", "perm1", "perm2"]), "outputs": np.array(ENS.OUTPUTS)}
+    combos17 = {171: "lw_rp_h", 172: "rw_lp", 173: "lp_h"}
+    g17["combos"] = np.array([combos17[s] for s in (171, 172, 173)])
+    with torch.no_grad():
+        for T in (2000, 2500, 3000):
+            for seed in (171, 172, 173):
+                imu17 = synthetic.make_imu(1, T, seed=seed, combo=combos17[seed])
+                m = model_from(sd_tr)
+                m.reset()
+                pose, joints, tran, contact = m.forward_offline(torch.from_numpy(imu17), [T])
+                m2 = model_from(sd_tr)                                   # (forward_offline keeps neither vel nor r6d: once more)
+                _, joints2, vel, _ = m2.forward(torch.from_numpy(imu17), [T])
+                assert torch.equal(joints, joints2)
+                r6d = m2.pose(torch.cat((joints2, torch.from_numpy(imu17)), dim=-1), [T])
+                ref = {"r6d": r6d.numpy().reshape(T, 96), "joints": joints.numpy().reshape(T, 72), "vel": vel.numpy().reshape(T, 72),
+                       "contact": contact.numpy().reshape(T, 2), "tran": tran.numpy().reshape(T, 3)}
+                truth = ENS.offline_outputs(sd_tr, smpl["J"], imu17, T, dtype=np.float64)
+                stats = [ENS.distance(ref, truth), ENS.distance(ENS.offline_outputs(sd_tr, smpl["J"], imu17, T), truth)]
+                stats += [ENS.distance(ENS.offline_outputs(sd_tr, smpl["J"], imu17, T, perm_seed=1700 + k), truth) for k in range(3)]
+                tag = "T%d_s%d" % (T, seed)
+                g17[tag + "_imu_sum"] = np.array(imu17.astype(np.float64).sum())              # the input is regenerated from its seed
+                for k in ("r6d", "joints", "vel"):
+                    g17[tag + "_" + k] = ref[k][(T - 1) % 8::8].copy()                         # every 8th frame, the last one included
+                g17[tag + "_contact"], g17[tag + "_tran"] = ref["contact"], ref["tran"]
+                # [member][output][max, mean] of |x - float64| over all frames
+                g17[tag + "_dist"] = np.array([[st[k] for k in ENS.OUTPUTS] for st in stats], dtype=np.float64)
+                print("G17 %s: max |x - f64| r6d %s" % (tag, " ".join("%.1e" % st["r6d"][0] for st in stats)), flush=True)
+    np.savez_compressed(os.path.join(HERE, "g17_single_sequence.npz"), **g17)
+
     print("golden vectors written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         print("  %-24s %8d B" % (fn, os.path.getsize(os.path.join(HERE, fn))))

@@ -1,0 +1,144 @@
+"""Round-6 GPU parity tests.
+
+  * G17 -- the reference's OWN call shape on trained-regime weights (evaluate.py:54-58, models/net.py:121-155): ONE sequence of
+    2000 / 2500 / 3000 frames x 3 input seeds, recorded from the reference together with the distances of an ensemble of fp32
+    evaluations from the float64 result (tests/golden/make_golden.py, oracle/ensemble.py).  The one-sequence kernels (mp_lstm_v1 /
+    mp_lstm_v1s, the default at B = 1) and the MFMA path (MP_VARIANT=vec=0) are both held to the band that ensemble occupies.
+  * configs[1] of BASELINE.json through its OWN entry point: mp_rnn_forward("joints") at 256 x 125 (models/joints.py:48-52),
+    ragged lengths and a carried state, against the oracle's rnn_forward.
+
+Why a band and not "1e-4 of the golden": at this length the trained-regime net is chaotic at fp32 resolution.  Permuting the
+summation order of the numpy oracle alone moves its maximum distance from the float64 result by up to 10 x, and float64 dot
+products with fp32 state do not lower it (profiles/r06_b1_precision_emulation.txt): the reference itself is 2e-5 ... 9e-4 from the
+float64 result on these nine cases.  The rule (NOISE_FACTOR_B1): per case and output, max |x - f64| <= 2 x the largest maximum of
+the ensemble (or the north-star bound, 1e-4 / 1 mm, where that is larger) AND mean |x - f64| <= 2 x the largest mean of the
+ensemble; over the nine cases, the geometric mean of (mean distance / median member's mean distance) <= 1.5 -- a kernel whose
+noise LEVEL is above fp32's shows up there even when every single draw is inside the band.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import cu, load_golden, npy
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"r6d": 1e-4, "joints": 1e-4, "vel": 1e-4, "contact": 1e-4, "tran": 1e-3}
+NOISE_FACTOR_B1 = 2.0        # per case: x the ensemble's envelope
+LEVEL_FACTOR_B1 = 1.5        # over all cases: geometric mean of (mean distance / the median member's)
+OUTPUTS = ("r6d", "joints", "vel", "contact", "tran")
+
+
+@pytest.fixture(scope="module")
+def g17():
+    return load_golden("g17_single_sequence.npz")
+
+
+@pytest.fixture(scope="module")
+def weights_trained():
+    from mobileposer_amd.synthetic import make_weights
+    return make_weights(0, profile="trained")
+
+
+@pytest.fixture(scope="module")
+def g17_truth(g17, weights_trained, smpl):
+    """The float64 result of every case (the oracle's arithmetic carried out in float64; ~4 s per case on the host)."""
+    from mobileposer_amd import synthetic
+    from oracle import ensemble as ENS
+    truth = {}
+    for T in g17["lengths"].tolist():
+        for k, seed in enumerate(g17["seeds"].tolist()):
+            imu = synthetic.make_imu(1, T, seed=seed, combo=str(g17["combos"][k]))
+            assert abs(float(imu.astype(np.float64).sum()) - float(g17["T%d_s%d_imu_sum" % (T, seed)])) < 1e-9      # the recorded input
+            truth[(T, seed)] = (imu, ENS.offline_outputs(weights_trained, smpl["J"], imu, T, dtype=np.float64))
+    return truth
+
+
+def _gpu_outputs(torch_mod, net, imu, T):
+    import ctypes as C
+    net.reset_all()
+    pose, joints, vel, contact, r6d = net.forward(cu(torch_mod, imu), [T], return_r6d=True)
+    tran = torch_mod.empty(1, T, 3, device="cuda")
+    net.translate_offline_into(joints, vel.reshape(1, T, 72), contact, (C.c_int32 * 1)(T), tran)
+    # (forward_offline itself -- the call evaluate.py makes -- must give the same bits)
+    net.reset_all()
+    pose2, joints2, tran2, contact2 = net.forward_offline(cu(torch_mod, imu), [T])
+    assert torch_mod.equal(tran2, tran[0]) and torch_mod.equal(joints2, joints) and torch_mod.equal(contact2, contact[0])
+    return {"r6d": npy(r6d).reshape(T, 96), "joints": npy(joints).reshape(T, 72), "vel": npy(vel).reshape(T, 72),
+            "contact": npy(contact).reshape(T, 2), "tran": npy(tran).reshape(T, 3)}
+
+
+@pytest.mark.parametrize("variant", ["", "vec=0"], ids=["one-sequence-kernels", "mfma-path"])
+def test_g17_single_sequence_trained_regime(torch_mod, g17, g17_truth, weights_trained, smpl, variant, monkeypatch):
+    from mobileposer_amd.net import MobilePoserNet
+    from oracle import ensemble as ENS
+    if variant:
+        monkeypatch.setenv("MP_VARIANT", variant)
+    members = [str(m) for m in g17["members"]]
+    stride = int(g17["stride"])
+    ratios = {k: [] for k in OUTPUTS}
+    report = {}
+    with MobilePoserNet.from_numpy(weights_trained, smpl) as net:
+        for (T, seed), (imu, truth) in g17_truth.items():
+            tag = "T%d_s%d" % (T, seed)
+            got = _gpu_outputs(torch_mod, net, imu, T)
+            assert net.device_error() == 0 and net.recovery_count == 0
+            d = ENS.distance(got, truth)
+            dist = g17[tag + "_dist"]                                   # [member][output][max, mean]
+            env_max, env_mean = dist[:, :, 0].max(axis=0), dist[:, :, 1].max(axis=0)
+            med_mean = np.median(dist[:, :, 1], axis=0)
+            report[tag] = {k: "%.1e/%.1e (band %.1e/%.1e)" % (d[k][0], d[k][1], env_max[i], env_mean[i]) for i, k in enumerate(OUTPUTS)}
+            for i, k in enumerate(OUTPUTS):
+                assert d[k][0] <= max(TOL[k], NOISE_FACTOR_B1 * env_max[i]), (tag, k, d[k], env_max[i])
+                assert d[k][1] <= max(0.01 * TOL[k], NOISE_FACTOR_B1 * env_mean[i]), (tag, k, d[k], env_mean[i])
+                ratios[k].append(max(d[k][1], 1e-12) / max(med_mean[i], 1e-12))
+            # against the reference's own outputs (every `stride`-th frame; contact and translation in full): by the triangle
+            # inequality no farther than the two distances from the float64 result -- a check of the golden's layout and of
+            # this test's indexing rather than of the kernels
+            ref_d = dist[members.index("reference")]
+            sub = slice((T - 1) % stride, None, stride)
+            for i, k in enumerate(OUTPUTS):
+                ref = g17[tag + "_" + k]
+                mine = got[k] if k in ("contact", "tran") else got[k][sub]
+                assert np.abs(mine - ref).max() <= 1.001 * (d[k][0] + ref_d[i, 0]) + 1e-7, (tag, k)
+    level = {k: float(np.exp(np.mean(np.log(v)))) for k, v in ratios.items()}
+    print("G17 (%s): noise level relative to the ensemble's median member (geometric mean over %d cases): %s"
+          % (variant or "default", len(g17_truth), {k: "%.2f" % v for k, v in level.items()}))
+    for tag, r in report.items():
+        print("   %s max/mean |x - f64|: %s" % (tag, r))
+    if not variant:                                     # keep the numbers (profiles/r06_accuracy_g17.json is a copy of this file)
+        import json
+        os.makedirs("gpurun_out", exist_ok=True)
+        json.dump({"level": level, "cases": report, "rule": {"per_case": NOISE_FACTOR_B1, "level": LEVEL_FACTOR_B1}},
+                  open(os.path.join("gpurun_out", "r06_accuracy_g17.json"), "w"), indent=1)
+    for k in OUTPUTS:
+        assert level[k] <= LEVEL_FACTOR_B1, (k, level)
+
+
+@pytest.mark.parametrize("profile", ["init", "trained"])
+def test_config1_joints_module_through_its_own_entry(torch_mod, smpl, profile):
+    """BASELINE configs[1]: the joints module alone, 256 x 125, through mp_rnn_forward (models/joints.py:48-52 -> rnn.py:20-33) --
+    the tail of this entry (joints.linear2 by itself) is not the one the full forward runs (mp_gemm_l2l1).  Full lengths, ragged
+    lengths, and a second call on the state the first one returned; outputs AND final states against the oracle."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    from oracle import mp_oracle as O
+    B, T = 256, 125
+    sd = synthetic.make_weights(0, profile=profile)
+    x = synthetic.make_imu(B, T, seed=91)
+    ragged = [T - (7 * b) % 60 for b in range(B)]
+    ragged[17] = T
+    with MobilePoserNet.from_numpy(sd, smpl) as net:
+        for lengths in ([T] * B, ragged):
+            y, (h, c) = net.rnn_forward("joints", cu(torch_mod, x), lengths)
+            ry, (rh, rc) = O.rnn_forward(sd, O.PREFIX["joints"], x, lengths)
+            for b in range(0, B, 5):                              # (rows past a sequence's length: linear2(0) = bias on both sides)
+                assert np.abs(npy(y)[b] - ry[b]).max() < 1e-4, (profile, b)
+            assert np.abs(npy(h) - rh).max() < 1e-4 and np.abs(npy(c) - rc).max() < 1e-4 * max(1.0, float(np.abs(rc).max()))
+            # carried state: the same input again, starting from (h, c)
+            y2, (h2, c2) = net.rnn_forward("joints", cu(torch_mod, x), lengths, (h, c))
+            ry2, (rh2, rc2) = O.rnn_forward(sd, O.PREFIX["joints"], x, lengths, (rh, rc))
+            assert np.abs(npy(y2) - ry2).max() < 1e-4, profile
+            assert np.abs(npy(h2) - rh2).max() < 1e-4 and np.abs(npy(c2) - rc2).max() < 1e-4 * max(1.0, float(np.abs(rc2).max()))
+        assert net.device_error() == 0 and net.recovery_count == 0

@@ -331,3 +331,36 @@ def test_g16_one_frame_calls_on_a_carried_state(weights_trained, smpl):
         assert np.abs(contact - g[f"one_contact{k}"]).max() < TOL
     h, c = net.velocity_rnn_state
     assert np.abs(h - g["one_vel_h"]).max() < TOL and np.abs(c - g["one_vel_c"]).max() < TOL
+
+
+def test_g17_single_sequence_trained_regime_band(weights_trained, smpl):
+    """Golden G17 (round 6): forward_offline of ONE 2000-frame sequence on trained-regime weights, recorded from the reference
+    (evaluate.py:54-58).  At this length the net is chaotic at fp32 resolution, so the file carries -- beside the reference's
+    outputs -- the distance of each member of an ensemble of fp32 evaluations (the reference, this oracle, the oracle with three
+    permuted summation orders: oracle/ensemble.py) from the float64 result.  Here: the input regenerates from its seed, the
+    oracle on this host lies inside that band, and it is as close to the reference's recorded outputs as the two distances from
+    the float64 result allow.  (The GPU test of the same golden: tests/test_gpu_round6.py.)"""
+    from mobileposer_amd import synthetic
+    from oracle import ensemble as ENS
+    g = load_golden("g17_single_sequence.npz")
+    assert [str(m) for m in g["members"]] == ["reference", "oracle", "perm0", "perm1", "perm2"] and tuple(str(o) for o in g["outputs"]) == ENS.OUTPUTS
+    T, seed, combo = 2000, int(g["seeds"][0]), str(g["combos"][0])
+    imu = synthetic.make_imu(1, T, seed=seed, combo=combo)
+    tag = "T%d_s%d" % (T, seed)
+    assert abs(float(imu.astype(np.float64).sum()) - float(g[tag + "_imu_sum"])) < 1e-9
+    truth = ENS.offline_outputs(weights_trained, smpl["J"], imu, T, dtype=np.float64)
+    got = ENS.offline_outputs(weights_trained, smpl["J"], imu, T)
+    d = ENS.distance(got, truth)
+    dist = g[tag + "_dist"]
+    tol = {"r6d": 1e-4, "joints": 1e-4, "vel": 1e-4, "contact": 1e-4, "tran": 1e-3}
+    sub = slice((T - 1) % int(g["stride"]), None, int(g["stride"]))
+    for i, k in enumerate(ENS.OUTPUTS):
+        assert d[k][0] <= max(tol[k], 2.0 * dist[:, i, 0].max()), (k, d[k], dist[:, i, 0])
+        assert d[k][1] <= max(0.01 * tol[k], 2.0 * dist[:, i, 1].max()), (k, d[k], dist[:, i, 1])
+        mine = got[k] if k in ("contact", "tran") else got[k][sub]
+        assert np.abs(mine - g[tag + "_" + k]).max() <= 1.001 * (d[k][0] + dist[0, i, 0]) + 1e-7, k
+    # every recorded member of every case is a finite, small distance: the band itself is sane (the widest case is 4e-3 on r6d)
+    for TT in g["lengths"].tolist():
+        for s in g["seeds"].tolist():
+            dd = g["T%d_s%d_dist" % (TT, s)]
+            assert dd.shape == (5, 5, 2) and np.isfinite(dd).all() and (dd[:, :4, 0] < 2e-2).all() and (dd[:, 4, 0] < 5e-3).all(), (TT, s)
