@@ -70,6 +70,59 @@ def host_cores():
         return n_log, n_log, "%d logical CPUs (os.cpu_count; lscpu unavailable)" % n_log
 
 
+def pin_to_gpu_numa_node(dev_index):
+    """Pin this rank's host threads to the CPUs of the NUMA node its GPU hangs off (sysfs: the PCI function's numa_node /
+    local_cpulist): with 8 busy ranks on 2 sockets a launch thread that wanders to the other socket adds microseconds to every
+    one of the ~20 launches of a step.  Returns what was done for the per_rank record; never raises."""
+    info = {"numa_node": None, "cpus_pinned": None}
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        base = "/sys/bus/pci/devices/" + bdf
+        node = int(open(base + "/numa_node").read().strip())
+        info["numa_node"] = node
+        cpus = set()
+        for part in open(base + "/local_cpulist").read().strip().split(","):
+            if part:
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)                       # (never widen what the launcher / cgroup allows)
+        if node >= 0 and cpus:
+            os.sched_setaffinity(0, cpus)
+            info["cpus_pinned"] = len(cpus)
+    except Exception as e:                                    # noqa: BLE001 -- no sysfs entry, no permission: run unpinned
+        info["error"] = str(e)[:120]
+    return info
+
+
+def arm_watchdog(seconds, rank, n_gpus):
+    """A hard limit for the whole run and ONE JSON line whatever happens: when the limit passes (a rank that died leaves the
+    others in a collective for ever) rank 0 prints an error line in the bench format and every rank exits with status 3; rank 0
+    does the same when the launcher terminates it (SIGTERM: another rank failed)."""
+    import signal
+    import threading
+
+    once = threading.Lock()
+
+    def bail(why):
+        if not once.acquire(blocking=False):                  # (the timer and the signal handler can both get here)
+            os._exit(3)
+        if rank == 0:
+            sys.stdout.write(json.dumps({"metric": metric_label("weak"), "value": None, "unit": "frames/s", "n_gpus": n_gpus,
+                                         "error": why, "higher_is_better": True}) + "\n")
+            sys.stdout.flush()
+        os._exit(3)
+
+    t = threading.Timer(seconds, bail, args=("bench.py: no result after %d s (--timeout): a rank hung or died" % seconds,))
+    t.daemon = True
+    t.start()
+    try:
+        signal.signal(signal.SIGTERM, lambda *_: bail("bench.py: terminated by the launcher (another rank failed?)"))
+    except ValueError:                                        # not the main thread
+        pass
+    return t
+
+
 def cpu_baseline(seconds=5.0):
     """The CPU path beside the GPU number, on bounded samples of the same workload (about 25 s in all):
     torch's own CPU nn.LSTM / nn.Linear (what the reference calls; oracle/torch_ref.py) + numpy FK / translation at
@@ -206,6 +259,8 @@ def bench_stream(args, net, dev, dist, rank, world):
         cursor[0] += 1
         net.stream_step_into(xin, io["pose"], io["joints"], io["root"], io["contact"])
 
+    if args.cadence_hz > 0:
+        return bench_stream_cadence(args, net, dev, dist, rank, world, tick, S)
     results = {}
     for name, gmode in (("eager", 0), ("graph_single_branch", 2)):
         net.set_graph_mode(gmode)
@@ -231,7 +286,74 @@ def bench_stream(args, net, dev, dist, rank, world):
         dist.destroy_process_group()
 
 
-def relaunch_with_ranks(n):
+def bench_stream_cadence(args, net, dev, dist, rank, world, tick, S):
+    """configs[4] the way a service runs it (live_demo.py:207-264, `clock.tick(fps)`): one tick per 1 / cadence seconds, the GPU
+    idle in between.  Latency of a tick = host time from handing the frames over until the results are on the stream
+    (synchronised) -- p50 / p99 / max over --steps ticks, eager launches and single-branch graph replay.  Then the question
+    round 5 left open: what do the first ticks after an idle stretch cost, and what clock does the GPU run at then?  After 1 s
+    of idleness, 30 ticks back to back with the shader clock probed (mp_debug_clock_probe) in front of the first one and
+    behind ticks 1, 2, 4, 8, 16, 30; the same after 50 ms of idleness."""
+    period = 1.0 / args.cadence_hz
+    lib, h = net._lib, net._h
+
+    def clock_mhz():
+        mhz, us = C.c_double(0), C.c_double(0)
+        lib.mp_debug_clock_probe(h, C.byref(mhz), C.byref(us))
+        return round(mhz.value, 1), round(us.value, 2)
+
+    def one_tick():
+        t0 = time.perf_counter()
+        tick()
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0
+
+    def spaced(n):
+        lat = []
+        nxt = time.perf_counter()
+        for _ in range(n):
+            nxt += period
+            lat.append(one_tick())
+            rest = nxt - time.perf_counter()
+            if rest > 0:
+                time.sleep(rest)
+        return np.array(lat) * 1e3
+
+    def after_idle(idle_s):
+        time.sleep(idle_s)
+        rec = {"idle_s": idle_s, "clock_before_mhz": clock_mhz(), "tick_ms": [], "clock_after_tick": {}}
+        for k in range(1, 31):
+            rec["tick_ms"].append(round(1e3 * one_tick(), 4))
+            if k in (1, 2, 4, 8, 16, 30):
+                rec["clock_after_tick"][k] = clock_mhz()[0]
+        return rec
+
+    modes = {}
+    for name, gmode in (("eager", 0), ("graph_single_branch", 2)):
+        net.set_graph_mode(gmode)
+        for _ in range(args.warmup):
+            one_tick()
+        back = np.array([one_tick() for _ in range(50)]) * 1e3
+        lat = spaced(args.steps)
+        modes[name] = {"back_to_back_ms": {"p50": round(float(np.median(back)), 4), "max": round(float(back.max()), 4)},
+                       "at_cadence_ms": {"p50": round(float(np.median(lat)), 4), "p90": round(float(np.quantile(lat, 0.9)), 4),
+                                         "p99": round(float(np.quantile(lat, 0.99)), 4), "max": round(float(lat.max()), 4),
+                                         "mean": round(float(lat.mean()), 4)},
+                       "deadline_misses": int((lat > period * 1e3).sum()),
+                       "after_1s_idle": after_idle(1.0), "after_50ms_idle": after_idle(0.05)}
+    net.set_graph_mode(0)
+    if rank == 0:
+        print(json.dumps({"metric": "tick latency (ms) at a %g Hz cadence, %d streams on one GPU" % (args.cadence_hz, S),
+                          "value": modes["eager"]["at_cadence_ms"]["p99"], "unit": "ms (p99, eager launches)", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "higher_is_better": False, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "configs[4] at cadence: %d streams, one tick every %.2f ms, latency = submit -> "
+                                                 "synchronised results" % (S, period * 1e3), "streams_per_gpu": S,
+                                     "cadence_hz": args.cadence_hz, "lstm_mode": args.lstm_mode},
+                          "modes": modes}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def relaunch_with_ranks(n, limit_s=1800):
     """`python bench.py --gpus N` outside of a launcher: start N ranks of this very command, one per GPU."""
     import socket
     import subprocess
@@ -242,7 +364,23 @@ def relaunch_with_ranks(n):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL across processes)
-    return subprocess.call(cmd, env=env)
+    # ONE JSON line whatever happens to the ranks: their output is passed through, and when none of them printed a line (a
+    # rank died before rank 0 got there, or the limit passed) this process prints the error line itself
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    why = None
+    try:
+        out, _ = proc.communicate(timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        out, _ = proc.communicate()
+        why = "bench.py --gpus %d: no result after %d s; ranks killed" % (n, limit_s)
+    sys.stdout.write(out or "")
+    if not any(l.startswith("{") for l in (out or "").splitlines()):
+        why = why or "bench.py --gpus %d: the ranks exited with status %s without a result line" % (n, proc.returncode)
+        sys.stdout.write(json.dumps({"metric": metric_label("weak"), "value": None, "unit": "frames/s", "n_gpus": n,
+                                     "error": why, "higher_is_better": True}) + "\n")
+    sys.stdout.flush()
+    return proc.returncode if proc.returncode else (3 if why else 0)
 
 
 def ranks_seen(dist, dev):
@@ -255,6 +393,7 @@ def ranks_seen(dist, dev):
     return int(sum(int(o.item()) for o in out))
 
 
+WATCHDOG = None        # the --timeout timer of this rank (arm_watchdog)
 HOST_GROUP = None      # gloo group of all ranks (GPU runs under a launcher): barriers without a device round trip
 
 
@@ -312,6 +451,11 @@ def bench_dry(args, dist, rank, world):
         if dist is not None:
             dist.barrier()
 
+    # (tests/test_bench_launcher_cpu.py: a rank that dies / hangs in front of the timed region must still end in ONE JSON line)
+    if os.environ.get("MP_BENCH_TEST_KILL_RANK") == str(rank):
+        os._exit(7)
+    if os.environ.get("MP_BENCH_TEST_HANG_RANK") == str(rank):
+        time.sleep(3600)
     elapsed, elapsed_local = timed_region(lambda: time.sleep(0.002), args.steps, args.warmup, sync, dist, dev)
     per_rank = gather_counts(B * T * args.steps, elapsed_local, dev) if dist is not None else None
     seen = ranks_seen(dist, dev)
@@ -326,6 +470,8 @@ def bench_dry(args, dist, rank, world):
                           "parallelism": "independent sequences sharded, dp%d" % world}}
         if per_rank is not None:
             out["per_rank"] = [{"rank": r, "frames": int(v[0]), "seconds": round(float(v[1]), 6)} for r, v in enumerate(per_rank)]
+        if WATCHDOG is not None:
+            WATCHDOG.cancel()
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
@@ -353,6 +499,11 @@ def main():
     ap.add_argument("--recovery", choices=["on", "off"], default="on",
                     help="on (library default): every call waits for itself and repairs a starved fused-LSTM launch; off: "
                          "asynchronous calls (mp_set_recovery(h, 0)) -- an A/B switch, the headline uses the default")
+    ap.add_argument("--timeout", type=int, default=1500, help="hard limit (s) for the whole run: past it rank 0 prints an error "
+                    "JSON line and every rank exits with status 3 (a rank that died must not hang the others for ever)")
+    ap.add_argument("--no-affinity", action="store_true", help="do not pin the rank's host threads to its GPU's NUMA node")
+    ap.add_argument("--cadence-hz", type=float, default=0.0, help="--workload stream: feed ticks at this rate (30 / 60) instead of "
+                    "back to back and report the latency distribution of a tick (submit -> results on the host)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo run of the launcher, rendezvous, broadcast, shard and "
                     "timing path with a stand-in step (no GPU, no kernels); the JSON line says dry_run: true")
     args = ap.parse_args()
@@ -362,13 +513,15 @@ def main():
         ap.error("--gpus must be >= 1")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:     # plain `python bench.py --gpus N`: become N ranks
-        sys.exit(relaunch_with_ranks(args.gpus))
+        sys.exit(relaunch_with_ranks(args.gpus, args.timeout + 120))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU "
                  "(python bench.py --gpus N does it by itself; or torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
+    global WATCHDOG
+    watchdog = WATCHDOG = arm_watchdog(args.timeout, rank, args.gpus)
     dist = None
     if world > 1 or "RANK" in os.environ:           # one process per GPU over RCCL (gloo for --dry-run)
         import torch.distributed as dist
@@ -395,6 +548,7 @@ def main():
         torch.cuda.set_device(0)
         local_rank = 0
     dev = torch.device("cuda", local_rank)
+    affinity = {"numa_node": None, "cpus_pinned": None} if args.no_affinity else pin_to_gpu_numa_node(local_rank)
 
     # the library must be the build of the sources beside it (mp_build_id = their md5): every rank asks, rank 0 rebuilds a
     # missing / stale one first (the build takes a file lock and re-checks under it, so a rank that gets there at the same
@@ -490,7 +644,7 @@ def main():
         raise RuntimeError("persistent-kernel wait timed out during the timed region (code %d)" % err.value)
     per_rank = None
     info = net.device_info()
-    rank_info = [dict(info, rank=rank, local_rank=local_rank)]
+    rank_info = [dict(info, rank=rank, local_rank=local_rank, **{k: affinity.get(k) for k in ("numa_node", "cpus_pinned")})]
     if dist is not None:
         per_rank = gather_counts(B * T * args.steps, elapsed_local, dev)
         gathered = [None] * world
@@ -601,6 +755,74 @@ def main():
         del imu1, o1
         lib.mp_reset_state(h, 1)
 
+    # ---- BASELINE configs[1] beside the headline: the joints module ALONE through its own entry (mp_rnn_forward), 256 x 125 ----
+    joints_only = None
+    if rank == 0 and args.lstm_mode == "fp32":
+        xj = torch.from_numpy(synthetic.make_imu(B_PER_GPU, T, seed=1)).to(dev)
+        yj = torch.empty(B_PER_GPU, T, 72, device=dev, dtype=f32)
+        lensj = (C.c_int32 * B_PER_GPU)(*([T] * B_PER_GPU))
+
+        def stepj():
+            rc = lib.mp_rnn_forward(h, 0, vp(xj), lensj, B_PER_GPU, T, vp(yj), None, None, stream)
+            if rc:
+                raise RuntimeError(lib.mp_last_error(h).decode())
+
+        net.set_lstm_mode(MODE_ID["fp32"])
+        for _ in range(5):
+            stepj()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(40):
+            stepj()
+        torch.cuda.synchronize(dev)
+        dtj = (time.perf_counter() - t0) / 40
+        flop_j = 2.0 * (60 * 256 + 2 * 4 * 256 * (256 + 256) + 2 * 4 * 256 * (512 + 256) + 512 * 72)    # per frame
+        joints_only = {"workload": "configs[1]: joints-module LSTM only (linear1 -> 2-layer bidirectional LSTM -> linear2, "
+                                   "models/joints.py:48-52) through mp_rnn_forward, batch %d x window %d" % (B_PER_GPU, T),
+                       "ms_per_call": round(1e3 * dtj, 4), "frames_per_s": round(B_PER_GPU * T / dtj, 1),
+                       "tflops": round(B_PER_GPU * T * flop_j / dtj / 1e12, 2),
+                       "frac_of_fp32_mfma_peak": round(B_PER_GPU * T * flop_j / dtj / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "calls": 40}
+        del xj, yj
+
+    # ---- BASELINE configs[4] beside the headline: 512 concurrent streams per GPU, one tick = one new frame per stream ----
+    stream_leg = None
+    if rank == 0 and args.lstm_mode == "fp32":
+        S4 = args.streams
+        lib.mp_reset_state(h, 1)                       # (one velocity state per model: the streams take it over)
+        frames4 = torch.from_numpy(synthetic.make_imu(S4, 300, seed=7)).to(dev)
+        net.stream_create(S4)
+        io4 = [torch.empty(S4, 24, 9, device=dev, dtype=f32), torch.empty(S4, 45, 72, device=dev, dtype=f32),
+               torch.empty(S4, 3, device=dev, dtype=f32), torch.empty(S4, 2, device=dev, dtype=f32)]
+        xin4 = torch.empty(S4, 60, device=dev, dtype=f32)
+        cur = [0]
+
+        def tick4():
+            xin4.copy_(frames4[:, cur[0] % 300])
+            cur[0] += 1
+            net.stream_step_into(xin4, *io4)
+
+        modes4 = {}
+        for name, gmode in (("eager", 0), ("graph_single_branch", 2)):
+            net.set_graph_mode(gmode)
+            for _ in range(20):
+                tick4()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(100):
+                tick4()
+            torch.cuda.synchronize(dev)
+            dt4 = (time.perf_counter() - t0) / 100
+            modes4[name] = {"ms_per_tick": round(1e3 * dt4, 4), "ticks_per_s": round(1.0 / dt4, 2), "meets_60hz": 1.0 / dt4 >= 60.0}
+        net.set_graph_mode(args.graph_mode)
+        stream_leg = {"workload": "configs[4]: %d concurrent streams on this GPU, one tick = one new 60-d frame per stream, the "
+                                  "45-frame window re-evaluated (forward_online, net.py:173-219), ticks back to back" % S4,
+                      "streams_per_gpu": S4, "modes": modes4, "ticks": 100,
+                      "frames_per_s": round(S4 / (modes4["eager"]["ms_per_tick"] * 1e-3), 1),
+                      "note": "tick LATENCY at a 30 / 60 Hz cadence (idle between ticks): bench.py --workload stream --cadence-hz, "
+                              "profiles/r06_tick_cadence.txt"}
+        del frames4, io4, xin4
+        lib.mp_reset_state(h, 1)
+
     if dist is not None:
         dist.barrier()
 
@@ -705,15 +927,20 @@ def main():
         out["configs3_strong"] = strong
     if single is not None:
         out["configs0_single_sequence"] = single
+    if joints_only is not None:
+        out["configs1_joints_only"] = joints_only
+    if stream_leg is not None:
+        out["configs4_stream"] = stream_leg
     if per_rank is not None:
         out["per_rank"] = [dict({"rank": r, "frames": int(v[0]), "seconds": round(float(v[1]), 6)},
-                                **{k: rank_info[r][k] for k in ("device", "local_rank", "n_cu", "xcd_round_robin", "build_id")})
+                                **{k: rank_info[r][k] for k in ("device", "local_rank", "n_cu", "xcd_round_robin", "build_id", "numa_node", "cpus_pinned")})
                            for r, v in enumerate(per_rank)]
     else:
         out["per_rank"] = [dict({"rank": 0, "frames": B * T * args.steps, "seconds": round(elapsed_local, 6)},
-                                **{k: rank_info[0][k] for k in ("device", "local_rank", "n_cu", "xcd_round_robin", "build_id")})]
+                                **{k: rank_info[0][k] for k in ("device", "local_rank", "n_cu", "xcd_round_robin", "build_id", "numa_node", "cpus_pinned")})]
     if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed on rank 0 of the single-GPU run only
         out["cpu_baseline"] = cpu_baseline()
+    watchdog.cancel()
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

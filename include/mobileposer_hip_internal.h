@@ -25,6 +25,15 @@ int mp_debug_read_prof(mp_handle* h, long long* out, int n_words);
  * run into their time bound, poison the slab and raise the error word.  Deterministic stand-in for real starvation. */
 int mp_debug_drop_workgroup(mp_handle* h, int block, int skip, int launches);
 
+/* Measurement hook (round 6): the shader clock (MHz) a one-wave probe kernel on the handle's main stream ran at -- ticks of
+ * s_memtime per tick of the constant 100 MHz s_memrealtime -- and how long the probe took.  Synchronises.  What
+ * `bench.py --workload stream --cadence-hz` samples around the first ticks after an idle stretch. */
+int mp_debug_clock_probe(mp_handle* h, double* shader_mhz, double* probe_us);
+/* Test hook (round 6): the workspace plans of the handle -- how many exist, how many were ever allocated, their capacity in rows
+ * (B * T) together.  Plans are kept by capacity class (mp_api.hip get_plan): a caller that walks through sequence lengths must
+ * not allocate per length. */
+int mp_debug_plan_stats(mp_handle* h, int* n_plans, int* n_allocs, long long* cap_rows);
+
 #ifdef __cplusplus
 }
 #endif

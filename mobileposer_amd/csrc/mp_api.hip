@@ -126,7 +126,11 @@ struct GraphKey {
 };
 
 struct Plan {
-    int B = 0, T = 0;
+    int B = 0, T = 0;                  // the shape of the call that is using the plan (set by get_plan)
+    int capB = 0;                      // capacity: batches of the class `capB` (plan_batch_class) ...
+    size_t capRows = 0;                // ... with B * T <= capRows rows
+    int lastB = 0;                     // B of the call before: another batch's words in the exchange areas
+    bool streaming = false;            // the (S, 45) plan of mp_stream_create: never evicted (its graphs are keyed by its buffers)
     unsigned long long last_use = 0;   // LRU stamp (plans and their graphs are evicted when shapes keep changing)
     ModuleWS ws[4];
     float* r6d = nullptr;            // [B,T,96] when the caller does not ask for it
@@ -211,7 +215,8 @@ struct mp_handle {
                                      // (default: the K_in = 512 layers, measured 373 vs 391 us; K_in = 256: 300 vs 285 us; MP_VARIANT x3w)
     int nslice_env = 0;              // 0: pick per module (8 slices / 8 waves for bidirectional layers that fill the
                                      // chip, 16 slices / 4 waves for unidirectional ones); MP_VARIANT slices=8|16 forces one             // LSTM recurrence: persistent kernel (default) or per-step launches
-    std::map<std::pair<int, int>, Plan*> plans;
+    std::vector<Plan*> plans;        // workspaces by capacity class (get_plan)
+    int plan_allocs = 0;             // plans allocated so far (mp_debug_plan_stats)
     struct GraphEntry { hipGraphExec_t exec; unsigned long long last_use; };
     std::map<GraphKey, GraphEntry> graphs;
     unsigned long long use_clock = 0;
@@ -222,6 +227,7 @@ struct mp_handle {
     StreamCtx sc;
     OnlineState st_snap;             // recovery: per-stream solver state a streaming tick started from
     bool vf_ok = true;               // MP_VARIANT vf=0: the foot-contact layers always run as launches of their own
+    bool one_stream_ok = true;       // MP_VARIANT one_stream=0: full batches on the round-3 three-stream schedule (forward_body's last branch)
     bool wf_ok = true;               // MP_VARIANT wf=0: velocity as two 16-slice layer launches (rounds 3-4), not as ONE two-layer wavefront launch
     bool late_pair_ok = true;        // MP_VARIANT late_pair=0: no schedule 4 (pose layer 0 alone, then pose layer 1 beside velocity + rider) for 64 < B <= 128
     const void* vf_foot = nullptr;   // forward_body -> rnn_rec: the foot-contact job that rides in this call's velocity launches
@@ -562,7 +568,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
             else if (key == "kin_fused") {}                    // read by mp_launch_r6d_ik_fk: 0 = IK and FK as two launches
             else if (key == "l2l1") {}                         // read by mp_launch_gemm_l2l1: 0 = joints.linear2 and the stacked linear1 as two launches
             else if (key == "gemm_wide") {}                    // read by mp_launch_gemm: 0 = wide linear1 layers on mp_gemm_f32_frag's small tiles
-            else if (key == "one_stream") {}                   // read by forward_body: 0 = the round-3 three-stream serial schedule
+            else if (key == "one_stream") h->one_stream_ok = v != 0;   // 0 = the round-3 three-stream serial schedule (a cross-check)
             else if (key == "vf") h->vf_ok = v != 0;
             else if (key == "wf") h->wf_ok = v != 0;
             else if (key == "late_pair") h->late_pair_ok = v != 0;
@@ -617,48 +623,78 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
 }
 
 // ------------------------------------------------------------------------------------------ plans
+// Workspaces by CAPACITY (round 6; rounds 1-5 kept one plan per exact (B, T), 0.4 GB at 256 x 125 and 60-110 ms to map, and
+// the facade cut a replayed sequence into power-of-two chunks so that a service would not thrash).  Internal activations are
+// time-major [T][B][C] with the batch as a run-time stride, per-sequence buffers are indexed by b alone and the exchange areas by
+// slab: a plan allocated for (capB, capRows) serves every call with B <= capB sequences and B * T <= capRows rows.  A call takes
+// the smallest plan of ITS batch class that has the rows; batch classes are exact up to 64 sequences (a handful of shapes: ticks,
+// evaluate.py's single sequence, small batches) and {2^k, 1.5 * 2^k} above; a class whose plan is too short gets a new one of at
+// least twice the rows, so a caller that walks through sequence lengths (evaluate.py) allocates a few times, not per length.
 void free_plan(mp_handle* h, Plan* p) {
-    // graphs captured for this shape reference its workspaces
-    for (auto it = h->graphs.begin(); it != h->graphs.end();) {
-        if (it->first.B == p->B && it->first.T == p->T) { (void)hipGraphExecDestroy(it->second.exec); it = h->graphs.erase(it); }
-        else ++it;
-    }
+    // captured graphs reference the workspaces of the plan they were captured on (and are few): all of them go
+    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second.exec);
+    h->graphs.clear();
     for (void* q : p->allocs) (void)hipFree(q);
     if (p->lengths_pin) (void)hipHostFree(p->lengths_pin);
     delete p;
 }
 
-// evaluate.py feeds one sequence length after another: keep only recent shapes -- at most kMaxPlans of them and at most kMaxRows
-// rows (B * T, ~12.5 KB of workspace each: 25 GB) together.  (Round 5: 8 -> 24 plans.  The ONLINE=1 branch replays a sequence in
-// chunks of 1024, 512, ... 1 frames -- net.py forward_online_replay -- so that its workspaces, up to 1.7 GB for 3000 frames
-// and 60-90 ms to map, are the same few shapes for every sequence.)
 constexpr size_t kMaxPlans = 24;
-constexpr size_t kMaxRows = (size_t)2 << 20;
+constexpr size_t kMaxRows = (size_t)4 << 20;      // rows (B * T, ~12.5 KB of workspace each) of all plans together: 50 GB
 
-int get_plan(mp_handle* h, int B, int T, Plan** out) {
-    auto it = h->plans.find({B, T});
-    if (it != h->plans.end()) { it->second->last_use = ++h->use_clock; *out = it->second; return MP_OK; }
+size_t round_class(size_t n) {                    // the next of {2^k, 1.5 * 2^k}
+    size_t p = 64;
     while (true) {
-        size_t rows = (size_t)B * T;
-        for (const auto& kv : h->plans) rows += (size_t)kv.second->B * kv.second->T;
-        if (h->plans.size() < kMaxPlans && rows <= kMaxRows) break;
-        auto victim = h->plans.end();
-        for (auto jt = h->plans.begin(); jt != h->plans.end(); ++jt) {
-            if (h->sc.S && jt->first == std::make_pair(h->sc.S, 45)) continue;      // the streaming plan stays
-            if (victim == h->plans.end() || jt->second->last_use < victim->second->last_use) victim = jt;
-        }
-        if (victim == h->plans.end()) break;
-        HIPCHK(h, hipDeviceSynchronize());
-        free_plan(h, victim->second);
-        h->plans.erase(victim);
+        if (n <= p) return p;
+        if (n <= p + p / 2) return p + p / 2;
+        p *= 2;
     }
+}
+int plan_batch_class(int B) { return B <= 64 ? B : (int)round_class((size_t)B); }
+
+// `keep`: a plan the caller is still using (mp_stream_replay holds two): never the victim of this call's eviction
+int get_plan(mp_handle* h, int B, int T, Plan** out, const Plan* keep = nullptr) {
     // (the layer kernels step through their output with a 32-bit row pitch: B * 512 floats must stay below 4 GB)
     if ((size_t)B * 512 * sizeof(float) > 0xffffffffull)
         return fail(h, MP_ERR_INVALID, "batch of %d sequences is beyond the supported 2^21 - 1; split it", B);
+    const int cls = plan_batch_class(B);
+    const size_t rows = (size_t)B * T;
+    Plan* best = nullptr;
+    size_t class_rows = 0;                         // the longest plan this class has so far
+    for (Plan* q : h->plans) {
+        if (q->capB != cls || q == keep) continue;
+        class_rows = q->capRows > class_rows ? q->capRows : class_rows;
+        if (q->capRows >= rows && (!best || q->capRows < best->capRows)) best = q;
+    }
+    if (best) {
+        if (best->lastB != B)                      // another batch size wrote the exchange areas last: start from zeroed ones
+            for (ModuleWS& w : best->ws) w.hx_epoch = 0;
+        best->B = B; best->T = T; best->lastB = B; best->last_use = ++h->use_clock;
+        *out = best;
+        return MP_OK;
+    }
+    size_t cap_rows = round_class(rows);
+    if (class_rows && cap_rows < 2 * class_rows) cap_rows = round_class(2 * class_rows);
+    while (true) {
+        size_t total = cap_rows;
+        for (const Plan* q : h->plans) total += q->capRows;
+        if (h->plans.size() < kMaxPlans && total <= kMaxRows) break;
+        size_t victim = h->plans.size();
+        for (size_t i = 0; i < h->plans.size(); ++i) {
+            const Plan* q = h->plans[i];
+            if (q->streaming || q == keep) continue;
+            if (victim == h->plans.size() || q->last_use < h->plans[victim]->last_use) victim = i;
+        }
+        if (victim == h->plans.size()) break;
+        HIPCHK(h, hipDeviceSynchronize());
+        free_plan(h, h->plans[victim]);
+        h->plans.erase(h->plans.begin() + (long)victim);
+    }
     Plan* p = new Plan();
-    p->B = B; p->T = T; p->last_use = ++h->use_clock;
-    h->plans[{B, T}] = p;
-    const size_t M = (size_t)B * T;
+    p->B = B; p->T = T; p->lastB = B; p->capB = cls; p->capRows = cap_rows; p->last_use = ++h->use_clock;
+    h->plans.push_back(p);
+    ++h->plan_allocs;
+    const size_t M = cap_rows, CB = (size_t)cls;
     for (int id = 0; id < 4; ++id) {
         const ModuleW& m = h->mod[id];
         ModuleWS& w = p->ws[id];
@@ -669,17 +705,17 @@ int get_plan(mp_handle* h, int B, int T, Plan** out) {
             if (int rc = dev_alloc(h, (void**)&w.x1, M * m.H * sizeof(float), &p->allocs)) return rc;
         for (int l = 0; l < 2; ++l)
             for (int d = 0; d < m.dirs; ++d) {
-                if (int rc = dev_alloc(h, (void**)&w.hbuf[l][d], (size_t)2 * B * m.H * sizeof(float), &p->allocs)) return rc;
-                if (int rc = dev_alloc(h, (void**)&w.cbuf[l][d], (size_t)B * m.H * sizeof(float), &p->allocs)) return rc;
+                if (int rc = dev_alloc(h, (void**)&w.hbuf[l][d], (size_t)2 * CB * m.H * sizeof(float), &p->allocs)) return rc;
+                if (int rc = dev_alloc(h, (void**)&w.cbuf[l][d], CB * m.H * sizeof(float), &p->allocs)) return rc;
             }
-        w.hx_bytes = (size_t)2 * ((B + 15) / 16) * ((size_t)4 * 16 * m.H + 16) * sizeof(unsigned long long);
+        w.hx_bytes = (size_t)2 * ((CB + 15) / 16) * ((size_t)4 * 16 * m.H + 16) * sizeof(unsigned long long);
         if (int rc = dev_alloc(h, (void**)&w.hx, w.hx_bytes, &p->allocs)) return rc;
         if (m.H == 256)
             if (int rc = dev_alloc(h, (void**)&w.hx2, w.hx_bytes, &p->allocs)) return rc;
     }
     if (int rc = dev_alloc(h, (void**)&p->r6d, M * 96 * sizeof(float), &p->allocs)) return rc;
-    if (int rc = dev_alloc(h, (void**)&p->lengths_dev, (size_t)B * sizeof(int), &p->allocs)) return rc;
-    HIPCHK(h, hipHostMalloc((void**)&p->lengths_pin, (size_t)B * sizeof(int), hipHostMallocDefault));
+    if (int rc = dev_alloc(h, (void**)&p->lengths_dev, CB * sizeof(int), &p->allocs)) return rc;
+    HIPCHK(h, hipHostMalloc((void**)&p->lengths_pin, CB * sizeof(int), hipHostMallocDefault));
     *out = p;
     return MP_OK;
 }
@@ -691,7 +727,7 @@ int ensure_step_ws(mp_handle* h, Plan* p) {
         const ModuleW& m = h->mod[id];
         ModuleWS& w = p->ws[id];
         if (!w.xproj)
-            if (int rc = dev_alloc(h, (void**)&w.xproj, (size_t)p->B * p->T * m.dirs * 4 * m.H * sizeof(float), &p->allocs)) return rc;
+            if (int rc = dev_alloc(h, (void**)&w.xproj, p->capRows * m.dirs * 4 * m.H * sizeof(float), &p->allocs)) return rc;
     }
     return MP_OK;
 }
@@ -989,7 +1025,9 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         if (h->err_host && *(volatile int*)h->err_host) w.hx_epoch = 0;
         if (!use_x3(h, m)) {
             if (!epoch_ok || w.hx_epoch == 0 || w.hx_epoch > 0xf0000000u || w.hx_tagged != tagged) {
-                HIPCHK(h, hipMemsetAsync(w.hx, 0, w.hx_bytes, s));
+                // (a plan's areas are sized for its capacity: this call's slabs are what the launches below can touch)
+                const size_t hx_need = (size_t)2 * nslab * ((size_t)4 * 16 * H + 16) * sizeof(unsigned long long);
+                HIPCHK(h, hipMemsetAsync(w.hx, 0, hx_need < w.hx_bytes ? hx_need : w.hx_bytes, s));
                 w.hx_epoch = epoch_ok ? h->epoch_start : 0u;
                 w.hx_flip = 3u;
                 w.hx_flipF = 3u;
@@ -1322,8 +1360,7 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         const ModuleW& vmod = h->mod[MP_MOD_VELOCITY];
         const bool vf = h->vf_ok && p->B > 128 && h->persist && !use_x3(h, vmod) && vmod.nslice == 16 &&
                         fp32_slices(h, vmod, p->B) == 16 && h->mod[MP_MOD_FOOT_CONTACT].wVF[0][0] != nullptr;
-        static const bool one_stream_ok = !(getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "one_stream=0"));
-        if (vf && one_stream_ok && h->lin1_pvf.Wf && mp_gemm_frag_enabled() && h->fuse_pv && !use_x3(h, h->mod[MP_MOD_POSE]) &&
+        if (vf && h->one_stream_ok && h->lin1_pvf.Wf && mp_gemm_frag_enabled() && h->fuse_pv && !use_x3(h, h->mod[MP_MOD_POSE]) &&
             side_by_side_plan(h, p->B) == 0) {
             RC(rnn_g0(J, sm)); RC(rnn_rec(J, 0, sm)); RC(rnn_g1(J, sm)); RC(rnn_rec(J, 1, sm));   // net.py:103
             int rc_pv = MP_OK;
@@ -1477,7 +1514,17 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
             RC(rnn_g0(V, sv)); RC(rec(1, sv));
             RC(rnn_g0(P, sm));
         }
-        RC(rnn_rec(P, 0, sm)); RC(rnn_rec(P, 1, sm)); RC(rec(2, sm));                       // net.py:106-107
+        // (when the velocity block below goes out as the two-layer wavefront, that launch carries foot-contact layer 1
+        //  only -- layer 0 has to ride in pose layer 0, as in the one-stream schedule; before round 6 this branch never asked for
+        //  it and foot contact's layer 1 read a stale out0)
+        const bool wfv = fuse_vf && wavefront_applies(h, vmod, p->B, p->T);
+        if (wfv) RC(wait(4, sm));                                // the rider reads foot contact's X1
+        {
+            ScheduleScope sched(h);
+            if (wfv) sched.rider(&F);
+            RC(rnn_rec(P, 0, sm));                                                          // net.py:106-107
+        }
+        RC(rnn_rec(P, 1, sm)); RC(rec(2, sm));
         // (captured BEFORE the side-stream work that hangs off the same event: the graph launches the successors of a
         //  node in creation order, and the velocity layers are the critical chain)
         if (!fused_pv) RC(wait(1, sm));
@@ -1494,7 +1541,7 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
             int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if (place_clusters(h, vf, 2, load, h->xcd_plan)) { excl_vf = kExclusiveLdsBytes; vf_tables = true; }
         }
-        if (fuse_vf) { excl_vf = 0; vf_tables = false; RC(wait(4, sm)); }
+        if (fuse_vf) { excl_vf = 0; vf_tables = false; if (!wfv) RC(wait(4, sm)); }
         {
             ScheduleScope sched(h);
             sched.exclusive_lds(excl_vf).tables(MP_MOD_VELOCITY, vf_tables).rider(fuse_vf ? &F : nullptr);
@@ -1576,8 +1623,8 @@ int run_maybe_graph(mp_handle* h, GraphKey key, Body body) {
 // words behind that no later launch's bookkeeping (ModuleWS::hx_flip) describes.
 void disable_xcd_tables(mp_handle* h) {
     h->xcd_rr = false;
-    for (auto& kv : h->plans)
-        for (ModuleWS& w : kv.second->ws) w.hx_epoch = 0;
+    for (Plan* q : h->plans)
+        for (ModuleWS& w : q->ws) w.hx_epoch = 0;
 }
 
 // A failed call without recovery has poisoned what it carries forward: the velocity LSTM state it updated in place is NaN for
@@ -1750,10 +1797,10 @@ void mp_destroy(mp_handle* h) {
         fprintf(stderr, "libmobileposer_hip: mp_destroy: an unreported device error was pending (code %d): a persistent LSTM "
                         "kernel gave up a wait; the affected outputs of that call were NaN\n", take_device_error(h, nullptr));
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second.exec);
-    for (auto& kv : h->plans) {
-        for (void* p : kv.second->allocs) (void)hipFree(p);
-        if (kv.second->lengths_pin) (void)hipHostFree(kv.second->lengths_pin);
-        delete kv.second;
+    for (Plan* q : h->plans) {
+        for (void* p : q->allocs) (void)hipFree(p);
+        if (q->lengths_pin) (void)hipHostFree(q->lengths_pin);
+        delete q;
     }
     h->plans.clear();
     for (ModuleW& m : h->mod) {
@@ -2212,6 +2259,7 @@ int mp_stream_create(mp_handle* h, int S) {
     c.S = S;
     Plan* p = nullptr;
     if (int rc = get_plan(h, S, W, &p)) return rc;
+    p->streaming = true;
     std::vector<int32_t> len(S, W);
     if (int rc = upload_lengths(h, p, len.data())) return rc;
     HIPCHK(h, hipStreamSynchronize(h->s_main));
@@ -2315,7 +2363,7 @@ int mp_stream_replay(mp_handle* h, const float* frames_dev, int N, float* pose_d
     // workspaces: the batch plan (N windows x 45), the chain plan (1 sequence x N*45), history / index-40 rows
     Plan *pb = nullptr, *pc = nullptr;
     if (int rc = get_plan(h, N, W, &pb)) return rc;
-    if (int rc = get_plan(h, 1, N * W, &pc)) return rc;
+    if (int rc = get_plan(h, 1, N * W, &pc, pb)) return rc;      // (pb is in use: neither the victim of this acquisition nor its result)
     {
         std::vector<int32_t> len(N, W);
         if (int rc = upload_lengths(h, pb, len.data())) return rc;
@@ -2539,6 +2587,35 @@ int mp_recovery_count(const mp_handle* h) { return h ? h->recoveries : 0; }
 
 namespace {
 MP_KERNEL void mp_poke_error(int* err, int code) { mp_set_error(code == 2000000 ? err + 1 : err, code); }
+// one wave, a dependent FMA chain between two looks at both clocks: ticks of the constant 100 MHz clock (s_memrealtime) and
+// of the shader clock (s_memtime) -- their ratio is the frequency the CU ran at during the probe
+MP_KERNEL void mp_clock_probe(unsigned long long* out, int spin) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    float x = (float)threadIdx.x;
+    for (int i = 0; i < spin; ++i) x = __builtin_fmaf(x, 1.0001f, 0.5f);
+    asm volatile("" :: "v"(x));
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[0] = r1 - r0; out[1] = c1 - c0; }
+}
+}
+
+int mp_debug_clock_probe(mp_handle* h, double* shader_mhz, double* probe_us) {
+    if (!h || !shader_mhz) return MP_ERR_INVALID;
+    ON_DEVICE(h);
+    unsigned long long* buf = nullptr;
+    HIPCHK(h, hipHostMalloc((void**)&buf, 16, hipHostMallocDefault));
+    buf[0] = buf[1] = 0;
+    hipLaunchKernelGGL(mp_clock_probe, dim3(1), dim3(64), 0, h->s_main, buf, 2000);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->s_main);
+    const double real = (double)buf[0], shader = (double)buf[1];
+    (void)hipHostFree(buf);
+    if (e != hipSuccess) return fail(h, MP_ERR_HIP, "mp_debug_clock_probe: %s", hipGetErrorString(e));
+    *shader_mhz = real > 0 ? shader / real * 100.0 : 0.0;
+    if (probe_us) *probe_us = real / 100.0;
+    return MP_OK;
 }
 
 int mp_debug_poke_error(mp_handle* h, int code) {
@@ -2547,6 +2624,14 @@ int mp_debug_poke_error(mp_handle* h, int code) {
     hipLaunchKernelGGL(mp_poke_error, dim3(1), dim3(1), 0, h->s_main, h->err_dev, code);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->s_main));
+    return MP_OK;
+}
+
+int mp_debug_plan_stats(mp_handle* h, int* n_plans, int* n_allocs, long long* cap_rows) {
+    if (!h) return MP_ERR_INVALID;
+    if (n_plans) *n_plans = (int)h->plans.size();
+    if (n_allocs) *n_allocs = h->plan_allocs;
+    if (cap_rows) { long long r = 0; for (const Plan* q : h->plans) r += (long long)q->capRows; *cap_rows = r; }
     return MP_OK;
 }
 

@@ -28,18 +28,6 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def replay_chunks(n, chunk=1024):
-    """Sizes of the library calls a replay of ``n`` frames is cut into: whole chunks, then the remainder in powers of two --
-    every sequence length uses the same dozen workspace shapes (MobilePoserNet.forward_online_replay)."""
-    out = [chunk] * (n // chunk)
-    n %= chunk
-    while n:
-        p = 1 << (n.bit_length() - 1)
-        out.append(p)
-        n -= p
-    return out
-
-
 _LIVE = weakref.WeakSet()       # nets that own a native handle
 
 
@@ -185,6 +173,8 @@ class MobilePoserNet:
         self._h = h
         self._recoveries = 0
         self._state_cache = {}
+        # (the library reads MP_LSTM_MODE at creation, csrc/mp_api.hip create_common: mirror it -- ADVICE r5)
+        self._lstm_mode = {"x3": 3, "step": 0}.get(os.environ.get("MP_LSTM_MODE", ""), 1)
         _LIVE.add(self)
         fy = C.c_float()
         fp = (C.c_float * 6)()
@@ -507,20 +497,13 @@ class MobilePoserNet:
         joints = torch.empty(N, 45, 72, device=dev, dtype=f32)
         root = torch.empty(N, 3, device=dev, dtype=f32)
         contact = torch.empty(N, 2, device=dev, dtype=f32)
-        # The library keeps workspaces per (batch, length) shape, and a replay of N frames needs ~0.6 MB per frame (1.7 GB for
-        # 3000 frames: 60-90 ms to map, against 160 ms of work).  Sequences come in every length, so a sequence is replayed in
-        # chunks of REPLAY_CHUNK frames and its remainder in powers of two: at most a dozen shapes for every sequence there will
-        # ever be (the state carries from call to call -- tests/test_gpu_round5.py::test_replay_of_the_online_goldens splits).
-        k = 0
-        for n in replay_chunks(N, self.REPLAY_CHUNK):
-            self._check(self._lib.mp_stream_replay(self._h, _ptr(x[k:k + n]), n, _ptr(pose[k:k + n]), _ptr(joints[k:k + n]),
-                                                   _ptr(root[k:k + n]), _ptr(contact[k:k + n]), self._stream()))
-            k += n
+        # ONE call for the whole sequence (round 6): the library keeps its workspaces by capacity class (csrc/mp_api.hip get_plan),
+        # so a sequence of a length never seen before runs on the plan the longest one so far left behind (round 5 cut the
+        # sequence into power-of-two chunks here because every (batch, length) shape had workspaces of its own)
+        self._check(self._lib.mp_stream_replay(self._h, _ptr(x), N, _ptr(pose), _ptr(joints), _ptr(root), _ptr(contact), self._stream()))
         self._tick += 1
         self._after_call()
         return pose, joints, root, contact
-
-    REPLAY_CHUNK = 1024
 
     # ---- the reference's state attributes (net.py:59-64,205-208), read back from the device ---------------
     def stream_state(self, s=0):

@@ -99,15 +99,30 @@ def test_bench_verify_rows_accepts_the_oracle_and_rejects_a_wrong_output():
         bench.verify_rows(bad, t(imu), B, T, rows=4, seed=1)
 
 
-def test_replay_chunks_cover_every_length_with_a_dozen_shapes():
-    """forward_online_replay cuts a sequence into chunks of 1024 frames and a power-of-two remainder (net.py replay_chunks): the
-    pieces add up, keep the order of the frames, and all lengths together use at most 11 shapes (1024, 512, ... 1)."""
-    from mobileposer_amd.net import replay_chunks
-    shapes = set()
-    for n in list(range(1, 2200)) + [3005, 4096, 10000, 12345]:
-        c = replay_chunks(n)
-        assert sum(c) == n and all(v == 1024 or (v < 1024 and v & (v - 1) == 0) for v in c)
-        assert c == sorted(c, reverse=True) and len(c) <= n // 1024 + 10
-        shapes.update(c)
-    assert shapes == {1 << k for k in range(11)}
-    assert replay_chunks(7, chunk=4) == [4, 2, 1]
+def test_bench_gpus_8_dry_run_weak_and_strong():
+    """The shape of the first real 8-GPU run (BASELINE configs[3] / the scaling curve), on CPU: 8 gloo ranks started by bench.py
+    itself, weak (256 sequences per rank) and strong (1024 split into 128 per rank) -- n_ranks_seen == 8, one line."""
+    r = _run(["--gpus", "8", "--steps", "3", "--warmup", "1", "--dry-run"], timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 8 and out["n_ranks_seen"] == 8 and out["weights_broadcast_ok"] is True
+    assert out["config"]["global_batch"] == 2048 and [p["rank"] for p in out["per_rank"]] == list(range(8))
+    r = _run(["--gpus", "8", "--steps", "3", "--warmup", "1", "--dry-run", "--scaling", "strong"], timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = _json_line(r.stdout)
+    assert out["n_ranks_seen"] == 8 and out["scaling"] == "strong" and out["config"]["global_batch"] == 1024
+    assert [p["frames"] for p in out["per_rank"]] == [128 * 125 * 3] * 8 and out["config"]["batch_per_gpu"] == 128
+
+
+def test_bench_prints_one_error_line_when_a_rank_dies_or_hangs():
+    """A rank that dies (exit in front of the timed region) or hangs (sleeps for ever) must not take the result line with it
+    or hang the job: ONE JSON line with value null and an error text, non-zero exit status, within --timeout."""
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "0", "--dry-run"], env_extra={"MP_BENCH_TEST_KILL_RANK": "1"}, timeout=300)
+    assert r.returncode != 0
+    out = _json_line(r.stdout)
+    assert out["value"] is None and out["n_gpus"] == 2 and "error" in out
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "0", "--dry-run", "--timeout", "20"],
+             env_extra={"MP_BENCH_TEST_HANG_RANK": "1"}, timeout=300)
+    assert r.returncode != 0
+    out = _json_line(r.stdout)
+    assert out["value"] is None and ("--timeout" in out["error"] or "terminated" in out["error"])   # (whichever rank's timer fires first)

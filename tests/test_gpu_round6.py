@@ -142,3 +142,108 @@ def test_config1_joints_module_through_its_own_entry(torch_mod, smpl, profile):
             assert np.abs(npy(y2) - ry2).max() < 1e-4, profile
             assert np.abs(npy(h2) - rh2).max() < 1e-4 and np.abs(npy(c2) - rc2).max() < 1e-4 * max(1.0, float(np.abs(rc2).max()))
         assert net.device_error() == 0 and net.recovery_count == 0
+
+
+def test_three_stream_schedule_at_full_batch_vs_oracle(torch_mod, weights, smpl, monkeypatch):
+    """MP_VARIANT=one_stream=0 (the round-3 three-stream schedule, the cross-check of tools/debug/fuzz_modes.py) at
+    B > 128 runs the velocity block as the two-layer wavefront, which carries foot-contact layer 1 only -- layer 0 has to ride in
+    pose layer 0 there too (it never did before round 6: stale foot-contact layer-0 output).  160 x 40 ragged against the oracle,
+    and bitwise against the default schedule."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    from oracle import mp_oracle as O
+    B, T = 160, 40
+    imu = synthetic.make_imu(B, T, seed=93)
+    lengths = [T - (b % 7) for b in range(B)]
+    rp, rj, rv, rc = O.OracleNet(weights, smpl["J"]).forward(imu, lengths)
+    outs = {}
+    for variant in ("", "one_stream=0"):
+        if variant:
+            monkeypatch.setenv("MP_VARIANT", variant)
+        with MobilePoserNet.from_numpy(weights, smpl) as net:
+            pose, joints, vel, contact = net.forward(cu(torch_mod, imu), lengths)
+            outs[variant] = [npy(t) for t in (joints, vel, contact, pose)]
+            for b, n in enumerate(lengths):
+                assert np.abs(outs[variant][0][b, :n] - rj[b, :n]).max() < 1e-4, (variant, b)
+                assert np.abs(outs[variant][1][b, :n] - rv.reshape(B, T, 72)[b, :n]).max() < 1e-4, (variant, b)
+                assert np.abs(outs[variant][2][b, :n] - rc[b, :n]).max() < 1e-4, (variant, b)
+            assert net.device_error() == 0 and net.recovery_count == 0
+    for a, b in zip(outs[""], outs["one_stream=0"]):          # same kernels, another launch order
+        assert np.array_equal(a, b)
+
+
+def _plan_stats(net):
+    import ctypes as C
+    n, a, r = C.c_int(0), C.c_int(0), C.c_longlong(0)
+    assert net._lib.mp_debug_plan_stats(net._h, C.byref(n), C.byref(a), C.byref(r)) == 0
+    return n.value, a.value, r.value
+
+
+def test_many_shapes_reuse_plans(torch_mod, weights, smpl):
+    """Workspaces by capacity class (csrc/mp_api.hip get_plan): 200 sequence lengths between 45 and 3000 at B = 1 -- the way
+    evaluate.py walks through a dataset -- allocate at most 4 plans; a length never seen before costs what a seen one costs; and
+    results on a shared plan are the bits a fresh handle computes (workspaces carry nothing from shape to shape)."""
+    import time
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    rng = np.random.Generator(np.random.PCG64(5))
+    Ts = [int(t) for t in rng.integers(45, 3001, size=200)]
+    imu = cu(torch_mod, synthetic.make_imu(1, 3000, seed=94))
+    with MobilePoserNet.from_numpy(weights, smpl) as net:
+        dt = {}
+        for k, T in enumerate(Ts):
+            net.reset_all()
+            torch_mod.cuda.synchronize()
+            t0 = time.perf_counter()
+            pose, joints, tran, contact = net.forward_offline(imu[:, :T].contiguous(), [T])
+            torch_mod.cuda.synchronize()
+            dt[k] = (T, time.perf_counter() - t0)
+        n, allocs, rows = _plan_stats(net)
+        print("200 lengths at B = 1: %d plans alive, %d allocated, %d rows of capacity" % (n, allocs, rows))
+        assert allocs <= 4 and rows <= 4 * 4096
+        # a length never seen before (the plan exists: no allocation) against the same length seen again, both warm
+        unseen = [T for T in range(1500, 1600) if T not in Ts][0]
+
+        def timed(T):
+            net.reset_all()
+            x = imu[:, :T].contiguous()
+            torch_mod.cuda.synchronize()
+            t0 = time.perf_counter()
+            net.forward_offline(x, [T])
+            torch_mod.cuda.synchronize()
+            return time.perf_counter() - t0
+
+        first = timed(unseen)
+        again = min(timed(unseen) for _ in range(3))
+        print("T = %d: first call %.2f ms, seen %.2f ms" % (unseen, 1e3 * first, 1e3 * again))
+        assert first < 1.10 * again + 2e-4
+        assert _plan_stats(net)[1] == allocs
+        # bits: three lengths on the shared plan against a fresh handle each
+        for T in (45, 777, 2999):
+            net.reset_all()
+            got = [npy(t) for t in net.forward_offline(imu[:, :T].contiguous(), [T])]
+            with MobilePoserNet.from_numpy(weights, smpl) as fresh:
+                want = [npy(t) for t in fresh.forward_offline(imu[:, :T].contiguous(), [T])]
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b), T
+        assert net.device_error() == 0 and net.recovery_count == 0
+
+
+def test_batch_classes_share_a_plan_and_stay_bitwise(torch_mod, weights, smpl):
+    """Batches above 64 sequences share plans by class ({2^k, 1.5 * 2^k}): 100, 128, 97 and 128 again on ONE plan (the exchange
+    areas are zeroed when the batch size changes), each bitwise what a fresh handle computes; the streaming plan is never
+    evicted or handed out with another shape's lengths in it."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    T = 30
+    imu = cu(torch_mod, synthetic.make_imu(128, T, seed=95))
+    with MobilePoserNet.from_numpy(weights, smpl) as net:
+        for B in (100, 128, 97, 128):
+            net.reset_all()
+            got = [npy(t) for t in net.forward(imu[:B].contiguous(), [T] * B)]
+            with MobilePoserNet.from_numpy(weights, smpl) as fresh:
+                want = [npy(t) for t in fresh.forward(imu[:B].contiguous(), [T] * B)]
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b), B
+        assert _plan_stats(net)[1] == 1
+        assert net.device_error() == 0 and net.recovery_count == 0
