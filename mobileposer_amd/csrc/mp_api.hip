@@ -566,6 +566,7 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
             else if (key == "gemm_frag") {}                    // read by mp_launch_gemm
             else if (key == "gemm_few") {}                     // read by mp_launch_gemm: 0 = M <= 128 rows on the tiles of the large batches
             else if (key == "kin_fused") {}                    // read by mp_launch_r6d_ik_fk: 0 = IK and FK as two launches
+            else if (key == "l2l1_opt") {}                     // read by mp_launch_gemm_l2l1: bits of mp_gemm_l2l1's OPT (A/B)
             else if (key == "l2l1") {}                         // read by mp_launch_gemm_l2l1: 0 = joints.linear2 and the stacked linear1 as two launches
             else if (key == "gemm_wide") {}                    // read by mp_launch_gemm: 0 = wide linear1 layers on mp_gemm_f32_frag's small tiles
             else if (key == "one_stream") h->one_stream_ok = v != 0;   // 0 = the round-3 three-stream serial schedule (a cross-check)
@@ -1411,7 +1412,19 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         }
     }
     // joints(batch)                                                                       net.py:103
-    RC(run_rnn(J, sm));
+    // (round 6: schedule 4 -- 64 < B <= 128, the share of one GPU in eight of configs[3] -- takes the joints -> pose seam as the
+    //  ONE launch the full-batch schedule uses, joints.linear2 + the stacked linear1 of pose | velocity | foot contact, instead of
+    //  three launches on two streams)
+    bool seam_fused = false;
+    if (h->persist && side_by_side_plan(h, p->B) == 4) {
+        RC(rnn_g0(J, sm)); RC(rnn_rec(J, 0, sm)); RC(rnn_g1(J, sm)); RC(rnn_rec(J, 1, sm));
+        int rc_f = MP_OK;
+        seam_fused = rnn_g2_g0_fused(J, P, V, F, sm, &rc_f);
+        RC(rc_f);
+        if (!seam_fused) RC(rnn_g2(J, sm));
+    } else {
+        RC(run_rnn(J, sm));
+    }
     HIPCHK(h, hipEventRecord(h->ev_j, sm));
     HIPCHK(h, hipStreamWaitEvent(sf, h->ev_j, 0));
     if (!h->persist) {
@@ -1442,10 +1455,12 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
             auto rec = [&](int i, hipStream_t on) -> int { HIPCHK(h, hipEventRecord(h->ev_x[i], on)); return MP_OK; };
             auto wait = [&](int i, hipStream_t on) -> int { HIPCHK(h, hipStreamWaitEvent(on, h->ev_x[i], 0)); return MP_OK; };
             // (two streams only: foot contact's linear layers go where its recurrent layers run, on s_vel)
-            RC(rnn_g0(F, sv));                                                            // linear1 of foot contact
-            int rc_pv = MP_OK;
-            if (!rnn_g0_pose_velocity(P, V, sm, &rc_pv)) { RC(rnn_g0(V, sm)); RC(rnn_g0(P, sm)); }
-            RC(rc_pv);
+            if (!seam_fused) {
+                RC(rnn_g0(F, sv));                                                        // linear1 of foot contact
+                int rc_pv = MP_OK;
+                if (!rnn_g0_pose_velocity(P, V, sm, &rc_pv)) { RC(rnn_g0(V, sm)); RC(rnn_g0(P, sm)); }
+                RC(rc_pv);
+            }
             RC(rnn_rec(P, 0, sm));                                                        // 16 slices, every CU
             RC(rec(1, sm));
             RC(wait(1, sv));                                                              // (the velocity grid must not start under it)
@@ -1456,9 +1471,8 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
                 RC(rnn_rec(P, 1, sm));                                                    // net.py:106-107
                 RC(rnn_rec(V, 1, sv));
             }
-            RC(rnn_g2(V, sv));                                                            // net.py:117
+            RC(rnn_g2_pair(V, F, sv));                                                    // net.py:117, 113-114: one launch
             HIPCHK(h, hipEventRecord(h->ev_v, sv));
-            RC(rnn_g2(F, sv));                                                            // net.py:113-114
             HIPCHK(h, hipEventRecord(h->ev_f, sv));
             RC(rec(4, sf)); RC(wait(4, sm));                // (s_foot was forked into the call above and gets no work here: join it)
             RC(rnn_g2(P, sm));

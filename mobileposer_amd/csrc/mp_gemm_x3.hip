@@ -125,6 +125,8 @@ MP_KERNEL __launch_bounds__(256) void mp_gemm_x3(GemmArgs g, int nTilesM, int nT
             for (int a = 0; a < NRT; ++a) acc[a][b] = mfma_bf16(ahi[a], wlo, acc[a][b]);
 #pragma unroll
             for (int a = 0; a < NRT; ++a) acc[a][b] = mfma_bf16(alo[a], whi, acc[a][b]);
+#pragma unroll
+            for (int a = 0; a < NRT; ++a) acc[a][b] = mfma_bf16(alo[a], wlo, acc[a][b]);      // lo*lo (round 6)
         }
         __syncthreads();
         if (kt + 1 < nk) {

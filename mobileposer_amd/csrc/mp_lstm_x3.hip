@@ -298,7 +298,8 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
     const u32x4* wxw = wxl + (size_t)wave * XLC * CH_U4 + lane;
 
     f32x4 acc[4];
-    // one chunk of a matrix product: 3 MFMAs per gate tile (hi*hi, hi*lo, lo*hi), tiles interleaved so that
+    // one chunk of a matrix product: 4 MFMAs per gate tile (hi*hi, hi*lo, lo*hi, lo*lo -- round 6: rounds 1-5 dropped the last
+    // one, 2^-22 relative per product = 4 x fp32's rounding unit, and sat at 1.8-3.3 x fp32's noise), tiles interleaved so that
     // consecutive MFMAs never depend on each other
     auto chunk_mma = [&](u32x4 x0, u32x4 x1, const u32x4 (&w)[8]) {
         u32x4 ahi, alo;
@@ -309,6 +310,8 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
         for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(ahi, w[2 * t + 1], acc[t]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(alo, w[2 * t], acc[t]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(alo, w[2 * t + 1], acc[t]);      // lo*lo (round 6): every product exact
     };
     // LDS-resident chunks: 8 fragments per chunk = (hi, lo) of the 4 gate tiles.  K_in = 256 fetches a whole chunk
     // at the top of a step (32 registers, under the register chunks).  K_in = 512 cannot hold that through the
@@ -333,6 +336,8 @@ MP_KERNEL __launch_bounds__(x3_threads(NSLICE), x3_wg_per_cu(NSLICE)) void mp_ls
             if (c + 1 < XLC) lds_fetch(c + 1, 0);
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(ahi, wl[2 * t + 1], acc[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(alo, wl[2 * t + 1], acc[t]);     // lo*lo (round 6)
             __builtin_amdgcn_sched_barrier(0);
             if (c + 1 < XLC) lds_fetch(c + 1, 1);
         } else {

@@ -228,7 +228,7 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
 #define PROF_E(i) do { if (PROF && prof) pt[i] += (long long)__builtin_amdgcn_s_memtime(); } while (0)
 
     f32x4 acc[UB][4];
-    // one chunk of a matrix product for both unit blocks: per block 3 MFMAs per gate tile (hi*hi, hi*lo, lo*hi)
+    // one chunk of a matrix product for both unit blocks: per block 4 MFMAs per gate tile (hi*hi, hi*lo, lo*hi, lo*lo)
     auto chunk_mma = [&](auto in_agpr, u32x4 x0, u32x4 x1, const u32x4 (&w)[UB][FR], bool first = false) {
         constexpr bool AG = decltype(in_agpr)::value;
         u32x4 ahi, alo;
@@ -249,6 +249,10 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
         for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
             for (int t = 0; t < 4; ++t) mfma_x<AG>(acc[ub][t], alo, w[ub][2 * t]);
+#pragma unroll
+        for (int ub = 0; ub < UB; ++ub)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) mfma_x<AG>(acc[ub][t], alo, w[ub][2 * t + 1]);      // lo*lo (round 6)
     };
     constexpr std::integral_constant<bool, true> IN_A{};
     constexpr std::integral_constant<bool, false> IN_V{};
@@ -270,6 +274,8 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_lstm_x3w(LstmPersistArgs a) {
             for (int t = 0; t < 4; ++t) mfma_x<false>(acc[ub][t], alo, wl[2 * t]);
 #pragma unroll
             for (int t = 0; t < 4; ++t) mfma_x<false>(acc[ub][t], ahi, wl[2 * t + 1]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) mfma_x<false>(acc[ub][t], alo, wl[2 * t + 1]);      // lo*lo (round 6)
         }
     };
     // the first register chunk of step t+1 is multiplied at the END of step t, right behind the stores of h_t
