@@ -75,7 +75,9 @@ def pin_to_gpu_numa_node(dev_index):
     local_cpulist): with 8 busy ranks on 2 sockets a launch thread that wanders to the other socket adds microseconds to every
     one of the ~20 launches of a step.  Returns what was done for the per_rank record; never raises."""
     info = {"numa_node": None, "cpus_pinned": None}
+    global AFFINITY_AT_START
     try:
+        AFFINITY_AT_START = os.sched_getaffinity(0)
         pr = torch.cuda.get_device_properties(dev_index)
         bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
         base = "/sys/bus/pci/devices/" + bdf
@@ -98,15 +100,35 @@ def pin_to_gpu_numa_node(dev_index):
 def arm_watchdog(seconds, rank, n_gpus):
     """A hard limit for the whole run and ONE JSON line whatever happens: when the limit passes (a rank that died leaves the
     others in a collective for ever) rank 0 prints an error line in the bench format and every rank exits with status 3; rank 0
-    does the same when the launcher terminates it (SIGTERM: another rank failed)."""
+    does the same when the launcher terminates it (SIGTERM: another rank failed).  Both also work while the main thread sits in a
+    HIP / RCCL call that never returns: the signal's C-level handler writes to a wake-up socket that a watcher thread reads (a
+    Python signal handler alone only runs when the main thread gets back to the interpreter -- round 6's first GPU run waited 4
+    minutes for that), and where every thread was at that moment goes to stderr (faulthandler)."""
+    import faulthandler
     import signal
     import threading
 
+    try:
+        faulthandler.enable(file=sys.stderr, all_threads=True)
+    except Exception:                                         # noqa: BLE001 -- no usable stderr: go without
+        pass
+    try:                                                      # MP_BENCH_TRACE_EVERY=s: where every thread is, every s seconds (debugging a slow leg)
+        every = float(os.environ.get("MP_BENCH_TRACE_EVERY", "0") or 0)
+        if every > 0:
+            faulthandler.dump_traceback_later(every, repeat=True, file=sys.stderr)
+    except Exception:                                         # noqa: BLE001
+        pass
     once = threading.Lock()
 
     def bail(why):
-        if not once.acquire(blocking=False):                  # (the timer and the signal handler can both get here)
+        if not once.acquire(blocking=False):                  # (the timer and the signal watcher can both get here)
             os._exit(3)
+        try:
+            sys.stderr.write("bench.py rank %d: %s\n" % (rank, why))
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            sys.stderr.flush()
+        except Exception:                                     # noqa: BLE001
+            pass
         if rank == 0:
             sys.stdout.write(json.dumps({"metric": metric_label("weak"), "value": None, "unit": "frames/s", "n_gpus": n_gpus,
                                          "error": why, "higher_is_better": True}) + "\n")
@@ -115,11 +137,28 @@ def arm_watchdog(seconds, rank, n_gpus):
 
     t = threading.Timer(seconds, bail, args=("bench.py: no result after %d s (--timeout): a rank hung or died" % seconds,))
     t.daemon = True
-    t.start()
+    why_term = "bench.py: terminated by the launcher (another rank failed?)"
     try:
-        signal.signal(signal.SIGTERM, lambda *_: bail("bench.py: terminated by the launcher (another rank failed?)"))
-    except ValueError:                                        # not the main thread
+        # C-level handler (whichever thread the kernel hands the signal to) -> one byte on a socket -> the watcher thread: nothing
+        # here needs the main thread, which may be inside hipStreamSynchronize / an RCCL collective for good
+        import socket
+        rd, wr = socket.socketpair()
+        wr.setblocking(False)
+        signal.signal(signal.SIGTERM, lambda *_: bail(why_term))            # (also: the main thread, if it is in the interpreter)
+        signal.set_wakeup_fd(wr.fileno(), warn_on_full_buffer=False)
+
+        def watch():
+            while True:
+                data = rd.recv(16)
+                if not data or signal.SIGTERM in data:
+                    bail(why_term)
+
+        w = threading.Thread(target=watch, name="sigterm-watcher", daemon=True)
+        w._keep = (rd, wr)
+        w.start()
+    except (ValueError, AttributeError, OSError):             # not the main thread / no socketpair: whatever could be installed stays
         pass
+    t.start()
     return t
 
 
@@ -130,6 +169,12 @@ def cpu_baseline(seconds=5.0):
     warm-up each; the numpy oracle (`kind: "port"`) for `seconds`.  The headline `value` is the best of them."""
     from mobileposer_amd import synthetic
     from oracle import mp_oracle as O
+    LEG_S = 8                                  # seconds a torch leg may take for its timed reps
+    if AFFINITY_AT_START is not None:          # the CPU leg runs on the box's host cores, not on the NUMA node the GPU rank was pinned to
+        try:
+            os.sched_setaffinity(0, AFFINITY_AT_START)
+        except OSError:
+            pass
     sd = synthetic.make_weights(0)
     smpl = synthetic.synthetic_smpl()
     n_log, n_phys, cores_txt = host_cores()
@@ -161,10 +206,10 @@ def cpu_baseline(seconds=5.0):
         imu_full = synthetic.make_imu(B_PER_GPU, T_WIN, seed=1)
         # (threads, sequences per rep): one thread gets a 32-sequence sample so that 1 + 3 reps stay within a few seconds
         plan = [(1, 32)]
-        if n_phys > 1:
-            plan.append((n_phys, B_PER_GPU))
         if min(32, n_log) not in (1, n_phys):
             plan.append((min(32, n_log), B_PER_GPU))
+        if n_phys > 1:
+            plan.append((n_phys, 64))               # (all physical cores: ATen's LSTM gets slower beyond ~32 threads; a 64-sequence sample)
         for nthr, nb in plan:
             torch.set_num_threads(nthr)
             tnet = TorchNet(sd, smpl["J"])
@@ -177,15 +222,24 @@ def cpu_baseline(seconds=5.0):
                 for b in range(nb):
                     O.translate_offline(joints[b].reshape(T_WIN, 24, 3), vel[b], contact[b], tnet.floor_y)
 
-            one_t()                                                   # 1 warm-up
             t0 = time.perf_counter()
-            for _ in range(3):                                        # 3 timed reps
+            one_t()                                                   # 1 warm-up
+            dt_w = time.perf_counter() - t0
+            # 3 timed reps -- fewer when a rep is slow (a leg gets about LEG_S seconds; the warm-up itself is the sample when
+            # even one more rep would not fit: ATen's 128-thread leg has been seen at 3 k frames/s and far below)
+            n_rep = max(0, min(3, int(LEG_S / max(dt_w, 1e-3)) - 1))
+            t0 = time.perf_counter()
+            for _ in range(n_rep):
                 one_t()
             dt_t = time.perf_counter() - t0
+            if n_rep == 0:
+                n_rep, dt_t, how = 1, dt_w, "1 rep, not warmed up (a rep takes longer than the leg's %d s budget)" % LEG_S
+            else:
+                how = "%d reps (after 1 warm-up)" % n_rep
             legs["torch_%dthr" % nthr] = {
-                "value": round(3 * nb * T_WIN / dt_t, 1), "unit": "frames/s", "threads": nthr,
-                "sample": "3 reps (after 1 warm-up) of %d sequences x %d frames through torch CPU nn.LSTM "
-                          "(oracle/torch_ref.py) + numpy FK / translation, %.1f s" % (nb, T_WIN, dt_t)}
+                "value": round(n_rep * nb * T_WIN / dt_t, 1), "unit": "frames/s", "threads": nthr,
+                "sample": "%s of %d sequences x %d frames through torch CPU nn.LSTM "
+                          "(oracle/torch_ref.py) + numpy FK / translation, %.1f s" % (how, nb, T_WIN, dt_t)}
     except Exception as e:
         legs["error"] = str(e)
     best = max((v for v in legs.values() if isinstance(v, dict) and "value" in v), key=lambda v: v["value"], default=None)
@@ -240,7 +294,8 @@ def bench_stream(args, net, dev, dist, rank, world):
     (graph mode 2); the headline is the mode --graph-mode selects (default 0 = eager)."""
     from mobileposer_amd import synthetic
     S = args.streams
-    frames = torch.from_numpy(synthetic.make_imu(S, 2 * (args.steps + args.warmup) + 2, seed=7 + rank)).to(dev)
+    n_frames = 2 * (args.steps + args.warmup) + 2
+    frames = torch.from_numpy(synthetic.make_imu(S, n_frames, seed=7 + rank)).to(dev)
     net.stream_create(S)
     f32 = torch.float32
     io = {"pose": torch.empty(S, 24, 9, device=dev, dtype=f32), "joints": torch.empty(S, 45, 72, device=dev, dtype=f32),
@@ -255,7 +310,7 @@ def bench_stream(args, net, dev, dist, rank, world):
     cursor = [0]
 
     def tick():
-        xin.copy_(frames[:, cursor[0]])
+        xin.copy_(frames[:, cursor[0] % n_frames])           # (the cadence mode ticks more often than 2 (K + W) times: wrap)
         cursor[0] += 1
         net.stream_step_into(xin, io["pose"], io["joints"], io["root"], io["contact"])
 
@@ -394,6 +449,7 @@ def ranks_seen(dist, dev):
 
 
 WATCHDOG = None        # the --timeout timer of this rank (arm_watchdog)
+AFFINITY_AT_START = None   # the CPUs the launcher allowed, before pin_to_gpu_numa_node narrowed them (cpu_baseline widens back)
 HOST_GROUP = None      # gloo group of all ranks (GPU runs under a launcher): barriers without a device round trip
 
 

@@ -109,18 +109,26 @@ def load():
         return _lib
     if LIB_PATH == _DEFAULT_LIB and file_build_id() != source_md5():
         # missing, or built from other sources than the ones beside it: a stale library must be neither timed nor tested.
-        # Rebuild in place (hipcc is part of the image, here and on the GPU box; the build takes a file lock, so ranks that
-        # start together build once) -- before the library is mapped into this process.
+        # In a SOURCE CHECKOUT (this repository: __graft_entry__.py beside the package) it is rebuilt in place, with a line on
+        # stderr that says so (hipcc is part of the image, here and on the GPU box; the build takes a file lock, so ranks that
+        # start together build once) -- before the library is mapped into this process.  MP_AUTO_REBUILD=0 refuses instead; an
+        # installed package (no __graft_entry__.py of ours beside it) always refuses.
+        entry = os.path.join(os.path.dirname(_HERE), "__graft_entry__.py")
+        ours = os.path.isfile(entry) and b"mobileposer_amd" in open(entry, "rb").read(4096)
+        stale = "mobileposer_amd: %s is missing or stale (build id %r, sources %s)" % (LIB_PATH, file_build_id(), source_md5())
+        if os.environ.get("MP_AUTO_REBUILD", "1") == "0" or not ours:
+            raise RuntimeError(stale + " -- build it with `python __graft_entry__.py` (hipcc, gfx950).  There is no CPU fallback.")
         try:
             import importlib.util
-            spec = importlib.util.spec_from_file_location("__graft_entry__", os.path.join(os.path.dirname(_HERE), "__graft_entry__.py"))
+            import sys
+            print(stale + ": rebuilding in place (MP_AUTO_REBUILD=0 refuses instead)", file=sys.stderr)
+            spec = importlib.util.spec_from_file_location("__graft_entry__", entry)
             ge = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(ge)
             ge.compile_library()
         except Exception as e:                                        # noqa: BLE001
-            raise RuntimeError(
-                "mobileposer_amd: %s is missing or stale (build id %r, sources %s) and rebuilding it failed: %s -- build it with "
-                "`python __graft_entry__.py` (hipcc, gfx950).  There is no CPU fallback." % (LIB_PATH, file_build_id(), source_md5(), e))
+            raise RuntimeError(stale + " and rebuilding it failed: %s -- build it with `python __graft_entry__.py` (hipcc, gfx950).  "
+                               "There is no CPU fallback." % e)
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "mobileposer_amd: %s not found -- build it with `python __graft_entry__.py` (hipcc, gfx950). "
@@ -137,10 +145,12 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if LIB_PATH == _DEFAULT_LIB:
-        got = lib.mp_build_id().decode()
-        if got != source_md5():
+    got = lib.mp_build_id().decode()
+    if got != source_md5():
+        if LIB_PATH == _DEFAULT_LIB:
             raise RuntimeError("mobileposer_amd: %s was built from other sources (build id %s, sources %s)" % (LIB_PATH, got, source_md5()))
+        import warnings                      # an MP_LIB_PATH library (A/B runs of kernel variants): allowed, but never silently
+        warnings.warn("mobileposer_amd: MP_LIB_PATH library %s has build id %s, the sources beside the package are %s" % (LIB_PATH, got, source_md5()))
     _lib = lib
     return lib
 

@@ -674,7 +674,7 @@ int get_plan(mp_handle* h, int B, int T, Plan** out, const Plan* keep = nullptr)
         *out = best;
         return MP_OK;
     }
-    size_t cap_rows = round_class(rows);
+    size_t cap_rows = round_class((size_t)cls * T);      // (a plan serves its whole batch class at this length: 100 x T and 128 x T share one)
     if (class_rows && cap_rows < 2 * class_rows) cap_rows = round_class(2 * class_rows);
     while (true) {
         size_t total = cap_rows;

@@ -79,6 +79,7 @@ def test_g17_single_sequence_trained_regime(torch_mod, g17, g17_truth, weights_t
     stride = int(g17["stride"])
     ratios = {k: [] for k in OUTPUTS}
     report = {}
+    failures = []
     with MobilePoserNet.from_numpy(weights_trained, smpl) as net:
         for (T, seed), (imu, truth) in g17_truth.items():
             tag = "T%d_s%d" % (T, seed)
@@ -89,9 +90,11 @@ def test_g17_single_sequence_trained_regime(torch_mod, g17, g17_truth, weights_t
             env_max, env_mean = dist[:, :, 0].max(axis=0), dist[:, :, 1].max(axis=0)
             med_mean = np.median(dist[:, :, 1], axis=0)
             report[tag] = {k: "%.1e/%.1e (band %.1e/%.1e)" % (d[k][0], d[k][1], env_max[i], env_mean[i]) for i, k in enumerate(OUTPUTS)}
-            for i, k in enumerate(OUTPUTS):
-                assert d[k][0] <= max(TOL[k], NOISE_FACTOR_B1 * env_max[i]), (tag, k, d[k], env_max[i])
-                assert d[k][1] <= max(0.01 * TOL[k], NOISE_FACTOR_B1 * env_mean[i]), (tag, k, d[k], env_mean[i])
+            for i, k in enumerate(OUTPUTS):                 # (collected, reported in full, asserted at the end)
+                if d[k][0] > max(TOL[k], NOISE_FACTOR_B1 * env_max[i]):
+                    failures.append((tag, k, "max", d[k][0], env_max[i]))
+                if d[k][1] > max(0.01 * TOL[k], NOISE_FACTOR_B1 * env_mean[i]):
+                    failures.append((tag, k, "mean", d[k][1], env_mean[i]))
                 ratios[k].append(max(d[k][1], 1e-12) / max(med_mean[i], 1e-12))
             # against the reference's own outputs (every `stride`-th frame; contact and translation in full): by the triangle
             # inequality no farther than the two distances from the float64 result -- a check of the golden's layout and of
@@ -107,11 +110,12 @@ def test_g17_single_sequence_trained_regime(torch_mod, g17, g17_truth, weights_t
           % (variant or "default", len(g17_truth), {k: "%.2f" % v for k, v in level.items()}))
     for tag, r in report.items():
         print("   %s max/mean |x - f64|: %s" % (tag, r))
-    if not variant:                                     # keep the numbers (profiles/r06_accuracy_g17.json is a copy of this file)
-        import json
-        os.makedirs("gpurun_out", exist_ok=True)
-        json.dump({"level": level, "cases": report, "rule": {"per_case": NOISE_FACTOR_B1, "level": LEVEL_FACTOR_B1}},
-                  open(os.path.join("gpurun_out", "r06_accuracy_g17.json"), "w"), indent=1)
+    import json                                         # keep the numbers (profiles/r06_accuracy_g17*.json are copies of these files)
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump({"level": level, "cases": report, "outside_band": [list(map(str, f)) for f in failures],
+               "rule": {"per_case": NOISE_FACTOR_B1, "level": LEVEL_FACTOR_B1}},
+              open(os.path.join("gpurun_out", "r06_accuracy_g17%s.json" % ("_" + variant.replace("=", "") if variant else "")), "w"), indent=1)
+    assert not failures, failures
     for k in OUTPUTS:
         assert level[k] <= LEVEL_FACTOR_B1, (k, level)
 
@@ -129,18 +133,43 @@ def test_config1_joints_module_through_its_own_entry(torch_mod, smpl, profile):
     x = synthetic.make_imu(B, T, seed=91)
     ragged = [T - (7 * b) % 60 for b in range(B)]
     ragged[17] = T
+
+    def exact(lengths, state=None):              # the oracle's arithmetic in float64 (the yardstick on trained-regime weights)
+        O.F32 = np.float64
+        try:
+            return O.rnn_forward(sd, O.PREFIX["joints"], x, lengths, state)
+        finally:
+            O.F32 = np.float32
+
+    def close(tag, got, ref, truth, scale=1.0):
+        """1e-4 against the fp32 oracle -- or, on the trained-regime net (250 steps of amplified rounding by the second call: two
+        fp32 evaluations are more than 1e-4 apart somewhere in 256 x 256 states), no farther from the float64 result than
+        NOISE_FACTOR x the fp32 oracle is (the rule of tests/test_gpu_round4.py at this size)."""
+        e = float(np.abs(np.asarray(got, np.float64) - ref).max())
+        if e < 1e-4 * scale:
+            return
+        assert truth is not None, (tag, e)
+        e64 = float(np.abs(np.asarray(got, np.float64) - truth).max())
+        n64 = float(np.abs(np.asarray(ref, np.float64) - truth).max())
+        print("   %s %s: %.2e from the fp32 oracle; from float64: library %.2e, fp32 oracle %.2e" % (profile, tag, e, e64, n64))
+        assert e64 < NOISE_FACTOR_B1 * n64, (tag, e, e64, n64)
+
     with MobilePoserNet.from_numpy(sd, smpl) as net:
         for lengths in ([T] * B, ragged):
             y, (h, c) = net.rnn_forward("joints", cu(torch_mod, x), lengths)
             ry, (rh, rc) = O.rnn_forward(sd, O.PREFIX["joints"], x, lengths)
-            for b in range(0, B, 5):                              # (rows past a sequence's length: linear2(0) = bias on both sides)
-                assert np.abs(npy(y)[b] - ry[b]).max() < 1e-4, (profile, b)
-            assert np.abs(npy(h) - rh).max() < 1e-4 and np.abs(npy(c) - rc).max() < 1e-4 * max(1.0, float(np.abs(rc).max()))
+            ty, (th, tc) = exact(lengths) if profile == "trained" else (None, (None, None))
+            # (rows past a sequence's length: linear2(0) = bias on both sides)
+            close("y", npy(y), ry, ty)
+            close("h", npy(h), rh, th)
+            close("c", npy(c), rc, tc, max(1.0, float(np.abs(rc).max())))
             # carried state: the same input again, starting from (h, c)
             y2, (h2, c2) = net.rnn_forward("joints", cu(torch_mod, x), lengths, (h, c))
             ry2, (rh2, rc2) = O.rnn_forward(sd, O.PREFIX["joints"], x, lengths, (rh, rc))
-            assert np.abs(npy(y2) - ry2).max() < 1e-4, profile
-            assert np.abs(npy(h2) - rh2).max() < 1e-4 and np.abs(npy(c2) - rc2).max() < 1e-4 * max(1.0, float(np.abs(rc2).max()))
+            ty2, (th2, tc2) = exact(lengths, (th, tc)) if profile == "trained" else (None, (None, None))
+            close("y2", npy(y2), ry2, ty2)
+            close("h2", npy(h2), rh2, th2)
+            close("c2", npy(c2), rc2, tc2, max(1.0, float(np.abs(rc2).max())))
         assert net.device_error() == 0 and net.recovery_count == 0
 
 
