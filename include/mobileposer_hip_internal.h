@@ -29,6 +29,10 @@ int mp_debug_drop_workgroup(mp_handle* h, int block, int skip, int launches);
  * s_memtime per tick of the constant 100 MHz s_memrealtime -- and how long the probe took.  Synchronises.  What
  * `bench.py --workload stream --cadence-hz` samples around the first ticks after an idle stretch. */
 int mp_debug_clock_probe(mp_handle* h, double* shader_mhz, double* probe_us);
+/* The same two clocks under load (round 6): n_cu workgroups x 4 waves each issue 4 * iters independent v_mfma_f32_32x32x2_f32
+ * between their looks at the clocks.  mean / minimum over the waves of the shader MHz, mean / maximum of the time a wave took
+ * (us; the work is fixed, so this is the speed of the matrix pipes whatever the counters say).  Synchronises. */
+int mp_debug_clock_probe_loaded(mp_handle* h, int iters, double* mhz_mean, double* mhz_min, double* us_mean, double* us_max);
 /* Test hook (round 6): the workspace plans of the handle -- how many exist, how many were ever allocated, their capacity in rows
  * (B * T) together.  Plans are kept by capacity class (mp_api.hip get_plan): a caller that walks through sequence lengths must
  * not allocate per length. */

@@ -96,6 +96,7 @@ SIGNATURES = {
     "mp_debug_read_prof": (_i, [_vp, C.POINTER(C.c_longlong), _i]),
     "mp_debug_drop_workgroup": (_i, [_vp, _i, _i, _i]),
     "mp_debug_clock_probe": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "mp_debug_clock_probe_loaded": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mp_debug_plan_stats": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_longlong)]),
 }
 

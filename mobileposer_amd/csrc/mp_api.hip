@@ -208,13 +208,10 @@ struct mp_handle {
     bool xcd_plan_on[4] = {false, false, false, false};   // forward_body -> rnn_rec: clusters per XCD of module id's layer launches
     unsigned char xcd_plan[4][8] = {};
     bool half_ok = true;             // MP_VARIANT half=0: no pose-on-half-the-chip schedule for 64 < B <= 128
-    bool fuse_pv = true;             // MP_VARIANT fuse_pv=0: separate linear1 launches for pose and velocity
     Packed lin1_pv;                  // pose.linear1 and velocity.linear1 stacked (split-bf16 mode: one GEMM over the shared rows)
     Packed lin1_pvf;                 // ... with foot_contact.linear1 on top (exact-fp32 mode, B > 128: one GEMM, three outputs)
     int x3w_mask = 2;                // split-bf16 layers run by the 4-wave kernel mp_lstm_x3w: bit 0 K_in = 256, bit 1 K_in = 512
                                      // (default: the K_in = 512 layers, measured 373 vs 391 us; K_in = 256: 300 vs 285 us; MP_VARIANT x3w)
-    int nslice_env = 0;              // 0: pick per module (8 slices / 8 waves for bidirectional layers that fill the
-                                     // chip, 16 slices / 4 waves for unidirectional ones); MP_VARIANT slices=8|16 forces one             // LSTM recurrence: persistent kernel (default) or per-step launches
     std::vector<Plan*> plans;        // workspaces by capacity class (get_plan)
     int plan_allocs = 0;             // plans allocated so far (mp_debug_plan_stats)
     struct GraphEntry { hipGraphExec_t exec; unsigned long long last_use; };
@@ -285,11 +282,11 @@ int pack_weights(mp_handle* h, const float* blob) {
         // B = 256 bidirectional = 2 x 16 slabs x 8 slices = 256 workgroups (one per CU); a unidirectional layer
         // reaches the same 256 with 16 slices.  (Two 4-wave workgroups per CU were measured slower: the
         // lock-step of a cluster turns any contention between co-resident workgroups into waiting for everyone.)
-        m.nslice = m.H != 256 ? 4 : (h->nslice_env ? h->nslice_env : (m.dirs == 2 ? 8 : 16));
+        m.nslice = m.H != 256 ? 4 : (m.dirs == 2 ? 8 : 16);       // 8 slices / four 512-register waves for bidirectional layers that fill the chip, 16 for unidirectional ones
         // split-bf16 kernels: 8 slices (8-wave workgroups) for every H = 256 layer -- the unidirectional velocity
         // layers then occupy 128 CUs and leave the other half of the chip to the foot-contact block (measured:
         // 312 vs 326 us per velocity layer, foot-contact layers 200 vs 265 us)
-        m.nsliceX = 8;                                   // (MP_VARIANT slices only concerns the fp32 kernels)
+        m.nsliceX = 8;
         if (int rc = alloc_packed(h, m.lin1, m.H, m.n_in)) return rc;
         if (int rc = alloc_packed(h, m.ih[0], m.dirs * 4 * m.H, m.H)) return rc;
         if (int rc = alloc_packed(h, m.ih[1], m.dirs * 4 * m.H, m.dirs * m.H)) return rc;
@@ -530,9 +527,9 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     // MP_VARIANT: ONE debug switch for the kernel / schedule variants kept for cross-checks and A/B runs -- a comma-separated
     // list of key=value (tests/test_gpu_parity.py exercises them; nothing here changes results beyond summation order):
     //   x3w=0..3       split-bf16 layers on the four-wave kernel: bit 0 K_in=256, bit 1 K_in=512 (2)
-    //   slices=8|16    force the slices per slab of the fp32 H=256 layers;  slices16=0 / slices32=0: no 16- / 32-slice kernels
+    //   slices16=0 / slices32=0: no 16- / 32-slice kernels (bidirectional fp32 layers always on 8 slices per slab)
     //   wide=0         never run pose / velocity / foot contact side by side;  half=0: no pose-on-half-the-chip schedule
-    //   exclusive=0    no LDS padding / XCD tables for concurrent persistent launches;  fuse_pv=0: separate linear1 launches
+    //   exclusive=0    no LDS padding / XCD tables for concurrent persistent launches
     //   epoch_tags=0   zero the exchange area before every fp32 layer launch;  epoch_start=N: first epoch base (wrap tests)
     //   vf=0           foot-contact layers as launches of their own beside velocity (B > 128), not as riders in its workgroups
     //   wf=0           velocity layers as two 16-slice launches (rounds 3-4), not as one two-layer wavefront launch (B > 128)
@@ -549,31 +546,20 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
             if (eq == std::string::npos) continue;
             const std::string key = tok.substr(0, eq);
             const unsigned long v = strtoul(tok.c_str() + eq + 1, nullptr, 0);
-            if (key == "wreg") { /* (round 5: the eight-wave kernels are gone; accepted and ignored) */ }
-            else if (key == "x3w") h->x3w_mask = (int)(v & 3);
-            else if (key == "slices") h->nslice_env = v == 8 ? 8 : (v == 16 ? 16 : 0);
+            if (key == "x3w") h->x3w_mask = (int)(v & 3);
             else if (key == "slices16") h->slices16_ok = v != 0;
             else if (key == "slices32") h->slices32_ok = v != 0;
             else if (key == "vec") h->vec_ok = v != 0;
             else if (key == "wide") h->wide_ok = v != 0;
             else if (key == "half") h->half_ok = v != 0;
             else if (key == "exclusive") h->exclusive_ok = v != 0;
-            else if (key == "fuse_pv") h->fuse_pv = v != 0;
             else if (key == "epoch_tags") h->epoch_tags = v != 0;
             else if (key == "epoch_start") { if (v >= 1 && v < 0xf0000000ul) h->epoch_start = (unsigned)v; }
-            else if (key == "gemm_staged") {}                  // read by mp_launch_gemm
             else if (key == "kin_scalar") {}                   // read by mp_kin.hip
-            else if (key == "gemm_frag") {}                    // read by mp_launch_gemm
-            else if (key == "gemm_few") {}                     // read by mp_launch_gemm: 0 = M <= 128 rows on the tiles of the large batches
-            else if (key == "kin_fused") {}                    // read by mp_launch_r6d_ik_fk: 0 = IK and FK as two launches
-            else if (key == "l2l1_opt") {}                     // read by mp_launch_gemm_l2l1: bits of mp_gemm_l2l1's OPT (A/B)
-            else if (key == "l2l1") {}                         // read by mp_launch_gemm_l2l1: 0 = joints.linear2 and the stacked linear1 as two launches
-            else if (key == "gemm_wide") {}                    // read by mp_launch_gemm: 0 = wide linear1 layers on mp_gemm_f32_frag's small tiles
             else if (key == "one_stream") h->one_stream_ok = v != 0;   // 0 = the round-3 three-stream serial schedule (a cross-check)
             else if (key == "vf") h->vf_ok = v != 0;
             else if (key == "wf") h->wf_ok = v != 0;
             else if (key == "late_pair") h->late_pair_ok = v != 0;
-            else if (key == "recovery") h->recovery = v != 0;   // (= mp_set_recovery)
             else { h->err = "MP_VARIANT: unknown key '" + key + "'"; return bail(MP_ERR_INVALID); }
         }
     }
@@ -909,7 +895,7 @@ bool rnn_g0_pose_velocity(const RnnJob& jp, const RnnJob& jv, hipStream_t s, int
     const ModuleW& mp = h->mod[jp.id];
     const ModuleW& mv = h->mod[jv.id];
     *rc = MP_OK;
-    if (!h->fuse_pv || !h->lin1_pv.Wp || !h->persist || use_x3(h, mp) != use_x3(h, mv)) return false;
+    if (!h->lin1_pv.Wp || !h->persist || use_x3(h, mp) != use_x3(h, mv)) return false;
     const bool x3 = use_x3(h, mp);
     if (jp.mode != STATE_ZERO || !(jv.mode == STATE_ZERO || (jv.out_h == jv.in_h && jv.out_h))) return false;
     if (jp.a0.base != jv.a0.base || jp.a1.base != jv.a1.base) return false;
@@ -917,7 +903,7 @@ bool rnn_g0_pose_velocity(const RnnJob& jp, const RnnJob& jv, hipStream_t s, int
     ModuleWS& wv = jv.p->ws[jv.id];
     const int B = jp.p->B, T = jp.p->T, M = B * T, H = mp.H;
     // (jf: the foot-contact block's linear1 as a third output of the same launch -- exact-fp32 operands, fragment-ordered W)
-    const bool three = jf != nullptr && !x3 && h->lin1_pvf.Wf != nullptr && mp_gemm_frag_enabled() && jf->mode == STATE_ZERO && jf->a0.base == jp.a0.base &&
+    const bool three = jf != nullptr && !x3 && h->lin1_pvf.Wf != nullptr && jf->mode == STATE_ZERO && jf->a0.base == jp.a0.base &&
                        jf->a1.base == jp.a1.base;
     if (jf != nullptr && !three) return false;
     const Packed& w = three ? h->lin1_pvf : h->lin1_pv;
@@ -951,7 +937,7 @@ bool rnn_g2_g0_fused(const RnnJob& jj, const RnnJob& jp, const RnnJob& jv, const
     const ModuleW& mp = h->mod[jp.id];
     const ModuleW& mv = h->mod[jv.id];
     const ModuleW& mf = h->mod[jf.id];
-    if (!h->persist || !h->fuse_pv || use_x3(h, mj) || use_x3(h, mp) || use_x3(h, mv) || !h->lin1_pvf.Wf || !mj.lin2.Wf) return false;
+    if (!h->persist || use_x3(h, mj) || use_x3(h, mp) || use_x3(h, mv) || !h->lin1_pvf.Wf || !mj.lin2.Wf) return false;
     if (jj.out_h || jp.mode != STATE_ZERO || jf.mode != STATE_ZERO || !(jv.mode == STATE_ZERO || (jv.out_h == jv.in_h && jv.out_h))) return false;
     // the stacked GEMM must read exactly what linear2 writes: cat(pred_joints, imu) with pred_joints = this call's output
     if (jp.a0.base != jj.y || jv.a0.base != jj.y || jf.a0.base != jj.y || jp.a1.base != jv.a1.base || jp.a1.base != jf.a1.base) return false;
@@ -1361,7 +1347,7 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         const ModuleW& vmod = h->mod[MP_MOD_VELOCITY];
         const bool vf = h->vf_ok && p->B > 128 && h->persist && !use_x3(h, vmod) && vmod.nslice == 16 &&
                         fp32_slices(h, vmod, p->B) == 16 && h->mod[MP_MOD_FOOT_CONTACT].wVF[0][0] != nullptr;
-        if (vf && h->one_stream_ok && h->lin1_pvf.Wf && mp_gemm_frag_enabled() && h->fuse_pv && !use_x3(h, h->mod[MP_MOD_POSE]) &&
+        if (vf && h->one_stream_ok && h->lin1_pvf.Wf && !use_x3(h, h->mod[MP_MOD_POSE]) &&
             side_by_side_plan(h, p->B) == 0) {
             RC(rnn_g0(J, sm)); RC(rnn_rec(J, 0, sm)); RC(rnn_g1(J, sm)); RC(rnn_rec(J, 1, sm));   // net.py:103
             int rc_pv = MP_OK;
@@ -2629,6 +2615,59 @@ int mp_debug_clock_probe(mp_handle* h, double* shader_mhz, double* probe_us) {
     if (e != hipSuccess) return fail(h, MP_ERR_HIP, "mp_debug_clock_probe: %s", hipGetErrorString(e));
     *shader_mhz = real > 0 ? shader / real * 100.0 : 0.0;
     if (probe_us) *probe_us = real / 100.0;
+    return MP_OK;
+}
+
+namespace {
+// The same two clocks under LOAD: every wave of a grid that fills the chip (n_cu workgroups x 4 waves) issues a stream of
+// independent fp32 MFMAs -- what the layer kernels do -- between its two looks at them.  The one-wave probe above runs on an
+// otherwise idle chip and cannot see what power management does to a chip that has just been handed 1 024 busy matrix pipes.
+MP_KERNEL __launch_bounds__(256) void mp_clock_probe_loaded(unsigned long long* out, int iters) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const float a = 1e-3f * (float)(threadIdx.x & 63), b = 0.5f;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[j]));
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) {
+        const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        out[2 * w] = r1 - r0; out[2 * w + 1] = c1 - c0;
+    }
+}
+}
+
+int mp_debug_clock_probe_loaded(mp_handle* h, int iters, double* mhz_mean, double* mhz_min, double* us_mean, double* us_max) {
+    if (!h || iters < 1 || iters > (1 << 20) || !mhz_mean) return MP_ERR_INVALID;
+    ON_DEVICE(h);
+    const int nw = h->n_cu * 4;
+    unsigned long long* buf = nullptr;
+    HIPCHK(h, hipHostMalloc((void**)&buf, (size_t)nw * 16, hipHostMallocDefault));
+    memset(buf, 0, (size_t)nw * 16);
+    hipLaunchKernelGGL(mp_clock_probe_loaded, dim3(h->n_cu), dim3(256), 0, h->s_main, buf, iters);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->s_main);
+    double sum = 0.0, mn = 1e30, us = 0.0, usmax = 0.0;
+    for (int w = 0; w < nw; ++w) {
+        const double real = (double)buf[2 * w], shader = (double)buf[2 * w + 1];
+        const double mhz = real > 0 ? shader / real * 100.0 : 0.0;
+        sum += mhz; mn = mhz < mn ? mhz : mn; us += real / 100.0; usmax = real / 100.0 > usmax ? real / 100.0 : usmax;
+    }
+    (void)hipHostFree(buf);
+    if (e != hipSuccess) return fail(h, MP_ERR_HIP, "mp_debug_clock_probe_loaded: %s", hipGetErrorString(e));
+    *mhz_mean = sum / nw;
+    if (mhz_min) *mhz_min = mn;
+    if (us_mean) *us_mean = us / nw;
+    if (us_max) *us_max = usmax;
     return MP_OK;
 }
 

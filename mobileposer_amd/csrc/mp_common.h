@@ -68,7 +68,6 @@ bool mp_launch_gemm_pair(const GemmArgs& g1, const GemmArgs& g2, hipStream_t s);
 // the number of y columns.  false = shapes not covered, nothing launched
 bool mp_launch_gemm_l2l1(const GemmArgs& g2, const GemmArgs& g1, hipStream_t s);
 bool mp_gemm_l2l1_applicable(const GemmArgs& g2, const GemmArgs& g1);
-bool mp_gemm_frag_enabled();          // false under MP_VARIANT gemm_frag=0 / gemm_staged=1 (A/B runs with the round-3 kernels)
 // W [Npad][Kpad] row-major -> fragment order [Kpad/32][4][Npad/32][64 lanes][4]: lane (li = lane & 31, lh = lane >> 5) of piece
 // (kt, q, b) holds W[b*32 + li][kt*32 + lh*16 + q*4 .. +3] -- what a lane of mp_gemm_f32_rows feeds its MFMAs of quarter q
 void mp_launch_pack_wfrag(const float* W, float* Wf, int Npad, int Kpad, hipStream_t s);

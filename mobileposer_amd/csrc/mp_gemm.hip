@@ -394,22 +394,19 @@ MP_KERNEL __launch_bounds__(256, 2) void mp_gemm_f32_frag(GemmArgs g, int nTiles
 // ramp and no tail between the two; the second GEMM then runs all NT1 64-column groups of the stacked output for those rows
 // from A fragments held in registers (80 VGPRs for K = 132) with W streamed in fragment order, one long MFMA stream per wave.
 // Same k pairing and MFMA order per output element as the separate launches: bit-identical results.
-constexpr int L2L1_OPT_DEFAULT = 0;      // (round 6 A/B: see mp_gemm_l2l1's OPT)
 constexpr int L2L1_YP = 76;     // LDS row pitch of the y tile in floats (16-byte aligned; 32 rows x b128 reads conflict-free)
 
 // FULL: M is a multiple of 32 -- no row of any wave's tile lies past M, and the per-group epilogues of phase 2 carry no branch:
 // behind a branch the compiler merges the wait counts of both paths into vmcnt(0), i.e. the first MFMAs of the next group
 // would wait for the 32 stores of this one to be acknowledged (measured: 128 -> ... us per launch).
-// OPT (round 6, the counter-named changes of profiles/r05_pmc_gemm_forward.txt; bit-identical outputs):
-//   bit 0: phase-2 outputs go out as BUFFER stores -- the X1 buffers are time-major, so a row's offset is m * H: one lane offset
-//          per 32-column tile, the 16 rows of an accumulator are scalar offsets, no 64-bit address arithmetic and no row-offset
-//          table per element (2.35 M VALU instructions beside 2.21 M MFMAs before); rows past M fall outside the descriptor;
-//   bit 1: the stores of column group g are issued inside group g + 1, behind the W requests of its second k-tile: the wait for
-//          those fragments no longer sits out the acknowledgement of 32 stores that were issued in front of them.
-template <int NK2, int NT1, bool FULL, int OPT = 0>
+// Round 6 measured the three changes the SQ counters of round 5 had named -- buffer stores with one lane offset per tile (no 64-bit
+// address arithmetic per element: 2.35 M VALU instructions beside 2.21 M MFMAs), the stores of a column group issued inside the next
+// group behind its W requests, both -- on one box, three rounds interleaved: 3.617-3.631 ms per step and 0.262-0.269 ms of linear
+// layers per forward for every variant, outputs bit-identical (profiles/r06_l2l1_ab.txt).  Neither the VALU count nor the store
+// acknowledgements are what holds this kernel at 0.65 of the MFMA time of its padded tiles; the variants were removed.
+template <int NK2, int NT1, bool FULL>
 MP_KERNEL __launch_bounds__(256, 1) void mp_gemm_l2l1(GemmArgs g2, GemmArgs g1) {
     constexpr int TN2 = 3, NK1 = 5, TN1 = 2;
-    constexpr bool BUF = (OPT & 1) != 0, LATE = (OPT & 2) != 0;
     __shared__ long rowOff2[4][32], rowOffA[4][32], rowOffF[4][32];
     __shared__ __attribute__((aligned(16))) float ytile[4][32 * L2L1_YP];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -514,40 +511,19 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_gemm_l2l1(GemmArgs g2, GemmArgs g1) 
     for (int q = 0; q < 4; ++q) request_w(q, 0);
     // (unrolled completely: with a real loop the compiler merges the wait counts at its header into one vmcnt(0), i.e. every
     //  group would wait for the previous group's 32 output stores to be acknowledged before its first MFMA)
-    // BUF: descriptors of the three outputs (num_records = M rows: a row past M is dropped by the hardware), this lane's byte offset
-    // in a row-major [M][Hc] buffer; the rows of an accumulator register r are (r & 3) + 8 (r >> 2) + 4 lh
-    const unsigned rowA = BUF ? (unsigned)g1.cStrideB * 4u : 0u, rowF = BUF ? (unsigned)g1.c3StrideB * 4u : 0u;
-    f32x16 held[TN1];                                            // LATE: the finished values of the group before
-    auto put_group = [&](int ng, const f32x16 (&val)[TN1], int part, int nparts) {      // stores rows [part, part + 1) / nparts of both tiles
+    auto put_group = [&](int ng, const f32x16 (&val)[TN1]) {
         const int n0 = ng * TN1 * 32;
         const bool toF = g1.nsplit3 > 0 && n0 >= g1.nsplit3, toB = !toF && g1.nsplit > 0 && n0 >= g1.nsplit;
         const int ncol0 = toF ? g1.nsplit3 : toB ? g1.nsplit : 0;
-        if constexpr (BUF) {
-            const unsigned rowb = toF ? rowF : rowA;
-            float* base = toF ? g1.C3 : toB ? g1.C2 : g1.C;      // (a scalar select, then the descriptor: four SGPRs per group)
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)((unsigned)g1.M * rowb), 0x00020000);
+        float* Cb = toF ? g1.C3 : toB ? g1.C2 : g1.C;
+        const long* roff = toF ? rowOffF[wave] : rowOffA[wave];
 #pragma unroll
-            for (int b = 0; b < TN1; ++b) {
-                const unsigned voff = (unsigned)(m0 + 4 * lh) * rowb + (unsigned)(n0 + b * 32 + li - ncol0) * 4u;
+        for (int b = 0; b < TN1; ++b) {
+            const int n = n0 + b * 32 + li;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (r * nparts / 16 != part) continue;
-                    const unsigned soff = (unsigned)((r & 3) + 8 * (r >> 2)) * rowb;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val[b][r]), rs, voff, soff, 0);
-                }
-            }
-        } else {
-            float* Cb = toF ? g1.C3 : toB ? g1.C2 : g1.C;
-            const long* roff = toF ? rowOffF[wave] : rowOffA[wave];
-#pragma unroll
-            for (int b = 0; b < TN1; ++b) {
-                const int n = n0 + b * 32 + li;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (r * nparts / 16 != part) continue;
-                    const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (FULL || m0 + ml < g1.M) Cb[roff[ml] + (n - ncol0)] = val[b][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (FULL || m0 + ml < g1.M) Cb[roff[ml] + (n - ncol0)] = val[b][r];
             }
         }
     };
@@ -570,8 +546,6 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_gemm_l2l1(GemmArgs g2, GemmArgs g1) 
                 __builtin_amdgcn_sched_barrier(0);
                 const int nxt = ng * NK1 + kt + 1;
                 if (nxt < NT1 * NK1) request_w(q, nxt);
-                // LATE: a quarter of the previous group's stores behind each quarter of this group's second-k-tile requests
-                if (LATE && ng > 0 && kt == 0) put_group(ng - 1, held, q, 4);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -581,14 +555,8 @@ MP_KERNEL __launch_bounds__(256, 1) void mp_gemm_l2l1(GemmArgs g2, GemmArgs g1) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][r] = relu_(acc[b][r] + bias);
         }
-        if constexpr (LATE) {
-#pragma unroll
-            for (int b = 0; b < TN1; ++b) held[b] = acc[b];
-        } else {
-            put_group(ng, acc, 0, 1);
-        }
+        put_group(ng, acc);
     }
-    if constexpr (LATE) put_group(NT1 - 1, held, 0, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -770,23 +738,13 @@ void mp_launch_pack_wfrag(const float* W, float* Wf, int Npad, int Kpad, hipStre
     hipLaunchKernelGGL(mp_pack_wfrag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, Wf, Npad, Kpad);
 }
 
-static bool frag_usable(const GemmArgs& g) {
-    static const bool staged = getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "gemm_staged=1");
-    static const bool no_frag = getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "gemm_frag=0");
-    return g.Wf && !staged && !no_frag && g.NB > 0 && (g.K & 3) == 0 && (g.a0.width & 3) == 0;
-}
-
-bool mp_gemm_frag_enabled() {
-    GemmArgs probe;
-    static const float one = 0.f;
-    probe.Wf = &one; probe.NB = 1; probe.K = 4; probe.a0.width = 4;
-    return frag_usable(probe);
-}
+// fragment-ordered W and rows of whole 16-byte pieces: the round-4 kernels; anything else (a caller's odd row width) falls through
+// to the row-streaming / LDS-staged kernels of rounds 1-3 at the end of mp_launch_gemm
+static bool frag_usable(const GemmArgs& g) { return g.Wf && g.NB > 0 && (g.K & 3) == 0 && (g.a0.width & 3) == 0; }
 
 bool mp_gemm_l2l1_applicable(const GemmArgs& g2, const GemmArgs& g1) {
     // joints.linear2 (K = 512, N = 72) -> stacked linear1 over cat(y, imu) (K = 72 + 60, N = 576 = nine 64-column groups)
-    static const bool off = getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "l2l1=0");
-    if (off || !frag_usable(g2) || !frag_usable(g1) || g2.a1.base || !g1.a1.base) return false;
+    if (!frag_usable(g2) || !frag_usable(g1) || g2.a1.base || !g1.a1.base) return false;
     if (!(g2.NB == 3 && g2.Kpad == 512 && g2.K == 512 && g2.N > 64 && g2.N <= L2L1_YP && (g2.N & 3) == 0 && !g2.relu && !g2.pairOut)) return false;
     return g1.Kpad == 160 && g1.a0.width == g2.N && g1.NB == 18 && g1.N == 576 && g1.relu && !g1.pairOut && g1.M == g2.M && g1.B == g2.B &&
            g1.nsplit > 0 && g1.nsplit % 64 == 0 && g1.nsplit3 > g1.nsplit && g1.nsplit3 % 64 == 0 && g1.C && g1.C2 && g1.C3;
@@ -795,17 +753,8 @@ bool mp_gemm_l2l1_applicable(const GemmArgs& g2, const GemmArgs& g1) {
 bool mp_launch_gemm_l2l1(const GemmArgs& g2, const GemmArgs& g1, hipStream_t s) {
     if (!mp_gemm_l2l1_applicable(g2, g1)) return false;
     const int blocks = (g2.M + 127) / 128;
-    // OPT (see the kernel): buffer stores need the X1 outputs row-major in m (time-major internal buffers: stride of t = B x stride
-    // of b) and below 2 GB; MP_VARIANT l2l1_opt=0..3 picks the bits for A/B runs
-    static const int opt_env = getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "l2l1_opt=") ? atoi(strstr(getenv("MP_VARIANT"), "l2l1_opt=") + 9) : L2L1_OPT_DEFAULT;
-    const bool linear = g1.cStrideT == (long)g1.B * g1.cStrideB && g1.c3StrideT == (long)g1.B * g1.c3StrideB &&
-                        (size_t)g1.M * (size_t)g1.cStrideB * 4 < 0x7fffffffull;
-    const int opt = linear ? (opt_env & 3) : (opt_env & 2);
-    const bool full = g2.M % 32 == 0;
-#define L2L1_GO(O) do { if (full) hipLaunchKernelGGL((mp_gemm_l2l1<16, 9, true, O>), dim3(blocks), dim3(256), 0, s, g2, g1); \
-                        else hipLaunchKernelGGL((mp_gemm_l2l1<16, 9, false, O>), dim3(blocks), dim3(256), 0, s, g2, g1); } while (0)
-    if (opt == 3) L2L1_GO(3); else if (opt == 2) L2L1_GO(2); else if (opt == 1) L2L1_GO(1); else L2L1_GO(0);
-#undef L2L1_GO
+    if (g2.M % 32 == 0) hipLaunchKernelGGL((mp_gemm_l2l1<16, 9, true>), dim3(blocks), dim3(256), 0, s, g2, g1);
+    else hipLaunchKernelGGL((mp_gemm_l2l1<16, 9, false>), dim3(blocks), dim3(256), 0, s, g2, g1);
     return true;
 }
 
@@ -820,12 +769,10 @@ bool mp_launch_gemm_pair(const GemmArgs& g1, const GemmArgs& g2, hipStream_t s) 
 }
 
 void mp_launch_gemm(const GemmArgs& g, int bn, hipStream_t s) {
-    static const bool staged = getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "gemm_staged=1");   // A/B runs: the LDS-staged kernel
-    static const int frag_tn = getenv("MP_GEMM_FRAG_TN") ? atoi(getenv("MP_GEMM_FRAG_TN")) : 0;          // micro-benchmark only
-    if (frag_usable(g)) {      // (MP_VARIANT gemm_frag=0: the round-3 kernels, A/B runs)
+    static const int frag_tn = getenv("MP_GEMM_FRAG_TN") ? atoi(getenv("MP_GEMM_FRAG_TN")) : 0;          // micro-benchmark only (tools/micro)
+    if (frag_usable(g)) {
         // full batches (at least three quarters of a wave per SIMD), wide outputs without padding columns: one wave = 32 rows x ALL columns
-        static const bool wide_ok = !(getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "gemm_wide=0"));
-        if (wide_ok && !frag_tn && !g.pairOut && g.M >= 24576 && g.N == g.NB * 32 && g.N % 64 == 0 && (g.nsplit % 64) == 0 && (g.nsplit3 % 64) == 0 &&
+        if (!frag_tn && !g.pairOut && g.M >= 24576 && g.N == g.NB * 32 && g.N % 64 == 0 && (g.nsplit % 64) == 0 && (g.nsplit3 % 64) == 0 &&
             (g.nsplit3 == 0 || g.C3) && (g.nsplit == 0 || g.C2)) {
             const int nk = g.Kpad / BK, nt = g.N / 64;
             if (nk == 2 && nt == 4) { launch_wide<2, 4>(g, s); return; }          // joints.linear1
@@ -840,8 +787,7 @@ void mp_launch_gemm(const GemmArgs& g, int bn, hipStream_t s) {
         // a handful of rows (one 128-row tile: a one-stream tick has 45): one 32-column tile per wave -- a wave's MFMA stream is
         // all there is (joints / pose linear2 at 45 rows: 768 MFMAs = 20 us for the one wave that owned 96 columns), so the
         // columns go to as many workgroups as there are tiles.  Same k order per output element: bit-identical.
-        static const bool few_ok = !(getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "gemm_few=0"));
-        if (few_ok && g.M <= 128) tn = 1;
+        if (g.M <= 128) tn = 1;
         if (frag_tn) tn = frag_tn;
         if (npad32 % tn == 0 && (g.nsplit == 0 || g.nsplit % (tn * 32) == 0) && (g.nsplit3 == 0 || g.nsplit3 % (tn * 32) == 0)) {
             const bool done = tn == 1 ? launch_frag_k<1>(g, s) : tn == 2 ? launch_frag_k<2>(g, s) : tn == 3 ? launch_frag_k<3>(g, s)
@@ -850,7 +796,7 @@ void mp_launch_gemm(const GemmArgs& g, int bn, hipStream_t s) {
         }
     }
     // (row-streaming kernel for the linear2 shapes -- few columns, K >= 128)
-    if (!staged && g.N <= 96 && g.Kpad >= 128) {
+    if (g.N <= 96 && g.Kpad >= 128) {
         // (W is padded to a multiple of bn rows: bn = 32 -> 1 tile, 96 -> up to 3)
         const bool done = g.N > 64 ? launch_rows_k<3>(g, s) : g.N > 32 ? launch_rows_k<2>(g, s) : launch_rows_k<1>(g, s);
         if (done) return;

@@ -513,14 +513,13 @@ void mp_launch_r6d_ik_strided(const float* r6d, long N, long rowStride, long row
 }
 
 // r6d -> local pose AND its forward kinematics (shared body, no translation) in one launch; false = buffers not 16-byte aligned
-// (or MP_VARIANT kin_scalar=1 / kin_fused=0): the caller runs mp_launch_r6d_ik_strided + mp_launch_fk instead
+// (or MP_VARIANT kin_scalar=1): the caller runs mp_launch_r6d_ik_strided + mp_launch_fk instead
 bool mp_launch_r6d_ik_fk(const float* r6d, long N, long rowStride, long rowOffset, float* pose, const float* bone_dev,
                          const int* parent_dev, float* rglobal, float* joint, hipStream_t s) {
-    static const bool off = getenv("MP_VARIANT") && strstr(getenv("MP_VARIANT"), "kin_fused=0");
     if (N <= 0) return true;
     const bool aligned = ((reinterpret_cast<uintptr_t>(r6d) | reinterpret_cast<uintptr_t>(pose)) & 15) == 0 &&
                          ((rowStride | rowOffset) & 3) == 0;
-    if (!aligned || off || mp_kin_scalar_forced()) return false;
+    if (!aligned || mp_kin_scalar_forced()) return false;
     hipLaunchKernelGGL(mp_r6d_ik_fk, dim3((unsigned)((N + kFkFrames - 1) / kFkFrames)), dim3(256), 0, s, r6d, N, rowStride, rowOffset,
                        pose, bone_dev, parent_dev, rglobal, joint);
     return true;

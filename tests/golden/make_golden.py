@@ -465,11 +465,13 @@ def main():
     # the trained-regime net amplifies rounding until two fp32 evaluations differ by 1e-4 ... 1e-3 somewhere, so beside the
     # reference's outputs (every 8th frame of r6d / joints / velocity, contact and translation in full) the file records how far
     # each member of an ENSEMBLE of fp32 evaluations is from the float64 result over ALL frames: the reference itself (torch
-    # CPU), the numpy oracle, and the oracle with three permuted summation orders (oracle/ensemble.py) -- the band a kernel with
+    # CPU), the numpy oracle, and the oracle with fourteen permuted summation orders (oracle/ensemble.py) -- the band a kernel with
     # yet another summation order has to stay inside (tests/test_gpu_round6.py).
     from oracle import ensemble as ENS
+    N_PERM = 14          # 16 members in all (the first version of this golden had 5: the maximum over 5 draws of a heavy-tailed
+    #                      distance is no envelope -- two of 90 checks of kernels AT the ensemble's level fell outside twice of it)
     g17 = {"lengths": np.array([2000, 2500, 3000]), "seeds": np.array([171, 172, 173]), "stride": np.array(8),
-           "members": np.array(["reference", "oracle", "perm0", "perm1", "perm2"]), "outputs": np.array(ENS.OUTPUTS)}
+           "members": np.array(["reference", "oracle"] + ["perm%d" % k for k in range(N_PERM)]), "outputs": np.array(ENS.OUTPUTS)}
     combos17 = {171: "lw_rp_h", 172: "rw_lp", 173: "lp_h"}
     g17["combos"] = np.array([combos17[s] for s in (171, 172, 173)])
     with torch.no_grad():
@@ -487,7 +489,7 @@ def main():
                        "contact": contact.numpy().reshape(T, 2), "tran": tran.numpy().reshape(T, 3)}
                 truth = ENS.offline_outputs(sd_tr, smpl["J"], imu17, T, dtype=np.float64)
                 stats = [ENS.distance(ref, truth), ENS.distance(ENS.offline_outputs(sd_tr, smpl["J"], imu17, T), truth)]
-                stats += [ENS.distance(ENS.offline_outputs(sd_tr, smpl["J"], imu17, T, perm_seed=1700 + k), truth) for k in range(3)]
+                stats += [ENS.distance(ENS.offline_outputs(sd_tr, smpl["J"], imu17, T, perm_seed=1700 + k), truth) for k in range(N_PERM)]
                 tag = "T%d_s%d" % (T, seed)
                 g17[tag + "_imu_sum"] = np.array(imu17.astype(np.float64).sum())              # the input is regenerated from its seed
                 for k in ("r6d", "joints", "vel"):

@@ -15,7 +15,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import cu, geodesic, load_golden, npy
+from conftest import cu, geodesic, load_golden, npy, lstm_test_modes
 
 pytestmark = pytest.mark.gpu
 
@@ -46,7 +46,7 @@ def weights_trained():
     return make_weights(0, profile="trained")
 
 
-@pytest.fixture(params=["fp32", "x3"])
+@pytest.fixture(params=lstm_test_modes())
 def tnet(request, torch_mod, weights_trained, smpl):
     """A net with trained-regime weights, once per operand mode."""
     from mobileposer_amd.net import MobilePoserNet
@@ -108,7 +108,7 @@ def test_g14_trained_online_50_frames(torch_mod, tnet):
 
 
 @pytest.mark.parametrize("tag", ["tr", "s1"])
-@pytest.mark.parametrize("mode", ["fp32", "x3"])
+@pytest.mark.parametrize("mode", lstm_test_modes())
 def test_g14_all_twelve_combos(torch_mod, weights_trained, smpl, tag, mode):
     """Row k of the batch keeps the devices of combo k: all 12 of config.py:60-73 through one forward; trained profile and
     a second init-scale seed (make_weights(1))."""

@@ -10,7 +10,9 @@
 Why a band and not "1e-4 of the golden": at this length the trained-regime net is chaotic at fp32 resolution.  Permuting the
 summation order of the numpy oracle alone moves its maximum distance from the float64 result by up to 10 x, and float64 dot
 products with fp32 state do not lower it (profiles/r06_b1_precision_emulation.txt): the reference itself is 2e-5 ... 9e-4 from the
-float64 result on these nine cases.  The rule (NOISE_FACTOR_B1): per case and output, max |x - f64| <= 2 x the largest maximum of
+float64 result on these nine cases.  The ensemble has 16 members (the reference, the oracle, 14 permuted orders); its first version
+had 5, and the maximum over 5 draws of so heavy-tailed a distance was no envelope: kernels whose LEVEL was 1.0-1.3 fell outside
+twice of it in 2 of 90 checks (profiles/r06_accuracy_g17_5members.txt).  The rule (NOISE_FACTOR_B1): per case and output, max |x - f64| <= 2 x the largest maximum of
 the ensemble (or the north-star bound, 1e-4 / 1 mm, where that is larger) AND mean |x - f64| <= 2 x the largest mean of the
 ensemble; over the nine cases, the geometric mean of (mean distance / median member's mean distance) <= 1.5 -- a kernel whose
 noise LEVEL is above fp32's shows up there even when every single draw is inside the band.
@@ -275,4 +277,33 @@ def test_batch_classes_share_a_plan_and_stay_bitwise(torch_mod, weights, smpl):
             for a, b in zip(got, want):
                 assert np.array_equal(a, b), B
         assert _plan_stats(net)[1] == 1
+        assert net.device_error() == 0 and net.recovery_count == 0
+
+
+def test_mode3_smoke(torch_mod, weights, smpl):
+    """What is left of the opt-in split-fp16 mode in the default suite (conftest.lstm_test_modes): the full forward against golden
+    G2 (equal and ragged lengths, carried velocity state) and 20 online frames against golden G5, at the bound of the exact mode
+    (init-scale weights: both modes are within 5e-7 there)."""
+    from conftest import geodesic
+    from mobileposer_amd.net import MobilePoserNet
+    g = load_golden("g2_forward.npz")
+    g5 = load_golden("g5_online.npz")
+    with MobilePoserNet.from_numpy(weights, smpl) as net:
+        net.set_lstm_mode(3)
+        for tag in ("eq", "rag"):
+            net.reset_all()
+            pose, joints, vel, contact, r6d = net.forward(cu(torch_mod, g["imu"]), g[f"{tag}_lengths"].tolist(), return_r6d=True)
+            for got, key in ((joints, "joints"), (vel, "vel"), (contact, "contact"), (r6d, "r6d")):
+                assert np.abs(npy(got) - g[f"{tag}_{key}"]).max() < 1e-4, (tag, key)
+            assert geodesic(npy(pose), g[f"{tag}_pose"]).max() < 1e-4
+            h, c = net.velocity.rnn_state
+            assert np.abs(npy(h) - g[f"{tag}_vel_h"]).max() < 1e-4 and np.abs(npy(c) - g[f"{tag}_vel_c"]).max() < 1e-4
+        net.reset_all()
+        net.reset()
+        for k, f in enumerate(g5["imu"][:20]):
+            pose, joints, tran, contact = net.forward_online(cu(torch_mod, f))
+            assert geodesic(npy(pose).reshape(24, 3, 3), g5["pose"][k].reshape(24, 3, 3)).max() < 1e-4, k
+            assert np.abs(npy(joints)[40] - g5["joints40"][k]).max() < 1e-4
+            assert np.abs(npy(contact) - g5["contact"][k]).max() < 1e-4
+            assert np.abs(npy(tran) - g5["tran"][k]).max() < 1e-3, k
         assert net.device_error() == 0 and net.recovery_count == 0

@@ -1,5 +1,5 @@
 """Randomised shapes, round 4: the split-fp16 mode (mode 3) against the exact-fp32 mode (mode 1) of the same handle, and the
-default one-stream full-batch schedule against the round-3 three-stream schedule (MP_VARIANT one_stream=0,gemm_frag=0 -- a second
+default one-stream full-batch schedule against the round-3 three-stream schedule (MP_VARIANT one_stream=0 -- a second
 handle), same inputs, two calls each (carried velocity state), ragged lengths, both weight profiles."""
 import os, sys
 import numpy as np, torch
@@ -13,7 +13,7 @@ for profile in ("init", "trained"):
     sd = synthetic.make_weights(0, profile=profile)
     os.environ["MP_VARIANT"] = ""
     new = MobilePoserNet.from_numpy(sd, smpl)
-    os.environ["MP_VARIANT"] = "one_stream=0,gemm_frag=0,kin_scalar=1"
+    os.environ["MP_VARIANT"] = "one_stream=0,kin_scalar=1"
     old = MobilePoserNet.from_numpy(sd, smpl)
     os.environ["MP_VARIANT"] = ""
     worst_sched, worst_mode = 0.0, 0.0
