@@ -34,7 +34,7 @@ int mp_debug_clock_probe(mp_handle* h, double* shader_mhz, double* probe_us);
  * (us; the work is fixed, so this is the speed of the matrix pipes whatever the counters say).  Synchronises. */
 int mp_debug_clock_probe_loaded(mp_handle* h, int iters, double* mhz_mean, double* mhz_min, double* us_mean, double* us_max);
 /* Test hook (round 6): the workspace plans of the handle -- how many exist, how many were ever allocated, their capacity in rows
- * (B * T) together.  Plans are kept by capacity class (mp_api.hip get_plan): a caller that walks through sequence lengths must
+ * (B * T) together.  Plans are kept by capacity class (mp_plans.hip get_plan): a caller that walks through sequence lengths must
  * not allocate per length. */
 int mp_debug_plan_stats(mp_handle* h, int* n_plans, int* n_allocs, long long* cap_rows);
 

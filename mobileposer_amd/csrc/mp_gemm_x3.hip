@@ -178,7 +178,7 @@ MP_KERNEL __launch_bounds__(256) void mp_gemm_x3(GemmArgs g, int nTilesM, int nT
 
 MP_KERNEL void mp_pairs(const float* __restrict__ src, unsigned* __restrict__ dst, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = wpair_of(src[i]);                      // weights only (mp_api.hip pack_weights)
+    if (i < n) dst[i] = wpair_of(src[i]);                      // weights only (mp_handle.hip pack_weights)
 }
 
 template <int BN, int BM>

@@ -88,7 +88,7 @@ constexpr unsigned XCC_TAG = 0x7fffffffu;
 // representation error becomes ABSOLUTE, 2^-25 = 3e-8 -- that of an fp32 value near 0.5.  Hidden states and layer inputs
 // live with that (it is what fp32 gives the large terms of a dot product); WEIGHTS (|w| ~ 0.05 .. 0.5) do not -- they are
 // multiplied by kPairWScale = 16 before they are split (exact) and the accumulated sum is multiplied by 1/16 (exact) where the
-// bias is added.  CPU emulation (tools/experiments/x3h_emulation.py): at or below plain fp32's distance from float64 on both
+// bias is added.  CPU emulation (round 4, tools/experiments/x3h_emulation.py in the history): at or below plain fp32's distance from float64 on both
 // weight profiles; without the weight scale 4 x above it.  Range: |value| <= 65504 (weights: 4094); beyond that an operand
 // becomes inf and the output NaN -- loud, and far outside anything an LSTM pose network produces.
 constexpr float kPairWScale = 16.0f;

@@ -32,7 +32,7 @@ _LIVE = weakref.WeakSet()       # nets that own a native handle
 
 
 def _env_graph_mode():
-    """MP_GRAPH as csrc/mp_api.hip reads it: unset, empty or starting with '0' = eager; starting with '2' = single-branch
+    """MP_GRAPH as csrc/mp_handle.hip reads it: unset, empty or starting with '0' = eager; starting with '2' = single-branch
     graphs; anything else = multi-branch graphs."""
     e = os.environ.get("MP_GRAPH", "")
     if not e or e[0] == "0":
@@ -201,7 +201,7 @@ class MobilePoserNet:
                 raise RuntimeError("libmobileposer_hip: %s (status %d)" % (msg, rc))
 
     def _check(self, rc):
-        """Raise on a failed library call.  A reported device error resets device-side state (mp_api.hip
+        """Raise on a failed library call.  A reported device error resets device-side state (mp_recovery.hip
         invalidate_carried_state: streams reset, velocity state dropped), so the read-back cache of the state attributes
         must not survive it."""
         if rc != _lib.MP_OK:
@@ -497,7 +497,7 @@ class MobilePoserNet:
         joints = torch.empty(N, 45, 72, device=dev, dtype=f32)
         root = torch.empty(N, 3, device=dev, dtype=f32)
         contact = torch.empty(N, 2, device=dev, dtype=f32)
-        # ONE call for the whole sequence (round 6): the library keeps its workspaces by capacity class (csrc/mp_api.hip get_plan),
+        # ONE call for the whole sequence (round 6): the library keeps its workspaces by capacity class (csrc/mp_plans.hip get_plan),
         # so a sequence of a length never seen before runs on the plan the longest one so far left behind (round 5 cut the
         # sequence into power-of-two chunks here because every (batch, length) shape had workspaces of its own)
         self._check(self._lib.mp_stream_replay(self._h, _ptr(x), N, _ptr(pose), _ptr(joints), _ptr(root), _ptr(contact), self._stream()))

@@ -211,7 +211,7 @@ def _plan_stats(net):
 
 
 def test_many_shapes_reuse_plans(torch_mod, weights, smpl):
-    """Workspaces by capacity class (csrc/mp_api.hip get_plan): 200 sequence lengths between 45 and 3000 at B = 1 -- the way
+    """Workspaces by capacity class (csrc/mp_plans.hip get_plan): 200 sequence lengths between 45 and 3000 at B = 1 -- the way
     evaluate.py walks through a dataset -- allocate at most 4 plans; a length never seen before costs what a seen one costs; and
     results on a shared plan are the bits a fresh handle computes (workspaces carry nothing from shape to shape)."""
     import time

@@ -8,14 +8,14 @@ float64 result under different arithmetic of the LSTM step?
   dot64-c64     ... and the cell state carried in float64 inside a call
 
 Prints max / mean |x - float64| per output for each (T, input seed).  Nothing here runs on the GPU; it decided the design of
-mp_lstm_v1's float64 accumulation.   python tools/experiments/b1_precision_emulation.py [T ...]
+mp_lstm_v1's float64 accumulation.   python tools/b1_precision_emulation.py [T ...]
 """
 import os
 import sys
 
 import numpy as np
 
-REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from mobileposer_amd import synthetic                      # noqa: E402
 from oracle import mp_oracle as O                          # noqa: E402
