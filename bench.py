@@ -121,18 +121,19 @@ def arm_watchdog(seconds, rank, n_gpus):
     once = threading.Lock()
 
     def bail(why):
-        if not once.acquire(blocking=False):                  # (the timer and the signal watcher can both get here)
-            os._exit(3)
+        if not once.acquire(blocking=False):                  # (the timer and the signal watcher can both get here: the second
+            time.sleep(60)                                    #  one must not end the process while the first is still writing
+            os._exit(3)                                       #  the line -- it did, in one of two runs of the CPU test)
+        if rank == 0:                                         # the line first, diagnostics after it
+            sys.stdout.write(json.dumps({"metric": metric_label("weak"), "value": None, "unit": "frames/s", "n_gpus": n_gpus,
+                                         "error": why, "higher_is_better": True}) + "\n")
+            sys.stdout.flush()
         try:
             sys.stderr.write("bench.py rank %d: %s\n" % (rank, why))
             faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
             sys.stderr.flush()
         except Exception:                                     # noqa: BLE001
             pass
-        if rank == 0:
-            sys.stdout.write(json.dumps({"metric": metric_label("weak"), "value": None, "unit": "frames/s", "n_gpus": n_gpus,
-                                         "error": why, "higher_is_better": True}) + "\n")
-            sys.stdout.flush()
         os._exit(3)
 
     t = threading.Timer(seconds, bail, args=("bench.py: no result after %d s (--timeout): a rank hung or died" % seconds,))
@@ -560,6 +561,10 @@ def main():
     ap.add_argument("--no-affinity", action="store_true", help="do not pin the rank's host threads to its GPU's NUMA node")
     ap.add_argument("--cadence-hz", type=float, default=0.0, help="--workload stream: feed ticks at this rate (30 / 60) instead of "
                     "back to back and report the latency distribution of a tick (submit -> results on the host)")
+    ap.add_argument("--legs", choices=["all", "headline"], default="all",
+                    help="all (default): after the headline, the legs of the other BASELINE configs -- one 3000-frame sequence, the "
+                         "joints module alone, 512-stream ticks; headline: without them (tools/profile.py: those legs launch the same "
+                         "kernels at other shapes, which would mix into rocprofv3's per-kernel averages and per-launch counters)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo run of the launcher, rendezvous, broadcast, shard and "
                     "timing path with a stand-in step (no GPU, no kernels); the JSON line says dry_run: true")
     args = ap.parse_args()
@@ -780,7 +785,7 @@ def main():
         dominant = max((c for c in KERNEL_CLASSES if acc[c][0]), key=lambda c: acc[c][1])
     # ---- BASELINE configs[0] beside the headline: the reference's own call shape, ONE sequence (evaluate.py:57-60), rank 0 only, after everything that feeds the headline line (a latency-bound leg leaves the clocks elsewhere) ----
     single = None
-    if rank == 0 and args.lstm_mode == "fp32":
+    if rank == 0 and args.lstm_mode == "fp32" and args.legs == "all":
         T1 = 3000
         imu1 = torch.from_numpy(synthetic.make_imu(1, T1, seed=7)).to(dev)
         o1 = [torch.empty(T1, 24, 3, 3, device=dev, dtype=f32), torch.empty(1, T1, 72, device=dev, dtype=f32),
@@ -813,7 +818,7 @@ def main():
 
     # ---- BASELINE configs[1] beside the headline: the joints module ALONE through its own entry (mp_rnn_forward), 256 x 125 ----
     joints_only = None
-    if rank == 0 and args.lstm_mode == "fp32":
+    if rank == 0 and args.lstm_mode == "fp32" and args.legs == "all":
         xj = torch.from_numpy(synthetic.make_imu(B_PER_GPU, T, seed=1)).to(dev)
         yj = torch.empty(B_PER_GPU, T, 72, device=dev, dtype=f32)
         lensj = (C.c_int32 * B_PER_GPU)(*([T] * B_PER_GPU))
@@ -842,7 +847,7 @@ def main():
 
     # ---- BASELINE configs[4] beside the headline: 512 concurrent streams per GPU, one tick = one new frame per stream ----
     stream_leg = None
-    if rank == 0 and args.lstm_mode == "fp32":
+    if rank == 0 and args.lstm_mode == "fp32" and args.legs == "all":
         S4 = args.streams
         lib.mp_reset_state(h, 1)                       # (one velocity state per model: the streams take it over)
         frames4 = torch.from_numpy(synthetic.make_imu(S4, 300, seed=7)).to(dev)
@@ -908,11 +913,11 @@ def main():
     # (2*FETCH_SIZE + WRITE_SIZE)*1024, corrected as MI355X_MICROARCH.md prescribes.  A PMC pass cannot run inside this timed
     # process, so the figure is quoted from the committed profile -- and ONLY while the library that just ran is the binary
     # that was profiled (the summary records its md5): a changed kernel must not inherit a stale counter.  null otherwise.
-    traffic, traffic_src = None, "no PMC summary of this library (profiles/r05_pmc_summary.json absent, or profiled from other sources / another binary)"
+    traffic, traffic_src = None, "no PMC summary of this library (profiles/r06_pmc_summary.json absent, or profiled from other sources / another binary)"
     import hashlib
     lib_md5 = hashlib.md5(open(__graft_entry__.LIB, "rb").read()).hexdigest()
     src_md5 = __graft_entry__.source_md5()       # (a rebuild of the same sources gives the same device code, another .so md5)
-    for prof in ("r05_pmc_summary.json", "r04_pmc_summary.json"):
+    for prof in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json"):
         try:
             summ = json.load(open(os.path.join(REPO, "profiles", prof)))
             if summ.get("lib_md5") != lib_md5 and summ.get("src_md5") != src_md5:

@@ -243,6 +243,7 @@ struct SegScope {
     ~SegScope() { if (on) (void)hipEventRecord(h->segs[idx].b, s); }
 };
 
+constexpr int kSeqClusterMax = 4;     // batches of up to this many sequences run on the one-sequence kernels (mp_schedule.hip seq_clusters)
 constexpr int kExclusiveLdsBytes = 84 * 1024;   // LstmPersistArgs::min_lds: more than half of a CU's 160 KB
 
 // The per-call schedule fields forward_body hands to rnn_rec through the handle (excl_lds, pose_slices8, xcd_plan_on[],

@@ -89,7 +89,9 @@ int get_plan(mp_handle* h, int B, int T, Plan** out, const Plan* keep) {
                 if (int rc = dev_alloc(h, (void**)&w.hbuf[l][d], (size_t)2 * CB * m.H * sizeof(float), &p->allocs)) return rc;
                 if (int rc = dev_alloc(h, (void**)&w.cbuf[l][d], CB * m.H * sizeof(float), &p->allocs)) return rc;
             }
-        w.hx_bytes = (size_t)2 * ((CB + 15) / 16) * ((size_t)4 * 16 * m.H + 16) * sizeof(unsigned long long);
+        // exchange areas: one per (direction, slab) -- or per (direction, sequence) where a few sequences run on the one-sequence kernels
+        const size_t units = CB <= (size_t)kSeqClusterMax ? CB : (CB + 15) / 16;
+        w.hx_bytes = (size_t)2 * units * ((size_t)4 * 16 * m.H + 16) * sizeof(unsigned long long);
         if (int rc = dev_alloc(h, (void**)&w.hx, w.hx_bytes, &p->allocs)) return rc;
         if (m.H == 256)
             if (int rc = dev_alloc(h, (void**)&w.hx2, w.hx_bytes, &p->allocs)) return rc;

@@ -49,6 +49,18 @@ int fp32_slices(const mp_handle* h, const ModuleW& m, int B) {
     return m.nslice;
 }
 
+// The one-sequence kernels (mp_lstm_v1 / mp_lstm_v1s) take a cluster per (direction, SEQUENCE) -- not per 16-sequence slab -- so
+// a handful of sequences are a handful of clusters: up to kSeqClusterMax sequences (2 directions x 4 sequences = 8 clusters, one
+// XCD each) run on them (round 6; round 5 routed B = 1 only).  A block gets them where its batch runs on the 32-slice family
+// (fp32_slices == 32: 256 CUs, and round-robin dispatch wherever blocks run side by side).
+bool seq_clusters(const mp_handle* h, const ModuleW& m, int B) {
+    if (!h->persist || !h->vec_ok || use_x3(h, m) || B > kSeqClusterMax || m.whhR[0][0] == nullptr) return false;
+    if (m.H == 256) return fp32_slices(h, m, B) == 32;
+    return m.H == 64 && fp32_slices(h, h->mod[MP_MOD_VELOCITY], B) == 32;
+}
+// units of a layer launch of module m: sequences on the one-sequence kernels, 16-sequence slabs everywhere else
+int launch_units(const mp_handle* h, const ModuleW& m, int B) { return seq_clusters(h, m, B) ? B : (B + 15) / 16; }
+
 int layer_workgroups(const mp_handle* h, const ModuleW& m, int B) {
     const int nslab = (B + 15) / 16;
     return m.dirs * nslab * (use_x3(h, m) ? m.nsliceX : fp32_slices(h, m, B));
@@ -180,7 +192,7 @@ bool wavefront_applies(const mp_handle* h, const ModuleW& m, int B, int T) {
 // block of a one-stream tick.  Both clusters (32 workgroups each) on ONE XCD, two workgroups per CU -- the schedules count the
 // block as one cluster, as without the wavefront.
 bool wavefront1_applies(const mp_handle* h, const ModuleW& m, int B) {
-    return h->persist && h->wf_ok && h->vec_ok && !use_x3(h, m) && m.H == 256 && m.dirs == 1 && m.whhR[0][0] != nullptr && B == 1 &&
+    return h->persist && h->wf_ok && h->vec_ok && !use_x3(h, m) && m.H == 256 && m.dirs == 1 && m.whhR[0][0] != nullptr && B <= kSeqClusterMax &&
            fp32_slices(h, m, B) == 32;
 }
 
@@ -194,7 +206,7 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
     const bool wf = wf32 || (wavefront_applies(h, m, B, T) && !h->xcd_plan_on[j.id]);
     if (wf && l == 1) return MP_OK;                          // both layers went out with the layer-0 call (below)
     if (h->persist) {
-        const int nslab = (B + 15) / 16;
+        const int nslab = launch_units(h, m, B);               // (sequences on the one-sequence kernels, else 16-sequence slabs)
         // every polled word is re-zeroed before every launch: all granules (fp32 kernels) or the flags (split-bf16 kernels)
         // (split-bf16 kernels: the flags of layer 0's area were zeroed by the linear1 GEMM, those of layer 1's area by the layer-0 launch)
         // exact-fp32 kernels: mp_lstm_fused tags its granules with a per-launch epoch base, so the area is zeroed only when
@@ -231,11 +243,10 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
         }
         unsigned long long* hx_l = (use_x3(h, m) && l == 1) ? w.hx2 : w.hx;
         const bool u8 = !use_x3(h, m) && H == 256 && nsl == 32;
-        const bool v1 = u8 && B == 1 && h->vec_ok && m.whhR[0][0] != nullptr;   // one sequence: matrix-vector steps (mp_lstm_v1)
-        // ... and the H = 64 block of one sequence: a whole direction per workgroup (mp_lstm_v1s).  Only where the H = 256 blocks
+        const bool v1 = u8 && seq_clusters(h, m, B);           // a few sequences: matrix-vector steps, a cluster per sequence (mp_lstm_v1)
+        // ... and the H = 64 block: a whole (direction, sequence) per workgroup (mp_lstm_v1s).  Only where the H = 256 blocks
         // of this batch run on the 32-slice family too (fp32_slices: 256 CUs, round-robin dispatch where blocks run side by side)
-        const bool v1s = !use_x3(h, m) && H == 64 && B == 1 && h->vec_ok && m.whhR[0][0] != nullptr &&
-                         fp32_slices(h, h->mod[MP_MOD_VELOCITY], B) == 32;
+        const bool v1s = H == 64 && seq_clusters(h, m, B);
         const int cus = h->n_cu < 256 ? h->n_cu : 256;
         // slabs per launch: grid <= #CUs, one workgroup per CU
         const int chunk = cus / ((wf ? 2 : dirs) * nsl) > 0 ? cus / ((wf ? 2 : dirs) * nsl) : 1;
@@ -313,9 +324,10 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
                 d1.cbuf = inplace ? j.out_c + (size_t)1 * B * H : w.cbuf[1][0];
                 d1.xproj = nullptr; d1.xprojStride = 0; d1.outStride = H; d1.reverse = 0;
                 unsigned char cnt[8];
-                // (one sequence: both clusters where forward_body's table has the block's one cluster, else on XCD 0)
+                // (a few sequences: both clusters of a sequence where forward_body's table has the sequence's one cluster, else
+                //  sequence k on XCD k)
                 for (int x = 0; x < 8; ++x)
-                    cnt[x] = (unsigned char)(2 * (wf32 ? (a.xcd_physical ? h->xcd_plan[j.id][x] : (x == 0 ? 1 : 0)) : (a.nslab + 7 - x) / 8));
+                    cnt[x] = (unsigned char)(2 * (wf32 && a.xcd_physical ? h->xcd_plan[j.id][x] : (a.nslab + 7 - x) / 8));
                 mp_fill_xcd_table(a, cnt);
                 if (wf32) a.min_lds = 0;                      // (two workgroups per CU are the point)
             }
@@ -483,9 +495,8 @@ int side_by_side_plan(mp_handle* h, int B) {
     const ModuleW& pm = h->mod[MP_MOD_POSE];
     const ModuleW& vm = h->mod[MP_MOD_VELOCITY];
     const ModuleW& fm = h->mod[MP_MOD_FOOT_CONTACT];
-    const int nslab = (B + 15) / 16;
     const bool any_x3 = use_x3(h, pm) || use_x3(h, vm);
-    auto job = [&](int id, const ModuleW& m, int slices) { return XcdJob{id, m.dirs * nslab, slices}; };
+    auto job = [&](int id, const ModuleW& m, int slices) { return XcdJob{id, m.dirs * launch_units(h, m, B), slices}; };
     const int pslices = use_x3(h, pm) ? pm.nsliceX : fp32_slices(h, pm, B);
     const int vslices = use_x3(h, vm) ? vm.nsliceX : fp32_slices(h, vm, B);
     XcdJob all[3] = {job(MP_MOD_POSE, pm, pslices), job(MP_MOD_VELOCITY, vm, vslices), job(MP_MOD_FOOT_CONTACT, fm, fm.nslice)};
@@ -740,9 +751,10 @@ int forward_body(mp_handle* h, Plan* p, const float* imu, float* pose, long pose
         // (without placement tables velocity and foot contact share CUs -- 80 + 48 KB of LDS, registers to match: a
         //  velocity and a foot-contact workgroup fit on one CU together, so both grids are always fully resident)
         if (h->exclusive_ok && h->xcd_rr && !use_x3(h, h->mod[MP_MOD_VELOCITY])) {
-            const int nslab = (p->B + 15) / 16;
-            const XcdJob vf[2] = {{MP_MOD_VELOCITY, h->mod[MP_MOD_VELOCITY].dirs * nslab, fp32_slices(h, h->mod[MP_MOD_VELOCITY], p->B)},
-                                  {MP_MOD_FOOT_CONTACT, h->mod[MP_MOD_FOOT_CONTACT].dirs * nslab, h->mod[MP_MOD_FOOT_CONTACT].nslice}};
+            const ModuleW& vm_ = h->mod[MP_MOD_VELOCITY];
+            const ModuleW& fm_ = h->mod[MP_MOD_FOOT_CONTACT];
+            const XcdJob vf[2] = {{MP_MOD_VELOCITY, vm_.dirs * launch_units(h, vm_, p->B), fp32_slices(h, vm_, p->B)},
+                                  {MP_MOD_FOOT_CONTACT, fm_.dirs * launch_units(h, fm_, p->B), fm_.nslice}};
             int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if (place_clusters(h, vf, 2, load, h->xcd_plan)) { excl_vf = kExclusiveLdsBytes; vf_tables = true; }
         }

@@ -307,3 +307,67 @@ def test_mode3_smoke(torch_mod, weights, smpl):
             assert np.abs(npy(contact) - g5["contact"][k]).max() < 1e-4
             assert np.abs(npy(tran) - g5["tran"][k]).max() < 1e-3, k
         assert net.device_error() == 0 and net.recovery_count == 0
+
+
+@pytest.mark.parametrize("B", [2, 3, 4])
+def test_few_sequences_run_as_sequence_clusters(torch_mod, weights, smpl, B, monkeypatch):
+    """Batches of 2 ... 4 sequences on the one-sequence kernels (mp_lstm_v1 / mp_lstm_v1s: a cluster per (direction, SEQUENCE),
+    mp_schedule.hip seq_clusters; B = 2 runs pose | velocity | foot contact side by side, B = 3, 4 the serial schedule): ragged
+    lengths against the oracle, twice (carried velocity state); every sequence BITWISE what it gives alone at B = 1 (same
+    kernels, same order of summation: a batch is its sequences); against the 32-slice MFMA kernels (MP_VARIANT=vec=0) to fp32
+    rounding; 30 ticks of B streams bitwise what B one-stream handles give."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    from oracle import mp_oracle as O
+    T = 90
+    imu = synthetic.make_imu(B, T, seed=96)
+    lengths = [T, 1, 37, 64][:B]
+    ref = O.OracleNet(weights, smpl["J"])
+    want = []
+    for call in range(2):                                # (the velocity state carries from call to call, velocity.py:45-48)
+        rpose, rjoints, rvel, rcontact = ref.forward(imu, lengths)
+        rvel = np.asarray(rvel).reshape(B, T, 72)
+        rtran = [O.translate_offline(rjoints[b, :n].reshape(n, 24, 3), rvel[b, :n], rcontact[b, :n], ref.floor_y) for b, n in enumerate(lengths)]
+        want.append((rjoints, rcontact, rtran))
+    outs = {}
+    for variant in ("", "vec=0"):
+        if variant:
+            monkeypatch.setenv("MP_VARIANT", variant)
+        with MobilePoserNet.from_numpy(weights, smpl) as net:
+            got = [[npy(t) for t in net.forward_offline(cu(torch_mod, imu), lengths)] for _ in range(2)]
+            outs[variant] = got
+            for call in range(2):
+                rjoints, rcontact, rtran = want[call]
+                pose, joints, tran, contact = got[call]
+                for b, n in enumerate(lengths):
+                    assert np.abs(joints[b, :n] - rjoints[b, :n]).max() < 1e-4, (variant, call, b)
+                    assert np.abs(contact[b, :n] - rcontact[b, :n]).max() < 1e-4, (variant, call, b)
+                    assert np.abs(tran[b, :n] - rtran[b]).max() < 1e-3, (variant, call, b)
+            assert net.device_error() == 0 and net.recovery_count == 0
+            if not variant:
+                # each sequence alone (B = 1, the same two calls): the same bits
+                for b, n in enumerate(lengths):
+                    with MobilePoserNet.from_numpy(weights, smpl) as one:
+                        for call in range(2):
+                            p1, j1, t1, c1 = [npy(t) for t in one.forward_offline(cu(torch_mod, imu[b:b + 1, :n]), [n])]
+                            assert np.array_equal(j1[0, :n], got[call][1][b, :n]), (b, call)
+                            assert np.array_equal(c1.reshape(-1, 2)[:n], got[call][3][b, :n]), (b, call)
+                            assert np.array_equal(t1.reshape(-1, 3)[:n], got[call][2][b, :n]), (b, call)
+                # streams: B streams on one handle against B one-stream handles
+                frames = synthetic.make_imu(B, 30, seed=97)
+                net.reset_all()
+                net.stream_create(B)
+                ticks = []
+                for k in range(30):
+                    ticks.append([npy(t) for t in net.stream_step(cu(torch_mod, frames[:, k]))])
+                for b in range(B):
+                    with MobilePoserNet.from_numpy(weights, smpl) as one:
+                        one.stream_create(1)
+                        for k in range(30):
+                            o1 = [npy(t) for t in one.stream_step(cu(torch_mod, frames[b:b + 1, k]))]
+                            for a, bb in zip(o1, ticks[k]):
+                                assert np.array_equal(a[0], bb[b]), (b, k)
+                assert net.device_error() == 0 and net.recovery_count == 0
+    for call in range(2):
+        for a, b in zip(outs[""][call], outs["vec=0"][call]):
+            assert np.abs(a - b).max() < 2e-5

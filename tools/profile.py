@@ -39,7 +39,13 @@ def run(cmd):
 def main():
     tag = sys.argv[1]
     extra = sys.argv[2:]
-    bench = [sys.executable, os.path.join(REPO, "bench.py"), "--no-cpu-baseline"] + extra
+    # --legs headline: the legs of the other BASELINE configs (ticks of 512 streams at T = 45, one 3000-frame sequence, the joints
+    # module alone) launch the SAME kernels at other shapes; in the default command they mix into the per-kernel averages and
+    # the per-launch counters below (round 6's first profile: mp_lstm_fused<256,8,512> "380 us" over 1 169 launches against
+    # 793 us by HIP events).  The profiled command is bench.py's default one without those legs; `<tag>_kernel_stats_all_legs.md`
+    # keeps the summary of the default command beside it.
+    bench = [sys.executable, os.path.join(REPO, "bench.py"), "--no-cpu-baseline", "--legs", "headline"] + extra
+    bench_all = [sys.executable, os.path.join(REPO, "bench.py"), "--no-cpu-baseline"] + extra
     os.makedirs(OUT, exist_ok=True)
     # ---- 1. kernel trace + stats
     d = os.path.join(OUT, "prof_" + tag)
@@ -54,10 +60,12 @@ def main():
     with open(os.path.join(OUT, tag + "_kernel_stats.md"), "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats (%s)\n\n" % tag)
         f.write("Command (MI355X, via gpurun): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
-                "--no-cpu-baseline %s --steps 20 --warmup 5`\n" % " ".join(extra))
+                "--no-cpu-baseline --legs headline %s --steps 20 --warmup 5`\n" % " ".join(extra))
         f.write("(bench.py in one process: 25 forwards of the headline mode (exact-fp32 operands, eager launches on the library's "
-                "streams), 23 of the opt-in split-fp16 mode, the configs[3] leg (B = 1024), 5 event-timed forwards of the "
-                "headline mode; B=256 x T=125; raw CSV next to this file)\n\n")
+                "streams), 23 of the opt-in split-fp16 mode, the configs[3] leg (B = 1024: chunks of 256 sequences, the same launches), "
+                "5 event-timed forwards of the headline mode; B=256 x T=125; `--legs headline` leaves out the legs of the other "
+                "BASELINE configs, which launch the same kernels at other shapes -- the default command's summary is "
+                "%s_kernel_stats_all_legs.md; raw CSV next to this file)\n\n" % tag)
         if bench_line:
             f.write("bench line of this (profiled) run: %.4f ms/step = %.0f frames/s headline (%s); modes: %s\n\n"
                     % (bench_line["ms_per_step"], bench_line["value"], bench_line["config"].get("lstm_mode"),
@@ -77,6 +85,24 @@ def main():
             f.write("| %s | %s | %.3f | %s | %.1f | %.1f | %.1f |\n" % (
                 short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, r["Percentage"],
                 float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
+    # ---- 1b. the default command (all legs), stats only
+    d_all = os.path.join(OUT, "prof_" + tag + "_all")
+    rc, log = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d_all, "-o", "bench", "--"]
+                  + bench_all + ["--steps", "20", "--warmup", "5"])
+    stats_all = glob.glob(os.path.join(d_all, "**", "bench_kernel_stats.csv"), recursive=True)
+    if stats_all:
+        rows_all = list(csv.DictReader(open(stats_all[0])))
+        with open(os.path.join(OUT, tag + "_kernel_stats_all_legs.md"), "w") as f:
+            f.write("# rocprofv3 --kernel-trace --stats of bench.py's DEFAULT command (%s): every leg\n\n" % tag)
+            f.write("`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline %s --steps 20 --warmup 5`.  "
+                    "The layer kernels appear with launches of three shapes here (256 x 125 forwards, 512 x 45 ticks, 1 x 3000): "
+                    "their averages describe no single launch -- the per-launch figures of the roofline are in %s_kernel_stats.md.\n\n"
+                    % (" ".join(extra), tag))
+            f.write("| kernel | calls | total ms | % | avg us | min us | max us |\n|---|---|---|---|---|---|---|\n")
+            for r in rows_all[:30]:
+                f.write("| %s | %s | %.3f | %s | %.1f | %.1f | %.1f |\n" % (
+                    short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, r["Percentage"],
+                    float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
     # ---- 2. PMC passes
     acc = {}
     for gi, group in enumerate(PMC_GROUPS):
