@@ -10,7 +10,7 @@ from mobileposer_amd.net import MobilePoserNet
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 net = MobilePoserNet.from_numpy(synthetic.make_weights(0), synthetic.synthetic_smpl())
 rng = np.random.default_rng(7)
-shapes = [(1, 300), (1, 45), (5, 1), (16, 125), (33, 60), (64, 125), (72, 90), (96, 125), (100, 31), (128, 125), (129, 40), (200, 77), (256, 125), (300, 50), (512, 25), (700, 20)]
+shapes = [(1, 300), (1, 45), (2, 200), (3, 90), (4, 125), (5, 1), (16, 125), (33, 60), (64, 125), (72, 90), (96, 125), (100, 31), (128, 125), (129, 40), (200, 77), (256, 125), (300, 50), (512, 25), (700, 20)]
 cases = []
 for B, T in shapes:
     L = [int(v) for v in rng.integers(1, T + 1, size=B)]
