@@ -87,7 +87,7 @@ def test_one_glitching_sensor_among_512_streams(torch_mod, weights, smpl):
     bad[bad_s, bad_k, 13] = np.nan
 
     def run(fr):
-        outs, dt = [], 0.0
+        outs, dts = [], []
         with MobilePoserNet.from_numpy(weights, smpl) as net:
             net.set_lstm_mode(1)
             net.stream_create(S)
@@ -100,11 +100,14 @@ def test_one_glitching_sensor_among_512_streams(torch_mod, weights, smpl):
                     o = net.stream_step(xk)
                     torch_mod.cuda.synchronize()
                     if k >= 10:
-                        dt += time.perf_counter() - t0
+                        dts.append(time.perf_counter() - t0)
                     outs.append([npy(t) for t in o])
             assert net.recovery_count == 0 and not w, [str(i.message) for i in w]
             assert net.device_error() == 0
-        return outs, dt / (n - 10)
+        # (the MEDIAN tick: every tick here follows a pause -- the copies of its results to the host -- and so runs on the restarting
+        #  loaded clock of profiles/r06_idle_probe_S512.txt, 3.0-3.2 ms instead of 2.75; the mean of 50 such ticks of two runs
+        #  differed by more than 15 % in one of three suite runs of round 6's validation)
+        return outs, float(np.median(dts))
 
     clean, t_clean = run(frames)
     got, t_bad = run(bad)
@@ -122,7 +125,7 @@ def test_one_glitching_sensor_among_512_streams(torch_mod, weights, smpl):
                 ok = ~np.isnan(r)
                 assert np.abs(g[ok] - r[ok]).max(initial=0.0) < (TOL_TRAN if name == "root" else TOL), (k, name)
     print("tick: clean %.3f ms, with one NaN stream %.3f ms" % (1e3 * t_clean, 1e3 * t_bad))
-    assert t_bad < 1.15 * t_clean + 2e-5        # (a slow path for the NaN stream would be 2 x and more; 15 %: box noise between two runs)
+    assert t_bad < 1.2 * t_clean + 2e-5         # (a slow path for the NaN stream would be 2 x and more; 20 %: box noise between two runs)
 
 
 def test_nan_sample_then_three_forwards_at_baseline_size(torch_mod, net, weights, smpl):

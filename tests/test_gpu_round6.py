@@ -309,19 +309,21 @@ def test_mode3_smoke(torch_mod, weights, smpl):
         assert net.device_error() == 0 and net.recovery_count == 0
 
 
-@pytest.mark.parametrize("B", [2, 3, 4])
+@pytest.mark.parametrize("B", [2, 3, 4, 5])
 def test_few_sequences_run_as_sequence_clusters(torch_mod, weights, smpl, B, monkeypatch):
     """Batches of 2 ... 4 sequences on the one-sequence kernels (mp_lstm_v1 / mp_lstm_v1s: a cluster per (direction, SEQUENCE),
-    mp_schedule.hip seq_clusters; B = 2 runs pose | velocity | foot contact side by side, B = 3, 4 the serial schedule): ragged
-    lengths against the oracle, twice (carried velocity state); every sequence BITWISE what it gives alone at B = 1 (same
-    kernels, same order of summation: a batch is its sequences); against the 32-slice MFMA kernels (MP_VARIANT=vec=0) to fp32
-    rounding; 30 ticks of B streams bitwise what B one-stream handles give."""
+    mp_schedule.hip seq_clusters; B = 2 runs pose | velocity | foot contact side by side, B = 3, 4 the serial schedule; B = 5 is the
+    first batch on the 32-slice MFMA kernels and runs the same checks): ragged lengths against the oracle, twice (carried velocity
+    state); sequences BITWISE what they give alone at B = 1 (B <= 4: same kernels, same order of summation -- a batch is its
+    sequences); against the 32-slice MFMA kernels (MP_VARIANT=vec=0) to fp32 rounding; 30 ticks of B streams bitwise what
+    one-stream handles give (B <= 4)."""
     from mobileposer_amd import synthetic
     from mobileposer_amd.net import MobilePoserNet
     from oracle import mp_oracle as O
     T = 90
     imu = synthetic.make_imu(B, T, seed=96)
-    lengths = [T, 1, 37, 64][:B]
+    lengths = ([T, 1, 37, 64, 90, 2, 45, 89, 17, 90, 33, 5, 71, 60, 9, 88])[:B]
+    sample = list(range(B)) if B <= 4 else [0, 1, B // 2, B - 1]         # sequences checked alone / as one-stream handles
     ref = O.OracleNet(weights, smpl["J"])
     want = []
     for call in range(2):                                # (the velocity state carries from call to call, velocity.py:45-48)
@@ -344,9 +346,10 @@ def test_few_sequences_run_as_sequence_clusters(torch_mod, weights, smpl, B, mon
                     assert np.abs(contact[b, :n] - rcontact[b, :n]).max() < 1e-4, (variant, call, b)
                     assert np.abs(tran[b, :n] - rtran[b]).max() < 1e-3, (variant, call, b)
             assert net.device_error() == 0 and net.recovery_count == 0
-            if not variant:
+            if not variant and B <= 4:
                 # each sequence alone (B = 1, the same two calls): the same bits
-                for b, n in enumerate(lengths):
+                for b in sample:
+                    n = lengths[b]
                     with MobilePoserNet.from_numpy(weights, smpl) as one:
                         for call in range(2):
                             p1, j1, t1, c1 = [npy(t) for t in one.forward_offline(cu(torch_mod, imu[b:b + 1, :n]), [n])]
@@ -360,7 +363,7 @@ def test_few_sequences_run_as_sequence_clusters(torch_mod, weights, smpl, B, mon
                 ticks = []
                 for k in range(30):
                     ticks.append([npy(t) for t in net.stream_step(cu(torch_mod, frames[:, k]))])
-                for b in range(B):
+                for b in sample:
                     with MobilePoserNet.from_numpy(weights, smpl) as one:
                         one.stream_create(1)
                         for k in range(30):

@@ -8,9 +8,9 @@ python -c "
 import sys; sys.path.insert(0, '.')
 from mobileposer_amd import _lib; print('build id', _lib.file_build_id())" >> $O
 echo "== suite x 2 (eager)" >> $O
-for i in 1 2; do timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu | tail -2 >> $O; done
+for i in 1 2; do timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu | grep -E "^E  |^FAILED|passed|failed" | head -40 >> $O; done
 echo "== suite under MP_GRAPH=2" >> $O
-MP_GRAPH=2 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu | tail -2 >> $O
+MP_GRAPH=2 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu | grep -E "^E  |^FAILED|passed|failed" | head -40 >> $O
 echo "== fuzz_shapes 300 (default vs plainest configuration)" >> $O
 timeout 1500 python tools/debug/fuzz_shapes.py 300 2>&1 | grep -v amdgpu | tail -3 >> $O
 echo "== fuzz_shapes 400 small (B <= 4)" >> $O
