@@ -307,9 +307,9 @@ class MobilePoserNet:
         return (p.clamp(lo, hi) - lo) / (hi - lo)
 
     def _lengths(self, input_lengths, B, T):
-        if input_lengths is None:
-            raise ValueError("input_lengths is required: with None the reference feeds nn.LSTM time-major data "
-                             "(rnn.py:15,25; SURVEY Q3), which no reference caller relies on")
+        if input_lengths is None:      # (forward / forward_offline handle None themselves -- the time-major quirk)
+            raise ValueError("input_lengths is required here: with None the reference feeds nn.LSTM time-major data "
+                             "(rnn.py:15,25; SURVEY Q3); only forward / forward_offline reproduce that")
         lens = [int(x) for x in input_lengths]
         if len(lens) != B:
             raise RuntimeError("len(input_lengths) = %d but batch = %d" % (len(lens), B))
@@ -364,6 +364,8 @@ class MobilePoserNet:
         if batch.dim() != 3 or batch.shape[-1] != model_config.n_imu:
             raise RuntimeError("expected batch of shape [B, T, 60], got %s" % (tuple(batch.shape),))
         B, T = int(batch.shape[0]), int(batch.shape[1])
+        if input_lengths is None:
+            return self._forward_time_major(batch, B, T, return_r6d)
         lens = self._lengths(input_lengths, B, T)
         x = self._input(batch, (B, T))
         o = self._outputs(B, T, ("pose", "joints", "vel", "contact") + (("r6d",) if return_r6d else ()))
@@ -371,6 +373,19 @@ class MobilePoserNet:
         o = {k: self._result(v) for k, v in o.items()}
         out = (o["pose"], o["joints"], o["vel"].squeeze(0), o["contact"])
         return out + (o["r6d"],) if return_r6d else out
+
+    def _forward_time_major(self, batch, B, T, return_r6d):
+        """forward(batch, None) as the reference computes it (no reference caller does this): nn.LSTM is built without
+        batch_first (rnn.py:15) and only the packed path is batch-first (rnn.py:25), so dim 0 of [B,T,60] is TIME and dim 1 the
+        batch -- T sequences of B steps.  The same call on the transposed input, the outputs transposed back; the carried
+        velocity state then has batch T, as the reference's."""
+        xt = batch.to(device=self.device, dtype=torch.float32).transpose(0, 1).contiguous()
+        out = self.forward(xt, [B] * T, return_r6d=True)
+        pose_t, joints_t, vel_t, contact_t, r6d_t = out
+        back = lambda t: t.reshape(T, B, -1).transpose(0, 1).contiguous()
+        pose = pose_t.reshape(T, B, 24, 3, 3).transpose(0, 1).reshape(B * T, 24, 3, 3).contiguous()
+        res = (pose, back(joints_t), back(vel_t).squeeze(0), back(contact_t))
+        return res + (back(r6d_t),) if return_r6d else res
 
     __call__ = forward
 
@@ -384,6 +399,16 @@ class MobilePoserNet:
         if imu.dim() != 3 or imu.shape[-1] != model_config.n_imu:
             raise RuntimeError("expected imu of shape [B, T, 60], got %s" % (tuple(imu.shape),))
         B, T = int(imu.shape[0]), int(imu.shape[1])
+        if input_lengths is None:
+            # net.py:121-155 on forward(imu, None): one "sequence" [1,T,60] is T one-step sequences, then the solver
+            # over the T frames as ever
+            if B != 1:
+                raise RuntimeError("forward_offline(imu, None) takes one sequence [1, T, 60] (net.py:126 squeezes the batch)")
+            pose, joints, vel, contact = self.forward(imu, None)
+            tran = torch.empty(1, T, 3, device=self.device, dtype=torch.float32)
+            self.translate_offline_into(joints.contiguous(), vel.reshape(1, T, 72).contiguous(), contact.contiguous(),
+                                        (C.c_int32 * 1)(T), tran)
+            return pose, joints, tran[0], contact[0]
         lens = self._lengths(input_lengths, B, T)
         x = self._input(imu, (B, T))
         o = self._outputs(B, T, ("pose", "joints", "vel", "contact", "tran"))

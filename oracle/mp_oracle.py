@@ -289,8 +289,17 @@ class OracleNet:
         self.last_root_pos = np.zeros(3, dtype=F32)
 
     def forward(self, batch, input_lengths):
-        """net.py:101-119."""
+        """net.py:101-119.  input_lengths=None: nn.LSTM is built without batch_first (rnn.py:15) and only the packed
+        path is batch-first (rnn.py:25), so dim 0 of [B,T,60] is TIME and dim 1 the batch -- T sequences of B steps, the carried
+        velocity state of batch T; the linear layers and net.py:110 work row by row, so the outputs keep the caller's layout."""
         batch = np.asarray(batch, dtype=F32)
+        if input_lengths is None:
+            B, T = batch.shape[0], batch.shape[1]
+            pose, joints, vel, contact = self.forward(np.ascontiguousarray(batch.transpose(1, 0, 2)), [B] * T)
+            back = lambda a: np.ascontiguousarray(np.asarray(a).reshape(T, B, -1).transpose(1, 0, 2))
+            self._last_r6d, self._last_vel = back(self._last_r6d), back(self._last_vel)
+            pose = np.ascontiguousarray(np.asarray(pose).reshape(T, B, 24, 3, 3).transpose(1, 0, 2, 3, 4)).reshape(B * T, 24, 3, 3)
+            return pose, back(joints), back(vel), back(contact)
         joints, _ = rnn_forward(self.sd, PREFIX["joints"], batch, input_lengths)                  # :103
         t_max = joints.shape[1]
         x132 = np.concatenate((joints, batch[:, :t_max]), axis=-1)                                  # :106

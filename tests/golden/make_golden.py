@@ -500,6 +500,24 @@ def main():
                 print("G17 %s: max |x - f64| r6d %s" % (tag, " ".join("%.1e" % st["r6d"][0] for st in stats)), flush=True)
     np.savez_compressed(os.path.join(HERE, "g17_single_sequence.npz"), **g17)
 
+    # ---- G18 (round 6) input_lengths=None, the time-major quirk (rnn.py:15 builds nn.LSTM without batch_first, only the
+    # packed path is batch-first): forward twice on [3,25,60] (the carried velocity state has batch 25) and forward_offline on
+    # [1,40,60] -- 40 one-step sequences, then the solver
+    g18 = {"imu": synthetic.make_imu(3, 25, seed=181), "imu1": synthetic.make_imu(1, 40, seed=182)}
+    with torch.no_grad():
+        m = new_model()
+        for call in (0, 1):
+            pose, joints, vel, contact = m.forward(torch.from_numpy(g18["imu"]), None)
+            g18[f"c{call}_pose"], g18[f"c{call}_joints"] = pose.numpy(), joints.numpy()
+            g18[f"c{call}_vel"], g18[f"c{call}_contact"] = vel.numpy(), contact.numpy()
+        h, c = m.velocity.rnn_state
+        g18["vel_h"], g18["vel_c"] = h.numpy(), c.numpy()
+        m = new_model()
+        m.reset()
+        pose, joints, tran, contact = m.forward_offline(torch.from_numpy(g18["imu1"]), None)
+        g18["off_pose"], g18["off_joints"], g18["off_tran"], g18["off_contact"] = pose.numpy(), joints.numpy(), tran.numpy(), contact.numpy()
+    np.savez_compressed(os.path.join(HERE, "g18_lengths_none.npz"), **g18)
+
     print("golden vectors written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         print("  %-24s %8d B" % (fn, os.path.getsize(os.path.join(HERE, fn))))

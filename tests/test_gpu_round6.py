@@ -374,3 +374,32 @@ def test_few_sequences_run_as_sequence_clusters(torch_mod, weights, smpl, B, mon
     for call in range(2):
         for a, b in zip(outs[""][call], outs["vec=0"][call]):
             assert np.abs(a - b).max() < 2e-5
+
+
+def test_g18_lengths_none_is_time_major(torch_mod, weights, smpl):
+    """forward(batch, None) / forward_offline(imu, None) as the reference computes them (golden G18; SURVEY Q3: without lengths the
+    reference's nn.LSTM reads dim 0 as time): T sequences of B steps, a carried velocity state of batch T, forward_offline of
+    one sequence = T one-step sequences + the solver.  Rounds 1-5 raised here."""
+    from conftest import geodesic
+    from mobileposer_amd.net import MobilePoserNet
+    g = load_golden("g18_lengths_none.npz")
+    with MobilePoserNet.from_numpy(weights, smpl) as net:
+        for call in (0, 1):
+            pose, joints, vel, contact = net.forward(cu(torch_mod, g["imu"]), None)
+            assert tuple(pose.shape) == g[f"c{call}_pose"].shape and tuple(joints.shape) == g[f"c{call}_joints"].shape
+            assert tuple(vel.shape) == g[f"c{call}_vel"].shape and tuple(contact.shape) == g[f"c{call}_contact"].shape
+            assert np.abs(npy(joints) - g[f"c{call}_joints"]).max() < 1e-4, call
+            assert np.abs(npy(vel) - g[f"c{call}_vel"]).max() < 1e-4, call
+            assert np.abs(npy(contact) - g[f"c{call}_contact"]).max() < 1e-4, call
+            assert geodesic(npy(pose), g[f"c{call}_pose"]).max() < 1e-4, call
+        h, c = net.velocity.rnn_state
+        assert tuple(h.shape) == g["vel_h"].shape
+        assert np.abs(npy(h) - g["vel_h"]).max() < 1e-4 and np.abs(npy(c) - g["vel_c"]).max() < 1e-4
+        net.reset_all()
+        net.reset()
+        pose, joints, tran, contact = net.forward_offline(cu(torch_mod, g["imu1"]), None)
+        assert tuple(tran.shape) == g["off_tran"].shape and tuple(contact.shape) == g["off_contact"].shape
+        assert geodesic(npy(pose), g["off_pose"]).max() < 1e-4
+        assert np.abs(npy(joints) - g["off_joints"]).max() < 1e-4 and np.abs(npy(contact) - g["off_contact"]).max() < 1e-4
+        assert np.abs(npy(tran) - g["off_tran"]).max() < 1e-3
+        assert net.device_error() == 0 and net.recovery_count == 0

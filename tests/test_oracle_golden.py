@@ -364,3 +364,23 @@ def test_g17_single_sequence_trained_regime_band(weights_trained, smpl):
         for s in g["seeds"].tolist():
             dd = g["T%d_s%d_dist" % (TT, s)]
             assert dd.shape == (16, 5, 2) and np.isfinite(dd).all() and (dd[:, :4, 0] < 2e-2).all() and (dd[:, 4, 0] < 5e-3).all(), (TT, s)
+
+
+def test_g18_lengths_none_is_time_major(weights, smpl):
+    """Golden G18 (round 6): input_lengths=None.  nn.LSTM is built without batch_first (rnn.py:15) and only the packed path is
+    batch-first (rnn.py:25), so the reference treats dim 0 of [B,T,60] as time (outputs differ from the batch-first
+    reading by 3.8e-2).  forward twice (the carried velocity state has batch T) and forward_offline of [1,40,60]."""
+    g = load_golden("g18_lengths_none.npz")
+    ref = O.OracleNet(weights, smpl["J"])
+    for call in (0, 1):
+        pose, joints, vel, contact = ref.forward(g["imu"], None)
+        assert pose.shape == g[f"c{call}_pose"].shape and joints.shape == g[f"c{call}_joints"].shape
+        assert np.abs(joints - g[f"c{call}_joints"]).max() < 2e-5
+        assert np.abs(np.asarray(vel).reshape(g[f"c{call}_vel"].shape) - g[f"c{call}_vel"]).max() < 2e-5
+        assert np.abs(contact - g[f"c{call}_contact"]).max() < 2e-5
+        assert geodesic(pose, g[f"c{call}_pose"]).max() < 2e-5
+    h, c = ref.velocity_rnn_state
+    assert h.shape == g["vel_h"].shape and np.abs(h - g["vel_h"]).max() < 2e-5 and np.abs(c - g["vel_c"]).max() < 2e-5
+    # ... and it is NOT what the batch-first reading gives
+    other = O.OracleNet(weights, smpl["J"]).forward(g["imu"], [25, 25, 25])
+    assert np.abs(other[1] - g["c0_joints"]).max() > 1e-3
