@@ -231,7 +231,8 @@ def test_error_behaviour(torch_mod, net):
     from mobileposer_amd import synthetic
     x = cu(torch_mod, synthetic.make_imu(2, 10, seed=2))
     with pytest.raises(ValueError):
-        net.forward(x, None)                       # Q3
+        net.rnn_forward("joints", x, None)         # Q3: a module's own entry needs lengths (forward / forward_offline
+                                                   # reproduce the reference's time-major reading since round 6: golden G18)
     with pytest.raises(RuntimeError):
         net.forward(x, [10, 11])                   # length > T
     with pytest.raises(RuntimeError):
