@@ -363,16 +363,27 @@ def bench_stream_cadence(args, net, dev, dist, rank, world, tick, S):
         torch.cuda.synchronize(dev)
         return time.perf_counter() - t0
 
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
     def spaced(n):
-        lat = []
+        """n ticks, one per period: host latency of each (submit -> synchronised) and, beside it, the time the GPU spent between
+        two events on the caller's stream around the tick (the library joins that stream on entry and exit) -- an outlier of
+        the host loop (scheduling, the wake-up from the synchronise) and one of the device look different there."""
+        lat, gpu = [], []
         nxt = time.perf_counter()
         for _ in range(n):
             nxt += period
-            lat.append(one_tick())
+            t0 = time.perf_counter()
+            ev0.record()
+            tick()
+            ev1.record()
+            torch.cuda.synchronize(dev)
+            lat.append(time.perf_counter() - t0)
+            gpu.append(ev0.elapsed_time(ev1))
             rest = nxt - time.perf_counter()
             if rest > 0:
                 time.sleep(rest)
-        return np.array(lat) * 1e3
+        return np.array(lat) * 1e3, np.array(gpu)
 
     def after_idle(idle_s):
         time.sleep(idle_s)
@@ -389,11 +400,16 @@ def bench_stream_cadence(args, net, dev, dist, rank, world, tick, S):
         for _ in range(args.warmup):
             one_tick()
         back = np.array([one_tick() for _ in range(50)]) * 1e3
-        lat = spaced(args.steps)
+        lat, gpu = spaced(args.steps)
+        worst = int(np.argmax(lat))
         modes[name] = {"back_to_back_ms": {"p50": round(float(np.median(back)), 4), "max": round(float(back.max()), 4)},
                        "at_cadence_ms": {"p50": round(float(np.median(lat)), 4), "p90": round(float(np.quantile(lat, 0.9)), 4),
                                          "p99": round(float(np.quantile(lat, 0.99)), 4), "max": round(float(lat.max()), 4),
                                          "mean": round(float(lat.mean()), 4)},
+                       "gpu_between_events_ms": {"p50": round(float(np.median(gpu)), 4), "p99": round(float(np.quantile(gpu, 0.99)), 4),
+                                                 "max": round(float(gpu.max()), 4)},
+                       "worst_tick": {"index": worst, "host_ms": round(float(lat[worst]), 4), "gpu_ms": round(float(gpu[worst]), 4)},
+                       "ticks_over_2x_p50": int((lat > 2.0 * np.median(lat)).sum()),
                        "deadline_misses": int((lat > period * 1e3).sum()),
                        "after_1s_idle": after_idle(1.0), "after_50ms_idle": after_idle(0.05)}
     net.set_graph_mode(0)
