@@ -33,6 +33,34 @@ size_t round_class(size_t n) {                    // the next of {2^k, 1.5 * 2^k
 }
 int plan_batch_class(int B) { return B <= 64 ? B : (int)round_class((size_t)B); }
 
+static int alloc_plan_workspaces(mp_handle* h, Plan* p) {
+    const size_t M = p->capRows, CB = (size_t)p->capB;
+    for (int id = 0; id < 4; ++id) {
+        const ModuleW& m = h->mod[id];
+        ModuleWS& w = p->ws[id];
+        w.xproj = nullptr;                                   // gate pre-activations: per-step mode only, allocated on demand
+        if (int rc = dev_alloc(h, (void**)&w.out0, M * m.dirs * m.H * sizeof(float), &p->allocs)) return rc;
+        if (int rc = dev_alloc(h, (void**)&w.out1, M * m.dirs * m.H * sizeof(float), &p->allocs)) return rc;
+        if (m.H == 256 && m.dirs == 1)
+            if (int rc = dev_alloc(h, (void**)&w.x1, M * m.H * sizeof(float), &p->allocs)) return rc;
+        for (int l = 0; l < 2; ++l)
+            for (int d = 0; d < m.dirs; ++d) {
+                if (int rc = dev_alloc(h, (void**)&w.hbuf[l][d], (size_t)2 * CB * m.H * sizeof(float), &p->allocs)) return rc;
+                if (int rc = dev_alloc(h, (void**)&w.cbuf[l][d], CB * m.H * sizeof(float), &p->allocs)) return rc;
+            }
+        // exchange areas: one per (direction, slab) -- or per (direction, sequence) where a few sequences run on the one-sequence kernels
+        const size_t units = CB <= (size_t)kSeqClusterMax ? CB : (CB + 15) / 16;
+        w.hx_bytes = (size_t)2 * units * ((size_t)4 * 16 * m.H + 16) * sizeof(unsigned long long);
+        if (int rc = dev_alloc(h, (void**)&w.hx, w.hx_bytes, &p->allocs)) return rc;
+        if (m.H == 256)
+            if (int rc = dev_alloc(h, (void**)&w.hx2, w.hx_bytes, &p->allocs)) return rc;
+    }
+    if (int rc = dev_alloc(h, (void**)&p->r6d, M * 96 * sizeof(float), &p->allocs)) return rc;
+    if (int rc = dev_alloc(h, (void**)&p->lengths_dev, CB * sizeof(int), &p->allocs)) return rc;
+    HIPCHK(h, hipHostMalloc((void**)&p->lengths_pin, CB * sizeof(int), hipHostMallocDefault));
+    return MP_OK;
+}
+
 // `keep`: a plan the caller is still using (mp_stream_replay holds two): never the victim of this call's eviction
 int get_plan(mp_handle* h, int B, int T, Plan** out, const Plan* keep) {
     // (the layer kernels step through their output with a 32-bit row pitch: B * 512 floats must stay below 4 GB)
@@ -73,32 +101,17 @@ int get_plan(mp_handle* h, int B, int T, Plan** out, const Plan* keep) {
     }
     Plan* p = new Plan();
     p->B = B; p->T = T; p->lastB = B; p->capB = cls; p->capRows = cap_rows; p->last_use = ++h->use_clock;
+    // (a plan enters the cache only when ALL of its workspaces exist: one that ran out of memory half-way would be handed to
+    //  the next call of its class with null buffers)
+    if (int rc = alloc_plan_workspaces(h, p)) {
+        for (void* q : p->allocs) (void)hipFree(q);
+        if (p->lengths_pin) (void)hipHostFree(p->lengths_pin);
+        delete p;
+        (void)hipGetLastError();                   // (hipMalloc's failure is not the next launch check's business)
+        return rc;
+    }
     h->plans.push_back(p);
     ++h->plan_allocs;
-    const size_t M = cap_rows, CB = (size_t)cls;
-    for (int id = 0; id < 4; ++id) {
-        const ModuleW& m = h->mod[id];
-        ModuleWS& w = p->ws[id];
-        w.xproj = nullptr;                                   // gate pre-activations: per-step mode only, allocated on demand
-        if (int rc = dev_alloc(h, (void**)&w.out0, M * m.dirs * m.H * sizeof(float), &p->allocs)) return rc;
-        if (int rc = dev_alloc(h, (void**)&w.out1, M * m.dirs * m.H * sizeof(float), &p->allocs)) return rc;
-        if (m.H == 256 && m.dirs == 1)
-            if (int rc = dev_alloc(h, (void**)&w.x1, M * m.H * sizeof(float), &p->allocs)) return rc;
-        for (int l = 0; l < 2; ++l)
-            for (int d = 0; d < m.dirs; ++d) {
-                if (int rc = dev_alloc(h, (void**)&w.hbuf[l][d], (size_t)2 * CB * m.H * sizeof(float), &p->allocs)) return rc;
-                if (int rc = dev_alloc(h, (void**)&w.cbuf[l][d], CB * m.H * sizeof(float), &p->allocs)) return rc;
-            }
-        // exchange areas: one per (direction, slab) -- or per (direction, sequence) where a few sequences run on the one-sequence kernels
-        const size_t units = CB <= (size_t)kSeqClusterMax ? CB : (CB + 15) / 16;
-        w.hx_bytes = (size_t)2 * units * ((size_t)4 * 16 * m.H + 16) * sizeof(unsigned long long);
-        if (int rc = dev_alloc(h, (void**)&w.hx, w.hx_bytes, &p->allocs)) return rc;
-        if (m.H == 256)
-            if (int rc = dev_alloc(h, (void**)&w.hx2, w.hx_bytes, &p->allocs)) return rc;
-    }
-    if (int rc = dev_alloc(h, (void**)&p->r6d, M * 96 * sizeof(float), &p->allocs)) return rc;
-    if (int rc = dev_alloc(h, (void**)&p->lengths_dev, CB * sizeof(int), &p->allocs)) return rc;
-    HIPCHK(h, hipHostMalloc((void**)&p->lengths_pin, CB * sizeof(int), hipHostMallocDefault));
     *out = p;
     return MP_OK;
 }

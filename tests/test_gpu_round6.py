@@ -280,6 +280,35 @@ def test_batch_classes_share_a_plan_and_stay_bitwise(torch_mod, weights, smpl):
         assert net.device_error() == 0 and net.recovery_count == 0
 
 
+def test_a_plan_that_does_not_fit_in_memory_never_enters_the_cache(torch_mod, weights, smpl):
+    """csrc/mp_plans.hip get_plan: a shape whose workspaces cannot be allocated (2^30 rows: 2 TB for the first buffer alone) is
+    MP_ERR_HIP with hipMalloc's message -- and nothing of the half-built plan stays behind: a plan with null buffers in the cache
+    would be handed to the next call of its batch class.  The handle keeps working, bitwise what a fresh one computes."""
+    import ctypes as C
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    B, T = 3, 20
+    imu = cu(torch_mod, synthetic.make_imu(B, T, seed=96))
+    with MobilePoserNet.from_numpy(weights, smpl) as net:
+        before = [npy(t) for t in net.forward_offline(imu, [T] * B)]
+        allocs0 = _plan_stats(net)[1]
+        big_b, big_t = 1 << 20, 1 << 10
+        lengths = (C.c_int32 * big_b)(*([big_t] * big_b))
+        dummy = torch_mod.zeros(16, device="cuda")
+        vp = C.c_void_p(dummy.data_ptr())
+        rc = net._lib.mp_translate_offline(net._h, vp, vp, vp, lengths, big_b, big_t, vp, None)
+        assert rc != 0
+        msg = net._lib.mp_last_error(net._h).decode()
+        assert "hipMalloc" in msg, msg
+        n, allocs, rows = _plan_stats(net)
+        assert allocs == allocs0 and rows < (1 << 30), (n, allocs, rows)       # nothing of the failed plan is in the cache
+        net.reset_all()
+        after = [npy(t) for t in net.forward_offline(imu, [T] * B)]
+        for a, b in zip(before, after):
+            assert np.array_equal(a, b)
+        assert net.device_error() == 0 and net.recovery_count == 0
+
+
 def test_mode3_smoke(torch_mod, weights, smpl):
     """What is left of the opt-in split-fp16 mode in the default suite (conftest.lstm_test_modes): the full forward against golden
     G2 (equal and ragged lengths, carried velocity state) and 20 online frames against golden G5, at the bound of the exact mode
