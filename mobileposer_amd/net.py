@@ -49,19 +49,57 @@ def _close_all():               # runs before interpreter finalisation, while th
             pass
 
 
-class _VelocityView:
-    """Stands in for ``model.velocity``: exposes the carried LSTM state as ``rnn_state`` (velocity.py:30,47).
+class _ModuleView:
+    """Stands in for a sub-module of the reference's net -- ``model.joints`` / ``model.pose`` / ``model.foot_contact`` /
+    ``model.velocity`` (models/joints.py:48-52, poser.py:60-63, footcontact.py:38-41, velocity.py:40-48): calling it runs that
+    block alone (linear1 + ReLU -> 2-layer LSTM, packed -> linear2, models/rnn.py:20-33) through ``mp_rnn_forward`` and returns what
+    the reference's ``forward`` returns, the block's output ``[B, T, n_out]``.  With ``input_lengths=None`` the reference feeds
+    nn.LSTM time-major data (rnn.py:15,25): dim 0 is time -- reproduced by transposition, as in ``forward``.
     Holds the net weakly: no reference cycle, so a net's native handle is released as soon as the net is."""
 
-    def __init__(self, net):
+    def __init__(self, net, name):
         self._ref = weakref.ref(net)
+        self._name = name
 
     @property
     def _net(self):
         net = self._ref()
         if net is None:
-            raise ReferenceError("the MobilePoserNet this velocity view belongs to is gone")
+            raise ReferenceError("the MobilePoserNet this %s view belongs to is gone" % self._name)
         return net
+
+    def _run(self, batch, input_lengths, state):
+        net = self._net
+        if batch.dim() != 3:
+            raise RuntimeError("expected a batch of shape [B, T, n_in], got %s" % (tuple(batch.shape),))
+        if input_lengths is None:          # dim 0 is time, dim 1 the batch; the returned state has batch T
+            B, T = int(batch.shape[0]), int(batch.shape[1])
+            xt = batch.to(device=net.device, dtype=torch.float32).transpose(0, 1).contiguous()
+            y, st = net.rnn_forward(self._name, xt, [B] * T, state)
+            return y.transpose(0, 1).contiguous(), st
+        return net.rnn_forward(self._name, batch, input_lengths, state)
+
+    def forward(self, batch, input_lengths=None):
+        return self._run(batch, input_lengths, None)[0]
+
+    __call__ = forward
+
+    def eval(self):
+        return self
+
+
+class _VelocityView(_ModuleView):
+    """``model.velocity``: the block itself (``forward``: zero initial state, velocity.py:40-43; ``forward_online``: on the carried
+    state, which it replaces, velocity.py:45-48) and the carried LSTM state as ``rnn_state`` (velocity.py:30,47) -- ONE state per
+    model, the one ``MobilePoserNet.forward`` runs on (net.py:117)."""
+
+    def __init__(self, net):
+        super().__init__(net, "velocity")
+
+    def forward_online(self, batch, input_lengths=None):
+        vel, state = self._run(batch, input_lengths, self.rnn_state)
+        self.rnn_state = state
+        return vel
 
     @property
     def rnn_state(self):
@@ -83,6 +121,17 @@ class _VelocityView:
         h, c = value
         buf = torch.stack((h, c)).to(device=net.device, dtype=torch.float32).contiguous()
         net._check(net._lib.mp_set_velocity_state(net._h, _ptr(buf), int(h.shape[1])))
+
+
+class _PoserView(_ModuleView):
+    """``model.pose``: the block (-> 6D rotations of the 16 reduced joints, [B, T, 96]) and ``_reduced_global_to_full``
+    (poser.py:52-58 = net.py:93-99)."""
+
+    def __init__(self, net):
+        super().__init__(net, "pose")
+
+    def _reduced_global_to_full(self, reduced_pose):
+        return self._net._reduced_global_to_full(reduced_pose)
 
 
 class MobilePoserNet:
@@ -119,6 +168,9 @@ class MobilePoserNet:
         # per-stream state on the device and are mirrored by the properties below
         self.rnn_state = None
         self.velocity = _VelocityView(self)
+        self.joints = _ModuleView(self, "joints")
+        self.pose = _PoserView(self)
+        self.foot_contact = _ModuleView(self, "foot_contact")
         self._h = None
         self._blob = None
         self._stream_S = 0

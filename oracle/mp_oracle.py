@@ -76,11 +76,18 @@ def _lstm_direction(xs, lengths, w_ih, w_hh, b_ih, b_hh, h0, c0, reverse):
 def rnn_forward(sd, prefix, x, lengths, state=None):
     """RNN.forward (models/rnn.py:20-33).
 
-    sd: state dict (key -> ndarray); prefix e.g. 'joints.joints.'; x [B,T,n_in]; lengths list[int].
+    sd: state dict (key -> ndarray); prefix e.g. 'joints.joints.'; x [B,T,n_in]; lengths list[int] or None (time-major, below).
     state: None or (h0, c0) each [layers*dirs, B, H] in nn.LSTM order (l0, l0_reverse, l1, l1_reverse).
     Returns y [B, max(lengths), n_out], (h_n, c_n).
     """
     x = np.asarray(x, dtype=F32)
+    if lengths is None:
+        # rnn.py:23-28: without seq_lengths nothing is packed and nn.LSTM -- built without batch_first (rnn.py:15) -- reads dim 0
+        # of [B,T,n] as TIME and dim 1 as the batch (SURVEY Q3): T sequences of B steps, a state of batch T; the linear layers
+        # work row by row, so the output keeps the caller's layout
+        B, T, _ = x.shape
+        y, st = rnn_forward(sd, prefix, np.ascontiguousarray(x.transpose(1, 0, 2)), [B] * T, state)
+        return np.ascontiguousarray(y.transpose(1, 0, 2)), st
     lengths = np.asarray(lengths, dtype=np.int64)
     B, T, _ = x.shape
     w1, b1 = sd[prefix + "linear1.weight"], sd[prefix + "linear1.bias"]

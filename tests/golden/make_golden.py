@@ -518,6 +518,31 @@ def main():
         g18["off_pose"], g18["off_joints"], g18["off_tran"], g18["off_contact"] = pose.numpy(), joints.numpy(), tran.numpy(), contact.numpy()
     np.savez_compressed(os.path.join(HERE, "g18_lengths_none.npz"), **g18)
 
+    # ---- G19 (round 6) the sub-modules called the way the reference's own code calls them (net.py:103-117): model.joints(x, l),
+    # model.pose(x, l), model.foot_contact(x, l), model.velocity(x, l) (zero state), model.velocity.forward_online(x, l) twice (the
+    # carried state) -- and each with input_lengths=None, where dim 0 is time (rnn.py:15,25)
+    g19 = {"lengths": np.array([11, 6, 11])}
+    with torch.no_grad():
+        m = new_model()
+        l19 = g19["lengths"].tolist()
+        for name, mod, n_in in (("joints", m.joints, 60), ("pose", m.pose, 132), ("foot_contact", m.foot_contact, 132),
+                                ("velocity", m.velocity, 132)):
+            rng = np.random.Generator(np.random.PCG64(190 + n_in + len(name)))
+            x = rng.standard_normal((3, 11, n_in)).astype(np.float32) * 0.5
+            g19[f"{name}_x"] = x
+            g19[f"{name}_y"] = mod(torch.from_numpy(x), l19).numpy()
+            g19[f"{name}_y_none"] = mod(torch.from_numpy(x)).numpy()
+        xv = torch.from_numpy(g19["velocity_x"])
+        m.velocity.rnn_state = None
+        for call in (0, 1):
+            g19[f"online{call}"] = m.velocity.forward_online(xv, l19).numpy()
+        g19["online_h"], g19["online_c"] = (t.numpy() for t in m.velocity.rnn_state)
+        m.velocity.rnn_state = None
+        for call in (0, 1):
+            g19[f"online_none{call}"] = m.velocity.forward_online(xv).numpy()
+        g19["online_none_h"], g19["online_none_c"] = (t.numpy() for t in m.velocity.rnn_state)
+    np.savez_compressed(os.path.join(HERE, "g19_submodules.npz"), **g19)
+
     print("golden vectors written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         print("  %-24s %8d B" % (fn, os.path.getsize(os.path.join(HERE, fn))))

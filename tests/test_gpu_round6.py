@@ -432,3 +432,33 @@ def test_g18_lengths_none_is_time_major(torch_mod, weights, smpl):
         assert np.abs(npy(joints) - g["off_joints"]).max() < 1e-4 and np.abs(npy(contact) - g["off_contact"]).max() < 1e-4
         assert np.abs(npy(tran) - g["off_tran"]).max() < 1e-3
         assert net.device_error() == 0 and net.recovery_count == 0
+
+
+def test_g19_submodule_views_golden(torch_mod, weights, smpl):
+    """Golden G19: the sub-modules as the reference's own code calls them (net.py:103-117) -- net.joints(x, l), net.pose(x, l),
+    net.foot_contact(x, l), net.velocity(x, l), net.velocity.forward_online(x, l) twice on the carried state (the ONE state
+    MobilePoserNet.forward runs on) -- and each with input_lengths=None (dim 0 is time, rnn.py:15,25)."""
+    from mobileposer_amd.net import MobilePoserNet
+    g = load_golden("g19_submodules.npz")
+    lengths = g["lengths"].tolist()
+    with MobilePoserNet.from_numpy(weights, smpl) as net:
+        for name, mod in (("joints", net.joints), ("pose", net.pose), ("foot_contact", net.foot_contact), ("velocity", net.velocity)):
+            x = cu(torch_mod, g[f"{name}_x"])
+            y = mod(x, lengths)
+            assert tuple(y.shape) == g[f"{name}_y"].shape and np.abs(npy(y) - g[f"{name}_y"]).max() < 1e-4, name
+            yn = mod.forward(x)
+            assert tuple(yn.shape) == g[f"{name}_y_none"].shape and np.abs(npy(yn) - g[f"{name}_y_none"]).max() < 1e-4, name
+            assert net.velocity.rnn_state is None                       # none of these touches the carried state
+        xv = cu(torch_mod, g["velocity_x"])
+        for tag, lens in (("online", lengths), ("online_none", None)):
+            net.velocity.rnn_state = None
+            for call in (0, 1):
+                y = net.velocity.forward_online(xv, lens)
+                assert np.abs(npy(y) - g[f"{tag}{call}"]).max() < 1e-4, (tag, call)
+            h, c = net.velocity.rnn_state
+            assert tuple(h.shape) == g[f"{tag}_h"].shape
+            assert np.abs(npy(h) - g[f"{tag}_h"]).max() < 1e-4 and np.abs(npy(c) - g[f"{tag}_c"]).max() < 1e-4
+        # poser.py:52-58 is net.py:93-99
+        g3 = load_golden("g3_r6d_ik.npz")
+        assert np.abs(npy(net.pose._reduced_global_to_full(cu(torch_mod, g3["r6d"]))) - g3["pose"]).max() < 1e-5
+        assert net.device_error() == 0 and net.recovery_count == 0

@@ -384,3 +384,24 @@ def test_g18_lengths_none_is_time_major(weights, smpl):
     # ... and it is NOT what the batch-first reading gives
     other = O.OracleNet(weights, smpl["J"]).forward(g["imu"], [25, 25, 25])
     assert np.abs(other[1] - g["c0_joints"]).max() > 1e-3
+
+
+def test_g19_submodules_as_the_reference_calls_them(weights):
+    """Golden G19 (round 6): model.joints / model.pose / model.foot_contact / model.velocity called directly (net.py:103-117), with
+    lengths and with input_lengths=None (time-major, rnn.py:15,25), and velocity.forward_online twice on its carried state
+    (velocity.py:45-48)."""
+    g = load_golden("g19_submodules.npz")
+    lengths = g["lengths"].tolist()
+    for name in ("joints", "pose", "foot_contact", "velocity"):
+        y, _ = O.rnn_forward(weights, O.PREFIX[name], g[f"{name}_x"], lengths)
+        assert y.shape == g[f"{name}_y"].shape and np.abs(y - g[f"{name}_y"]).max() < TIGHT, name
+        yn, _ = O.rnn_forward(weights, O.PREFIX[name], g[f"{name}_x"], None)
+        assert yn.shape == g[f"{name}_y_none"].shape and np.abs(yn - g[f"{name}_y_none"]).max() < TIGHT, name
+        assert np.abs(yn - g[f"{name}_y"]).max() > 1e-3, name          # ... which is NOT the batch-first reading
+    for tag, lens in (("online", lengths), ("online_none", None)):
+        state = None
+        for call in (0, 1):
+            y, state = O.rnn_forward(weights, O.PREFIX["velocity"], g["velocity_x"], lens, state)
+            assert np.abs(y - g[f"{tag}{call}"]).max() < TIGHT, (tag, call)
+        assert state[0].shape == g[f"{tag}_h"].shape
+        assert np.abs(state[0] - g[f"{tag}_h"]).max() < TIGHT and np.abs(state[1] - g[f"{tag}_c"]).max() < TIGHT
