@@ -21,3 +21,4 @@ for k,v in d['modes'].items(): print('S=$S ${hz}Hz', k, 'b2b', v['back_to_back_m
 done; done > gpurun_out/r06_tick_cadence.txt 2>&1; grep cadence gpurun_out/r06_tick_cadence.txt | cut -c1-200
 timeout 600 python tools/debug/small_batches.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_small_batches.txt; head -24 gpurun_out/r06_small_batches.txt
 timeout 600 python tools/debug/online_timing.py 3000 2>&1 | grep -v amdgpu.ids | tail -4 > gpurun_out/r06_online_timing.txt; cat gpurun_out/r06_online_timing.txt
+timeout 300 python tools/pcie_inclusive.py 2>&1 | grep -v amdgpu.ids | tail -1 > gpurun_out/r06_pcie_inclusive.json; cut -c1-400 gpurun_out/r06_pcie_inclusive.json
