@@ -139,6 +139,11 @@ int mp_rnn_forward(mp_handle* h, int module, const float* x_dev, const int32_t* 
 /* MobilePoserNet._reduced_global_to_full (models/net.py:93-99): r6d [N,96] -> pose [N,24,3,3]. */
 int mp_reduced_global_to_full(mp_handle* h, const float* r6d_dev, int64_t N, float* pose_dev, void* stream);
 
+/* ParametricModel.inverse_kinematics_R (articulate/model.py:146-164 -> articulate/math/spatial.py:197-221): global joint
+ * rotations [N,24,3,3] -> local ones, R_local[i] = R_global[parent[i]]^T R_global[i], R_local[0] = R_global[0] -- what
+ * MobilePoserNet.global_to_local_pose is bound to (models/net.py:38).  Distinct buffers; works on a body-only handle. */
+int mp_inverse_kinematics_r(mp_handle* h, const float* rglobal_dev, int64_t N, float* rlocal_dev, void* stream);
+
 /* art.math.r6d_to_rotation_matrix (articulate/math/angular.py:167-182) on n six-vectors [n,6] -> [n,3,3]: the first two
  * COLUMNS of R, Gram-Schmidt, NaN -> 0.  What evaluate.py:60 applies to the ground-truth pose of a dataset item. */
 int mp_r6d_to_rotation_matrix(mp_handle* h, const float* r6d_dev, int64_t n, float* rot_dev, void* stream);

@@ -63,6 +63,7 @@ SIGNATURES = {
     "mp_forward_offline": (_i, [_vp, _vp, _ip, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_rnn_forward": (_i, [_vp, _i, _vp, _ip, _i, _i, _vp, _vp, _vp, _vp]),
     "mp_reduced_global_to_full": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "mp_inverse_kinematics_r": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "mp_r6d_to_rotation_matrix": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "mp_translate_offline": (_i, [_vp, _vp, _vp, _vp, _ip, _i, _i, _vp, _vp]),
     "mp_fk": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),

@@ -123,6 +123,24 @@ class ParametricModel:
         return fk_call(lib, h, dev, state, pose, shape, tran, calc_mesh)
 
 
+    def forward_kinematics_R(self, R_local):
+        """articulate/model.py:126-144: local joint rotations [N, *] (reshapeable to [N,24,3,3]) -> global ones [N,24,3,3] -- the
+        rotation half of forward_kinematics (mp_fk; the joint positions it also computes are dropped)."""
+        R = torch.as_tensor(R_local)
+        return self.forward_kinematics(R.reshape(R.shape[0], -1, 3, 3))[0]
+
+    def inverse_kinematics_R(self, R_global):
+        """articulate/model.py:146-164: global joint rotations [N, *] (reshapeable to [N,24,3,3]) -> local ones [N,24,3,3],
+        R_local[i] = R_global[parent[i]]^T R_global[i] (mp_inverse_kinematics_r)."""
+        lib, h, dev = self._handle()
+        R = torch.as_tensor(R_global)
+        g = R.to(device=dev, dtype=torch.float32).reshape(R.shape[0], 24, 3, 3).contiguous()
+        out = torch.empty_like(g)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.mp_inverse_kinematics_r(h, _ptr(g), int(g.shape[0]), _ptr(out), stream), h)
+        return out
+
+
 def _destroy(lib, h):
     try:
         lib.mp_destroy(h)

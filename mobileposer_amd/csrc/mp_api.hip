@@ -152,6 +152,16 @@ int mp_reduced_global_to_full(mp_handle* h, const float* r6d_dev, int64_t N, flo
     return leave(h, stream);
 }
 
+int mp_inverse_kinematics_r(mp_handle* h, const float* rglobal_dev, int64_t N, float* rlocal_dev, void* stream) {
+    if (!h || !rglobal_dev || !rlocal_dev || N < 0) return h ? fail(h, MP_ERR_INVALID, "mp_inverse_kinematics_r: bad argument") : MP_ERR_INVALID;
+    if (rglobal_dev == rlocal_dev) return fail(h, MP_ERR_INVALID, "mp_inverse_kinematics_r: in-place call (a joint reads its parent's INPUT)");
+    ON_DEVICE(h);
+    if (int rc = enter(h, stream)) return rc;
+    mp_launch_global_to_local(rglobal_dev, (long)N, rlocal_dev, h->parent_dev, h->s_main);
+    HIPCHK(h, hipGetLastError());
+    return leave(h, stream);
+}
+
 int mp_r6d_to_rotation_matrix(mp_handle* h, const float* r6d_dev, int64_t n, float* rot_dev, void* stream) {
     if (!h || !r6d_dev || !rot_dev || n < 0) return h ? fail(h, MP_ERR_INVALID, "mp_r6d_to_rotation_matrix: bad argument") : MP_ERR_INVALID;
     ON_DEVICE(h);

@@ -221,6 +221,8 @@ hipError_t mp_lstm_x3w_device_attrs();
 // ---------------------------------------------------------------- K4/K5: kinematics
 void mp_launch_r6d_ik(const float* r6d, long N, float* pose, const int* parent_dev, hipStream_t s);
 void mp_launch_r6d_to_rot(const float* r6d, long n, float* out, hipStream_t s);   // n six-vectors -> n 3x3 matrices
+// ParametricModel.inverse_kinematics_R (articulate/model.py:146-164): rglobal [N,24,3,3] -> rlocal [N,24,3,3] (distinct buffers)
+void mp_launch_global_to_local(const float* rglobal, long N, float* rlocal, const int* parent_dev, hipStream_t s);
 // frame n reads its 96 numbers at r6d + n*rowStride + rowOffset
 void mp_launch_r6d_ik_strided(const float* r6d, long N, long rowStride, long rowOffset, float* pose,
                               const int* parent_dev, hipStream_t s);

@@ -240,6 +240,70 @@ MP_KERNEL __launch_bounds__(192) void mp_r6d_ik_lds(const float* __restrict__ r6
     for (int e = tid; e < nf * 54; e += 192) dst[e] = src[e];
 }
 
+// ParametricModel.inverse_kinematics_R (articulate/model.py:146-164 -> spatial.py:197-221, _inverse_tree :115-123) on its own:
+// R_local[i] = R_global[parent[i]]^T R_global[i], R_local[0] = R_global[0] -- no chain (only INPUTS of the parent are read), so a
+// thread per (frame, joint).  HBM-bound: 864 B in + 864 B out per frame; 8 frames per workgroup staged through LDS in 16-byte
+// pieces of one contiguous 6912-byte run, records picked out of LDS at word stride 9 (conflict-free), as mp_r6d_ik_lds does.
+MP_KERNEL __launch_bounds__(192) void mp_global_to_local_lds(const float* __restrict__ rglobal, long N, float* __restrict__ rlocal,
+                                                               const int* __restrict__ parent) {
+    __shared__ __attribute__((aligned(16))) float sG[kFkFrames * 216];
+    __shared__ __attribute__((aligned(16))) float sO[kFkFrames * 216];
+    const long n0 = (long)blockIdx.x * kFkFrames;
+    const int nf = (int)(N - n0 < kFkFrames ? N - n0 : kFkFrames);
+    const int tid = threadIdx.x;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(rglobal + n0 * 216);
+        f32x4* dst = reinterpret_cast<f32x4*>(sG);
+        for (int e = tid; e < nf * 54; e += 192) dst[e] = src[e];
+    }
+    __syncthreads();
+    const int f = tid / 24, i = tid - f * 24;
+    if (f < nf) {
+        const float* G = sG + tid * 9;
+        float* o = sO + tid * 9;
+        if (i == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) o[k] = G[k];
+        } else {
+            const float* P = sG + (f * 24 + parent[i]) * 9;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    o[r * 3 + c] = P[0 * 3 + r] * G[0 * 3 + c] + P[1 * 3 + r] * G[1 * 3 + c] + P[2 * 3 + r] * G[2 * 3 + c];
+        }
+    }
+    __syncthreads();
+    const f32x4* src = reinterpret_cast<const f32x4*>(sO);
+    f32x4* dst = reinterpret_cast<f32x4*>(rlocal + n0 * 216);
+    for (int e = tid; e < nf * 54; e += 192) dst[e] = src[e];
+}
+
+// ... and for buffers that are not 16-byte aligned: scalar accesses, a thread per (frame, joint)
+MP_KERNEL __launch_bounds__(256) void mp_global_to_local(const float* __restrict__ rglobal, long N, float* __restrict__ rlocal,
+                                                           const int* __restrict__ parent) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= N * 24) return;
+    const long n = gid / 24;
+    const int i = (int)(gid - n * 24);
+    const float* G = rglobal + gid * 9;
+    float out[9];
+    if (i == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) out[k] = G[k];
+    } else {
+        const float* P = rglobal + (n * 24 + parent[i]) * 9;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                out[r * 3 + c] = P[0 * 3 + r] * G[0 * 3 + c] + P[1 * 3 + r] * G[1 * 3 + c] + P[2 * 3 + r] * G[2 * 3 + c];
+    }
+    float* o = rlocal + gid * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = out[k];
+}
+
 // mp_r6d_ik_lds and mp_fk in ONE kernel (round 5: the tail of a forward that also wants the FK outputs -- bench.py's call): the local
 // rotations go out to `pose` through LDS as above AND stay in registers as the start values of the tree walk; thread (frame f =
 // tid / 32, joint i = tid % 32 < 24) is lane (f & 1) * 32 + i of wave f / 2 -- mp_fk's mapping.  Same arithmetic in the same order
@@ -523,6 +587,18 @@ bool mp_launch_r6d_ik_fk(const float* r6d, long N, long rowStride, long rowOffse
     hipLaunchKernelGGL(mp_r6d_ik_fk, dim3((unsigned)((N + kFkFrames - 1) / kFkFrames)), dim3(256), 0, s, r6d, N, rowStride, rowOffset,
                        pose, bone_dev, parent_dev, rglobal, joint);
     return true;
+}
+
+void mp_launch_global_to_local(const float* rglobal, long N, float* rlocal, const int* parent_dev, hipStream_t s) {
+    if (N <= 0) return;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(rglobal) | reinterpret_cast<uintptr_t>(rlocal)) & 15) == 0;
+    if (aligned && !mp_kin_scalar_forced()) {
+        hipLaunchKernelGGL(mp_global_to_local_lds, dim3((unsigned)((N + kFkFrames - 1) / kFkFrames)), dim3(192), 0, s, rglobal, N,
+                           rlocal, parent_dev);
+        return;
+    }
+    const long threads = N * 24;
+    hipLaunchKernelGGL(mp_global_to_local, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, rglobal, N, rlocal, parent_dev);
 }
 
 void mp_launch_r6d_to_rot(const float* r6d, long n, float* out, hipStream_t s) {

@@ -155,11 +155,13 @@ class MobilePoserNet:
         else:                                                  # licensed file absent: synthetic body
             self.bodymodel = ParametricModel.synthetic(device=device)
         self.bodymodel.bind(self)
+        self.global_to_local_pose = self.bodymodel.inverse_kinematics_R          # net.py:38
         # base joints (net.py:47-49)
         self.j, _ = self.bodymodel.get_zero_pose_joint_and_vertex()
         self.feet_pos = torch.from_numpy(self.j[10:12].copy())
         self.floor_y = float(self.j[10:12, 1].min())
         # constants (net.py:52-56)
+        self.gravity_velocity = torch.tensor([0.0, joint_set.gravity_velocity, 0.0], device=self.device)      # net.py:52
         self.prob_threshold = (0.5, 0.9)
         self.num_past_frames = model_config.past_frames
         self.num_future_frames = model_config.future_frames
@@ -167,6 +169,7 @@ class MobilePoserNet:
         # variables (net.py:59-64): last_root_pos / current_root_y / imu / last_{l,r}foot_pos live in the library's
         # per-stream state on the device and are mirrored by the properties below
         self.rnn_state = None
+        self.last_joints = torch.zeros(24, 3, device=self.device)                # net.py:62 (never read by the reference either)
         self.velocity = _VelocityView(self)
         self.joints = _ModuleView(self, "joints")
         self.pose = _PoserView(self)
@@ -190,6 +193,16 @@ class MobilePoserNet:
             self.load_state_dict(sd)
 
     # ------------------------------------------------------------------ construction helpers
+    @classmethod
+    def from_pretrained(cls, model_path, **kw):
+        """models/net.py:76-82: the model of a (Lightning) checkpoint, marked for fine-tuning -- the weights through
+        ``model_utils.load_model`` (same file formats, same refusal of untrusted pickles; ``kw``: smpl_file / device / smpl / trusted).
+        Training itself is out of scope: ``finetune`` is carried, ``hypers`` is not."""
+        from .model_utils import load_model
+        m = load_model(model_path, **kw)
+        m.finetune = True
+        return m
+
     @classmethod
     def from_numpy(cls, state_dict, smpl=None, device="cuda:0"):
         net = cls(smpl=smpl, device=device)

@@ -543,6 +543,22 @@ def main():
         g19["online_none_h"], g19["online_none_c"] = (t.numpy() for t in m.velocity.rnn_state)
     np.savez_compressed(os.path.join(HERE, "g19_submodules.npz"), **g19)
 
+    # ---- G20 (round 6) the rotation kinematics of the body model on their own (articulate/model.py:126-164): forward_kinematics_R,
+    # inverse_kinematics_R -- what MobilePoserNet.global_to_local_pose is bound to (net.py:38) -- on random rotations, and the round trip
+    rng = np.random.Generator(np.random.PCG64(200))
+    q = rng.standard_normal((37, 24, 4))
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    R20 = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                    2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                    2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], axis=-1).reshape(37, 24, 3, 3).astype(np.float32)
+    with torch.no_grad():
+        m = new_model()
+        Rg = m.bodymodel.forward_kinematics_R(torch.from_numpy(R20))
+        Rl = m.global_to_local_pose(torch.from_numpy(R20))
+        back = m.bodymodel.inverse_kinematics_R(Rg)
+    np.savez_compressed(os.path.join(HERE, "g20_rotation_kinematics.npz"), R=R20, fk_R=Rg.numpy(), ik_R=Rl.numpy(), ik_of_fk=back.numpy())
+
     print("golden vectors written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         print("  %-24s %8d B" % (fn, os.path.getsize(os.path.join(HERE, fn))))

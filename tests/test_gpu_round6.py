@@ -462,3 +462,45 @@ def test_g19_submodule_views_golden(torch_mod, weights, smpl):
         g3 = load_golden("g3_r6d_ik.npz")
         assert np.abs(npy(net.pose._reduced_global_to_full(cu(torch_mod, g3["r6d"]))) - g3["pose"]).max() < 1e-5
         assert net.device_error() == 0 and net.recovery_count == 0
+
+
+def test_g20_rotation_kinematics_golden_and_edges(torch_mod, weights, smpl):
+    """Golden G20: ParametricModel.forward_kinematics_R / inverse_kinematics_R (articulate/model.py:126-164) and
+    MobilePoserNet.global_to_local_pose (net.py:38) through mp_fk / mp_inverse_kinematics_r -- bound to a net and on a body-only
+    handle; every frame count around the 8-frame workgroup; a buffer that is not 16-byte aligned (the scalar kernel) bitwise what
+    the staged kernel gives; an in-place call is refused."""
+    import ctypes as C
+    from mobileposer_amd.body_model import ParametricModel
+    from mobileposer_amd.net import MobilePoserNet
+    from oracle import mp_oracle as O
+    g = load_golden("g20_rotation_kinematics.npz")
+    R = cu(torch_mod, g["R"])
+    with MobilePoserNet.from_numpy(weights, smpl) as net:
+        bm = net.bodymodel
+        assert np.abs(npy(bm.forward_kinematics_R(R)) - g["fk_R"]).max() < 1e-5
+        assert np.abs(npy(bm.forward_kinematics_R(R.reshape(37, -1))) - g["fk_R"]).max() < 1e-5      # "[batch_size, *]"
+        loc = npy(net.global_to_local_pose(R))
+        assert loc.shape == g["ik_R"].shape and np.abs(loc - g["ik_R"]).max() < 1e-5
+        assert np.abs(npy(bm.inverse_kinematics_R(cu(torch_mod, g["fk_R"]))) - g["ik_of_fk"]).max() < 1e-5
+        assert float(net.gravity_velocity[1]) == pytest.approx(-0.018) and tuple(net.last_joints.shape) == (24, 3)
+        # frame counts around a workgroup's 8 frames, against the oracle; unaligned buffers bitwise the same
+        big = cu(torch_mod, np.concatenate([g["fk_R"]] * 3))
+        pad = torch_mod.empty(big.numel() + 1, device="cuda")
+        pad[1:] = big.reshape(-1)
+        for n in (1, 7, 8, 9, 16, 17, 100):
+            got = bm.inverse_kinematics_R(big[:n])
+            assert np.abs(npy(got) - O.inverse_kinematics_R(npy(big[:n]))).max() < 1e-6, n
+            out = torch_mod.empty(n * 216 + 1, device="cuda")
+            rc = net._lib.mp_inverse_kinematics_r(net._h, C.c_void_p(pad.data_ptr() + 4), n, C.c_void_p(out.data_ptr() + 4), None)
+            assert rc == 0
+            torch_mod.cuda.synchronize()
+            assert np.array_equal(npy(out[1:]).reshape(n, 24, 3, 3), npy(got)), n
+        rc = net._lib.mp_inverse_kinematics_r(net._h, C.c_void_p(big.data_ptr()), 4, C.c_void_p(big.data_ptr()), None)
+        assert rc != 0 and "in-place" in net._lib.mp_last_error(net._h).decode()
+        assert net.device_error() == 0
+    body = ParametricModel(data=smpl)                       # a body-only handle (mp_create_body), as data.py:24 builds one
+    try:
+        assert np.abs(npy(body.inverse_kinematics_R(R)) - g["ik_R"]).max() < 1e-5
+        assert np.abs(npy(body.forward_kinematics_R(R)) - g["fk_R"]).max() < 1e-5
+    finally:
+        body.close()

@@ -405,3 +405,14 @@ def test_g19_submodules_as_the_reference_calls_them(weights):
             assert np.abs(y - g[f"{tag}{call}"]).max() < TIGHT, (tag, call)
         assert state[0].shape == g[f"{tag}_h"].shape
         assert np.abs(state[0] - g[f"{tag}_h"]).max() < TIGHT and np.abs(state[1] - g[f"{tag}_c"]).max() < TIGHT
+
+
+def test_g20_rotation_kinematics(smpl):
+    """Golden G20 (round 6): ParametricModel.forward_kinematics_R / inverse_kinematics_R on their own (articulate/model.py:126-164;
+    the latter is what MobilePoserNet.global_to_local_pose is bound to, net.py:38) on random rotations, and the round trip."""
+    g = load_golden("g20_rotation_kinematics.npz")
+    Rg, _ = O.forward_kinematics(g["R"], smpl["J"])
+    assert np.abs(Rg - g["fk_R"]).max() < TIGHT
+    assert np.abs(O.inverse_kinematics_R(g["R"]) - g["ik_R"]).max() < TIGHT
+    assert np.abs(O.inverse_kinematics_R(g["fk_R"]) - g["ik_of_fk"]).max() < TIGHT
+    assert np.abs(g["ik_of_fk"] - g["R"]).max() < 1e-5                      # IK(FK(R)) = R
