@@ -141,6 +141,16 @@ class ParametricModel:
         return out
 
 
+    def eval_metrics(self, pose_p, pose_t, tran_p=None, tran_t=None, fps=60, align_joint=0, joint_mask=None, ignored=()):
+        """FullMotionEvaluator.__call__ (articulate/evaluator.py:292-343) on this body: the error table [10,2] in ONE library
+        call (mp_eval_metrics) -- what the reference's evaluator computes with the CPU body model it builds from a model file."""
+        lib, h, dev = self._handle()
+        net = self._net
+        state = net._mesh_state if (net is not None and net._h is not None) else self._own_state
+        return eval_metrics_call(lib, h, dev, state.get("n_vertex", 0), pose_p, pose_t, tran_p, tran_t, fps, align_joint,
+                                 joint_mask, ignored)
+
+
 def _destroy(lib, h):
     try:
         lib.mp_destroy(h)
@@ -196,6 +206,28 @@ def fk_call(lib, h, dev, state, pose, shape, tran, calc_mesh):
     else:
         _lib.check(lib.mp_fk(h, _ptr(p), _ptr(t), N, _ptr(Rg), _ptr(jg), stream), h)
     return (Rg, jg, vg) if calc_mesh else (Rg, jg)
+
+
+def eval_metrics_call(lib, h, dev, n_vertex, pose_p, pose_t, tran_p, tran_t, fps, align_joint, joint_mask, ignored):
+    f = lambda t: None if t is None else torch.as_tensor(t).to(device=dev, dtype=torch.float32).contiguous()
+    pp, pt = f(pose_p).reshape(-1, 24, 3, 3), f(pose_t).reshape(-1, 24, 3, 3)
+    N = int(pp.shape[0])
+    if int(pt.shape[0]) != N:
+        raise RuntimeError("prediction has %d frames, ground truth %d" % (N, int(pt.shape[0])))
+    tp = None if tran_p is None else f(tran_p).reshape(N, 3)
+    tt = None if tran_t is None else f(tran_t).reshape(N, 3)
+
+    def bits(js):
+        js = [] if js is None else [int(j) for j in js]
+        if any(j < 0 or j > 23 for j in js):
+            raise ValueError("joint indices must be in 0..23, got %s" % (js,))
+        return sum(1 << j for j in set(js))
+
+    table = torch.empty(10, 2, device=dev, dtype=torch.float32)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(lib.mp_eval_metrics(h, _ptr(pp), _ptr(pt), _ptr(tp), _ptr(tt), N, int(fps), int(align_joint), bits(joint_mask),
+                                   bits(ignored), int(n_vertex > 0), _ptr(table), stream), h)
+    return table
 
 
 assert SMPL_PARENT[0] == -1

@@ -27,12 +27,22 @@ def getenv(key, default=0):
 class FullMotionEvaluator:
     """articulate/evaluator.py:269-343: 10 x [mean, std] error table (mean shape, rotation-matrix inputs) -- computed by
     ONE library call (mp_eval_metrics: FK + skinning of prediction and ground truth and all ten metrics on the GPU).
-    ``model``: a MobilePoserNet (or anything with its ``eval_metrics``)."""
+    ``model``: a MobilePoserNet or a ParametricModel (anything with their ``eval_metrics``) -- or, as in the reference
+    (``FullMotionEvaluator(paths.smpl_file, joint_mask=..., fps=...)``, evaluate.py:18), the path of an SMPL model file, from which
+    a body-only native handle is built.  ``align_joint``: a joint index (the reference takes an enum member and reads ``.value``)."""
 
-    def __init__(self, model, joint_mask=None, fps=60, align_joint=0, ignored=()):
+    def __init__(self, model, joint_mask=None, fps=60, align_joint=0, ignored=(), device="cuda:0"):
+        if isinstance(model, (str, os.PathLike)):
+            from .body_model import ParametricModel
+            model = ParametricModel(str(model), device=device)
+        if joint_mask is not None and hasattr(joint_mask, "tolist"):
+            joint_mask = joint_mask.tolist()
+        align_joint = 0 if align_joint is None else int(getattr(align_joint, "value", align_joint))
         self.model, self.joint_mask, self.fps, self.align_joint, self.ignored = model, joint_mask, fps, align_joint, ignored
 
-    def __call__(self, pose_p, pose_t, tran_p=None, tran_t=None):
+    def __call__(self, pose_p, pose_t, shape_p=None, shape_t=None, tran_p=None, tran_t=None):
+        if shape_p is not None or shape_t is not None:
+            raise NotImplementedError("per-sequence shapes in the evaluator (no reference caller passes them: evaluate.py:28)")
         return self.model.eval_metrics(pose_p, pose_t, tran_p, tran_t, fps=self.fps, align_joint=self.align_joint,
                                        joint_mask=self.joint_mask, ignored=self.ignored)
 
@@ -46,13 +56,16 @@ METRICS = (("SIP Error (deg)", 9, 1.0), ("Angular Error (deg)", 3, 1.0), ("Maske
 
 
 class PoseEvaluator:
-    """evaluate.py:16-36.  ``model``: the MobilePoserNet whose handle runs FK / skinning (the reference builds its own
-    CPU body model from paths.smpl_file; here the constants already live on the GPU)."""
+    """evaluate.py:16-36.  ``model``: the MobilePoserNet whose handle runs FK / skinning (its body constants already live on the
+    GPU); ``PoseEvaluator()`` as the reference writes it builds a body-only model from ``paths.smpl_file`` (evaluate.py:18)."""
 
-    def __init__(self, model, joint_mask=(2, 5, 16, 20), fps=datasets.fps):
-        self.model = model
+    def __init__(self, model=None, joint_mask=(2, 5, 16, 20), fps=datasets.fps):
+        if model is None:
+            from .config import paths
+            model = str(paths.smpl_file)
         # joints the network does not predict count as identity in both poses (evaluate.py:25-26): done inside the call
         self._eval_fn = FullMotionEvaluator(model, joint_mask=list(joint_mask), fps=fps, ignored=joint_set.ignored)
+        self.model = self._eval_fn.model
         self._rows = torch.tensor([row for _, row, _ in METRICS])
         self._scale = torch.tensor([scale for _, _, scale in METRICS], dtype=torch.float32).unsqueeze(1)
 

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .body_model import ParametricModel, fk_call, upload_mesh
+from .body_model import ParametricModel, eval_metrics_call, fk_call, upload_mesh
 from .config import joint_set, model_config, paths
 from .manifest import state_dict_manifest
 from .model_utils import blob_to_state_dict, state_dict_to_blob
@@ -687,22 +687,9 @@ class MobilePoserNet:
         """mp_eval_metrics: FullMotionEvaluator.__call__ (articulate/evaluator.py:292-343) -> error table [10,2] on the
         device, in ONE library call (identity on ``ignored`` joints, FK + skinning of both poses, all ten metrics)."""
         self._require_weights()
-        f = lambda t: None if t is None else torch.as_tensor(t).to(device=self.device, dtype=torch.float32).contiguous()
-        pp, pt = f(pose_p).reshape(-1, 24, 3, 3), f(pose_t).reshape(-1, 24, 3, 3)
-        N = int(pp.shape[0])
-        if int(pt.shape[0]) != N:
-            raise RuntimeError("prediction has %d frames, ground truth %d" % (N, int(pt.shape[0])))
-        tp = None if tran_p is None else f(tran_p).reshape(N, 3)
-        tt = None if tran_t is None else f(tran_t).reshape(N, 3)
-        def bits(js):
-            js = [] if js is None else [int(j) for j in js]
-            if any(j < 0 or j > 23 for j in js):
-                raise ValueError("joint indices must be in 0..23, got %s" % (js,))
-            return sum(1 << j for j in set(js))
-        table = torch.empty(10, 2, device=self.device, dtype=torch.float32)
-        self._check(self._lib.mp_eval_metrics(self._h, _ptr(pp), _ptr(pt), _ptr(tp), _ptr(tt), N, int(fps), int(align_joint),
-                                             bits(joint_mask), bits(ignored), int(self.n_vertex > 0), _ptr(table),
-                                             self._stream()))
+        table = eval_metrics_call(self._lib, self._h, self.device, self.n_vertex, pose_p, pose_t, tran_p, tran_t, fps,
+                                  align_joint, joint_mask, ignored)
+        self._after_call()
         return table
 
     def rnn_forward(self, module, x, input_lengths, state=None):

@@ -559,6 +559,37 @@ def main():
         back = m.bodymodel.inverse_kinematics_R(Rg)
     np.savez_compressed(os.path.join(HERE, "g20_rotation_kinematics.npz"), R=R20, fk_R=Rg.numpy(), ik_R=Rl.numpy(), ik_of_fk=back.numpy())
 
+    # ---- G21 (round 6) the call surface of the path: parameter names and defaults of the reference's callables that a
+    # caller of the hot path touches, as inspect.signature reports them -- names and literals only, no source text
+    import inspect
+    from mobileposer.models import Joints, Poser, FootContact, Velocity   # noqa: E402
+    from mobileposer.utils.model_utils import load_model as ref_load_model     # noqa: E402
+
+    def sig(fn):
+        out = []
+        for name, prm in inspect.signature(fn).parameters.items():
+            if name == "self":
+                continue
+            d = prm.default
+            out.append([name, None if d is inspect.Parameter.empty else repr(d) if isinstance(d, (int, float, bool, str, type(None), tuple)) else "<object>"])
+        return out
+
+    surface = {
+        "MobilePoserNet": {n: sig(getattr(MobilePoserNet, n)) for n in ("__init__", "from_pretrained", "reset", "_prob_to_weight", "_reduced_global_to_full", "forward", "forward_offline", "forward_online")},
+        "Joints": {"forward": sig(Joints.forward)}, "Poser": {"forward": sig(Poser.forward), "_reduced_global_to_full": sig(Poser._reduced_global_to_full)},
+        "FootContact": {"forward": sig(FootContact.forward)}, "Velocity": {"forward": sig(Velocity.forward), "forward_online": sig(Velocity.forward_online)},
+        "ParametricModel": {n: sig(getattr(art.model.ParametricModel, n)) for n in ("__init__", "get_zero_pose_joint_and_vertex", "forward_kinematics_R", "inverse_kinematics_R", "forward_kinematics")},
+        "PoseDataset": {n: sig(getattr(PoseDataset, n)) for n in ("__init__", "__len__", "__getitem__")},
+        "PoseEvaluator": {n: sig(getattr(ref_eval.PoseEvaluator, n)) for n in ("__init__", "eval", "print")},
+        "functions": {"load_model": sig(ref_load_model), "evaluate_pose": sig(ref_eval.evaluate_pose)},
+    }
+    m = new_model()
+    surface["MobilePoserNet_attributes"] = sorted(k for k in vars(m) if not k.startswith("_") and k not in (
+        "training", "hypers", "validation_step_loss", "training_step_loss"))          # (module internals / training bookkeeping aside)
+    surface["MobilePoserNet_submodules"] = sorted(k for k, _ in m.named_children())
+    with open(os.path.join(HERE, "g21_call_surface.json"), "w") as f:
+        json.dump(surface, f, indent=0, sort_keys=True)
+
     print("golden vectors written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         print("  %-24s %8d B" % (fn, os.path.getsize(os.path.join(HERE, fn))))

@@ -116,6 +116,20 @@ for tag, key in (("a", "imu_a"), ("b", "imu_b"), ("a_again", "imu_a")):
     assert geo(pose.cpu().numpy(), g4[tag + "_pose"]).max() < 1e-4, tag
     assert np.abs(tran.cpu().numpy() - g4[tag + "_tran"]).max() < 1e-3, tag
 assert model.device_error() == 0
+# ---- golden G21: every attribute and sub-module the reference's instance has (net.py:28-74) is there ----
+import json
+g21 = json.load(open(os.path.join(golden, "g21_call_surface.json")))
+for name in g21["MobilePoserNet_attributes"] + g21["MobilePoserNet_submodules"]:
+    assert hasattr(model, name), name
+# ---- evaluate.py:16-18: PoseEvaluator() with no argument builds its body model from paths.smpl_file ----
+from mobileposer_amd.evaluate import PoseEvaluator
+g9 = dict(np.load(os.path.join(golden, "g9_evaluator.npz")))
+ev_file, ev_model = PoseEvaluator(), PoseEvaluator(model)
+args = [torch.from_numpy(g9[k]).cuda() for k in ("pose_p", "pose_t")]
+kw = {k: torch.from_numpy(g9[k]).cuda() for k in ("tran_p", "tran_t")}
+t_file, t_model = ev_file.eval(*args, **kw), ev_model.eval(*args, **kw)
+assert t_file.shape == (8, 2) and torch.equal(t_file, t_model)
+ev_file.model.close()
 model.close()
 print("LAYOUT-OK")
 '''
