@@ -22,7 +22,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import cu, load_golden, npy
+from conftest import cu, geodesic, load_golden, npy
 
 pytestmark = pytest.mark.gpu
 
@@ -504,3 +504,32 @@ def test_g20_rotation_kinematics_golden_and_edges(torch_mod, weights, smpl):
         assert np.abs(npy(body.forward_kinematics_R(R)) - g["fk_R"]).max() < 1e-5
     finally:
         body.close()
+
+
+@pytest.mark.parametrize("B", [4, 5, 16, 17, 32, 33, 64, 65, 96, 97, 128, 129])
+def test_schedule_boundaries_vs_oracle(torch_mod, weights, smpl, B):
+    """Every batch size at which the library changes the kernels or the schedule of a forward (csrc/mp_schedule.hip: per-sequence
+    clusters up to 4 sequences, the 32-slice kernels up to 32, three blocks side by side up to 64, the half-chip schedules up to 96 /
+    128, the one-stream schedule above) and the size right behind it: a ragged forward_offline against the oracle, twice -- the
+    second call runs on the velocity state the first one left."""
+    from mobileposer_amd import synthetic
+    from mobileposer_amd.net import MobilePoserNet
+    from oracle import mp_oracle as O
+    T = 11
+    rng = np.random.Generator(np.random.PCG64(600 + B))
+    lengths = rng.integers(1, T + 1, size=B).tolist()
+    lengths[int(rng.integers(0, B))] = T
+    imu = synthetic.make_imu(B, T, seed=600 + B)
+    ref = O.OracleNet(weights, smpl["J"])
+    with MobilePoserNet.from_numpy(weights, smpl) as net:
+        x = cu(torch_mod, imu)
+        for call in (0, 1):
+            pose, joints, vel, contact = net.forward(x, lengths)
+            rpose, rjoints, rvel, rcontact = ref.forward(imu, lengths)
+            assert np.abs(npy(joints) - rjoints).max() < 1e-4, (B, call)
+            assert np.abs(npy(vel).reshape(rvel.shape) - rvel).max() < 1e-4, (B, call)
+            assert np.abs(npy(contact) - rcontact).max() < 1e-4, (B, call)
+            assert geodesic(npy(pose), rpose).max() < 1e-4, (B, call)
+        h, c = net.velocity.rnn_state
+        assert np.abs(npy(h) - ref.velocity_rnn_state[0]).max() < 1e-4 and np.abs(npy(c) - ref.velocity_rnn_state[1]).max() < 1e-4
+        assert net.device_error() == 0 and net.recovery_count == 0
