@@ -297,14 +297,6 @@ int mp_set_graph_mode(mp_handle* h, int on);
  *       kernel; since round 5 mode 1's full-batch schedule runs the velocity block as a wavefront of the 8-slice kernel anyway);
  *   0 (env MP_LSTM_MODE=step): input-projection GEMM + one launch per time step. */
 int mp_set_lstm_mode(mp_handle* h, int mode);
-
-/* Opt-in (default 32): with 64 the kernels that run ONE sequence per cluster -- batches of up to 4 sequences: evaluate.py's own
- * call (evaluate.py:54-58), a one-stream tick, mp_stream_replay's chain -- accumulate every gate pre-activation (the K_in + H
- * products of a gate row and the bias) in float64 and round it to fp32 once; state, activations and outputs stay fp32.  Another
- * legal evaluation of the reference's arithmetic (models/rnn.py:27): within the same bounds on every golden, closer to the exact
- * result on average where the network is chaotic at fp32 resolution (golden G17), ~10 % slower per step.
- * Larger batches run on the MFMA kernels whatever this says. */
-int mp_set_accumulation(mp_handle* h, int bits);
 /* ---- error behaviour of the persistent LSTM kernels ---------------------------------------------------------------
  * A fused layer launch is a grid of workgroups that wait for each other's hidden state every time step; all of them
  * must be resident at once.  The library plans its launches for a GPU it has to itself; when something else (another

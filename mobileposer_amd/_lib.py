@@ -88,7 +88,6 @@ SIGNATURES = {
     "mp_timing_read": (_i, [_vp, _i, C.POINTER(_i), _fp, C.POINTER(C.c_double)]),
     "mp_set_graph_mode": (_i, [_vp, _i]),
     "mp_set_lstm_mode": (_i, [_vp, _i]),
-    "mp_set_accumulation": (_i, [_vp, _i]),
     "mp_set_transport": (_i, [_vp, _i]),
     "mp_device_error": (_i, [_vp, C.POINTER(_i)]),
     "mp_finish": (_i, [_vp]),

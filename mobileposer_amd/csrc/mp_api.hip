@@ -411,16 +411,6 @@ int mp_set_lstm_mode(mp_handle* h, int mode) {
     return MP_OK;
 }
 
-int mp_set_accumulation(mp_handle* h, int bits) {
-    if (!h || (bits != 32 && bits != 64)) return h ? fail(h, MP_ERR_INVALID, "mp_set_accumulation: 32 or 64") : MP_ERR_INVALID;
-    ON_DEVICE(h);
-    HIPCHK(h, hipDeviceSynchronize());
-    h->acc64 = bits == 64;
-    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second.exec);   // captured launches carry the other kernels
-    h->graphs.clear();
-    return MP_OK;
-}
-
 int mp_set_graph_mode(mp_handle* h, int on) {
     if (!h || on < 0 || on > 2) return MP_ERR_INVALID;
     ON_DEVICE(h);

@@ -199,9 +199,9 @@ void mp_launch_pack_w_u8(const float* w, float* dst, int K, hipStream_t s);
 hipError_t mp_lstm_u8_device_attrs();
 // mp_lstm_v1.hip: one sequence per cluster (B = 1), matrix-vector steps on the vector ALU; d[].wpack / wihpack from mp_launch_pack_w_v1
 // (H = 256) or torch's row-major matrices (mp_lstm_v1s, H = 64)
-void mp_launch_lstm_v1(const LstmPersistArgs& a, int KIN, bool wavefront, hipStream_t s, bool acc64 = false);   // acc64: gate pre-activations accumulated in float64 (mp_set_accumulation)
+void mp_launch_lstm_v1(const LstmPersistArgs& a, int KIN, bool wavefront, hipStream_t s);
 void mp_launch_pack_w_v1(const float* w, float* dst, int K, hipStream_t s);   // W [1024][K] -> the per-lane order of mp_lstm_v1
-void mp_launch_lstm_v1s(const LstmPersistArgs& a, int KIN, hipStream_t s, bool acc64 = false);   // H = 64: one workgroup per (direction, sequence)
+void mp_launch_lstm_v1s(const LstmPersistArgs& a, int KIN, hipStream_t s);   // H = 64: one workgroup per (direction, sequence)
 hipError_t mp_lstm_v1_device_attrs();
 void mp_launch_pack_whh_persist(const float* whh, float* dst, int H, int nslice, hipStream_t s);
 void mp_launch_pack_wih_persist(const float* wih, float* dst, int H, int KIN, int nslice, hipStream_t s);

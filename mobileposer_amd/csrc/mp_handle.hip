@@ -313,7 +313,6 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
     //   vf=0           foot-contact layers as launches of their own beside velocity (B > 128), not as riders in its workgroups
     //   wf=0           velocity layers as two 16-slice launches (rounds 3-4), not as one two-layer wavefront launch (B > 128)
     //   late_pair=0    64 < B <= 128: both pose layers on 8 slices beside velocity (schedules 2 / 3) instead of schedule 4
-    //   acc64=1        the one-sequence kernels accumulate gate pre-activations in float64 (= mp_set_accumulation(h, 64))
     if (const char* e = getenv("MP_VARIANT")) {
         std::string all(e);
         size_t pos = 0;
@@ -330,7 +329,6 @@ int create_common(mp_handle** out, int device, const float* blob, bool blob_on_d
             else if (key == "slices16") h->slices16_ok = v != 0;
             else if (key == "slices32") h->slices32_ok = v != 0;
             else if (key == "vec") h->vec_ok = v != 0;
-            else if (key == "acc64") h->acc64 = v != 0;
             else if (key == "wide") h->wide_ok = v != 0;
             else if (key == "half") h->half_ok = v != 0;
             else if (key == "exclusive") h->exclusive_ok = v != 0;

@@ -144,8 +144,6 @@ struct mp_handle {
     bool epoch_tags = true;          // MP_VARIANT epoch_tags=0: zero the exchange area before every fp32 layer launch (as round 1 did)
     bool slices16_ok = true;         // MP_VARIANT slices16=0: bidirectional fp32 layers always on 8 slices
     bool vec_ok = true;              // MP_VARIANT vec=0: B = 1 on the 32-slice MFMA kernel (mp_lstm_u8), not on the matrix-vector kernel (mp_lstm_v1)
-    bool acc64 = false;              // mp_set_accumulation(h, 64) / MP_VARIANT acc64=1: the one-sequence kernels (B <= 4: mp_lstm_v1 / mp_lstm_v1s)
-                                     // accumulate gate pre-activations in float64 (opt-in; default fp32 FMAs)
     bool slices32_ok = true;         // MP_VARIANT slices32=0: no 32-slice kernels for batches of one or two slabs
     bool wide_ok = true;             // MP_VARIANT wide=0: never run pose / velocity / foot-contact side by side (small batches)
     bool exclusive_ok = true;        // MP_VARIANT exclusive=0: never pad the LDS request of concurrent persistent launches (below)

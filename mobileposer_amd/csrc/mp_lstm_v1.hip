@@ -31,7 +31,6 @@
 // word and XCD table as the other persistent kernels.  Another order of summation than theirs: equal to fp32 rounding, not
 // bitwise (tests/test_gpu_round5.py::test_single_sequence_kernel_*).
 #include "mp_lstm_dev.h"
-#include <type_traits>
 
 namespace {
 
@@ -84,48 +83,10 @@ static __device__ __forceinline__ float sum_over_segments(float v) {
     return v;
 }
 
-// (A64 in mp_lstm_v1s: a weight is converted where it is used -- without this the compiler hoists the 48 conversions of a lane's
-//  loop-invariant weights out of the step loop and spills the doubles: 16 waves per CU leave 128 registers per lane)
-static __device__ __forceinline__ float opaque(float w) { asm volatile("" : "+v"(w)); return w; }
-// the same in float64 (A64, below): both halves of the double go through the same DPP / permlane instructions
-static __device__ __forceinline__ double make_f64(unsigned lo, unsigned hi) {
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
-}
-template <bool ROR8>
-static __device__ __forceinline__ double sum_over_segments64(double v) {
-    if (ROR8) {
-        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-        const int lo = (int)(unsigned)b, hi = (int)(unsigned)(b >> 32);
-        v += make_f64((unsigned)__builtin_amdgcn_update_dpp(lo, lo, 0x128 /* row_ror:8 */, 0xf, 0xf, false),
-                      (unsigned)__builtin_amdgcn_update_dpp(hi, hi, 0x128, 0xf, 0xf, false));
-    }
-    {
-        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-        const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
-        const auto pl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-        const auto ph = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-        v = make_f64(pl[0], ph[0]) + make_f64(pl[1], ph[1]);
-    }
-    {
-        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-        const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
-        const auto pl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-        const auto ph = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-        v = make_f64(pl[0], ph[0]) + make_f64(pl[1], ph[1]);
-    }
-    return v;
-}
-
 constexpr int kLead = 16;      // WF: a layer-1 wave that has to wait for layer 0 waits for this many steps at once
 
 // ROLE: 0 = a layer of its own, 1 = layer 0 of a wavefront launch, 2 = layer 1 of one
-// A64 (round 6, opt-in: mp_set_accumulation(h, 64)): the gate pre-activations -- the K_in + 256 products of a gate row, the sum
-// over the 8 K segments, the bias -- are accumulated in float64 and rounded to fp32 ONCE; weights are converted when they are
-// loaded (2 registers each), x_t / h_{t-1} values as they are used; cell state, activations and everything that travels stay fp32.
-// On the reference's own call shape with trained-regime weights (golden G17, where the net is chaotic at fp32 resolution) that
-// puts the result closer to the float64 result than any fp32 evaluation is on average -- measured level and price: DESIGN.md
-// section 2 / profiles/r06_acc64.txt -- and changes nothing about the contract: another legal evaluation of the same arithmetic.
-template <int KIN, bool PROF, int ROLE, bool A64>
+template <int KIN, bool PROF, int ROLE>
 static __device__ __forceinline__ void v1_cluster(const LstmPersistArgs& a, float* smem, int cl, int dir, int seq, int slice) {
     using C = V1Cfg<KIN>;
     constexpr int H = C::H, NSLICE = C::NSLICE, KS = C::KS, XSTR = C::XSTR, HSTR = C::HSTR, NX = C::NX;
@@ -142,8 +103,7 @@ static __device__ __forceinline__ void v1_cluster(const LstmPersistArgs& a, floa
     // ---- weights of gate row g * H + junit, segment s: packed [slice][wave][16-byte piece][lane] (mp_pack_w_v1), so that a
     // wave's load is one contiguous KB (straight from the row-major matrices every lane walked a 128-byte line of its own, 64
     // lines per load and 4 waves per CU: the prologue was 8 / 17 us of a 45-step launch)
-    using acc_t = typename std::conditional<A64, double, float>::type;
-    acc_t wx[KS], wh[32];
+    float wx[KS], wh[32];
     {
         const f32x4* px = reinterpret_cast<const f32x4*>(d.wihpack) + (size_t)(slice * 4 + wave) * (KS / 4) * 64 + lane;
 #pragma unroll
@@ -301,15 +261,12 @@ static __device__ __forceinline__ void v1_cluster(const LstmPersistArgs& a, floa
         // ---- input projection: x_t (requested a step ago) through this wave's LDS strip
         stage_x();
         asm volatile("" ::: "memory");
-        acc_t acc[4] = {0, 0, 0, 0};
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < KS / 4; ++i) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(xseg + 4 * i);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (A64) acc[j] = __builtin_fma(wx[4 * i + j], (double)v[j], acc[j]);
-                else acc[j] = __builtin_fmaf(wx[4 * i + j], v[j], acc[j]);
-            }
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(wx[4 * i + j], v[j], acc[j]);
         }
         V1_E(0); V1_T(1);
         // ---- h_{t-1}: all 256 granules of the parity slot, epoch = epoch_base + step.  (The first poll BEHIND the input
@@ -356,15 +313,10 @@ static __device__ __forceinline__ void v1_cluster(const LstmPersistArgs& a, floa
         for (int i = 0; i < 8; ++i) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(hseg + 4 * i);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (A64) acc[j] = __builtin_fma(wh[4 * i + j], (double)v[j], acc[j]);
-                else acc[j] = __builtin_fmaf(wh[4 * i + j], v[j], acc[j]);
-            }
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(wh[4 * i + j], v[j], acc[j]);
         }
         V1_E(2); V1_T(3);
-        float gate;
-        if constexpr (A64) gate = (float)(sum_over_segments64<true>((acc[0] + acc[1]) + (acc[2] + acc[3])) + (double)bias);
-        else gate = sum_over_segments((acc[0] + acc[1]) + (acc[2] + acc[3])) + bias;
+        const float gate = sum_over_segments((acc[0] + acc[1]) + (acc[2] + acc[3])) + bias;
         V1_E(3); V1_T(4);
         // ---- cell: every lane its gate's non-linearity (sigmoidf_ / tanhf_ of mp_lstm_dev.h by per-lane constants), quad exchange
         const float e = __builtin_amdgcn_exp2f(cx * gate);
@@ -406,7 +358,7 @@ static __device__ __forceinline__ void v1_cluster(const LstmPersistArgs& a, floa
     }
 }
 
-template <int KIN, bool PROF, bool WF, bool A64>
+template <int KIN, bool PROF, bool WF>
 MP_KERNEL __launch_bounds__(256, (WF ? 2 : 1)) void mp_lstm_v1(LstmPersistArgs a) {
     if (PROF && a.debug_drop && (int)blockIdx.x == a.debug_drop - 1) return;      // test hook (mp_debug_drop_workgroup)
     constexpr int NSLICE = V1Cfg<KIN>::NSLICE;
@@ -420,10 +372,10 @@ MP_KERNEL __launch_bounds__(256, (WF ? 2 : 1)) void mp_lstm_v1(LstmPersistArgs a
     const int cl = mp_xcd_first(a, xcd) + kth;
     if (cl >= ncl) return;
     if (WF) {
-        if (cl & 1) v1_cluster<KIN, PROF, 2, A64>(a, smem, cl, 1, cl >> 1, slice);
-        else v1_cluster<KIN, PROF, 1, A64>(a, smem, cl, 0, cl >> 1, slice);
+        if (cl & 1) v1_cluster<KIN, PROF, 2>(a, smem, cl, 1, cl >> 1, slice);
+        else v1_cluster<KIN, PROF, 1>(a, smem, cl, 0, cl >> 1, slice);
     } else {
-        v1_cluster<KIN, PROF, 0, A64>(a, smem, cl, cl / a.nslab, cl % a.nslab, slice);
+        v1_cluster<KIN, PROF, 0>(a, smem, cl, cl / a.nslab, cl % a.nslab, slice);
     }
 }
 
@@ -437,9 +389,8 @@ MP_KERNEL __launch_bounds__(256, (WF ? 2 : 1)) void mp_lstm_v1(LstmPersistArgs a
 // and cell as mp_lstm_v1.  Placement: LstmPersistArgs' XCD table with one workgroup per cluster (beside the other blocks'
 // clusters the host gives every cluster an XCD with room).
 
-template <int KIN, bool A64>
+template <int KIN>
 MP_KERNEL __launch_bounds__(1024, 1) void mp_lstm_v1s(LstmPersistArgs a) {
-    using acc_t = typename std::conditional<A64, double, float>::type;
     constexpr int H = 64, KS = KIN / 4, HSTR = 16 + 4, XSTR = KS + 4;
     __shared__ __attribute__((aligned(16))) float hs[2][4 * HSTR];
     __shared__ __attribute__((aligned(16))) float xs[2][4 * XSTR];
@@ -459,7 +410,7 @@ MP_KERNEL __launch_bounds__(1024, 1) void mp_lstm_v1s(LstmPersistArgs a) {
     const bool in = b < B;
     const int len = in ? a.lengths[b] : 0;
 
-    float wx[KS], wh[16];               // (A64: converted where they are used -- 16 waves per CU leave 128 registers per lane)
+    float wx[KS], wh[16];
     {
         const float* px = d.wihpack + (size_t)(g * H + junit) * KIN + s * KS;
 #pragma unroll
@@ -514,44 +465,33 @@ MP_KERNEL __launch_bounds__(1024, 1) void mp_lstm_v1s(LstmPersistArgs a) {
     };
     auto one_step = [&](int step, const f32x4& row_next) {
         if (loader) *reinterpret_cast<f32x4*>(xput + ((step + 1) & 1) * 4 * XSTR) = row_next;     // x_{step+1} into the other slot
-        acc_t acc[4] = {0, 0, 0, 0};
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
         const float* xseg = &xs[step & 1][s * XSTR];
 #pragma unroll
         for (int i = 0; i < KS / 4; ++i) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(xseg + 4 * i);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (A64) acc[j] = __builtin_fma((double)opaque(wx[4 * i + j]), (double)v[j], acc[j]);
-                else acc[j] = __builtin_fmaf(wx[4 * i + j], v[j], acc[j]);
-            }
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(wx[4 * i + j], v[j], acc[j]);
         }
         const float* hseg = &hs[(step + 1) & 1][s * HSTR];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(hseg + 4 * i);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (A64) acc[j] = __builtin_fma((double)opaque(wh[4 * i + j]), (double)v[j], acc[j]);
-                else acc[j] = __builtin_fmaf(wh[4 * i + j], v[j], acc[j]);
-            }
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(wh[4 * i + j], v[j], acc[j]);
         }
-        float gate;
-        if constexpr (A64) {
-            gate = (float)(sum_over_segments64<false>((acc[0] + acc[1]) + (acc[2] + acc[3])) + (double)bias);
-        } else {
-            float sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-            {
-                const unsigned u = __float_as_uint(sum);
-                const auto p = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-                sum = __uint_as_float(p[0]) + __uint_as_float(p[1]);
-            }
-            {
-                const unsigned u = __float_as_uint(sum);
-                const auto p = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-                sum = __uint_as_float(p[0]) + __uint_as_float(p[1]);
-            }
-            gate = sum + bias;
+        float sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        {
+            const unsigned u = __float_as_uint(sum);
+            const auto p = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+            sum = __uint_as_float(p[0]) + __uint_as_float(p[1]);
         }
+        {
+            const unsigned u = __float_as_uint(sum);
+            const auto p = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            sum = __uint_as_float(p[0]) + __uint_as_float(p[1]);
+        }
+        const float gate = sum + bias;
         const float e = __builtin_amdgcn_exp2f(cx * gate);
         const float r = __builtin_amdgcn_rcpf(1.0f + e);
         const float tv = 1.0f - 2.0f * r;
@@ -605,7 +545,7 @@ MP_KERNEL void mp_pack_w_v1(const float* __restrict__ w, float* __restrict__ dst
     dst[idx] = w[(size_t)row * K + k];
 }
 
-template <int KIN, bool WF, bool A64>
+template <int KIN, bool WF>
 void launch_v1(const LstmPersistArgs& a, hipStream_t s) {
     LstmPersistArgs b = a;
     int most = 0, total = 0;
@@ -617,39 +557,33 @@ void launch_v1(const LstmPersistArgs& a, hipStream_t s) {
     size_t lds = V1Cfg<KIN>::LDS_BYTES;
     if ((size_t)a.min_lds > lds) lds = (size_t)a.min_lds;
     const dim3 grid(8 * most * 32);
-    if (a.prof || a.debug_drop) hipLaunchKernelGGL((mp_lstm_v1<KIN, true, WF, A64>), grid, dim3(256), lds, s, b);
-    else hipLaunchKernelGGL((mp_lstm_v1<KIN, false, WF, A64>), grid, dim3(256), lds, s, b);
+    if (a.prof || a.debug_drop) hipLaunchKernelGGL((mp_lstm_v1<KIN, true, WF>), grid, dim3(256), lds, s, b);
+    else hipLaunchKernelGGL((mp_lstm_v1<KIN, false, WF>), grid, dim3(256), lds, s, b);
 }
 
-template <int KIN, bool WF, bool A64>
+template <int KIN, bool WF>
 hipError_t v1_attrs() {
     const int lds = 96 * 1024;                                          // (room for LstmPersistArgs::min_lds)
-    hipError_t e = hipFuncSetAttribute((const void*)mp_lstm_v1<KIN, true, WF, A64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)mp_lstm_v1<KIN, true, WF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)mp_lstm_v1<KIN, false, WF, A64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return hipFuncSetAttribute((const void*)mp_lstm_v1<KIN, false, WF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
 }  // namespace
 
 // a.nslab = number of sequences (one cluster per direction and sequence); d[].wpack / wihpack = W_hh / W_ih from
 // mp_launch_pack_w_v1.  wavefront: a.ndir = 2, d[0] = layer 0, d[1] = layer 1 reading d[0].out (K_in = 256).
-void mp_launch_lstm_v1(const LstmPersistArgs& a, int KIN, bool wavefront, hipStream_t s, bool acc64) {
-    if (acc64) {
-        if (wavefront) launch_v1<256, true, true>(a, s);
-        else if (KIN == 256) launch_v1<256, false, true>(a, s);
-        else launch_v1<512, false, true>(a, s);
-        return;
-    }
-    if (wavefront) launch_v1<256, true, false>(a, s);
-    else if (KIN == 256) launch_v1<256, false, false>(a, s);
-    else launch_v1<512, false, false>(a, s);
+void mp_launch_lstm_v1(const LstmPersistArgs& a, int KIN, bool wavefront, hipStream_t s) {
+    if (wavefront) launch_v1<256, true>(a, s);
+    else if (KIN == 256) launch_v1<256, false>(a, s);
+    else launch_v1<512, false>(a, s);
 }
 void mp_launch_pack_w_v1(const float* w, float* dst, int K, hipStream_t s) {
     const size_t n = (size_t)4 * 256 * K;
     hipLaunchKernelGGL(mp_pack_w_v1, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, dst, K);
 }
 // H = 64, one workgroup per (direction, sequence); the ROW-MAJOR W_hh [256][64], W_ih [256][K_in] of torch.nn.LSTM
-void mp_launch_lstm_v1s(const LstmPersistArgs& a, int KIN, hipStream_t s, bool acc64) {
+void mp_launch_lstm_v1s(const LstmPersistArgs& a, int KIN, hipStream_t s) {
     LstmPersistArgs b = a;
     int most = 0, total = 0;
     for (int x = 0; x < 8; ++x) { most = b.xcd_cnt[x] > most ? b.xcd_cnt[x] : most; total += b.xcd_cnt[x]; }
@@ -658,20 +592,12 @@ void mp_launch_lstm_v1s(const LstmPersistArgs& a, int KIN, hipStream_t s, bool a
         most = (a.nslab * a.ndir + 7) / 8;
     }
     const dim3 grid(8 * most);
-    if (acc64) {
-        if (KIN == 64) hipLaunchKernelGGL((mp_lstm_v1s<64, true>), grid, dim3(1024), 0, s, b);
-        else hipLaunchKernelGGL((mp_lstm_v1s<128, true>), grid, dim3(1024), 0, s, b);
-        return;
-    }
-    if (KIN == 64) hipLaunchKernelGGL((mp_lstm_v1s<64, false>), grid, dim3(1024), 0, s, b);
-    else hipLaunchKernelGGL((mp_lstm_v1s<128, false>), grid, dim3(1024), 0, s, b);
+    if (KIN == 64) hipLaunchKernelGGL((mp_lstm_v1s<64>), grid, dim3(1024), 0, s, b);
+    else hipLaunchKernelGGL((mp_lstm_v1s<128>), grid, dim3(1024), 0, s, b);
 }
 hipError_t mp_lstm_v1_device_attrs() {
-    hipError_t e = v1_attrs<256, false, false>();
-    if (!e) e = v1_attrs<512, false, false>();
-    if (!e) e = v1_attrs<256, true, false>();
-    if (!e) e = v1_attrs<256, false, true>();
-    if (!e) e = v1_attrs<512, false, true>();
-    if (!e) e = v1_attrs<256, true, true>();
+    hipError_t e = v1_attrs<256, false>();
+    if (!e) e = v1_attrs<512, false>();
+    if (!e) e = v1_attrs<256, true>();
     return e;
 }

@@ -339,8 +339,8 @@ int rnn_rec(const RnnJob& j, int l, hipStream_t s) {
                 a.f_out = f_layer == 0 ? fws.out0 : fws.out1;
             }
             const int fk = fj ? (f_layer == 0 ? fm_kin0(h) : 2 * h->mod[MP_MOD_FOOT_CONTACT].H) : 0;
-            if (v1) mp_launch_lstm_v1(a, kin, wf32, s, h->acc64);
-            else if (v1s) mp_launch_lstm_v1s(a, kin, s, h->acc64);
+            if (v1) mp_launch_lstm_v1(a, kin, wf32, s);
+            else if (v1s) mp_launch_lstm_v1s(a, kin, s);
             else if (wf || (fj && nsl == 8)) {
                 if (!mp_launch_lstm_persist8(a, fk, wf, s)) return fail(h, MP_ERR_INVALID, "internal: 8-slice launch (rider %d, wavefront %d) not built", fk, (int)wf);
             } else if (fj) mp_launch_lstm_vf(a, fk, s);

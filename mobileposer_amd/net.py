@@ -726,12 +726,6 @@ class MobilePoserNet:
         self._check(self._lib.mp_set_lstm_mode(self._h, int(mode)))
         self._lstm_mode = int(mode)
 
-    def set_accumulation(self, bits):
-        """mp_set_accumulation: 64 = the one-sequence kernels (batches of up to 4 sequences) accumulate gate pre-activations in
-        float64 (opt-in; default 32)."""
-        self._check(self._lib.mp_set_accumulation(self._h, int(bits)))
-        self._graph_bufs.clear()
-
     def set_transport(self, force_remote):
         """Test hook: force the any-placement (sc1) hidden-state transport of the persistent kernels."""
         self._check(self._lib.mp_set_transport(self._h, int(bool(force_remote))))
