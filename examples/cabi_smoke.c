@@ -92,6 +92,33 @@ int main(void) {
         for (int k = 0; k < 3; ++k)
             if (tran_h[((size_t)3 * T + t) * 3 + k] != tran_h[((size_t)3 * T + lengths[3] - 1) * 3 + k]) {
                 fprintf(stderr, "translation changed after the end of sequence 3\n"); return 1; }
+    /* ParametricModel.forward_kinematics (articulate/model.py:208-232) and inverse_kinematics_R (:146-164) through the ABI:
+     * IK(FK(local pose)) gives the local pose back */
+    {
+        const long N = (long)B * T;
+        float *rglob = NULL, *jglob = NULL, *back = NULL;
+        CHECK_HIP(hipMalloc((void**)&rglob, n_pose * 4));
+        CHECK_HIP(hipMalloc((void**)&jglob, (size_t)N * 72 * 4));
+        CHECK_HIP(hipMalloc((void**)&back, n_pose * 4));
+        CHECK_MP(mp_fk(h, pose, NULL, N, rglob, jglob, NULL));
+        CHECK_MP(mp_inverse_kinematics_r(h, rglob, N, back, NULL));
+        if (mp_inverse_kinematics_r(h, rglob, N, rglob, NULL) != MP_ERR_INVALID) { fprintf(stderr, "in-place IK accepted\n"); return 1; }
+        CHECK_HIP(hipDeviceSynchronize());
+        float* back_h = (float*)malloc(n_pose * 4);
+        CHECK_HIP(hipMemcpy(back_h, back, n_pose * 4, hipMemcpyDeviceToHost));
+        double werr = 0.0;
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < lengths[b]; ++t)
+                for (int k = 0; k < 216; ++k) {
+                    const size_t i = ((size_t)b * T + t) * 216 + k;
+                    const double e = fabs((double)back_h[i] - (double)pose_h[i]);
+                    if (e > werr) werr = e;
+                }
+        printf("IK(FK(pose)) - pose: max %.2e\n", werr);
+        if (werr > 1e-3) return 1;                                 /* (as above: rotations orthonormal to 1e-3 only) */
+        free(back_h);
+        (void)hipFree(rglob); (void)hipFree(jglob); (void)hipFree(back);
+    }
     mp_destroy(h);
     printf("cabi_smoke: ok\n");
     return 0;
