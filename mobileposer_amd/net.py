@@ -704,6 +704,10 @@ class MobilePoserNet:
         st_out = torch.empty(2, 2 * dirs, B, H, device=self.device, dtype=torch.float32)
         st_in = None
         if state is not None:
+            want = (2 * dirs, B, H)
+            for name, t in (("h0", state[0]), ("c0", state[1])):
+                if tuple(t.shape) != want:       # (nn.LSTM raises "Expected hidden size ..." here: SURVEY Q2, a batch-size change)
+                    raise RuntimeError("Expected %s of shape %s for a batch of %d sequences, got %s" % (name, want, B, tuple(t.shape)))
             st_in = torch.stack((state[0], state[1])).to(device=self.device, dtype=torch.float32).contiguous()
         rc = self._lib.mp_rnn_forward(self._h, mod, _ptr(x), lens, B, T, _ptr(y), _ptr(st_in), _ptr(st_out), self._stream())
         self._check(rc)

@@ -458,6 +458,11 @@ def test_g19_submodule_views_golden(torch_mod, weights, smpl):
             h, c = net.velocity.rnn_state
             assert tuple(h.shape) == g[f"{tag}_h"].shape
             assert np.abs(npy(h) - g[f"{tag}_h"]).max() < 1e-4 and np.abs(npy(c) - g[f"{tag}_c"]).max() < 1e-4
+        # a carried state of another batch size is refused (nn.LSTM raises there too) -- not read as if it fitted
+        with pytest.raises(RuntimeError):
+            net.velocity.forward_online(xv[:2].contiguous(), lengths[:2])
+        with pytest.raises(RuntimeError):
+            net.rnn_forward("joints", cu(torch_mod, g["joints_x"]), lengths, (torch_mod.zeros(4, 2, 256, device="cuda"), torch_mod.zeros(4, 2, 256, device="cuda")))
         # poser.py:52-58 is net.py:93-99
         g3 = load_golden("g3_r6d_ik.npz")
         assert np.abs(npy(net.pose._reduced_global_to_full(cu(torch_mod, g3["r6d"]))) - g3["pose"]).max() < 1e-5
