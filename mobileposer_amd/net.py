@@ -119,6 +119,8 @@ class _VelocityView(_ModuleView):
             net._check(net._lib.mp_reset_state(net._h, 1))
             return
         h, c = value
+        if h.dim() != 3 or tuple(h.shape) != tuple(c.shape) or int(h.shape[0]) != 2 or int(h.shape[2]) != 256:
+            raise RuntimeError("velocity.rnn_state is (h, c), each [2, B, 256] (velocity.py:29-30), got %s / %s" % (tuple(h.shape), tuple(c.shape)))
         buf = torch.stack((h, c)).to(device=net.device, dtype=torch.float32).contiguous()
         net._check(net._lib.mp_set_velocity_state(net._h, _ptr(buf), int(h.shape[1])))
 
@@ -697,6 +699,9 @@ class MobilePoserNet:
         self._require_weights()
         mod = {"joints": 0, "pose": 1, "foot_contact": 2, "velocity": 3}[module]
         n_out, H, dirs = {0: (72, 256, 2), 1: (96, 256, 2), 2: (2, 64, 2), 3: (72, 256, 1)}[mod]
+        n_in = model_config.n_imu if mod == 0 else model_config.n_imu + 72          # joints: imu; the others: cat(pred_joints, imu)
+        if x.dim() != 3 or int(x.shape[-1]) != n_in:
+            raise RuntimeError("%s takes [B, T, %d], got %s" % (module, n_in, tuple(x.shape)))
         x = x.to(device=self.device, dtype=torch.float32).contiguous()
         B, T = int(x.shape[0]), int(x.shape[1])
         lens = self._lengths(input_lengths, B, T)

@@ -463,6 +463,10 @@ def test_g19_submodule_views_golden(torch_mod, weights, smpl):
             net.velocity.forward_online(xv[:2].contiguous(), lengths[:2])
         with pytest.raises(RuntimeError):
             net.rnn_forward("joints", cu(torch_mod, g["joints_x"]), lengths, (torch_mod.zeros(4, 2, 256, device="cuda"), torch_mod.zeros(4, 2, 256, device="cuda")))
+        with pytest.raises(RuntimeError):                         # a sub-module fed the other one's input width
+            net.pose(cu(torch_mod, g["joints_x"]), lengths)
+        with pytest.raises(RuntimeError):
+            net.velocity.rnn_state = (torch_mod.zeros(2, 3, 128, device="cuda"), torch_mod.zeros(2, 3, 128, device="cuda"))
         # poser.py:52-58 is net.py:93-99
         g3 = load_golden("g3_r6d_ik.npz")
         assert np.abs(npy(net.pose._reduced_global_to_full(cu(torch_mod, g3["r6d"]))) - g3["pose"]).max() < 1e-5
