@@ -67,10 +67,10 @@ def test_one_rank_rccl_launch_matches_the_plain_run():
     assert ranked["output_sha1"] == plain["output_sha1"]
     # and the process group costs no step time (host-side barriers; same box, back to back): `value` within 1 % (round 6;
     # measured 0.9997, 1.0039 -- and once 1.022: two processes, a 0.18 s timed region each, and a step whose launches wait for the
-    # host after every synchronised call.  A pair that disagrees is measured again, up to twice, and the FASTEST run of each kind
+    # host after every synchronised call.  A pair that disagrees is measured again, up to three times, and the FASTEST run of each kind
     # is compared: a cost of the process group shows in every ranked run, a slow process start in one)
     t_plain, t_ranked = [plain["ms_per_step"]], [ranked["ms_per_step"]]
-    for _ in range(2):
+    for _ in range(3):
         if 0.99 < min(t_ranked) / min(t_plain) < 1.01:
             break
         t_plain.append(_bench(args, launcher=False)["ms_per_step"])
